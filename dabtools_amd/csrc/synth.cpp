@@ -1,0 +1,348 @@
+// synth.cpp — synthetic DAB Mode-I modulator (host only): ensemble configuration ->
+// 2.048 Msps cu8 IQ.  The reference contains no transmitter; this is the workload
+// generator for tests and bench.py, built as the exact inverse of the receive chain the
+// reference implements (fic.c:47-130 FIG parsing, depuncture.c, misc.c:29-58,
+// input_sdr.c:132-162 demap, sdr_prstab.c PRS, dab_tables.c tables).
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dabhip.h"
+#include "dab_bits.hpp"
+#include "dab_tables.hpp"
+
+namespace dabhip {
+void set_error(const std::string& msg);
+
+namespace {
+
+// counter-based generator: value = f(seed, stream of keys); reproducible on any machine
+inline uint64_t mix64(uint64_t z)
+{
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+inline uint64_t key(uint64_t seed, uint64_t a, uint64_t b, uint64_t c) { return mix64(mix64(mix64(seed ^ mix64(a)) + b) + c); }
+
+enum : uint64_t { kDomPayload = 1, kDomFiller = 2, kDomNoise = 3 };
+
+SubChannel to_subchannel(const dabhip_subch_cfg& c)
+{
+  SubChannel sc;
+  sc.id = c.id;
+  sc.start_cu = c.start_cu;
+  sc.slform = c.slform;
+  if (!c.slform) {
+    const UepProfile& u = uep_table()[c.uep_index & 63];
+    sc.uep_index = c.uep_index & 63;
+    sc.size_cu = u.size_cu;
+    sc.bitrate = u.bitrate;
+    sc.protlev = u.protlevel;
+  } else {
+    sc.protlev = c.eep_protlev & 7;
+    sc.size_cu = c.size_cu;
+    sc.bitrate = (c.size_cu / eep_size_multiple(sc.protlev)) * ((sc.protlev & 4) ? 32 : 8);
+  }
+  return sc;
+}
+
+bool validate(const dabhip_synth_cfg& cfg)
+{
+  if (cfg.nsub < 0 || cfg.nsub > 64) { set_error("synth: nsub out of range"); return false; }
+  std::vector<char> used(864, 0);
+  for (int k = 0; k < cfg.nsub; ++k) {
+    const SubChannel sc = to_subchannel(cfg.sub[k]);
+    if (sc.id < 0 || sc.id > 63 || sc.bitrate <= 0 || sc.start_cu < 0 || sc.start_cu + sc.size_cu > 864) {
+      set_error("synth: sub-channel " + std::to_string(k) + " does not fit the CIF");
+      return false;
+    }
+    if (puncture_plan(sc).coded_bits() > sc.size_cu * 64) { set_error("synth: sub-channel over-long"); return false; }
+    for (int cu = sc.start_cu; cu < sc.start_cu + sc.size_cu; ++cu) {
+      if (used[cu]) { set_error("synth: overlapping sub-channels"); return false; }
+      used[cu] = 1;
+    }
+  }
+  if (cfg.skip_samples < 0 || cfg.skip_samples >= kTfSamples) { set_error("synth: skip_samples out of range"); return false; }
+  return true;
+}
+
+void payload_bytes(const dabhip_synth_cfg& cfg, int cif, int slot, uint8_t* out, int n)
+{
+  for (int i = 0; i < n; i += 8) {
+    uint64_t v = key(cfg.seed, kDomPayload, (static_cast<uint64_t>(static_cast<uint32_t>(cif)) << 8) | static_cast<uint64_t>(slot), static_cast<uint64_t>(i));
+    for (int b = 0; b < 8 && i + b < n; ++b) out[i + b] = static_cast<uint8_t>(v >> (8 * b));
+  }
+}
+
+// the three FIBs of one CIF: FIG 0/0 (ensemble, CIF counter) and FIG 0/1 (sub-channel
+// organisation) entries packed greedily, then end marker / padding and the FIB CRC
+void build_fibs(const dabhip_synth_cfg& cfg, int cif, uint8_t* out96)
+{
+  const int count = ((cfg.cif_count0 + cif) % 5000 + 5000) % 5000;
+  std::vector<std::vector<uint8_t>> entries;
+  for (int k = 0; k < cfg.nsub; ++k) {
+    const SubChannel sc = to_subchannel(cfg.sub[k]);
+    std::vector<uint8_t> e;
+    e.push_back(static_cast<uint8_t>((sc.id << 2) | ((sc.start_cu >> 8) & 3)));
+    e.push_back(static_cast<uint8_t>(sc.start_cu & 0xff));
+    if (!sc.slform) {
+      e.push_back(static_cast<uint8_t>(sc.uep_index & 0x3f));
+    } else {
+      e.push_back(static_cast<uint8_t>(0x80 | ((sc.protlev >> 2) << 4) | ((sc.protlev & 3) << 2) | ((sc.size_cu >> 8) & 3)));
+      e.push_back(static_cast<uint8_t>(sc.size_cu & 0xff));
+    }
+    entries.push_back(e);
+  }
+  size_t next = 0;
+  for (int f = 0; f < 3; ++f) {
+    uint8_t* fib = out96 + 32 * f;
+    std::memset(fib, 0, 32);
+    int pos = 0;
+    if (f == 0) {
+      const uint8_t fig00[6] = {0x05, 0x00, static_cast<uint8_t>(cfg.eid >> 8), static_cast<uint8_t>(cfg.eid & 0xff),
+                                static_cast<uint8_t>(count / 250), static_cast<uint8_t>(count % 250)};
+      std::memcpy(fib, fig00, 6);
+      pos = 6;
+    }
+    if (next < entries.size() && pos + 2 + static_cast<int>(entries[next].size()) <= 30) {
+      const int hdr = pos;
+      pos += 2;
+      int len = 1;
+      while (next < entries.size() && pos + static_cast<int>(entries[next].size()) <= 30 && len + entries[next].size() <= 31) {
+        std::memcpy(fib + pos, entries[next].data(), entries[next].size());
+        pos += static_cast<int>(entries[next].size());
+        len += static_cast<int>(entries[next].size());
+        ++next;
+      }
+      fib[hdr] = static_cast<uint8_t>(len);   // FIG type 0, length
+      fib[hdr + 1] = 0x01;                    // C/N=0 OE=0 P/D=0 extension 1
+    }
+    if (pos < 30) fib[pos] = 0xff;            // end marker, rest zero padding
+    const uint16_t crc = static_cast<uint16_t>(~crc16_ccitt(fib, 30));
+    fib[30] = static_cast<uint8_t>(crc >> 8);
+    fib[31] = static_cast<uint8_t>(crc & 0xff);
+  }
+}
+
+// keep the mother-code bits the puncturing plan transmits
+void puncture(const std::vector<uint8_t>& mother, const PuncturePlan& plan, std::vector<uint8_t>& out)
+{
+  size_t x = 0;
+  for (int s = 0; s < 4; ++s) {
+    const uint32_t m = puncture_mask(plan.pi[s]);
+    for (int i = 0; i < 128 * plan.blocks[s]; ++i, ++x)
+      if ((m >> (i & 31)) & 1u) out.push_back(mother[x]);
+  }
+  const uint32_t mt = puncture_mask(8);
+  for (int i = 0; i < 24; ++i, ++x)
+    if ((mt >> i) & 1u) out.push_back(mother[x]);
+}
+
+// logical (pre time-interleaving) CIF r: 55296 bits
+void logical_cif(const dabhip_synth_cfg& cfg, int r, uint8_t* bits)
+{
+  for (int i = 0; i < kCifBits; i += 64) {
+    const uint64_t v = key(cfg.seed, kDomFiller, static_cast<uint64_t>(static_cast<uint32_t>(r)), static_cast<uint64_t>(i));
+    for (int b = 0; b < 64; ++b) bits[i + b] = static_cast<uint8_t>((v >> b) & 1u);
+  }
+  if (r < 0) return;   // before the start of the transmission: filler only
+  std::vector<uint8_t> data, coded;
+  for (int k = 0; k < cfg.nsub; ++k) {
+    const SubChannel sc = to_subchannel(cfg.sub[k]);
+    const int nbytes = sc.bitrate * 3;
+    data.resize(static_cast<size_t>(nbytes));
+    payload_bytes(cfg, r, k, data.data(), nbytes);
+    energy_dispersal(data.data(), data.size());
+    const std::vector<uint8_t> mother = conv_encode(data.data(), nbytes * 8);
+    coded.clear();
+    puncture(mother, puncture_plan(sc), coded);
+    std::memcpy(bits + sc.start_cu * 64, coded.data(), coded.size());
+  }
+}
+
+void fic_bits_of_cif(const dabhip_synth_cfg& cfg, int cif, uint8_t* bits2304)
+{
+  uint8_t fibs[96];
+  build_fibs(cfg, cif, fibs);
+  energy_dispersal(fibs, 96);
+  const std::vector<uint8_t> mother = conv_encode(fibs, 768);
+  std::vector<uint8_t> coded;
+  puncture(mother, fic_plan(), coded);
+  std::memcpy(bits2304, coded.data(), 2304);
+}
+
+// in-place radix-2 complex DFT, sign = +1 for the synthesis direction
+void fft2048(double* re, double* im, int sign)
+{
+  static std::vector<double> wr, wi;
+  const int n = 2048;
+  if (wr.empty()) {
+    wr.resize(n / 2);
+    wi.resize(n / 2);
+    for (int k = 0; k < n / 2; ++k) { wr[k] = std::cos(2 * M_PI * k / n); wi[k] = std::sin(2 * M_PI * k / n); }
+  }
+  for (int i = 1, j = 0; i < n; ++i) {
+    int bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+  }
+  for (int len = 2; len <= n; len <<= 1) {
+    const int step = n / len;
+    for (int i = 0; i < n; i += len)
+      for (int k = 0; k < len / 2; ++k) {
+        const double cr = wr[k * step], ci = sign * wi[k * step];
+        const int a = i + k, b = a + len / 2;
+        const double tr = re[b] * cr - im[b] * ci, ti = re[b] * ci + im[b] * cr;
+        re[b] = re[a] - tr; im[b] = im[a] - ti;
+        re[a] += tr; im[a] += ti;
+      }
+  }
+}
+
+struct Gauss {
+  uint64_t seed, ctr = 0;
+  bool have = false;
+  double spare = 0;
+  double next()
+  {
+    if (have) { have = false; return spare; }
+    const uint64_t a = key(seed, kDomNoise, ctr, 0), b = key(seed, kDomNoise, ctr, 1);
+    ++ctr;
+    const double u1 = (static_cast<double>(a >> 11) + 1.0) / 9007199254740993.0;
+    const double u2 = static_cast<double>(b >> 11) / 9007199254740992.0;
+    const double r = std::sqrt(-2.0 * std::log(u1));
+    spare = r * std::sin(2 * M_PI * u2);
+    have = true;
+    return r * std::cos(2 * M_PI * u2);
+  }
+};
+
+}  // namespace
+}  // namespace dabhip
+
+using namespace dabhip;
+
+extern "C" int dabhip_synth_preset(int preset, dabhip_synth_cfg* cfg)
+{
+  if (!cfg) return -1;
+  std::memset(cfg, 0, sizeof *cfg);
+  cfg->eid = 0xC181;
+  cfg->seed = 1;
+  cfg->amplitude = 1.0;
+  cfg->snr_db = 1000.0;
+  auto uep = [&](int id, int cu, int idx) { cfg->sub[cfg->nsub++] = dabhip_subch_cfg{id, cu, 0, idx, 0, 0}; };
+  auto eep = [&](int id, int cu, int lev, int size) { cfg->sub[cfg->nsub++] = dabhip_subch_cfg{id, cu, 1, 0, lev, size}; };
+  if (preset == 0) {          // 12 sub-channels, 1136 kbit/s, 862 of 864 CU
+    uep(1, 0, 35); uep(2, 96, 35); uep(3, 192, 35); uep(4, 288, 35);   // 128 kbit/s PL3
+    uep(5, 384, 45); uep(6, 524, 45);                                  // 192 kbit/s PL3
+    eep(7, 664, 2, 48); eep(8, 712, 2, 48);                            // 64 kbit/s 3-A
+    eep(9, 760, 0, 48);                                                // 32 kbit/s 1-A
+    eep(10, 808, 5, 42);                                               // 64 kbit/s 2-B
+    eep(11, 850, 1, 8);                                                // 8 kbit/s 2-A (special case)
+    eep(12, 858, 3, 4);                                                // 8 kbit/s 4-A
+  } else if (preset == 1) {   // 4 light sub-channels
+    uep(1, 0, 35); eep(2, 100, 2, 48); eep(5, 200, 5, 21); eep(9, 300, 1, 8);
+  } else {
+    set_error("synth: unknown preset");
+    return -1;
+  }
+  return 0;
+}
+
+extern "C" size_t dabhip_synth_bytes(const dabhip_synth_cfg* cfg, int ntf)
+{
+  if (!cfg || ntf <= 0) return 0;
+  return (static_cast<size_t>(ntf) * kTfSamples - static_cast<size_t>(cfg->skip_samples)) * 2;
+}
+
+extern "C" int dabhip_synth_payload(const dabhip_synth_cfg* cfg, int cif_index, int slot, uint8_t* out, int cap)
+{
+  if (!cfg || slot < 0 || slot >= cfg->nsub) { set_error("synth_payload: bad slot"); return -1; }
+  const int n = to_subchannel(cfg->sub[slot]).bitrate * 3;
+  if (cap < n) { set_error("synth_payload: buffer too small"); return -1; }
+  payload_bytes(*cfg, cif_index, slot, out, n);
+  return n;
+}
+
+extern "C" int dabhip_synth_fibs(const dabhip_synth_cfg* cfg, int cif_index, uint8_t* out96)
+{
+  if (!cfg || !out96) return -1;
+  build_fibs(*cfg, cif_index, out96);
+  return 96;
+}
+
+extern "C" int64_t dabhip_synth_generate(const dabhip_synth_cfg* cfg, int ntf, uint8_t* iq, size_t cap)
+{
+  if (!cfg || !iq || ntf <= 0) { set_error("synth_generate: bad arguments"); return -1; }
+  if (!validate(*cfg)) return -1;
+  const size_t total = dabhip_synth_bytes(cfg, ntf);
+  if (cap < total) { set_error("synth_generate: buffer too small"); return -1; }
+
+  static const int tmap[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+  const auto& qpsk_of_carrier = carrier_to_qpsk();
+  const auto& prs = prs_quarter_turns();
+  const int ncif = ntf * 4;
+  // logical CIFs -15 .. ncif-1, kept in a sliding window of 16
+  std::vector<std::vector<uint8_t>> window(16, std::vector<uint8_t>(kCifBits));
+  for (int r = -15; r < 0; ++r) logical_cif(*cfg, r, window[(r + 16) & 15].data());
+
+  const double noise_rms_rail =
+      cfg->snr_db >= 100.0 ? 0.0 : cfg->amplitude * std::sqrt(static_cast<double>(kCarriers)) / std::pow(10.0, cfg->snr_db / 20.0) / std::sqrt(2.0);
+  Gauss gauss{cfg->seed};
+  std::vector<uint8_t> symbits(static_cast<size_t>(kBitsPerSym) * 75);   // data symbols 1..75 of one TF
+  std::vector<uint8_t> txcif(kCifBits);
+  std::vector<double> re(2048), im(2048);
+  std::vector<uint8_t> phase(kCarriers);                                  // in eighth turns
+  static const double c8[8] = {1, M_SQRT1_2, 0, -M_SQRT1_2, -1, -M_SQRT1_2, 0, M_SQRT1_2};
+  static const double s8[8] = {0, M_SQRT1_2, 1, M_SQRT1_2, 0, -M_SQRT1_2, -1, -M_SQRT1_2};
+  size_t outpos = 0;
+  long long sample_index = 0;
+  auto emit = [&](double xr, double xi) {
+    if (sample_index++ < cfg->skip_samples) return;
+    if (noise_rms_rail > 0) { xr += noise_rms_rail * gauss.next(); xi += noise_rms_rail * gauss.next(); }
+    double a = std::floor(127.0 + xr + 0.5), b = std::floor(127.0 + xi + 0.5);
+    a = a < 1 ? 1 : (a > 254 ? 254 : a);
+    b = b < 1 ? 1 : (b > 254 ? 254 : b);
+    iq[outpos++] = static_cast<uint8_t>(a);
+    iq[outpos++] = static_cast<uint8_t>(b);
+  };
+
+  for (int tf = 0; tf < ntf; ++tf) {
+    for (int q = 0; q < 4; ++q) {
+      const int c = 4 * tf + q;
+      fic_bits_of_cif(*cfg, c, symbits.data() + 2304 * q);
+      logical_cif(*cfg, c, window[c & 15].data());
+      // time interleaving: inverse of misc.c:29-39 (tx CIF c carries logical CIF c - map[i&15])
+      for (int i = 0; i < kCifBits; ++i) txcif[i] = window[(c - tmap[i & 15]) & 15][i];
+      std::memcpy(symbits.data() + 3 * kBitsPerSym + static_cast<size_t>(q) * kCifBits, txcif.data(), kCifBits);
+    }
+    for (int n = 0; n < kNullSamples; ++n) emit(0, 0);
+    for (int l = 0; l < kSymbolsPerTf; ++l) {
+      if (l == 0) {
+        for (int k = 0; k < kCarriers; ++k) phase[k] = static_cast<uint8_t>(2 * prs[k]);
+      } else {
+        const uint8_t* p = symbits.data() + static_cast<size_t>(l - 1) * kBitsPerSym;
+        for (int k = 0; k < kCarriers; ++k) {
+          const int n = qpsk_of_carrier[k];
+          static const uint8_t inc[4] = {1, 3, 7, 5};   // (b0,b1): 00->45deg 10->135 01->315 11->225
+          phase[k] = static_cast<uint8_t>((phase[k] + inc[p[n] | (p[1536 + n] << 1)]) & 7);
+        }
+      }
+      std::fill(re.begin(), re.end(), 0.0);
+      std::fill(im.begin(), im.end(), 0.0);
+      for (int k = 0; k < kCarriers; ++k) {
+        const int bin = k < 768 ? 1280 + k : k - 767;
+        re[bin] = cfg->amplitude * c8[phase[k]];
+        im[bin] = cfg->amplitude * s8[phase[k]];
+      }
+      fft2048(re.data(), im.data(), +1);
+      for (int n = 2048 - kCpSamples; n < 2048; ++n) emit(re[n], im[n]);
+      for (int n = 0; n < 2048; ++n) emit(re[n], im[n]);
+    }
+  }
+  return static_cast<int64_t>(outpos);
+}

@@ -1,0 +1,167 @@
+/*
+ * dabhip.h — C ABI of libdabhip.so, the MI355X-native DSP back end for dab2eti.
+ *
+ * Plain C, caller-owned buffers, int error codes (0 = ok, <0 = error, see
+ * dabhip_last_error()).  No C++ or torch types cross this boundary.
+ *
+ * The reference (linuxstb/dabtools) has no plugin system; its seams are C function
+ * signatures chosen at link time.  Each entry point below names the reference interface
+ * (file:line under src/) it replaces.  INTEGRATION.md shows the reference-side binding.
+ *
+ *   S1  decoder seam      viterbi.h:6-8, viterbi_spiral.h:22-23   -> dabhip_*viterbi*
+ *   S2  front-end seam    input_sdr.h:43-44                        -> dabhip_sdr_*
+ *   S3  back-end seam     dab.h:91-92 (+ eti_callback dab.h:88)    -> dabhip_dab_*
+ *   batch engine (new: B independent ensembles resident in HBM)    -> dabhip_engine_*
+ *   stage entries for parity tests                                 -> dabhip_stage_*
+ *   synthetic Mode-I modulator (host only, workload generator)     -> dabhip_synth_*
+ */
+#ifndef DABHIP_H
+#define DABHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DABHIP_TF_BYTES 393216        /* one transmission frame of cu8 IQ (input_sdr.h:16) */
+#define DABHIP_CHUNK_BYTES 262144     /* DEFAULT_BUF_LENGTH, input_sdr.h:9 */
+#define DABHIP_FIC_BITS 9216          /* fic_symbols_demapped[3][3072], dab.h:29 */
+#define DABHIP_MSC_BITS 221184        /* msc_symbols_demapped[72][3072], dab.h:32 */
+#define DABHIP_ETI_BYTES 6144         /* dab2eti.c:132-135 */
+
+/* ---- library ------------------------------------------------------------------------ */
+const char *dabhip_last_error(void);          /* thread-local text of the last failure */
+int dabhip_device_count(void);                /* number of visible HIP devices (0 without a GPU) */
+
+/* ---- S1: decoder seam ---------------------------------------------------------------- */
+/* Replaces init_viterbi() (viterbi.h:6, viterbi.c:455) / create_viterbi(len)
+ * (viterbi_spiral.h:22).  Returns an opaque handle (never NULL on success). */
+void *dabhip_create_viterbi(int len);
+int dabhip_init_viterbi(void);
+/* Replaces viterbi(p, symbols, data, framebits) (viterbi.h:8, viterbi.c:352-451; called
+ * from fic.c:186 and misc.c:262).  symbols: 4*(framebits+6) bytes, 127/129 hard values,
+ * 128 = erasure (depuncture.c:36-43).  data: (framebits+7)/8 bytes, MSB first.  Decisions
+ * are those of the scalar reference decoder (metrics 3/-7/0, ties keep the low
+ * predecessor).  p may be NULL (uses a process-wide engine on device 0). */
+void dabhip_viterbi(void *p, unsigned char *symbols, unsigned char *data, int framebits);
+/* Batch form: n code words of equal length, symbols packed back to back. */
+int dabhip_viterbi_batch(void *p, const unsigned char *symbols, unsigned char *data, int framebits, int n);
+
+/* ---- S2: front-end seam --------------------------------------------------------------- */
+typedef struct dabhip_sdr dabhip_sdr;
+/* Replaces sdr_init(struct sdr_state_t*) (input_sdr.h:44, input_sdr.c:167-186). */
+dabhip_sdr *dabhip_sdr_init(int device);
+void dabhip_sdr_free(dabhip_sdr *s);
+/* Replaces sdr_demod(tf, sdr) (input_sdr.h:43, input_sdr.c:27-165).  input_buffer /
+ * input_buffer_len are what rtlsdr_callback stores in sdr->input_buffer (dab2eti.c:125-126).
+ * On return 1 the two arrays hold tf->fic_symbols_demapped (9216 bytes of 0/1) and
+ * tf->msc_symbols_demapped (221184 bytes of 0/1); on return 0 they are untouched.
+ * <0 = error. */
+int dabhip_sdr_demod(dabhip_sdr *s, const uint8_t *input_buffer, int input_buffer_len,
+                     uint8_t *fic_symbols_demapped, uint8_t *msc_symbols_demapped);
+/* The side-channel outputs dab2eti.c:76-103 reads after each call. */
+int32_t dabhip_sdr_coarse_timeshift(const dabhip_sdr *s);
+int32_t dabhip_sdr_fine_timeshift(const dabhip_sdr *s);
+int32_t dabhip_sdr_coarse_freq_shift(const dabhip_sdr *s);
+double dabhip_sdr_fine_freq_shift(const dabhip_sdr *s);
+
+/* ---- S3: back-end seam ---------------------------------------------------------------- */
+typedef struct dabhip_dab dabhip_dab;
+typedef void (*dabhip_eti_callback)(uint8_t *eti);                    /* dab.h:88 */
+typedef void (*dabhip_eti_sink)(const uint8_t *eti, int stream, void *user);
+/* Replaces init_dab_state(&dab, device_state, eti_callback) (dab.h:91, dab.c:14-33). */
+dabhip_dab *dabhip_dab_init(int device, dabhip_eti_callback cb);
+void dabhip_dab_free(dabhip_dab *d);
+/* The caller fills these before each dabhip_dab_process_frame(), exactly as sdr_demod
+ * fills dab->tfs[dab->tfidx] (dab2eti.c:68). */
+uint8_t *dabhip_dab_tf_fic(dabhip_dab *d);   /* 9216 bytes */
+uint8_t *dabhip_dab_tf_msc(dabhip_dab *d);   /* 221184 bytes */
+/* Replaces dab_process_frame(dab) (dab.h:92, dab.c:35-98): invokes the callback 0 or 4
+ * times, synchronously, with a pointer to a 6144-byte frame valid during the call. */
+int dabhip_dab_process_frame(dabhip_dab *d);
+int dabhip_dab_locked(const dabhip_dab *d);
+/* FIBs (12 x 32 bytes) and CRC flags (12) of the TF processed last (struct tf_fibs_t, dab.h:21-25). */
+int dabhip_dab_last_fibs(const dabhip_dab *d, uint8_t *fibs, uint8_t *crc_ok);
+
+/* ---- batch engine ---------------------------------------------------------------------- */
+typedef struct dabhip_engine dabhip_engine;
+dabhip_engine *dabhip_engine_create(int device);
+void dabhip_engine_destroy(dabhip_engine *e);
+
+/* Decode B independent cu8 streams (the replay loop of dab2eti.c:60-130 per stream, in
+ * 262144-byte chunks, trailing partial chunk dropped).  iq[b] are DEVICE pointers when
+ * on_device != 0, host pointers otherwise.  ETI frames stay in device memory; query
+ * them with the calls below.  Returns total ETI frames produced, <0 on error. */
+int64_t dabhip_engine_decode(dabhip_engine *e, const uint8_t *const *iq, const size_t *nbytes, int nstreams,
+                             int on_device);
+int64_t dabhip_engine_eti_count(const dabhip_engine *e, int stream);      /* frames of one stream */
+/* Copy the ETI frames of one stream (in emission order) to host memory. */
+int64_t dabhip_engine_eti_read(dabhip_engine *e, int stream, uint8_t *dst, int64_t cap_frames);
+/* Deliver all frames, stream by stream in emission order, to a sink (stdout contract helper). */
+int64_t dabhip_engine_eti_drain(dabhip_engine *e, dabhip_eti_sink sink, void *user);
+const void *dabhip_engine_eti_device_ptr(const dabhip_engine *e, int64_t *nframes); /* all frames, stream-major */
+
+/* Per sdr_demod call trace of one stream, for parity with the reference's state after each
+ * call: {ok, frame_read, coarse_timeshift, fine_timeshift, coarse_freq_shift, fifo_count}
+ * as int32[6] per call plus fine_freq_shift as double per call. */
+int dabhip_engine_trace(const dabhip_engine *e, int stream, int32_t *ints6, double *ffs, int cap_calls);
+
+/* Timing of the stages of the last decode (milliseconds, HIP events on the engine's stream).
+ * names: "sync", "fft", "demap", "fic", "control", "gather", "viterbi", "eti".  Returns
+ * number of entries written. */
+int dabhip_engine_stage_ms(const dabhip_engine *e, const char **names, float *ms, int cap);
+/* Per-launch statistics of the OFDM FFT kernel in the last decode: number of launches,
+ * transmission frames transformed, total kernel milliseconds (HIP events). */
+int dabhip_engine_fft_stats(const dabhip_engine *e, int64_t *launches, int64_t *tfs, double *ms);
+
+/* ---- stage entries (parity tests) ------------------------------------------------------ */
+/* OFDM FFT stage alone (replaces input_sdr.c:115-130): nframes contiguous cu8 frames of
+ * 393216 bytes each (device pointers when on_device) -> fftshifted complex64 spectra
+ * [nframes][76][2048][2].  `reps` > 1 repeats the launch for timing; kernel_ms (optional)
+ * receives the mean duration of one launch from HIP events. */
+int dabhip_stage_ofdm_fft(dabhip_engine *e, const uint8_t *frames, int nframes, float *spectra, int on_device,
+                          int reps, float *kernel_ms);
+/* DQPSK + demap + frequency de-interleave (input_sdr.c:132-162): spectra of nframes ->
+ * fic bytes [nframes][9216] and msc bytes [nframes][221184] (host pointers). */
+int dabhip_stage_demap(dabhip_engine *e, const float *spectra, int nframes, uint8_t *fic, uint8_t *msc);
+/* FIC decode of nframes TFs (fic.c:160-208): 9216 demapped bytes each -> 12x32 FIB bytes + 12 flags each. */
+int dabhip_stage_fic_decode(dabhip_engine *e, const uint8_t *fic, int nframes, uint8_t *fibs, uint8_t *crc_ok);
+
+/* ---- synthetic Mode-I modulator (host only) --------------------------------------------- */
+typedef struct dabhip_subch_cfg {
+  int32_t id;          /* SubChId 0..63 */
+  int32_t start_cu;    /* 0..863 */
+  int32_t slform;      /* 0 = UEP (uep_index), 1 = EEP (eep_protlev, size_cu) */
+  int32_t uep_index;   /* 0..63, ETSI Table 7 */
+  int32_t eep_protlev; /* option<<2 | level: 0..3 = 1-A..4-A, 4..7 = 1-B..4-B */
+  int32_t size_cu;     /* EEP only */
+} dabhip_subch_cfg;
+
+typedef struct dabhip_synth_cfg {
+  uint32_t eid;
+  int32_t nsub;
+  dabhip_subch_cfg sub[64];
+  uint64_t seed;          /* payload / filler / noise seed */
+  int32_t cif_count0;     /* CIF counter of the first CIF, 0..4999 */
+  int32_t skip_samples;   /* drop this many samples from the start (0..196607): unaligned capture */
+  double amplitude;       /* LSB per unit carrier of the unnormalised IDFT (1.0 -> ~28 LSB rms per rail) */
+  double snr_db;          /* signal/noise power over the 2.048 MHz band; >= 100 -> no noise */
+} dabhip_synth_cfg;
+
+/* preset 0: 12 sub-channels, 1136 kbit/s, 862 CU (the benchmark mix); 1: 4 light sub-channels. */
+int dabhip_synth_preset(int preset, dabhip_synth_cfg *cfg);
+size_t dabhip_synth_bytes(const dabhip_synth_cfg *cfg, int ntf);
+/* Generate ntf transmission frames of cu8 IQ into iq (capacity cap bytes). Returns bytes written or <0. */
+int64_t dabhip_synth_generate(const dabhip_synth_cfg *cfg, int ntf, uint8_t *iq, size_t cap);
+/* The payload (before energy dispersal) carried by sub-channel slot k in logical CIF n:
+ * bitrate*3 bytes.  Returns the byte count, <0 on error. */
+int dabhip_synth_payload(const dabhip_synth_cfg *cfg, int cif_index, int slot, uint8_t *out, int cap);
+/* The 96 FIB bytes (3 FIBs with CRC) carried by CIF n. */
+int dabhip_synth_fibs(const dabhip_synth_cfg *cfg, int cif_index, uint8_t *out96);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,116 @@
+/*
+ * dab_oracle.h — CPU restatement of the dab2eti IQ->ETI hot path (plain C).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the shipped
+ * product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load liboracle.so, and there only as the checker / reported
+ * baseline, never as the thing measured or shipped.
+ *
+ * Every function cites the reference file:line (relative to
+ * /root/reference/src) whose behaviour it restates.
+ *
+ * Pinning status:
+ *   back end (depuncture, viterbi, descramble, CRC, FIC decode, FIB parse,
+ *   lock FSM, CIF ring, time de-interleave, ETI assembly): PINNED against the
+ *   real reference objects built from /root/reference/src into
+ *   oracle/_ref/libdabref.so (tests/test_oracle_vs_ref.py, tests/golden/).
+ *   front end (sdr_demod, sdr_sync): PARITY UNPINNED.  input_sdr.c and
+ *   sdr_sync.c need <fftw3.h> (libfftw3, version unpinned in the reference's
+ *   Makefile:3), which this image lacks, so they cannot be built here.  The
+ *   restatement follows the reference line by line with its own
+ *   double-precision DFT and is anchored indirectly: synthetic IQ ->
+ *   front-end restatement -> REAL reference back end yields byte-correct ETI
+ *   carrying the modulated payload.  sdr_fifo.c (the timing actuator) does
+ *   build and pins or_fifo_*.
+ */
+#ifndef DAB_ORACLE_H
+#define DAB_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OR_TF_SAMPLES 196608
+#define OR_TF_BYTES (OR_TF_SAMPLES * 2)
+#define OR_CHUNK_BYTES 262144
+#define OR_FIC_BITS (3 * 3072)
+#define OR_MSC_BITS (72 * 3072)
+#define OR_CIF_BITS (18 * 3072)
+#define OR_ETI_BYTES 6144
+
+/* ---- tables (dab_tables.c, sdr_prstab.c) ------------------------------- */
+struct or_uep_profile { int bitrate, size_cu, protlevel, l[4], pi[4]; }; /* pi: 1..24, 0 = unused */
+const struct or_uep_profile *or_uep_table(void);          /* 64 rows, dab_tables.c:16-81 */
+const uint32_t *or_puncture_masks(void);                   /* 24 masks, bit i = pvec[PI-1][i], dab_tables.c:102-127 */
+const uint16_t *or_rev_freq_deint_tab(void);               /* 1536, dab_tables.c:164-357 */
+const int8_t *or_prs_phase(void);                          /* 1536 values 0..3 = 1,j,-1,-j; sdr_prstab.c:1 */
+
+/* a sub-channel's depuncture plan: segments of (blocks of 128 mother bits, PI) */
+struct or_subch {
+  int id, slform, uep_index, start_cu, size, bitrate, protlev, ascty;
+};
+struct or_punct_plan { int nseg; int blocks[4]; int pi[4]; };
+void or_subch_plan(const struct or_subch *sc, struct or_punct_plan *plan); /* depuncture.c:84-132 */
+
+/* ---- back end ----------------------------------------------------------- */
+void or_encode(uint8_t *symbols, const uint8_t *data, unsigned nbytes);            /* viterbi.c:322-347 (start/end state 0) */
+void or_viterbi(const uint8_t *symbols, uint8_t *data, int nbits);                 /* viterbi.c:352-451 */
+void or_viterbi_mettab(int tab[2][256]);                                           /* viterbi.c:126-191,455-462 */
+void or_fic_depuncture(uint8_t *out, const uint8_t *in);                           /* depuncture.c:45-82 */
+int  or_msc_depuncture(uint8_t *out, const uint8_t *in, const struct or_subch *sc);/* depuncture.c:84-132; returns len */
+void or_descramble(uint8_t *buf, int nbytes);                                      /* misc.c:41-58 */
+uint16_t or_crc16_ccitt(const uint8_t *data, int len, uint16_t crc);               /* misc.c:131-143 with crctab_1021 */
+int  or_check_fib_crc(const uint8_t *fib);                                         /* misc.c:145-150 */
+void or_time_deinterleave(uint8_t *dst, const uint8_t *const cifs[16]);            /* misc.c:29-39 */
+
+struct or_ens_info { uint16_t eid; uint8_t cif_hi, cif_lo; struct or_subch sub[64]; };
+void or_fib_decode(struct or_ens_info *info, const uint8_t fib[12][32], const uint8_t crc_ok[12]); /* fic.c:47-147 */
+int  or_init_eti(uint8_t *eti, const struct or_ens_info *info);                    /* misc.c:153-213 */
+
+/* FIC decode of one TF: 9216 demapped bits -> 12 FIBs + CRC flags; returns ok_count (fic.c:160-208) */
+int  or_fic_decode(const uint8_t *fic_bits, uint8_t fib[12][32], uint8_t crc_ok[12]);
+
+typedef void (*or_eti_cb)(const uint8_t *eti, void *user);
+struct or_dab;                                                                     /* dab.h:70-89 */
+struct or_dab *or_dab_new(or_eti_cb cb, void *user);                               /* dab.c:14-33 */
+void or_dab_free(struct or_dab *d);
+uint8_t *or_dab_tf_fic(struct or_dab *d);  /* current tfs[tfidx].fic_symbols_demapped, 9216 B */
+uint8_t *or_dab_tf_msc(struct or_dab *d);  /* current tfs[tfidx].msc_symbols_demapped, 221184 B */
+void or_dab_process_frame(struct or_dab *d);                                       /* dab.c:35-98 */
+int  or_dab_locked(const struct or_dab *d);
+const uint8_t *or_dab_last_fibs(const struct or_dab *d, uint8_t crc_ok[12]);
+
+/* ---- front end ----------------------------------------------------------- */
+/* double-precision DFT used by the front-end restatement: out[k] = sum in[j] exp(sign*2*pi*i*jk/n) */
+void or_dft(int n, const double *in, double *out, int sign);
+
+uint32_t or_coarse_time_sync(const int8_t *real, int force);                       /* sdr_sync.c:34-68 */
+int32_t  or_fine_time_sync(const double *frame /* [196608][2] */);                 /* sdr_sync.c:71-202 */
+int32_t  or_coarse_freq_sync(const double *shifted_sym /* [2048][2] */);           /* sdr_sync.c:205-258 */
+double   or_fine_freq_corr(const double *frame);                                   /* sdr_sync.c:259-302 */
+
+struct or_sdr;                                                                     /* input_sdr.h:12-41 */
+struct or_sdr *or_sdr_new(void);                                                   /* input_sdr.c:167-186 */
+void or_sdr_free(struct or_sdr *s);
+/* one call of sdr_demod (input_sdr.c:27-165): returns 1 and fills fic/msc when a TF was produced */
+int  or_sdr_demod(struct or_sdr *s, const uint8_t *chunk, int len, uint8_t *fic_bits, uint8_t *msc_bits);
+struct or_sdr_trace {
+  int32_t ok, read_frame, coarse_timeshift, fine_timeshift, coarse_freq_shift, fifo_count;
+  double fine_freq_shift;
+};
+void or_sdr_get_trace(const struct or_sdr *s, struct or_sdr_trace *t);
+const double *or_sdr_symbols(const struct or_sdr *s); /* [76][2048][2] fftshifted spectra of the last TF */
+const uint8_t *or_sdr_buffer(const struct or_sdr *s); /* the 393216-byte frame buffer after the last read */
+
+/* whole replay (dab2eti.c:60-130 minus USB and tuner): cu8 stream in 262144-byte chunks -> ETI frames.
+ * returns number of ETI frames written (each 6144 B) into eti_out (capacity in frames). */
+int or_replay(const uint8_t *iq, size_t nbytes, uint8_t *eti_out, int cap_frames,
+              struct or_sdr_trace *trace, int trace_cap, int *ntrace);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
