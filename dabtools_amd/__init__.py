@@ -1,0 +1,336 @@
+"""dabtools_amd — Python host side over libdabhip.so (the C ABI of include/dabhip.h).
+
+The product is the shared library; this module is plumbing: it loads the library, declares
+the C signatures and offers thin numpy-facing wrappers whose names follow the reference
+(`sdr_demod`, `dab_process_frame`, `viterbi`, ...).  There is NO CPU fallback: if the
+library is missing, or no MI355X is visible when a decode entry point is used, the call
+raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdabhip.so")
+
+TF_BYTES = 393216
+CHUNK_BYTES = 262144
+FIC_BITS = 9216
+MSC_BITS = 221184
+ETI_BYTES = 6144
+
+u8p = C.POINTER(C.c_uint8)
+
+
+class DabhipError(RuntimeError):
+    pass
+
+
+class SubChCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("id", "start_cu", "slform", "uep_index", "eep_protlev", "size_cu")]
+
+
+class SynthCfg(C.Structure):
+    _fields_ = [("eid", C.c_uint32), ("nsub", C.c_int32), ("sub", SubChCfg * 64), ("seed", C.c_uint64),
+                ("cif_count0", C.c_int32), ("skip_samples", C.c_int32), ("amplitude", C.c_double),
+                ("snr_db", C.c_double)]
+
+
+ETI_CALLBACK = C.CFUNCTYPE(None, u8p)
+
+_SIGNATURES = {
+    "dabhip_last_error": (C.c_char_p, []),
+    "dabhip_device_count": (C.c_int, []),
+    "dabhip_create_viterbi": (C.c_void_p, [C.c_int]),
+    "dabhip_init_viterbi": (C.c_int, []),
+    "dabhip_viterbi": (None, [C.c_void_p, u8p, u8p, C.c_int]),
+    "dabhip_viterbi_batch": (C.c_int, [C.c_void_p, u8p, u8p, C.c_int, C.c_int]),
+    "dabhip_sdr_init": (C.c_void_p, [C.c_int]),
+    "dabhip_sdr_free": (None, [C.c_void_p]),
+    "dabhip_sdr_demod": (C.c_int, [C.c_void_p, u8p, C.c_int, u8p, u8p]),
+    "dabhip_sdr_coarse_timeshift": (C.c_int32, [C.c_void_p]),
+    "dabhip_sdr_fine_timeshift": (C.c_int32, [C.c_void_p]),
+    "dabhip_sdr_coarse_freq_shift": (C.c_int32, [C.c_void_p]),
+    "dabhip_sdr_fine_freq_shift": (C.c_double, [C.c_void_p]),
+    "dabhip_dab_init": (C.c_void_p, [C.c_int, ETI_CALLBACK]),
+    "dabhip_dab_free": (None, [C.c_void_p]),
+    "dabhip_dab_tf_fic": (u8p, [C.c_void_p]),
+    "dabhip_dab_tf_msc": (u8p, [C.c_void_p]),
+    "dabhip_dab_process_frame": (C.c_int, [C.c_void_p]),
+    "dabhip_dab_locked": (C.c_int, [C.c_void_p]),
+    "dabhip_dab_last_fibs": (C.c_int, [C.c_void_p, u8p, u8p]),
+    "dabhip_engine_create": (C.c_void_p, [C.c_int]),
+    "dabhip_engine_destroy": (None, [C.c_void_p]),
+    "dabhip_engine_decode": (C.c_int64, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int]),
+    "dabhip_engine_eti_count": (C.c_int64, [C.c_void_p, C.c_int]),
+    "dabhip_engine_eti_read": (C.c_int64, [C.c_void_p, C.c_int, u8p, C.c_int64]),
+    "dabhip_engine_eti_drain": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dabhip_engine_eti_device_ptr": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "dabhip_engine_trace": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int]),
+    "dabhip_engine_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
+    "dabhip_engine_fft_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "dabhip_stage_ofdm_fft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "dabhip_stage_demap": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, u8p, u8p]),
+    "dabhip_stage_fic_decode": (C.c_int, [C.c_void_p, u8p, C.c_int, u8p, u8p]),
+    "dabhip_synth_preset": (C.c_int, [C.c_int, C.POINTER(SynthCfg)]),
+    "dabhip_synth_bytes": (C.c_size_t, [C.POINTER(SynthCfg), C.c_int]),
+    "dabhip_synth_generate": (C.c_int64, [C.POINTER(SynthCfg), C.c_int, u8p, C.c_size_t]),
+    "dabhip_synth_payload": (C.c_int, [C.POINTER(SynthCfg), C.c_int, C.c_int, u8p, C.c_int]),
+    "dabhip_synth_fibs": (C.c_int, [C.POINTER(SynthCfg), C.c_int, u8p]),
+}
+
+_lib = None
+
+
+def build_library(force=False):
+    """Compile dabtools_amd/csrc into dabtools_amd/libdabhip.so (hipcc, gfx950)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", csrc, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", csrc, "-j8"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded libdabhip.so.  Raises if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DabhipError("libdabhip.so is missing (%s): run __graft_entry__.build() / make -C dabtools_amd/csrc" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            f = getattr(L, name)   # AttributeError here = header/library mismatch
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def last_error():
+    return (lib().dabhip_last_error() or b"").decode()
+
+
+def _p(a):
+    return a.ctypes.data_as(u8p)
+
+
+def _need(cond, what):
+    if not cond:
+        raise DabhipError("%s: %s" % (what, last_error()))
+
+
+# ---- synthetic modulator --------------------------------------------------------------------
+def synth_preset(preset=0, seed=1, cif_count0=0, skip_samples=0, snr_db=1000.0, amplitude=1.0):
+    cfg = SynthCfg()
+    _need(lib().dabhip_synth_preset(preset, C.byref(cfg)) == 0, "synth_preset")
+    cfg.seed = seed
+    cfg.cif_count0 = cif_count0
+    cfg.skip_samples = skip_samples
+    cfg.snr_db = snr_db
+    cfg.amplitude = amplitude
+    return cfg
+
+
+def synth_generate(cfg, ntf):
+    n = lib().dabhip_synth_bytes(C.byref(cfg), ntf)
+    iq = np.empty(n, dtype=np.uint8)
+    got = lib().dabhip_synth_generate(C.byref(cfg), ntf, _p(iq), n)
+    _need(got == n, "synth_generate")
+    return iq
+
+
+def synth_payload(cfg, cif_index, slot):
+    buf = np.zeros(1152 * 2, dtype=np.uint8)
+    n = lib().dabhip_synth_payload(C.byref(cfg), cif_index, slot, _p(buf), buf.size)
+    _need(n >= 0, "synth_payload")
+    return buf[:n].copy()
+
+
+def synth_fibs(cfg, cif_index):
+    buf = np.zeros(96, dtype=np.uint8)
+    _need(lib().dabhip_synth_fibs(C.byref(cfg), cif_index, _p(buf)) == 96, "synth_fibs")
+    return buf
+
+
+# ---- S1 -----------------------------------------------------------------------------------------
+def viterbi(symbols, framebits, n=1):
+    """Batch form of the reference's viterbi(p, symbols, data, framebits) (viterbi.h:8)."""
+    sym = np.ascontiguousarray(symbols, dtype=np.uint8)
+    assert sym.size == n * 4 * (framebits + 6)
+    out = np.zeros((n, framebits // 8), dtype=np.uint8)
+    r = lib().dabhip_viterbi_batch(None, _p(sym), _p(out), framebits, n)
+    _need(r == n, "viterbi")
+    return out
+
+
+# ---- S2 -----------------------------------------------------------------------------------------
+class Sdr:
+    """sdr_init + sdr_demod (input_sdr.h:43-44) for one stream."""
+
+    def __init__(self, device=0):
+        self._h = lib().dabhip_sdr_init(device)
+        _need(self._h, "sdr_init")
+        self.fic = np.zeros(FIC_BITS, dtype=np.uint8)
+        self.msc = np.zeros(MSC_BITS, dtype=np.uint8)
+
+    def demod(self, chunk):
+        chunk = np.ascontiguousarray(chunk, dtype=np.uint8)
+        r = lib().dabhip_sdr_demod(self._h, _p(chunk), chunk.size, _p(self.fic), _p(self.msc))
+        _need(r >= 0, "sdr_demod")
+        return r
+
+    @property
+    def state(self):
+        L = lib()
+        return (L.dabhip_sdr_coarse_timeshift(self._h), L.dabhip_sdr_fine_timeshift(self._h),
+                L.dabhip_sdr_coarse_freq_shift(self._h), L.dabhip_sdr_fine_freq_shift(self._h))
+
+    def close(self):
+        if self._h:
+            lib().dabhip_sdr_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+# ---- S3 -----------------------------------------------------------------------------------------
+class Dab:
+    """init_dab_state + dab_process_frame (dab.h:91-92) for one stream."""
+
+    def __init__(self, device=0):
+        self.frames = []
+        self._cb = ETI_CALLBACK(lambda p: self.frames.append(np.ctypeslib.as_array(p, (ETI_BYTES,)).copy()))
+        self._h = lib().dabhip_dab_init(device, self._cb)
+        _need(self._h, "dab_init")
+        self.fic = np.ctypeslib.as_array(lib().dabhip_dab_tf_fic(self._h), (FIC_BITS,))
+        self.msc = np.ctypeslib.as_array(lib().dabhip_dab_tf_msc(self._h), (MSC_BITS,))
+
+    def process_frame(self):
+        r = lib().dabhip_dab_process_frame(self._h)
+        _need(r >= 0, "dab_process_frame")
+        return r
+
+    @property
+    def locked(self):
+        return bool(lib().dabhip_dab_locked(self._h))
+
+    def last_fibs(self):
+        fibs = np.zeros((12, 32), dtype=np.uint8)
+        ok = np.zeros(12, dtype=np.uint8)
+        lib().dabhip_dab_last_fibs(self._h, _p(fibs), _p(ok))
+        return fibs, ok
+
+    def close(self):
+        if self._h:
+            lib().dabhip_dab_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+# ---- batch engine -------------------------------------------------------------------------------
+class Engine:
+    def __init__(self, device=0):
+        self._h = lib().dabhip_engine_create(device)
+        _need(self._h, "engine_create")
+        self.nstreams = 0
+
+    def decode(self, streams):
+        """streams: list of numpy uint8 arrays (host) -> total ETI frames."""
+        arrs = [np.ascontiguousarray(s, dtype=np.uint8) for s in streams]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        sizes = (C.c_size_t * len(arrs))(*[a.size for a in arrs])
+        n = lib().dabhip_engine_decode(self._h, ptrs, sizes, len(arrs), 0)
+        _need(n >= 0, "engine_decode")
+        self.nstreams = len(arrs)
+        return n
+
+    def decode_device(self, ptrs, sizes):
+        """ptrs: device addresses (ints, e.g. torch tensor.data_ptr()), sizes: byte counts."""
+        p = (C.c_void_p * len(ptrs))(*ptrs)
+        s = (C.c_size_t * len(sizes))(*sizes)
+        n = lib().dabhip_engine_decode(self._h, p, s, len(ptrs), 1)
+        _need(n >= 0, "engine_decode")
+        self.nstreams = len(ptrs)
+        return n
+
+    def eti(self, stream):
+        n = lib().dabhip_engine_eti_count(self._h, stream)
+        _need(n >= 0, "eti_count")
+        out = np.zeros((n, ETI_BYTES), dtype=np.uint8)
+        if n:
+            _need(lib().dabhip_engine_eti_read(self._h, stream, _p(out), n) == n, "eti_read")
+        return out
+
+    def eti_count(self, stream):
+        return lib().dabhip_engine_eti_count(self._h, stream)
+
+    def eti_device_ptr(self):
+        n = C.c_int64(0)
+        p = lib().dabhip_engine_eti_device_ptr(self._h, C.byref(n))
+        return p, n.value
+
+    def trace(self, stream, ncalls):
+        ints = np.zeros((ncalls, 6), dtype=np.int32)
+        ffs = np.zeros(ncalls, dtype=np.float64)
+        n = lib().dabhip_engine_trace(self._h, stream, ints.ctypes.data_as(C.POINTER(C.c_int32)),
+                                      ffs.ctypes.data_as(C.POINTER(C.c_double)), ncalls)
+        _need(n >= 0, "engine_trace")
+        return ints[:n], ffs[:n]
+
+    def stage_ms(self):
+        names = (C.c_char_p * 8)()
+        ms = (C.c_float * 8)()
+        n = lib().dabhip_engine_stage_ms(self._h, names, ms, 8)
+        return {names[i].decode(): ms[i] for i in range(n)}
+
+    def fft_stats(self):
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_double(0)
+        lib().dabhip_engine_fft_stats(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def stage_ofdm_fft(self, frames, reps=1, device_ptr=None, nframes=None, want_output=True):
+        if device_ptr is None:
+            frames = np.ascontiguousarray(frames, dtype=np.uint8)
+            nframes = frames.size // TF_BYTES
+            src, on_dev = frames.ctypes.data, 0
+        else:
+            src, on_dev = device_ptr, 1
+        out = np.zeros((nframes, 76, 2048, 2), dtype=np.float32) if want_output else None
+        ms = C.c_float(0)
+        r = lib().dabhip_stage_ofdm_fft(self._h, src, nframes, out.ctypes.data_as(C.POINTER(C.c_float)) if want_output else None,
+                                        on_dev, reps, C.byref(ms))
+        _need(r == nframes, "stage_ofdm_fft")
+        return out, ms.value
+
+    def stage_demap(self, spectra):
+        spectra = np.ascontiguousarray(spectra, dtype=np.float32)
+        n = spectra.shape[0]
+        fic = np.zeros((n, FIC_BITS), dtype=np.uint8)
+        msc = np.zeros((n, MSC_BITS), dtype=np.uint8)
+        _need(lib().dabhip_stage_demap(self._h, spectra.ctypes.data_as(C.POINTER(C.c_float)), n, _p(fic), _p(msc)) == n, "stage_demap")
+        return fic, msc
+
+    def stage_fic_decode(self, fic):
+        fic = np.ascontiguousarray(fic, dtype=np.uint8).reshape(-1, FIC_BITS)
+        n = fic.shape[0]
+        fibs = np.zeros((n, 12, 32), dtype=np.uint8)
+        ok = np.zeros((n, 12), dtype=np.uint8)
+        _need(lib().dabhip_stage_fic_decode(self._h, _p(fic), n, _p(fibs), _p(ok)) == n, "stage_fic_decode")
+        return fibs, ok
+
+    def close(self):
+        if self._h:
+            lib().dabhip_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()

@@ -1,0 +1,277 @@
+// capi.cpp — the C ABI of libdabhip.so (include/dabhip.h): the three reference seams
+// (S1 viterbi, S2 sdr_demod, S3 dab_process_frame) as single-stream shims over the same
+// HIP kernels the batch engine uses, plus the batch and stage entry points.
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/dabhip.h"
+#include "engine.hpp"
+
+using namespace dabhip;
+
+struct dabhip_engine {
+  Engine eng;
+  explicit dabhip_engine(int device) : eng(device) {}
+};
+
+namespace {
+
+Engine* default_engine()
+{
+  static std::mutex mu;
+  static std::unique_ptr<Engine> eng;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!eng) {
+    std::unique_ptr<Engine> e(new Engine(0));
+    if (!e->ok()) return nullptr;
+    eng = std::move(e);
+  }
+  return eng.get();
+}
+
+}  // namespace
+
+extern "C" {
+
+int dabhip_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ---- batch engine -----------------------------------------------------------------------------
+dabhip_engine* dabhip_engine_create(int device)
+{
+  dabhip_engine* e = new (std::nothrow) dabhip_engine(device);
+  if (e && !e->eng.ok()) { delete e; return nullptr; }
+  return e;
+}
+void dabhip_engine_destroy(dabhip_engine* e) { delete e; }
+
+int64_t dabhip_engine_decode(dabhip_engine* e, const uint8_t* const* iq, const size_t* nbytes, int nstreams, int on_device)
+{
+  if (!e || !iq || !nbytes) { set_error("engine_decode: null argument"); return -1; }
+  return e->eng.decode(iq, nbytes, nstreams, on_device != 0);
+}
+int64_t dabhip_engine_eti_count(const dabhip_engine* e, int stream) { return e ? e->eng.eti_count(stream) : -1; }
+int64_t dabhip_engine_eti_read(dabhip_engine* e, int stream, uint8_t* dst, int64_t cap_frames)
+{
+  if (!e || !dst) { set_error("eti_read: null argument"); return -1; }
+  return e->eng.eti_read(stream, dst, cap_frames);
+}
+int64_t dabhip_engine_eti_drain(dabhip_engine* e, dabhip_eti_sink sink, void* user)
+{
+  if (!e || !sink) { set_error("eti_drain: null argument"); return -1; }
+  int64_t total = 0;
+  std::vector<uint8_t> buf;
+  for (int b = 0;; ++b) {
+    const int64_t n = e->eng.eti_count(b);
+    if (n < 0) break;
+    buf.resize(static_cast<size_t>(n) * DABHIP_ETI_BYTES);
+    if (e->eng.eti_read(b, buf.data(), n) != n) return -1;
+    for (int64_t f = 0; f < n; ++f) sink(buf.data() + f * DABHIP_ETI_BYTES, b, user);
+    total += n;
+  }
+  return total;
+}
+const void* dabhip_engine_eti_device_ptr(const dabhip_engine* e, int64_t* nframes) { return e ? e->eng.eti_device(nframes) : nullptr; }
+int dabhip_engine_trace(const dabhip_engine* e, int stream, int32_t* ints6, double* ffs, int cap_calls)
+{
+  if (!e || !ints6) return -1;
+  return e->eng.trace(stream, ints6, ffs, cap_calls);
+}
+int dabhip_engine_stage_ms(const dabhip_engine* e, const char** names, float* ms, int cap)
+{
+  if (!e) return -1;
+  static const char* kNames[8] = {"sync", "fft", "demap", "fic", "control", "gather", "viterbi", "eti"};
+  const StageTimes& t = e->eng.stage_times();
+  const float v[8] = {t.sync, t.fft, t.demap, t.fic, t.control, t.gather, t.viterbi, t.eti};
+  int n = 0;
+  for (; n < 8 && n < cap; ++n) {
+    if (names) names[n] = kNames[n];
+    if (ms) ms[n] = v[n];
+  }
+  return n;
+}
+int dabhip_engine_fft_stats(const dabhip_engine* e, int64_t* launches, int64_t* tfs, double* ms)
+{
+  if (!e) return -1;
+  e->eng.fft_stats(launches, tfs, ms);
+  return 0;
+}
+
+// ---- stage entries ----------------------------------------------------------------------------
+int dabhip_stage_ofdm_fft(dabhip_engine* e, const uint8_t* frames, int nframes, float* spectra, int on_device, int reps, float* kernel_ms)
+{
+  if (!e || !frames) { set_error("stage_ofdm_fft: null argument"); return -1; }
+  return e->eng.stage_ofdm_fft(frames, nframes, spectra, on_device != 0, reps, kernel_ms);
+}
+int dabhip_stage_demap(dabhip_engine* e, const float* spectra, int nframes, uint8_t* fic, uint8_t* msc)
+{
+  if (!e || !spectra || !fic || !msc) { set_error("stage_demap: null argument"); return -1; }
+  return e->eng.stage_demap(spectra, nframes, fic, msc);
+}
+int dabhip_stage_fic_decode(dabhip_engine* e, const uint8_t* fic, int nframes, uint8_t* fibs, uint8_t* crc_ok)
+{
+  if (!e || !fic || !fibs || !crc_ok) { set_error("stage_fic_decode: null argument"); return -1; }
+  return e->eng.stage_fic_decode(fic, nframes, fibs, crc_ok);
+}
+
+// ---- S1: decoder seam ---------------------------------------------------------------------------
+void* dabhip_create_viterbi(int /*len*/) { return default_engine(); }
+int dabhip_init_viterbi(void) { return default_engine() ? 0 : -1; }
+
+int dabhip_viterbi_batch(void* p, const unsigned char* symbols, unsigned char* data, int framebits, int n)
+{
+  Engine* eng = p ? static_cast<Engine*>(p) : default_engine();
+  if (!eng) return -1;
+  if (!symbols || !data) { set_error("viterbi: null argument"); return -1; }
+  return eng->viterbi_batch(symbols, data, framebits, n);
+}
+void dabhip_viterbi(void* p, unsigned char* symbols, unsigned char* data, int framebits)
+{
+  (void)dabhip_viterbi_batch(p, symbols, data, framebits, 1);   // like the reference: no error return
+}
+
+}  // extern "C"
+
+// ---- S2: front-end seam ---------------------------------------------------------------------------
+struct dabhip_sdr {
+  Engine eng;
+  DeviceBuffer<uint8_t> window;      // the most recent IQ bytes, device resident
+  DeviceBuffer<StreamState> state;
+  int64_t base = 0;                  // stream offset of window[0]
+  int64_t fed = 0;                   // bytes received so far
+  int64_t carry = 0;                 // bytes of a partial 262144-byte call not yet scanned
+  int call = 0;
+  CallDesc last{};
+  explicit dabhip_sdr(int device) : eng(device) {}
+};
+
+namespace {
+constexpr int64_t kWindowBytes = int64_t(48) << 20;
+constexpr int64_t kKeepBytes = int64_t(16) << 20;
+}  // namespace
+
+extern "C" {
+
+dabhip_sdr* dabhip_sdr_init(int device)
+{
+  dabhip_sdr* s = new (std::nothrow) dabhip_sdr(device);
+  if (!s) return nullptr;
+  if (!s->eng.ok() || !s->window.reserve(kWindowBytes) || !s->state.reserve(1)) { delete s; return nullptr; }
+  StreamState st;
+  std::memset(&st, 0, sizeof st);
+  st.view.nseg = 1;
+  for (int i = 0; i < kMaxSeg; ++i) { st.view.seg_end[i] = kTfBytes; st.view.seg_src[i] = -1; }
+  if (hipMemcpy(s->state.get(), &st, sizeof st, hipMemcpyHostToDevice) != hipSuccess) { set_error("sdr_init: state upload failed"); delete s; return nullptr; }
+  std::memset(&s->last, 0, sizeof s->last);
+  return s;
+}
+void dabhip_sdr_free(dabhip_sdr* s) { delete s; }
+
+int dabhip_sdr_demod(dabhip_sdr* s, const uint8_t* input_buffer, int input_buffer_len, uint8_t* fic, uint8_t* msc)
+{
+  if (!s || !input_buffer || !fic || !msc) { set_error("sdr_demod: null argument"); return -1; }
+  // The scan kernel advances in whole DEFAULT_BUF_LENGTH calls, which is what librtlsdr delivers (dab2eti.c:238).
+  if (input_buffer_len != kChunkBytes) { set_error("sdr_demod: input_buffer_len must be 262144 (DEFAULT_BUF_LENGTH)"); return -1; }
+  if (s->fed - s->base + input_buffer_len > kWindowBytes) {   // slide the device window
+    const int64_t keep_from = s->fed - kKeepBytes;
+    DeviceBuffer<uint8_t> tmp;
+    if (!tmp.reserve(kKeepBytes)) return -1;
+    if (hipMemcpy(tmp.get(), s->window.get() + (keep_from - s->base), kKeepBytes, hipMemcpyDeviceToDevice) != hipSuccess ||
+        hipMemcpy(s->window.get(), tmp.get(), kKeepBytes, hipMemcpyDeviceToDevice) != hipSuccess) {
+      set_error("sdr_demod: window slide failed");
+      return -1;
+    }
+    s->base = keep_from;
+  }
+  if (hipMemcpy(s->window.get() + (s->fed - s->base), input_buffer, input_buffer_len, hipMemcpyHostToDevice) != hipSuccess) {
+    set_error("sdr_demod: IQ upload failed");
+    return -1;
+  }
+  s->fed += input_buffer_len;
+  const uint8_t* virtual_base = s->window.get() - s->base;    // stream offset x lives at virtual_base + x
+  if (!s->eng.scan_one_call(virtual_base, s->fed, s->state.get(), s->call, &s->last)) return -1;
+  ++s->call;
+  if (s->last.status != 2) return 0;
+  for (int i = 0; i < s->last.view.nseg; ++i)
+    if (s->last.view.seg_src[i] >= 0 && s->last.view.seg_src[i] < s->base) { set_error("sdr_demod: stale frame tail older than the device window"); return -1; }
+  return s->eng.demod_one_frame(virtual_base, s->last, fic, msc) ? 1 : -1;
+}
+
+int32_t dabhip_sdr_coarse_timeshift(const dabhip_sdr* s) { return s ? s->last.coarse_timeshift : 0; }
+int32_t dabhip_sdr_fine_timeshift(const dabhip_sdr* s) { return s ? s->last.fine_timeshift : 0; }
+int32_t dabhip_sdr_coarse_freq_shift(const dabhip_sdr* s) { return s ? s->last.coarse_freq_shift : 0; }
+double dabhip_sdr_fine_freq_shift(const dabhip_sdr* s) { return s ? s->last.fine_freq_shift : 0.0; }
+
+}  // extern "C"
+
+// ---- S3: back-end seam ----------------------------------------------------------------------------
+struct dabhip_dab {
+  Engine eng;
+  ControlPlane plane;
+  dabhip_eti_callback cb = nullptr;
+  std::vector<uint8_t> fic, msc, fibs, ok, eti;
+  int slot = 0;                      // TF slot the next frame goes to
+  int ordinal = 0;                   // == slot + dropped
+  int dropped = 0;                   // TF slots discarded from the front so far
+  explicit dabhip_dab(int device) : eng(device), fic(kFicBits), msc(kMscBits), fibs(384), ok(12), eti(4 * kEtiBytes) {}
+};
+
+namespace {
+constexpr int kDabSlots = 64;
+}
+
+extern "C" {
+
+dabhip_dab* dabhip_dab_init(int device, dabhip_eti_callback cb)
+{
+  dabhip_dab* d = new (std::nothrow) dabhip_dab(device);
+  if (!d) return nullptr;
+  if (!d->eng.ok() || !d->eng.reserve_tf_slots(kDabSlots)) { delete d; return nullptr; }
+  d->cb = cb;
+  return d;
+}
+void dabhip_dab_free(dabhip_dab* d) { delete d; }
+uint8_t* dabhip_dab_tf_fic(dabhip_dab* d) { return d ? d->fic.data() : nullptr; }
+uint8_t* dabhip_dab_tf_msc(dabhip_dab* d) { return d ? d->msc.data() : nullptr; }
+int dabhip_dab_locked(const dabhip_dab* d) { return d && d->plane.locked(); }
+int dabhip_dab_last_fibs(const dabhip_dab* d, uint8_t* fibs, uint8_t* crc_ok)
+{
+  if (!d || !fibs || !crc_ok) return -1;
+  std::memcpy(fibs, d->fibs.data(), 384);
+  std::memcpy(crc_ok, d->ok.data(), 12);
+  return 0;
+}
+
+int dabhip_dab_process_frame(dabhip_dab* d)
+{
+  if (!d) { set_error("dab_process_frame: null handle"); return -1; }
+  if (d->slot == kDabSlots) {        // keep the 4 most recent TFs (16 CIFs of interleaver history)
+    if (!d->eng.move_tf_slots(0, kDabSlots - 4, 4)) return -1;
+    d->plane.rebase(4 * (kDabSlots - 4));
+    d->dropped += kDabSlots - 4;
+    d->slot = 4;
+  }
+  if (!d->eng.store_tf_bytes(d->slot, d->fic.data(), d->msc.data())) return -1;
+  if (!d->eng.fic_decode_slots(d->slot, 1, d->fibs.data(), d->ok.data())) return -1;
+  std::vector<EtiJob> jobs;
+  d->plane.on_tf(d->slot, d->fibs.data(), d->ok.data(), jobs);
+  ++d->slot;
+  if (jobs.empty()) return 0;
+  std::vector<int> job_stream(jobs.size(), 0), cif_base = {0};
+  std::vector<const ControlPlane*> planes = {&d->plane};
+  if (!d->eng.msc_decode(job_stream, jobs, planes, cif_base)) return -1;
+  if (!d->eng.read_eti(0, static_cast<int64_t>(jobs.size()), d->eti.data())) return -1;
+  if (d->cb)
+    for (size_t f = 0; f < jobs.size(); ++f) d->cb(d->eti.data() + f * kEtiBytes);
+  return static_cast<int>(jobs.size());
+}
+
+}  // extern "C"

@@ -1,0 +1,217 @@
+// control_plane.hpp — the per-ensemble control plane that stays on the host:
+// FIG 0/0, 0/1, 0/2 parsing, ensemble-information merge, the 10-TF lock rule, the 16-CIF
+// ring and the ETI(NI) header.  384 bytes in, a few hundred bytes out per transmission
+// frame; everything data-heavy is on the device.
+//
+// Reference behaviour reproduced (file:line under src/):
+//   fib_parse / fib_decode    fic.c:47-147
+//   merge_info                misc.c:14-27
+//   dab_process_frame         dab.c:35-98   (lock FSM, ring of 16 CIF pointers over 5 TF buffers)
+//   init_eti                  misc.c:153-213
+//   CIF counter increment     misc.c:306-313
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "dab_bits.hpp"
+#include "dab_tables.hpp"
+#include "device_types.hpp"
+
+namespace dabhip {
+
+struct EnsembleInfo {
+  uint16_t eid = 0;
+  uint8_t cif_hi = 0, cif_lo = 0;
+  SubChannel sub[64];
+};
+
+// Parse the FIGs of one FIB into `info`.  `limit` bounds reads for FIGs whose length field
+// runs past the FIB: the reference reads on into the following FIBs / CRC flags of
+// struct tf_fibs_t (dab.h:21-25); the caller passes an image with that layout.
+inline void parse_fib(EnsembleInfo& info, const uint8_t* fib, const uint8_t* limit)
+{
+  auto at = [&](int i) -> int { return fib + i < limit ? fib[i] : 0; };
+  int i = 0;
+  while (at(i) != 0xff && i < 30) {
+    const int type = at(i) >> 5, len = at(i) & 0x1f;
+    ++i;
+    if (type == 0) {
+      const int ext = at(i) & 0x1f, pd = (at(i) >> 5) & 1;
+      if (ext == 0) {                     // FIG 0/0: ensemble id and CIF counter
+        info.eid = static_cast<uint16_t>((at(i + 1) << 8) | at(i + 2));
+        info.cif_hi = static_cast<uint8_t>(at(i + 3) & 0x1f);
+        info.cif_lo = static_cast<uint8_t>(at(i + 4));
+      } else if (ext == 1) {              // FIG 0/1: sub-channel organisation
+        int j = i + 1;
+        while (j < i + len) {
+          const int id = at(j) >> 2;
+          SubChannel& sc = info.sub[id];
+          sc.id = id;
+          sc.start_cu = ((at(j) & 3) << 8) | at(j + 1);
+          sc.slform = at(j + 2) >> 7;
+          if (!sc.slform) {
+            sc.uep_index = at(j + 2) & 0x3f;
+            const UepProfile& u = uep_table()[sc.uep_index];
+            sc.size_cu = u.size_cu;
+            sc.bitrate = u.bitrate;
+            sc.protlev = u.protlevel;
+            j += 3;
+          } else {
+            sc.protlev = ((at(j + 2) >> 2) & 3) | (((at(j + 2) >> 4) & 7) << 2);
+            sc.size_cu = ((at(j + 2) & 3) << 8) | at(j + 3);
+            sc.bitrate = (sc.size_cu / eep_size_multiple(sc.protlev)) * ((sc.protlev & 4) ? 32 : 8);
+            j += 4;
+          }
+        }
+      } else if (ext == 2) {              // FIG 0/2: only the audio service component type is kept
+        int j = i + 1;
+        while (j < i + len) {
+          j += pd ? 4 : 2;
+          const int ncomp = at(j) & 0x0f;
+          ++j;
+          for (int k = 0; k < ncomp; ++k) {
+            if ((at(j) >> 6) == 0) info.sub[at(j + 1) >> 2].ascty = at(j) & 0x3f;
+            j += 2;
+          }
+        }
+      }
+    }
+    i += len;
+  }
+}
+
+inline void decode_fibs(EnsembleInfo& info, const uint8_t* fibs /*12 x 32*/, const uint8_t* crc_ok /*12*/)
+{
+  uint8_t image[12 * 32 + 12];
+  std::memcpy(image, fibs, 12 * 32);
+  std::memcpy(image + 12 * 32, crc_ok, 12);
+  info = EnsembleInfo{};
+  for (int f = 0; f < 12; ++f)
+    if (crc_ok[f]) parse_fib(info, image + 32 * f, image + sizeof image);
+}
+
+// SYNC, FC, STC, EOH of one ETI(NI) frame; returns the byte count (8 + 4 NST + 4).
+inline int build_eti_header(uint8_t* eti, const EnsembleInfo& info)
+{
+  int n = 0, nst = 0, fl = 0;
+  eti[n++] = 0xff;                                              // ERR
+  const bool odd = info.cif_lo & 1;
+  eti[n++] = odd ? 0xf8 : 0x07;                                 // FSYNC alternates
+  eti[n++] = odd ? 0xc5 : 0x3a;
+  eti[n++] = odd ? 0x49 : 0xb6;
+  eti[n++] = info.cif_lo;                                       // FCT
+  for (const SubChannel& sc : info.sub)
+    if (sc.id >= 0) { ++nst; fl += sc.bitrate * 3 / 4; }
+  fl += nst + 1 + 24;                                           // STC + EOH + FIC (Mode I) in words
+  eti[n++] = static_cast<uint8_t>(0x80 | nst);                  // FICF | NST
+  const int fp = (info.cif_hi * 250 + info.cif_lo) % 8;
+  eti[n++] = static_cast<uint8_t>((fp << 5) | (1 << 3) | ((fl & 0x700) >> 8));   // FP, MID = 1, FL
+  eti[n++] = static_cast<uint8_t>(fl & 0xff);
+  for (const SubChannel& sc : info.sub) {
+    if (sc.id < 0) continue;
+    const int tpl = sc.slform ? (0x20 | sc.protlev) : (0x10 | (sc.protlev - 1));
+    const int stl = sc.bitrate * 3 / 8;
+    eti[n++] = static_cast<uint8_t>((sc.id << 2) | ((sc.start_cu & 0x300) >> 8));
+    eti[n++] = static_cast<uint8_t>(sc.start_cu & 0xff);
+    eti[n++] = static_cast<uint8_t>((tpl << 2) | ((stl & 0x300) >> 8));
+    eti[n++] = static_cast<uint8_t>(stl & 0xff);
+  }
+  eti[n++] = 0xff;                                              // MNSC
+  eti[n++] = 0xff;
+  const uint16_t hcrc = static_cast<uint16_t>(~crc16_ccitt(eti + 4, static_cast<size_t>(n - 4)));
+  eti[n++] = static_cast<uint8_t>(hcrc >> 8);
+  eti[n++] = static_cast<uint8_t>(hcrc & 0xff);
+  return n;
+}
+
+// One ETI frame to assemble: the 16 consecutive CIFs starting at `first_cif` (linear CIF
+// index within the stream's demodulated TFs) are time de-interleaved; sub-channels of
+// `layout` are decoded in SubChId order.
+struct EtiJob {
+  int32_t first_cif;
+  int32_t layout;                  // index into ControlPlane::layouts()
+  int32_t header_len;
+  uint8_t header[kEtiHeaderMax];
+};
+
+class ControlPlane {
+ public:
+  ControlPlane()
+  {
+    ens_.cif_hi = 0xff;            // "CIF counter not latched yet" (dab.c:24-25)
+    ens_.cif_lo = 0xff;
+  }
+
+  // Feed the decoded FIBs of the next demodulated TF (ordinal = its index among the
+  // stream's demodulated TFs).  Appends 0 or 4 jobs.  Mirrors dab_process_frame.
+  int on_tf(int ordinal, const uint8_t* fibs, const uint8_t* crc_ok, std::vector<EtiJob>& jobs)
+  {
+    int ok_count = 0;
+    for (int f = 0; f < 12; ++f) ok_count += crc_ok[f] ? 1 : 0;
+    if (ok_count > 0) decode_fibs(tf_info_, fibs, crc_ok);
+    if (ok_count == 12) {
+      ++okcount_;
+      if (okcount_ >= 10 && !locked_) locked_ = true;
+    } else {
+      okcount_ = 0;
+      if (locked_) {                 // lock lost: ring is dropped (dab.c:55-61)
+        locked_ = false;
+        ncifs_ = 0;
+        return 0;
+      }
+    }
+    if (!locked_) return 0;
+
+    bool layout_changed = layouts_.empty();
+    for (int i = 0; i < 64; ++i) {
+      const SubChannel& s = tf_info_.sub[i];
+      if (s.id < 0) continue;
+      SubChannel& d = ens_.sub[i];
+      if (d.id != s.id || d.slform != s.slform || d.uep_index != s.uep_index || d.start_cu != s.start_cu ||
+          d.size_cu != s.size_cu || d.bitrate != s.bitrate || d.protlev != s.protlev)
+        layout_changed = true;
+      d = s;
+    }
+    ens_.eid = tf_info_.eid;
+    if (ens_.cif_hi == 0xff) { ens_.cif_hi = tf_info_.cif_hi; ens_.cif_lo = tf_info_.cif_lo; }
+    if (layout_changed) {
+      std::vector<SubChannel> active;
+      for (const SubChannel& sc : ens_.sub)
+        if (sc.id >= 0) active.push_back(sc);
+      layouts_.push_back(std::move(active));
+    }
+
+    if (ncifs_ < 16) {               // initial fill of the 16-CIF history (dab.c:66-76)
+      if (ncifs_ == 0) ring_first_ = 4 * ordinal;
+      ncifs_ += 4;
+      return 0;
+    }
+    for (int i = 0; i < 4; ++i) {    // emit the oldest CIF, then slide (dab.c:85-95)
+      EtiJob job;
+      job.first_cif = ring_first_++;
+      job.layout = static_cast<int32_t>(layouts_.size()) - 1;
+      job.header_len = build_eti_header(job.header, ens_);
+      jobs.push_back(job);
+      if (++ens_.cif_lo == 250) {
+        ens_.cif_lo = 0;
+        if (++ens_.cif_hi == 20) ens_.cif_hi = 0;
+      }
+    }
+    return 4;
+  }
+
+  bool locked() const { return locked_; }
+  const std::vector<std::vector<SubChannel>>& layouts() const { return layouts_; }
+  // streaming use: CIF indices are rebased when old TF slots are dropped
+  void rebase(int cif_shift) { ring_first_ -= cif_shift; }
+
+ private:
+  EnsembleInfo tf_info_, ens_;
+  bool locked_ = false;
+  int okcount_ = 0, ncifs_ = 0, ring_first_ = 0;
+  std::vector<std::vector<SubChannel>> layouts_;
+};
+
+}  // namespace dabhip

@@ -1,0 +1,69 @@
+// device_types.hpp — plain structs shared by host code and HIP kernels.
+#pragma once
+
+#include <cstdint>
+
+namespace dabhip {
+
+constexpr int kMaxSeg = 12;
+
+// How the 393216-byte frame buffer of the reference (sdr->buffer, input_sdr.h:16) looks
+// after one sdr_read_fifo() call, expressed as views into the never-modified IQ stream:
+// buffer position p in [seg_end[i-1], seg_end[i]) holds stream byte seg_src[i] + p
+// (seg_src < 0: the calloc'ed zero byte).  Segment 0 is what this call read; later
+// segments are the stale tail left by earlier, longer reads (sdr_fifo.c:56-59).
+struct FrameView {
+  int32_t nseg;
+  int32_t seg_end[kMaxSeg];
+  int64_t seg_src[kMaxSeg];
+};
+
+// Result of one sdr_demod() call (input_sdr.c:27-165) for one stream.
+struct CallDesc {
+  int32_t status;        // 0 = no frame read, 1 = frame read but dropped, 2 = demodulated
+  int32_t ordinal;       // dense index of this TF among the demodulated TFs of the stream
+  int32_t coarse_timeshift, fine_timeshift, coarse_freq_shift, fifo_count;
+  double fine_freq_shift;
+  FrameView view;
+};
+
+// Front-end state carried from call to call (struct sdr_state_t, input_sdr.h:12-41)
+struct StreamState {
+  int64_t consumed;      // stream offset of the FIFO read pointer
+  int64_t fed;           // bytes written to the FIFO so far
+  int32_t coarse_timeshift, fine_timeshift;
+  int32_t startup_delay, force_timesync;
+  int32_t next_ordinal;
+  int32_t overflow;      // set if the stale-tail bookkeeping exceeded kMaxSeg
+  double fine_freq_shift;
+  FrameView view;
+};
+
+// A rate-compatible punctured code word to decode: where its bits come from, how they
+// are punctured and where the decoded bytes go.
+struct CodewordPlan {
+  int32_t blocks[4];     // segments of 128 mother-code bits
+  uint32_t mask[4];      // puncturing masks of the segments
+  int32_t nsteps;        // trellis steps = data bits + 6
+  int32_t start_bit;     // first bit inside the (time de-interleaved) CIF, or inside the FIC block
+  int32_t out_offset;    // byte offset of the decoded data inside the output record
+  int32_t out_bytes;     // (nsteps - 6) / 8
+};
+
+struct CodewordItem {
+  int32_t stream;
+  int32_t cif;           // MSC: linear index of the oldest of the 16 CIFs; FIC: 4*tf + block
+  int32_t plan;          // index into the plan table
+  int32_t out_record;    // ETI frame index (MSC) or FIC block index (FIC)
+};
+
+// Per ETI frame: what eti_finish_kernel needs besides the decoded sub-channel data.
+constexpr int kEtiHeaderMax = 272;   // 8 + 4*64 + 4 bytes of SYNC/FC/STC/EOH, rounded up
+struct EtiFrameMeta {
+  int32_t header_len;    // bytes produced by the header builder (misc.c:153-213)
+  int32_t mst_bytes;     // decoded sub-channel bytes following the 96 FIB bytes
+  int32_t fib_block;     // index of the 96-byte FIB triple of the oldest CIF (4*tf_slot + cif)
+  int32_t pad;
+};
+
+}  // namespace dabhip

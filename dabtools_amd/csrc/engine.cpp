@@ -1,0 +1,646 @@
+// engine.cpp — host side of the batch engine (see engine.hpp for the pipeline).
+#include "engine.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "dab_bits.hpp"
+#include "dab_tables.hpp"
+#include "kernels.hpp"
+
+namespace dabhip {
+
+namespace {
+constexpr int kFftChunkTfs = 1024;                        // spectra buffer: 1024 TF x 1.19 MiB = 1.2 GiB
+constexpr int64_t kMaxDecisionRows = int64_t(12) << 20;   // x 512 B = 6 GiB of survivor decisions per launch
+constexpr int kFicWords = kFicBits / 32;                  // 288
+constexpr int kMscWords = kMscBits / 32;                  // 6912
+
+StreamState initial_state()
+{
+  StreamState st;
+  std::memset(&st, 0, sizeof st);
+  st.view.nseg = 1;                                       // the calloc'ed frame buffer: all zero bytes
+  for (int i = 0; i < kMaxSeg; ++i) { st.view.seg_end[i] = kTfBytes; st.view.seg_src[i] = -1; }
+  return st;
+}
+
+void unpack_bits(const uint32_t* words, int nbits, uint8_t* bytes)
+{
+  for (int i = 0; i < nbits; ++i) bytes[i] = static_cast<uint8_t>((words[i >> 5] >> (i & 31)) & 1u);
+}
+void pack_bits(const uint8_t* bytes, int nbits, uint32_t* words)
+{
+  std::memset(words, 0, static_cast<size_t>(nbits / 32) * 4);
+  for (int i = 0; i < nbits; ++i) words[i >> 5] |= static_cast<uint32_t>(bytes[i] & 1u) << (i & 31);
+}
+}  // namespace
+
+bool Engine::check(hipError_t e, const char* what)
+{
+  if (e == hipSuccess) return true;
+  set_error(std::string(what) + ": " + hipGetErrorString(e));
+  return false;
+}
+
+Engine::Engine(int device) : device_(device)
+{
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device: libdabhip has no CPU fallback"); return; }
+  if (device < 0 || device >= ndev) { set_error("device index out of range"); return; }
+  if (!check(hipSetDevice(device), "hipSetDevice")) return;
+  if (!check(hipStreamCreate(&stream_), "hipStreamCreate")) return;
+  for (auto& e : ev_)
+    if (!check(hipEventCreate(&e), "hipEventCreate")) return;
+
+  std::vector<double2> tw2048(2048), tw1536(1536);
+  std::vector<float2> twf(2048);
+  for (int k = 0; k < 2048; ++k) {
+    const double a = 2 * M_PI * k / 2048;
+    tw2048[k] = make_double2(std::cos(a), std::sin(a));
+    twf[k] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(-std::sin(a)));   // forward kernel
+  }
+  for (int k = 0; k < 1536; ++k) tw1536[k] = make_double2(std::cos(2 * M_PI * k / 1536), std::sin(2 * M_PI * k / 1536));
+  std::vector<uint8_t> prs(prs_quarter_turns().begin(), prs_quarter_turns().end());
+  std::vector<uint16_t> qpsk(carrier_to_qpsk().begin(), carrier_to_qpsk().end());
+  std::vector<uint16_t> crc(256);
+  for (int v = 0; v < 256; ++v) {
+    const uint8_t b = static_cast<uint8_t>(v);
+    crc[v] = crc16_ccitt(&b, 1, 0);
+  }
+  std::vector<uint32_t> prbs(1024), zeros(1024, 0u);     // 4096 bytes >= the largest sub-channel (1152 bytes per CIF at 384 kbit/s)
+  {
+    Prbs g;
+    for (auto& w : prbs) {
+      uint32_t x = 0;
+      for (int b = 0; b < 4; ++b) x |= static_cast<uint32_t>(g.next_byte()) << (8 * b);
+      w = x;
+    }
+  }
+  if (!d_tw2048_.upload(tw2048, stream_) || !d_tw1536_.upload(tw1536, stream_) || !d_twf_.upload(twf, stream_) ||
+      !d_prs_.upload(prs, stream_) || !d_qpsk_.upload(qpsk, stream_) || !d_crc_tab_.upload(crc, stream_) ||
+      !d_prbs_.upload(prbs, stream_) || !d_zero_words_.upload(zeros, stream_))
+    return;
+  if (!check(hipStreamSynchronize(stream_), "table upload")) return;
+  ok_ = true;
+}
+
+Engine::~Engine()
+{
+  for (auto& e : ev_)
+    if (e) (void)hipEventDestroy(e);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+// ---------------------------------------------------------------------------------------------
+int Engine::plan_id(const CodewordPlan& p)
+{
+  std::vector<int32_t> key = {p.blocks[0], p.blocks[1], p.blocks[2], p.blocks[3],
+                              static_cast<int32_t>(p.mask[0]), static_cast<int32_t>(p.mask[1]), static_cast<int32_t>(p.mask[2]),
+                              static_cast<int32_t>(p.mask[3]), p.nsteps, p.start_bit, p.out_offset, p.out_bytes};
+  auto it = plan_index_.find(key);
+  if (it != plan_index_.end()) return it->second;
+  const int id = static_cast<int>(plans_.size());
+  plans_.push_back(p);
+  plan_index_.emplace(std::move(key), id);
+  return id;
+}
+
+static CodewordPlan make_plan(const PuncturePlan& pp, int start_bit, int out_offset)
+{
+  CodewordPlan p;
+  for (int s = 0; s < 4; ++s) { p.blocks[s] = pp.blocks[s]; p.mask[s] = puncture_mask(pp.pi[s]); }
+  p.nsteps = pp.trellis_steps();
+  p.start_bit = start_bit;
+  p.out_offset = out_offset;
+  p.out_bytes = (p.nsteps - 6) / 8;
+  return p;
+}
+
+// sort code words into wave-groups of 64 with equal trellis length, longest first
+void Engine::build_batch(const std::vector<CodewordItem>& items, const std::vector<int>& item_nsteps, DecodeBatch& out)
+{
+  out = DecodeBatch{};
+  std::map<int, std::vector<int>, std::greater<int>> by_len;
+  for (size_t i = 0; i < items.size(); ++i) by_len[item_nsteps[i]].push_back(static_cast<int>(i));
+  for (auto& kv : by_len) {
+    const std::vector<int>& idx = kv.second;
+    for (size_t g = 0; g < idx.size(); g += 64) {
+      for (size_t l = 0; l < 64; ++l) {
+        if (g + l < idx.size()) out.items.push_back(items[idx[g + l]]);
+        else out.items.push_back(CodewordItem{0, 0, -1, 0});
+      }
+      out.group_nsteps.push_back(kv.first);
+      out.group_n16.push_back((kv.first + 15) / 16);
+    }
+  }
+}
+
+// run gather + Viterbi over a batch, in slices that bound the decision buffer
+bool Engine::run_decode_batch(const DecodeBatch& b, bool fic, const uint32_t* bits, const int* d_stream_cif_base,
+                              const uint32_t* prbs, uint8_t* out, int record_stride, float* gather_ms, float* viterbi_ms)
+{
+  const int ng = b.ngroups();
+  if (ng == 0) return true;
+  if (!d_plans_.upload(plans_, stream_)) return false;
+  if (!d_items_.upload(b.items, stream_)) return false;
+  int g0 = 0;
+  while (g0 < ng) {
+    std::vector<int64_t> base, dec_base;
+    int64_t step_rows = 0, dec_rows = 0;
+    int g1 = g0, max_n16 = 0;
+    while (g1 < ng) {
+      const int64_t dr = (b.group_nsteps[g1] + 3) / 4 * 4;
+      if (g1 > g0 && dec_rows + dr > kMaxDecisionRows) break;
+      base.push_back(step_rows);
+      dec_base.push_back(dec_rows);
+      step_rows += b.group_n16[g1];
+      dec_rows += dr;
+      max_n16 = std::max(max_n16, b.group_n16[g1]);
+      ++g1;
+    }
+    const int n = g1 - g0;
+    if (!d_group_nsteps_.upload(b.group_nsteps.data() + g0, n, stream_) || !d_group_n16_.upload(b.group_n16.data() + g0, n, stream_) ||
+        !d_group_base_.upload(base, stream_) || !d_group_dec_base_.upload(dec_base, stream_))
+      return false;
+    if (!d_steps_.reserve(static_cast<size_t>(step_rows) * 64) || !d_decisions_.reserve(static_cast<size_t>(dec_rows) * 64)) return false;
+    (void)hipEventRecord(ev_[0], stream_);
+    if (!check(launch_gather(fic, d_items_.get() + static_cast<size_t>(g0) * 64, d_plans_.get(), d_group_n16_.get(), d_group_base_.get(), n,
+                             max_n16, bits, d_stream_cif_base, d_steps_.get(), stream_),
+               "gather launch"))
+      return false;
+    (void)hipEventRecord(ev_[1], stream_);
+    if (!check(launch_viterbi(d_items_.get() + static_cast<size_t>(g0) * 64, d_plans_.get(), d_group_nsteps_.get(), d_group_base_.get(),
+                              d_group_dec_base_.get(), n, d_steps_.get(), d_decisions_.get(), prbs, out, record_stride, stream_),
+               "viterbi launch"))
+      return false;
+    (void)hipEventRecord(ev_[2], stream_);
+    if (!check(hipEventSynchronize(ev_[2]), "decode batch")) return false;
+    float ms = 0;
+    if (gather_ms && hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) *gather_ms += ms;
+    if (viterbi_ms && hipEventElapsedTime(&ms, ev_[1], ev_[2]) == hipSuccess) *viterbi_ms += ms;
+    g0 = g1;
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+bool Engine::reserve_tf_slots(int nslots)
+{
+  if (nslots <= tf_slots_) return true;
+  // growth discards contents: callers reserve before filling
+  if (!d_fic_bits_.reserve(static_cast<size_t>(nslots) * kFicWords) || !d_msc_bits_.reserve(static_cast<size_t>(nslots) * kMscWords) ||
+      !d_fibs_.reserve(static_cast<size_t>(nslots) * 384) || !d_fib_ok_.reserve(static_cast<size_t>(nslots) * 12))
+    return false;
+  tf_slots_ = nslots;
+  return true;
+}
+
+bool Engine::store_tf_bytes(int slot, const uint8_t* fic_bytes, const uint8_t* msc_bytes)
+{
+  std::vector<uint32_t> f(kFicWords), m(kMscWords);
+  pack_bits(fic_bytes, kFicBits, f.data());
+  pack_bits(msc_bytes, kMscBits, m.data());
+  return check(hipMemcpy(d_fic_bits_.get() + static_cast<size_t>(slot) * kFicWords, f.data(), f.size() * 4, hipMemcpyHostToDevice), "fic upload") &&
+         check(hipMemcpy(d_msc_bits_.get() + static_cast<size_t>(slot) * kMscWords, m.data(), m.size() * 4, hipMemcpyHostToDevice), "msc upload");
+}
+
+bool Engine::move_tf_slots(int dst, int src, int n)
+{
+  // ranges may overlap only when dst < src; stage through the spectra scratch
+  if (!d_bytes_.reserve(static_cast<size_t>(n) * kMscWords * 4)) return false;
+  auto mv = [&](void* base, size_t slot_bytes) {
+    uint8_t* b = static_cast<uint8_t*>(base);
+    return check(hipMemcpy(d_bytes_.get(), b + src * slot_bytes, n * slot_bytes, hipMemcpyDeviceToDevice), "slot move") &&
+           check(hipMemcpy(b + dst * slot_bytes, d_bytes_.get(), n * slot_bytes, hipMemcpyDeviceToDevice), "slot move");
+  };
+  return mv(d_fic_bits_.get(), kFicWords * 4) && mv(d_msc_bits_.get(), kMscWords * 4) && mv(d_fibs_.get(), 384) && mv(d_fib_ok_.get(), 12);
+}
+
+bool Engine::unpack_tf_slot(int slot, uint8_t* fic_bytes, uint8_t* msc_bytes)
+{
+  std::vector<uint32_t> f(kFicWords), m(kMscWords);
+  if (!check(hipMemcpy(f.data(), d_fic_bits_.get() + static_cast<size_t>(slot) * kFicWords, f.size() * 4, hipMemcpyDeviceToHost), "fic download") ||
+      !check(hipMemcpy(m.data(), d_msc_bits_.get() + static_cast<size_t>(slot) * kMscWords, m.size() * 4, hipMemcpyDeviceToHost), "msc download"))
+    return false;
+  unpack_bits(f.data(), kFicBits, fic_bytes);
+  unpack_bits(m.data(), kMscBits, msc_bytes);
+  return true;
+}
+
+bool Engine::fic_decode_slots(int first, int n, uint8_t* fibs_host, uint8_t* ok_host)
+{
+  if (n <= 0) return true;
+  const PuncturePlan pp = fic_plan();
+  int ids[4];
+  for (int blk = 0; blk < 4; ++blk) ids[blk] = plan_id(make_plan(pp, 2304 * blk, 0));
+  std::vector<CodewordItem> items;
+  std::vector<int> lens;
+  items.reserve(static_cast<size_t>(n) * 4);
+  for (int s = first; s < first + n; ++s)
+    for (int blk = 0; blk < 4; ++blk) {
+      items.push_back(CodewordItem{0, 4 * s + blk, ids[blk], 4 * s + blk});
+      lens.push_back(plans_[ids[blk]].nsteps);
+    }
+  DecodeBatch batch;
+  build_batch(items, lens, batch);
+  float g = 0, v = 0;
+  if (!run_decode_batch(batch, true, d_fic_bits_.get(), nullptr, d_prbs_.get(), d_fibs_.get(), 96, &g, &v)) return false;
+  if (!check(launch_fib_crc(d_fibs_.get() + static_cast<size_t>(first) * 384, n * 12, d_crc_tab_.get(), d_fib_ok_.get() + static_cast<size_t>(first) * 12, stream_), "fib crc launch")) return false;
+  if (!check(hipMemcpyAsync(fibs_host, d_fibs_.get() + static_cast<size_t>(first) * 384, static_cast<size_t>(n) * 384, hipMemcpyDeviceToHost, stream_), "fib download") ||
+      !check(hipMemcpyAsync(ok_host, d_fib_ok_.get() + static_cast<size_t>(first) * 12, static_cast<size_t>(n) * 12, hipMemcpyDeviceToHost, stream_), "fib flag download"))
+    return false;
+  return check(hipStreamSynchronize(stream_), "fic decode");
+}
+
+bool Engine::msc_decode(const std::vector<int>& job_stream, const std::vector<EtiJob>& jobs,
+                        const std::vector<const ControlPlane*>& planes, const std::vector<int>& stream_cif_base)
+{
+  const size_t nf = jobs.size();
+  if (nf == 0) return true;
+  std::vector<CodewordItem> items;
+  std::vector<int> lens;
+  std::vector<EtiFrameMeta> meta(nf);
+  std::vector<uint8_t> headers(nf * kEtiHeaderMax, 0);
+  // plan ids per (stream, layout) are cached: the layout of an ensemble rarely changes
+  std::map<std::pair<int, int>, std::vector<int>> layout_plans;
+  std::map<std::pair<int, int>, int> layout_mst;
+  for (size_t f = 0; f < nf; ++f) {
+    const int b = job_stream[f];
+    const EtiJob& job = jobs[f];
+    const auto key = std::make_pair(b, static_cast<int>(job.layout));
+    auto it = layout_plans.find(key);
+    if (it == layout_plans.end()) {
+      std::vector<int> ids;
+      int off = job.header_len + 96;
+      for (const SubChannel& sc : planes[b]->layouts()[job.layout]) {
+        const PuncturePlan pp = puncture_plan(sc);
+        CodewordPlan cp = make_plan(pp, sc.start_cu * 64, off);
+        // misc.c:259-260: bits = len/4 - 6, obytes = ((bits/8)+7) & 0xfff8
+        const int obytes = (cp.out_bytes + 7) & 0xfff8;
+        ids.push_back(plan_id(cp));
+        off += obytes;
+      }
+      layout_mst[key] = off - job.header_len - 96;
+      it = layout_plans.emplace(key, std::move(ids)).first;
+    }
+    for (int id : it->second) {
+      items.push_back(CodewordItem{b, job.first_cif, id, static_cast<int32_t>(f)});
+      lens.push_back(plans_[id].nsteps);
+    }
+    meta[f].header_len = job.header_len;
+    meta[f].mst_bytes = layout_mst[key];
+    meta[f].fib_block = stream_cif_base[b] + job.first_cif;
+    meta[f].pad = 0;
+    if (meta[f].header_len + 96 + meta[f].mst_bytes + 8 > kEtiBytes) { set_error("ETI frame overflow: sub-channels exceed 6144 bytes"); return false; }
+    std::memcpy(headers.data() + f * kEtiHeaderMax, job.header, kEtiHeaderMax);
+  }
+  DecodeBatch batch;
+  build_batch(items, lens, batch);
+  if (!d_eti_.reserve(nf * kEtiBytes) || !d_meta_.upload(meta, stream_) || !d_headers_.upload(headers, stream_) ||
+      !d_stream_cif_base_.upload(stream_cif_base, stream_))
+    return false;
+  if (!check(hipMemsetAsync(d_eti_.get(), 0x55, nf * kEtiBytes, stream_), "eti memset")) return false;   // padding, misc.c:295
+  if (!run_decode_batch(batch, false, d_msc_bits_.get(), d_stream_cif_base_.get(), d_prbs_.get(), d_eti_.get(), kEtiBytes,
+                        &times_.gather, &times_.viterbi))
+    return false;
+  (void)hipEventRecord(ev_[0], stream_);
+  if (!check(launch_eti_finish(d_meta_.get(), static_cast<int>(nf), d_headers_.get(), d_fibs_.get(), d_crc_tab_.get(), d_eti_.get(), stream_), "eti finish launch"))
+    return false;
+  (void)hipEventRecord(ev_[1], stream_);
+  if (!check(hipEventSynchronize(ev_[1]), "eti finish")) return false;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) times_.eti += ms;
+  return true;
+}
+
+bool Engine::read_eti(int64_t first, int64_t n, uint8_t* dst)
+{
+  if (n <= 0) return true;
+  return check(hipMemcpy(dst, d_eti_.get() + first * kEtiBytes, static_cast<size_t>(n) * kEtiBytes, hipMemcpyDeviceToHost), "eti download");
+}
+
+// ---------------------------------------------------------------------------------------------
+int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device)
+{
+  if (!ok_) { set_error("engine not initialised (no GPU?)"); return -1; }
+  if (nstreams <= 0) { set_error("decode: no streams"); return -1; }
+  if (!check(hipSetDevice(device_), "hipSetDevice")) return -1;
+  times_ = StageTimes{};
+  fft_launches_ = fft_tfs_ = 0;
+  fft_ms_ = 0;
+  nstreams_ = nstreams;
+  eti_base_.assign(nstreams, 0);
+  eti_count_.assign(nstreams, 0);
+  total_eti_ = 0;
+
+  std::vector<const uint8_t*> ptrs(nstreams);
+  std::vector<int64_t> nb(nstreams);
+  max_calls_ = 1;
+  size_t total = 0;
+  for (int b = 0; b < nstreams; ++b) {
+    nb[b] = static_cast<int64_t>(nbytes[b]);
+    max_calls_ = std::max<int>(max_calls_, static_cast<int>(nbytes[b] / kChunkBytes));
+    total += (nbytes[b] + 15) & ~size_t(15);
+  }
+  if (on_device) {
+    for (int b = 0; b < nstreams; ++b) ptrs[b] = iq[b];
+  } else {
+    if (!d_iq_own_.reserve(total)) return -1;
+    size_t off = 0;
+    for (int b = 0; b < nstreams; ++b) {
+      if (!check(hipMemcpyAsync(d_iq_own_.get() + off, iq[b], nbytes[b], hipMemcpyHostToDevice, stream_), "IQ upload")) return -1;
+      ptrs[b] = d_iq_own_.get() + off;
+      off += (nbytes[b] + 15) & ~size_t(15);
+    }
+  }
+  std::vector<StreamState> states(nstreams, initial_state());
+  const size_t ndesc = static_cast<size_t>(nstreams) * max_calls_;
+  if (!d_iq_ptrs_.upload(ptrs, stream_) || !d_nbytes_.upload(nb, stream_) || !d_states_.upload(states, stream_) || !d_descs_.reserve(ndesc)) return -1;
+  if (!check(hipMemsetAsync(d_descs_.get(), 0, ndesc * sizeof(CallDesc), stream_), "desc memset")) return -1;
+
+  // K1
+  (void)hipEventRecord(ev_[0], stream_);
+  if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), nstreams, max_calls_, 0, -1,
+                              d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), stream_),
+             "sync scan launch"))
+    return -1;
+  (void)hipEventRecord(ev_[1], stream_);
+  h_descs_.resize(ndesc);
+  if (!check(hipMemcpyAsync(h_descs_.data(), d_descs_.get(), ndesc * sizeof(CallDesc), hipMemcpyDeviceToHost, stream_), "desc download") ||
+      !check(hipMemcpyAsync(states.data(), d_states_.get(), states.size() * sizeof(StreamState), hipMemcpyDeviceToHost, stream_), "state download") ||
+      !check(hipStreamSynchronize(stream_), "sync scan"))
+    return -1;
+  (void)hipEventElapsedTime(&times_.sync, ev_[0], ev_[1]);
+  for (const StreamState& st : states)
+    if (st.overflow) { set_error("sync scan: stale-tail bookkeeping overflow (more than kMaxSeg nested short reads)"); return -1; }
+
+  // frame list: demodulated TFs, stream-major
+  std::vector<int2> frames;
+  std::vector<int> frame_slot, tf_base(nstreams + 1, 0), cif_base(nstreams);
+  for (int b = 0; b < nstreams; ++b) {
+    int n = 0;
+    const int ncalls = static_cast<int>(nbytes[b] / kChunkBytes);
+    for (int k = 0; k < ncalls; ++k) {
+      const CallDesc& d = h_descs_[static_cast<size_t>(b) * max_calls_ + k];
+      if (d.status == 2) {
+        frames.push_back(make_int2(b, k));
+        frame_slot.push_back(tf_base[b] + d.ordinal);
+        ++n;
+      }
+    }
+    tf_base[b + 1] = tf_base[b] + n;
+    cif_base[b] = 4 * tf_base[b];
+  }
+  const int ntf = static_cast<int>(frames.size());
+  if (ntf == 0) return 0;
+  if (!reserve_tf_slots(ntf) || !d_frames_.upload(frames, stream_) || !d_frame_slot_.upload(frame_slot, stream_)) return -1;
+
+  // K2 + K2b in chunks
+  const int chunk = std::min(ntf, kFftChunkTfs);
+  if (!d_spectra_.reserve(static_cast<size_t>(chunk) * kSymbolsPerTf * 2048)) return -1;
+  for (int first = 0; first < ntf; first += chunk) {
+    const int n = std::min(chunk, ntf - first);
+    (void)hipEventRecord(ev_[0], stream_);
+    if (!check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(), stream_), "fft launch")) return -1;
+    (void)hipEventRecord(ev_[1], stream_);
+    if (!check(launch_demap(d_spectra_.get(), d_frames_.get(), first, n, d_frame_slot_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch")) return -1;
+    (void)hipEventRecord(ev_[2], stream_);
+    if (!check(hipEventSynchronize(ev_[2]), "fft/demap")) return -1;
+    float a = 0, c = 0;
+    (void)hipEventElapsedTime(&a, ev_[0], ev_[1]);
+    (void)hipEventElapsedTime(&c, ev_[1], ev_[2]);
+    times_.fft += a;
+    times_.demap += c;
+    fft_ms_ += a;
+    fft_launches_ += 1;
+    fft_tfs_ += n;
+  }
+
+  // K3
+  std::vector<uint8_t> fibs(static_cast<size_t>(ntf) * 384), ok(static_cast<size_t>(ntf) * 12);
+  (void)hipEventRecord(ev_[3], stream_);
+  if (!fic_decode_slots(0, ntf, fibs.data(), ok.data())) return -1;
+  {
+    // ev_[0..2] were reused inside; time FIC by wall clock of the stream segment
+    hipEvent_t end = ev_[0];
+    (void)hipEventRecord(end, stream_);
+    (void)hipEventSynchronize(end);
+    (void)hipEventElapsedTime(&times_.fic, ev_[3], end);
+  }
+
+  // control plane
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<ControlPlane> planes(nstreams);
+  std::vector<const ControlPlane*> plane_ptrs(nstreams);
+  std::vector<EtiJob> jobs;
+  std::vector<int> job_stream;
+  for (int b = 0; b < nstreams; ++b) {
+    plane_ptrs[b] = &planes[b];
+    eti_base_[b] = static_cast<int64_t>(jobs.size());
+    for (int s = tf_base[b]; s < tf_base[b + 1]; ++s) planes[b].on_tf(s - tf_base[b], fibs.data() + static_cast<size_t>(s) * 384, ok.data() + static_cast<size_t>(s) * 12, jobs);
+    eti_count_[b] = static_cast<int64_t>(jobs.size()) - eti_base_[b];
+    job_stream.resize(jobs.size(), b);
+  }
+  total_eti_ = static_cast<int64_t>(jobs.size());
+  times_.control = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+
+  // K4 + K5
+  if (!msc_decode(job_stream, jobs, plane_ptrs, cif_base)) return -1;
+  return total_eti_;
+}
+
+int64_t Engine::eti_count(int stream) const { return (stream >= 0 && stream < nstreams_) ? eti_count_[stream] : -1; }
+
+int64_t Engine::eti_read(int stream, uint8_t* dst, int64_t cap_frames)
+{
+  if (stream < 0 || stream >= nstreams_) { set_error("eti_read: bad stream"); return -1; }
+  const int64_t n = std::min(cap_frames, eti_count_[stream]);
+  return read_eti(eti_base_[stream], n, dst) ? n : -1;
+}
+
+const uint8_t* Engine::eti_device(int64_t* nframes) const
+{
+  if (nframes) *nframes = total_eti_;
+  return d_eti_.get();
+}
+
+int Engine::trace(int stream, int32_t* ints6, double* ffs, int cap_calls) const
+{
+  if (stream < 0 || stream >= nstreams_) return -1;
+  int n = 0;
+  for (int k = 0; k < max_calls_ && n < cap_calls; ++k, ++n) {
+    const CallDesc& d = h_descs_[static_cast<size_t>(stream) * max_calls_ + k];
+    int32_t* o = ints6 + 6 * k;
+    o[0] = d.status == 2; o[1] = d.status >= 1; o[2] = d.coarse_timeshift; o[3] = d.fine_timeshift;
+    o[4] = d.coarse_freq_shift; o[5] = d.fifo_count;
+    if (ffs) ffs[k] = d.fine_freq_shift;
+  }
+  return n;
+}
+
+void Engine::fft_stats(int64_t* launches, int64_t* tfs, double* ms) const
+{
+  if (launches) *launches = fft_launches_;
+  if (tfs) *tfs = fft_tfs_;
+  if (ms) *ms = fft_ms_;
+}
+
+// ---------------------------------------------------------------------------------------------
+int Engine::stage_ofdm_fft(const uint8_t* frames, int nframes, float* spectra, bool on_device, int reps, float* kernel_ms)
+{
+  if (!ok_) { set_error("engine not initialised (no GPU?)"); return -1; }
+  if (nframes <= 0) return 0;
+  const size_t bytes = static_cast<size_t>(nframes) * kTfBytes;
+  const uint8_t* d_in = frames;
+  if (!on_device) {
+    if (!d_iq_own_.reserve(bytes) || !check(hipMemcpy(d_iq_own_.get(), frames, bytes, hipMemcpyHostToDevice), "frame upload")) return -1;
+    d_in = d_iq_own_.get();
+  }
+  std::vector<CallDesc> descs(nframes);
+  std::vector<int2> list(nframes);
+  for (int j = 0; j < nframes; ++j) {
+    std::memset(&descs[j], 0, sizeof(CallDesc));
+    descs[j].status = 2;
+    descs[j].ordinal = j;
+    descs[j].view = initial_state().view;
+    descs[j].view.seg_src[0] = static_cast<int64_t>(j) * kTfBytes;
+    list[j] = make_int2(0, j);
+  }
+  std::vector<const uint8_t*> ptrs = {d_in};
+  const size_t nspec = static_cast<size_t>(nframes) * kSymbolsPerTf * 2048;
+  if (!d_iq_ptrs_.upload(ptrs, stream_) || !d_descs_.upload(descs, stream_) || !d_frames_.upload(list, stream_) || !d_spectra_.reserve(nspec)) return -1;
+  reps = std::max(reps, 1);
+  // one untimed launch first when timing
+  if (reps > 1 && !check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), nframes, d_frames_.get(), 0, nframes, d_spectra_.get(), d_twf_.get(), stream_), "fft launch")) return -1;
+  (void)hipEventRecord(ev_[0], stream_);
+  for (int r = 0; r < reps; ++r)
+    if (!check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), nframes, d_frames_.get(), 0, nframes, d_spectra_.get(), d_twf_.get(), stream_), "fft launch")) return -1;
+  (void)hipEventRecord(ev_[1], stream_);
+  if (!check(hipEventSynchronize(ev_[1]), "fft")) return -1;
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ev_[0], ev_[1]);
+  if (kernel_ms) *kernel_ms = ms / reps;
+  if (spectra && !check(hipMemcpy(spectra, d_spectra_.get(), nspec * sizeof(float2), hipMemcpyDeviceToHost), "spectra download")) return -1;
+  return nframes;
+}
+
+int Engine::stage_demap(const float* spectra, int nframes, uint8_t* fic, uint8_t* msc)
+{
+  if (!ok_) { set_error("engine not initialised (no GPU?)"); return -1; }
+  if (nframes <= 0) return 0;
+  const size_t nspec = static_cast<size_t>(nframes) * kSymbolsPerTf * 2048;
+  std::vector<int2> list(nframes);
+  std::vector<int> slots(nframes);
+  for (int j = 0; j < nframes; ++j) { list[j] = make_int2(0, j); slots[j] = j; }
+  if (!reserve_tf_slots(nframes) || !d_spectra_.reserve(nspec) || !d_frames_.upload(list, stream_) || !d_frame_slot_.upload(slots, stream_)) return -1;
+  if (!check(hipMemcpyAsync(d_spectra_.get(), spectra, nspec * sizeof(float2), hipMemcpyHostToDevice, stream_), "spectra upload")) return -1;
+  if (!check(launch_demap(d_spectra_.get(), d_frames_.get(), 0, nframes, d_frame_slot_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch") ||
+      !check(hipStreamSynchronize(stream_), "demap"))
+    return -1;
+  for (int j = 0; j < nframes; ++j)
+    if (!unpack_tf_slot(j, fic + static_cast<size_t>(j) * kFicBits, msc + static_cast<size_t>(j) * kMscBits)) return -1;
+  return nframes;
+}
+
+int Engine::stage_fic_decode(const uint8_t* fic, int nframes, uint8_t* fibs, uint8_t* crc_ok)
+{
+  if (!ok_) { set_error("engine not initialised (no GPU?)"); return -1; }
+  if (nframes <= 0) return 0;
+  if (!reserve_tf_slots(nframes)) return -1;
+  std::vector<uint32_t> words(static_cast<size_t>(nframes) * kFicWords);
+  for (int j = 0; j < nframes; ++j) pack_bits(fic + static_cast<size_t>(j) * kFicBits, kFicBits, words.data() + static_cast<size_t>(j) * kFicWords);
+  if (!check(hipMemcpy(d_fic_bits_.get(), words.data(), words.size() * 4, hipMemcpyHostToDevice), "fic upload")) return -1;
+  return fic_decode_slots(0, nframes, fibs, crc_ok) ? nframes : -1;
+}
+
+// S1: n code words of `framebits` data bits, symbols 127/129 hard, 128 erased (depuncture.c:36-43)
+int Engine::viterbi_batch(const uint8_t* symbols, uint8_t* data, int framebits, int n)
+{
+  if (!ok_) { set_error("engine not initialised (no GPU?)"); return -1; }
+  if (n <= 0) return 0;
+  if (framebits <= 0 || framebits % 32 != 0) { set_error("viterbi: framebits must be a positive multiple of 32"); return -1; }
+  const int nsteps = framebits + 6, n16 = (nsteps + 15) / 16;
+  const int ngroups = (n + 63) / 64;
+  CodewordPlan plan;
+  std::memset(&plan, 0, sizeof plan);
+  plan.nsteps = nsteps;
+  plan.out_bytes = framebits / 8;
+  const int pid = plan_id(plan);
+  DecodeBatch batch;
+  std::vector<uint4> steps(static_cast<size_t>(ngroups) * n16 * 64, make_uint4(0, 0, 0, 0));
+  for (int g = 0; g < ngroups; ++g) {
+    batch.group_nsteps.push_back(nsteps);
+    batch.group_n16.push_back(n16);
+    for (int l = 0; l < 64; ++l) {
+      const int cw = g * 64 + l;
+      batch.items.push_back(cw < n ? CodewordItem{0, 0, pid, cw} : CodewordItem{0, 0, -1, 0});
+      if (cw >= n) continue;
+      const uint8_t* sym = symbols + static_cast<size_t>(cw) * 4 * nsteps;
+      for (int t = 0; t < nsteps; ++t) {
+        unsigned byte = 0;
+        for (int j = 0; j < 4; ++j) {
+          const uint8_t s = sym[4 * t + j];
+          if (s != 128) byte |= (1u << (4 + j)) | ((s > 128 ? 1u : 0u) << j);
+        }
+        uint4& u = steps[(static_cast<size_t>(g) * n16 + t / 16) * 64 + l];
+        uint32_t* w = &u.x;
+        w[(t % 16) / 4] |= byte << (8 * (t % 4));
+      }
+    }
+  }
+  // no gather: upload the step rows directly, then run the decoder with an all-zero scrambler
+  std::vector<int64_t> base(ngroups), dec_base(ngroups);
+  const int64_t dr = (nsteps + 3) / 4 * 4;
+  for (int g = 0; g < ngroups; ++g) { base[g] = static_cast<int64_t>(g) * n16; dec_base[g] = g * dr; }
+  const size_t out_bytes = static_cast<size_t>(n) * (framebits / 8);
+  if (!d_plans_.upload(plans_, stream_) || !d_items_.upload(batch.items, stream_) || !d_group_nsteps_.upload(batch.group_nsteps, stream_) ||
+      !d_group_base_.upload(base, stream_) || !d_group_dec_base_.upload(dec_base, stream_) || !d_steps_.upload(steps, stream_) ||
+      !d_decisions_.reserve(static_cast<size_t>(ngroups) * dr * 64) || !d_bytes_.reserve(out_bytes) || !d_zero_words_.reserve(1))
+    return -1;
+  if (framebits / 32 > 1024) { set_error("viterbi: code word too long"); return -1; }
+  if (!check(launch_viterbi(d_items_.get(), d_plans_.get(), d_group_nsteps_.get(), d_group_base_.get(), d_group_dec_base_.get(), ngroups,
+                            d_steps_.get(), d_decisions_.get(), d_zero_words_.get(), d_bytes_.get(), framebits / 8, stream_),
+             "viterbi launch") ||
+      !check(hipMemcpyAsync(data, d_bytes_.get(), out_bytes, hipMemcpyDeviceToHost, stream_), "decoded download") ||
+      !check(hipStreamSynchronize(stream_), "viterbi"))
+    return -1;
+  return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// S2 building blocks: one sdr_demod call on an explicit stream
+bool Engine::scan_one_call(const uint8_t* iq_virtual_base, int64_t fed_bytes, StreamState* d_state, int call, CallDesc* out)
+{
+  std::vector<const uint8_t*> ptrs = {iq_virtual_base};
+  std::vector<int64_t> nb = {fed_bytes};
+  if (!d_iq_ptrs_.upload(ptrs, stream_) || !d_nbytes_.upload(nb, stream_) || !d_descs_.reserve(1)) return false;
+  // the kernel indexes descs[stream * max_calls + call]; with max_calls = 0 and the pointer moved back by `call` it hits slot 0
+  if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_state, d_descs_.get() - call, 1, 0, call, call + 1, d_tw2048_.get(),
+                              d_tw1536_.get(), d_prs_.get(), stream_),
+             "sync scan launch"))
+    return false;
+  return check(hipMemcpyAsync(out, d_descs_.get(), sizeof(CallDesc), hipMemcpyDeviceToHost, stream_), "desc download") &&
+         check(hipStreamSynchronize(stream_), "sync scan");
+}
+
+bool Engine::demod_one_frame(const uint8_t* iq_virtual_base, const CallDesc& desc, uint8_t* fic_bytes, uint8_t* msc_bytes)
+{
+  std::vector<const uint8_t*> ptrs = {iq_virtual_base};
+  std::vector<int2> list = {make_int2(0, 0)};
+  std::vector<int> slots = {0};
+  std::vector<CallDesc> d = {desc};
+  if (!reserve_tf_slots(1) || !d_iq_ptrs_.upload(ptrs, stream_) || !d_descs_.upload(d, stream_) || !d_frames_.upload(list, stream_) ||
+      !d_frame_slot_.upload(slots, stream_) || !d_spectra_.reserve(static_cast<size_t>(kSymbolsPerTf) * 2048))
+    return false;
+  if (!check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), 1, d_frames_.get(), 0, 1, d_spectra_.get(), d_twf_.get(), stream_), "fft launch") ||
+      !check(launch_demap(d_spectra_.get(), d_frames_.get(), 0, 1, d_frame_slot_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch") ||
+      !check(hipStreamSynchronize(stream_), "demod"))
+    return false;
+  return unpack_tf_slot(0, fic_bytes, msc_bytes);
+}
+
+}  // namespace dabhip

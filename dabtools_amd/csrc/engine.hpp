@@ -1,0 +1,172 @@
+// engine.hpp — batch engine: B independent cu8 IQ streams resident in HBM -> ETI frames.
+//
+// Pipeline of one decode() (kernel files in brackets):
+//   K1  sync scan            [k_sync.hip]   one workgroup per stream, sequential over its TFs
+//   K2  OFDM FFT             [k_fft.hip]    all demodulated TFs, chunked to bound the spectra buffer
+//   K2b DQPSK/demap          [k_fft.hip]    -> bit-packed FIC / MSC rows, kept for the whole batch
+//   K3  FIC decode           [k_decode.hip] gather + Viterbi + CRC -> 12 FIBs per TF  (D2H: 396 B/TF)
+//   --  control plane        [control_plane.hpp, host] lock FSM, CIF ring, ETI headers, work lists
+//   K4  MSC decode           [k_decode.hip] gather (time de-interleave + de-puncture) + Viterbi
+//   K5  ETI finish           [k_decode.hip] header, FIBs, EOF CRC, trailer
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "control_plane.hpp"
+#include "device_types.hpp"
+
+namespace dabhip {
+
+void set_error(const std::string& msg);
+
+// grow-only device allocation; contents are NOT preserved on growth
+template <class T>
+class DeviceBuffer {
+ public:
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  ~DeviceBuffer() { release(); }
+  bool reserve(size_t n)
+  {
+    if (n <= cap_) return true;
+    release();
+    if (hipMalloc(reinterpret_cast<void**>(&p_), n * sizeof(T)) != hipSuccess) {
+      p_ = nullptr;
+      set_error("hipMalloc of " + std::to_string(n * sizeof(T)) + " bytes failed");
+      return false;
+    }
+    cap_ = n;
+    return true;
+  }
+  void release()
+  {
+    if (p_) (void)hipFree(p_);
+    p_ = nullptr;
+    cap_ = 0;
+  }
+  bool upload(const T* src, size_t n, hipStream_t s)
+  {
+    if (!reserve(n ? n : 1)) return false;
+    return n == 0 || hipMemcpyAsync(p_, src, n * sizeof(T), hipMemcpyHostToDevice, s) == hipSuccess;
+  }
+  bool upload(const std::vector<T>& v, hipStream_t s) { return upload(v.data(), v.size(), s); }
+  T* get() const { return p_; }
+  size_t capacity() const { return cap_; }
+
+ private:
+  T* p_ = nullptr;
+  size_t cap_ = 0;
+};
+
+struct StageTimes {
+  float sync = 0, fft = 0, demap = 0, fic = 0, control = 0, gather = 0, viterbi = 0, eti = 0;
+};
+
+// Work list for Viterbi launches: code words sorted into wave-groups of 64 of equal length.
+struct DecodeBatch {
+  std::vector<CodewordItem> items;        // ngroups * 64, padded with plan = -1
+  std::vector<int> group_nsteps, group_n16;
+  std::vector<int64_t> group_base;        // step buffer offsets (rows of 64 x 16 bytes)
+  std::vector<int64_t> group_dec_base;    // decision buffer offsets (rows of 64 x 8 bytes)
+  int ngroups() const { return static_cast<int>(group_nsteps.size()); }
+};
+
+class Engine {
+ public:
+  explicit Engine(int device);
+  ~Engine();
+  Engine(const Engine&) = delete;
+  Engine& operator=(const Engine&) = delete;
+  bool ok() const { return ok_; }
+
+  // -- batch path ---------------------------------------------------------------------------
+  int64_t decode(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device);
+  int64_t eti_count(int stream) const;
+  int64_t eti_read(int stream, uint8_t* dst, int64_t cap_frames);
+  const uint8_t* eti_device(int64_t* nframes) const;
+  int trace(int stream, int32_t* ints6, double* ffs, int cap_calls) const;
+  const StageTimes& stage_times() const { return times_; }
+  void fft_stats(int64_t* launches, int64_t* tfs, double* ms) const;
+
+  // -- stage entries --------------------------------------------------------------------------
+  int stage_ofdm_fft(const uint8_t* frames, int nframes, float* spectra, bool on_device, int reps, float* kernel_ms);
+  int stage_demap(const float* spectra, int nframes, uint8_t* fic, uint8_t* msc);
+  int stage_fic_decode(const uint8_t* fic, int nframes, uint8_t* fibs, uint8_t* crc_ok);
+  int viterbi_batch(const uint8_t* symbols, uint8_t* data, int framebits, int n);
+
+  // -- building blocks shared with the streaming seams (capi.cpp) ------------------------------
+  bool reserve_tf_slots(int nslots);
+  // host 0/1 bytes of one demapped TF -> bit rows of TF slot `slot`
+  bool store_tf_bytes(int slot, const uint8_t* fic_bytes, const uint8_t* msc_bytes);
+  bool move_tf_slots(int dst, int src, int n);
+  // FIC-decode TF slots [first, first+n): FIBs and CRC flags to host
+  bool fic_decode_slots(int first, int n, uint8_t* fibs_host, uint8_t* ok_host);
+  // decode the ETI frames described by jobs into the ETI buffer (frame order = job order)
+  bool msc_decode(const std::vector<int>& job_stream, const std::vector<EtiJob>& jobs,
+                  const std::vector<const ControlPlane*>& planes, const std::vector<int>& stream_cif_base);
+  bool read_eti(int64_t first, int64_t n, uint8_t* dst);
+  // front end on an explicit single stream (S2 seam): calls [call, call+1)
+  bool scan_one_call(const uint8_t* iq_virtual_base, int64_t fed_bytes, StreamState* d_state, int call, CallDesc* out);
+  bool demod_one_frame(const uint8_t* iq_virtual_base, const CallDesc& desc, uint8_t* fic_bytes, uint8_t* msc_bytes);
+  hipStream_t stream() const { return stream_; }
+
+ private:
+  bool check(hipError_t e, const char* what);
+  void build_batch(const std::vector<CodewordItem>& items, const std::vector<int>& item_nsteps, DecodeBatch& out);
+  bool run_decode_batch(const DecodeBatch& b, bool fic, const uint32_t* bits, const int* d_stream_cif_base,
+                        const uint32_t* prbs, uint8_t* out, int record_stride, float* gather_ms, float* viterbi_ms);
+  int plan_id(const CodewordPlan& p);
+  bool unpack_tf_slot(int slot, uint8_t* fic_bytes, uint8_t* msc_bytes);
+
+  bool ok_ = false;
+  int device_ = 0;
+  hipStream_t stream_ = nullptr;
+  hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+
+  // constant tables
+  DeviceBuffer<double2> d_tw2048_, d_tw1536_;
+  DeviceBuffer<uint8_t> d_prs_;
+  DeviceBuffer<float2> d_twf_;
+  DeviceBuffer<uint16_t> d_qpsk_, d_crc_tab_;
+  DeviceBuffer<uint32_t> d_prbs_, d_zero_words_;
+
+  // batch state
+  DeviceBuffer<uint8_t> d_iq_own_;
+  DeviceBuffer<const uint8_t*> d_iq_ptrs_;
+  DeviceBuffer<int64_t> d_nbytes_;
+  DeviceBuffer<StreamState> d_states_;
+  DeviceBuffer<CallDesc> d_descs_;
+  DeviceBuffer<int2> d_frames_;
+  DeviceBuffer<int> d_frame_slot_, d_stream_cif_base_;
+  DeviceBuffer<float2> d_spectra_;
+  DeviceBuffer<uint32_t> d_fic_bits_, d_msc_bits_;
+  DeviceBuffer<uint8_t> d_fibs_, d_fib_ok_;
+  DeviceBuffer<CodewordItem> d_items_;
+  DeviceBuffer<CodewordPlan> d_plans_;
+  DeviceBuffer<int> d_group_nsteps_, d_group_n16_;
+  DeviceBuffer<int64_t> d_group_base_, d_group_dec_base_;
+  DeviceBuffer<uint4> d_steps_;
+  DeviceBuffer<uint2> d_decisions_;
+  DeviceBuffer<EtiFrameMeta> d_meta_;
+  DeviceBuffer<uint8_t> d_headers_, d_eti_, d_bytes_;
+  int tf_slots_ = 0;
+
+  std::vector<CodewordPlan> plans_;
+  std::map<std::vector<int32_t>, int> plan_index_;
+
+  std::vector<CallDesc> h_descs_;
+  int max_calls_ = 0, nstreams_ = 0;
+  std::vector<int64_t> eti_base_, eti_count_;
+  int64_t total_eti_ = 0;
+  StageTimes times_;
+  int64_t fft_launches_ = 0, fft_tfs_ = 0;
+  double fft_ms_ = 0;
+};
+
+}  // namespace dabhip

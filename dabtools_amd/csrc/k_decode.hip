@@ -1,0 +1,306 @@
+// k_decode.hip — K3/K4: channel decoding of the FIC and of every MSC sub-channel, and K5:
+// ETI frame completion.
+//
+//  gather_kernel   time de-interleave (misc.c:29-39) + de-puncture (depuncture.c:45-132)
+//                  fused into one gather: demapped bit rows -> one byte per trellis step
+//                  (4 received bits + 4 "was transmitted" flags).
+//  viterbi_kernel  K=7 rate-1/4 maximum-likelihood decoder with the decisions of the
+//                  reference's scalar viterbi() (viterbi.c:352-451): one LANE per code word,
+//                  all 64 path metrics of that code word live in the lane's VGPRs, so the
+//                  add-compare-select needs no cross-lane traffic; 64 code words of equal
+//                  length per wave.  Followed in the same kernel by the chain-back,
+//                  energy-dispersal descrambling (misc.c:41-58) and MSB-first byte packing.
+//  eti_finish_kernel  header + FIBs + EOF CRC + trailer of each ETI frame (misc.c:218-296).
+//
+// Metric equivalence (bit-exactness argument).  The reference adds, per transmitted symbol,
+// +3 if the hypothesis agrees with the hard bit and -7 if not, and 0 for an erasure
+// (mettab from gen_met(amp=1,noise=1,bias=0,scale=4), viterbi.c:455-462).  That is
+// 10*agree - 7 per transmitted symbol; the number of transmitted symbols up to a step is
+// the same for every path, so every compare "m1 > m0" at a step equals the compare of the
+// agreement counts.  The kernel therefore accumulates agreement counts (0..4 per step);
+// decisions, ties (strict '>' keeps the low predecessor) and the start condition (state 0
+// reachable, others far below) are identical.
+#include <hip/hip_runtime.h>
+
+#include <utility>
+
+#include "dab_tables.hpp"
+#include "device_types.hpp"
+#include "kernels.hpp"
+
+namespace dabhip {
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// gather: one thread per (item, 16 trellis steps)
+template <bool kFic>
+__global__ __launch_bounds__(256) void gather_kernel(const CodewordItem* __restrict__ items,
+                                                     const CodewordPlan* __restrict__ plans,
+                                                     const int* __restrict__ group_n16,        // per wave-group: ceil(nsteps/16)
+                                                     const int64_t* __restrict__ group_base,   // per wave-group: offset in 16-byte units
+                                                     int ngroups, const uint32_t* __restrict__ bits,
+                                                     const int* __restrict__ stream_cif_base,   // MSC: first CIF row of each stream
+                                                     uint4* __restrict__ steps)
+{
+  const int group = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int t16 = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (group >= ngroups || t16 >= group_n16[group]) return;
+  const CodewordItem it = items[group * 64 + lane];
+  uint32_t w[4] = {0, 0, 0, 0};
+  if (it.plan >= 0) {
+    const CodewordPlan pl = plans[it.plan];
+    const int x0 = 64 * t16;                     // first mother-code bit of this thread
+    // locate the segment holding x0 (segments are multiples of 128 mother bits)
+    int seg_start = 0, j0 = 0, s = 0;
+    uint32_t mask = 0;
+    for (; s < 4; ++s) {
+      const int seg_bits = 128 * pl.blocks[s];
+      if (x0 < seg_start + seg_bits) { mask = pl.mask[s]; break; }
+      j0 += pl.blocks[s] * 4 * __popc(pl.mask[s]);
+      seg_start += seg_bits;
+    }
+    const bool tail = (s == 4);                  // 24 tail bits at PI 8 (depuncture.c:97-103)
+    int j = j0 + ((x0 - seg_start) >> 5) * __popc(mask);
+    const uint32_t* row0;
+    if (kFic) row0 = bits + static_cast<size_t>(it.cif >> 2) * 288;
+    else row0 = bits + (static_cast<size_t>(stream_cif_base[it.stream]) + it.cif) * 1728;
+    for (int g = 0; g < 2; ++g) {
+      uint32_t m = mask;
+      if (tail) m = (g == 0) ? (puncture_mask(8) & 0x00ffffffu) : 0u;
+      uint32_t val = 0;
+      for (int u = 0; u < 32; ++u) {
+        if ((m >> u) & 1u) {
+          const int i = pl.start_bit + j++;
+          uint32_t word;
+          if (kFic) {
+            word = row0[i >> 5];
+          } else {
+            // out[i] = cifs[map[i & 15]][i], map = bit reversal of 4 bits (misc.c:32)
+            const int r = static_cast<int>(__brev(static_cast<unsigned>(i & 15)) >> 28);
+            word = row0[static_cast<size_t>(r) * 1728 + (i >> 5)];
+          }
+          val |= ((word >> (i & 31)) & 1u) << u;
+        }
+      }
+      // 8 steps: byte = value nibble | mask nibble << 4
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint32_t byte = ((val >> (4 * q)) & 15u) | (((m >> (4 * q)) & 15u) << 4);
+        w[2 * g + (q >> 2)] |= byte << (8 * (q & 3));
+      }
+    }
+  }
+  steps[(group_base[group] + t16) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ---------------------------------------------------------------------------------------
+// branch code words: bit j of code(i) = parity(i & poly_j), i = 7-bit register with the
+// low predecessor's oldest bit 0 (viterbi.c:373-381).  poly 0 == poly 3, so bit 3 == bit 0.
+__host__ __device__ constexpr unsigned parity_u(unsigned x)
+{
+  x ^= x >> 4;
+  x ^= x >> 2;
+  x ^= x >> 1;
+  return x & 1u;
+}
+__host__ __device__ constexpr unsigned branch_code3(unsigned i)   // bits 0..2 of the code word
+{
+  return parity_u(i & 0x6d) | (parity_u(i & 0x4f) << 1) | (parity_u(i & 0x53) << 2);
+}
+
+template <int kJ>
+__device__ __forceinline__ void butterfly(const int (&old)[64], int (&nw)[64], const int (&bm)[8], int ntx, uint32_t& dlo,
+                                          uint32_t& dhi)
+{
+  constexpr unsigned c = branch_code3(2 * kJ);
+  const int b1 = bm[c], b2 = ntx - b1;
+  const int lo = old[kJ], hi = old[kJ + 32];
+  const int e0 = lo + b1, e1 = hi + b2;       // into state 2j   (viterbi.c:404-414)
+  const int o0 = lo + b2, o1 = hi + b1;       // into state 2j+1 (viterbi.c:415-421)
+  nw[2 * kJ] = max(e0, e1);
+  nw[2 * kJ + 1] = max(o0, o1);
+  constexpr int be = 2 * kJ, bo = 2 * kJ + 1;
+  if (be < 32) { dlo |= (e1 > e0 ? 1u : 0u) << be; dlo |= (o1 > o0 ? 1u : 0u) << bo; }
+  else { dhi |= (e1 > e0 ? 1u : 0u) << (be - 32); dhi |= (o1 > o0 ? 1u : 0u) << (bo - 32); }
+}
+
+template <int... kJs>
+__device__ __forceinline__ void all_butterflies(const int (&old)[64], int (&nw)[64], const int (&bm)[8], int ntx,
+                                                uint32_t& dlo, uint32_t& dhi, std::integer_sequence<int, kJs...>)
+{
+  (butterfly<kJs>(old, nw, bm, ntx, dlo, dhi), ...);
+}
+
+__device__ __forceinline__ void acs_step(unsigned sb, const int (&old)[64], int (&nw)[64], uint2& dec)
+{
+  const unsigned v = sb & 15u, m = (sb >> 4) & 15u;
+  // agreement count of the 8 distinct code words (bit3 = bit0) with the received nibble
+  int bm[8];
+#pragma unroll
+  for (unsigned c = 0; c < 8; ++c) {
+    const unsigned cw = c | ((c & 1u) << 3);
+    bm[c] = __popc(~(v ^ cw) & m);
+  }
+  const int ntx = __popc(m);
+  uint32_t dlo = 0, dhi = 0;
+  all_butterflies(old, nw, bm, ntx, dlo, dhi, std::make_integer_sequence<int, 32>{});
+  dec = make_uint2(dlo, dhi);
+}
+
+// one wave (64 lanes) per group of 64 equal-length code words
+__global__ __launch_bounds__(64) void viterbi_kernel(const CodewordItem* __restrict__ items,
+                                                     const CodewordPlan* __restrict__ plans,
+                                                     const int* __restrict__ group_nsteps,
+                                                     const int64_t* __restrict__ group_base,      // step buffer, 16-byte units
+                                                     const int64_t* __restrict__ group_dec_base,  // decision buffer, steps
+                                                     const uint4* __restrict__ steps, uint2* __restrict__ decisions,
+                                                     const uint32_t* __restrict__ prbs_words, uint8_t* __restrict__ out,
+                                                     int record_stride)
+{
+  const int group = blockIdx.x, lane = threadIdx.x;
+  const int nsteps = group_nsteps[group];
+  const CodewordItem it = items[group * 64 + lane];
+  const uint4* my_steps = steps + group_base[group] * 64 + lane;
+  uint2* my_dec = decisions + group_dec_base[group] * 64 + lane;
+
+  int pm[64], pn[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) pm[i] = -1024;   // "unreachable" (viterbi.c:387-389, scaled)
+  pm[0] = 0;
+
+  const int n16 = (nsteps + 15) >> 4;
+  for (int t16 = 0; t16 < n16; ++t16) {
+    const uint4 pack = my_steps[static_cast<size_t>(t16) * 64];
+    const uint32_t w[4] = {pack.x, pack.y, pack.z, pack.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = 16 * t16 + 4 * q;
+      if (t >= nsteps) break;
+      uint2 d0, d1, d2, d3;
+      acs_step(w[q] & 0xff, pm, pn, d0);
+      acs_step((w[q] >> 8) & 0xff, pn, pm, d1);
+      acs_step((w[q] >> 16) & 0xff, pm, pn, d2);
+      acs_step(w[q] >> 24, pn, pm, d3);
+      // steps past nsteps (only in the last word) write into slack space of the buffer
+      my_dec[static_cast<size_t>(t) * 64] = d0;
+      my_dec[static_cast<size_t>(t + 1) * 64] = d1;
+      my_dec[static_cast<size_t>(t + 2) * 64] = d2;
+      my_dec[static_cast<size_t>(t + 3) * 64] = d3;
+    }
+  }
+  if (it.plan < 0) return;
+
+  // chain back from state 0 (viterbi.c:438-450), descramble, pack MSB first
+  const CodewordPlan pl = plans[it.plan];
+  uint32_t* dst = reinterpret_cast<uint32_t*>(out + static_cast<size_t>(it.out_record) * record_stride + pl.out_offset);
+  unsigned state = 0;
+  uint32_t acc = 0;
+  for (int t = nsteps - 1; t >= 6; --t) {
+    const uint2 d = my_dec[static_cast<size_t>(t) * 64];
+    const unsigned bit = ((state & 32u) ? (d.y >> (state & 31u)) : (d.x >> state)) & 1u;
+    state = (state | (bit << 6)) >> 1;
+    const int i = t - 6;                               // data bit index
+    acc |= bit << (8 * ((i >> 3) & 3) + (7 - (i & 7)));
+    if ((i & 31) == 0) {
+      dst[i >> 5] = acc ^ prbs_words[i >> 5];
+      acc = 0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// CRC of the 12 FIBs of each TF (misc.c:145-150)
+__device__ __forceinline__ uint16_t crc16_step(uint16_t crc, uint8_t byte, const uint16_t* tab)
+{
+  return static_cast<uint16_t>(tab[(byte ^ (crc >> 8)) & 0xff] ^ (crc << 8));
+}
+
+__global__ void fib_crc_kernel(const uint8_t* __restrict__ fibs, int nfib, const uint16_t* __restrict__ crc_tab,
+                               uint8_t* __restrict__ ok)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nfib) return;
+  const uint8_t* f = fibs + static_cast<size_t>(i) * 32;
+  uint16_t crc = 0xffff;
+  for (int k = 0; k < 32; ++k) crc = crc16_step(crc, f[k], crc_tab);
+  ok[i] = crc == 0x1d0f;
+}
+
+// one thread per ETI frame: header bytes (built by the host control plane, init_eti
+// misc.c:153-213), the 96 FIB bytes of the oldest CIF (misc.c:239), EOF CRC over FIC+MST,
+// RFU, TIST (misc.c:281-292).  The 0x55 padding was laid down by a memset beforehand.
+__global__ void eti_finish_kernel(const EtiFrameMeta* __restrict__ meta, int nframes, const uint8_t* __restrict__ headers,
+                                  const uint8_t* __restrict__ fibs, const uint16_t* __restrict__ crc_tab,
+                                  uint8_t* __restrict__ eti)
+{
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nframes) return;
+  const EtiFrameMeta m = meta[f];
+  uint8_t* e = eti + static_cast<size_t>(f) * kEtiBytes;
+  const uint8_t* h = headers + static_cast<size_t>(f) * kEtiHeaderMax;
+  for (int i = 0; i < m.header_len; ++i) e[i] = h[i];
+  const uint8_t* fb = fibs + static_cast<size_t>(m.fib_block) * 96;
+  uint16_t crc = 0xffff;
+  for (int i = 0; i < 96; ++i) {
+    e[m.header_len + i] = fb[i];
+    crc = crc16_step(crc, fb[i], crc_tab);
+  }
+  int pos = m.header_len + 96;
+  for (int i = 0; i < m.mst_bytes; ++i) crc = crc16_step(crc, e[pos + i], crc_tab);
+  pos += m.mst_bytes;
+  crc = static_cast<uint16_t>(~crc);
+  e[pos++] = static_cast<uint8_t>(crc >> 8);
+  e[pos++] = static_cast<uint8_t>(crc & 0xff);
+  for (int i = 0; i < 6; ++i) e[pos++] = 0xff;
+}
+
+}  // namespace
+
+hipError_t launch_gather(bool fic, const CodewordItem* items, const CodewordPlan* plans, const int* group_n16,
+                         const int64_t* group_base, int ngroups, int max_n16, const uint32_t* bits,
+                         const int* stream_cif_base, uint4* steps, hipStream_t stream)
+{
+  if (ngroups <= 0) return hipSuccess;
+  // grid.y is limited to 65535: slice the groups
+  for (int g0 = 0; g0 < ngroups; g0 += 32768) {
+    const int ng = min(32768, ngroups - g0);
+    dim3 grid((max_n16 + 3) / 4, ng);
+    if (fic)
+      hipLaunchKernelGGL(gather_kernel<true>, grid, dim3(256), 0, stream, items + static_cast<size_t>(g0) * 64, plans,
+                         group_n16 + g0, group_base + g0, ng, bits, stream_cif_base, steps);
+    else
+      hipLaunchKernelGGL(gather_kernel<false>, grid, dim3(256), 0, stream, items + static_cast<size_t>(g0) * 64, plans,
+                         group_n16 + g0, group_base + g0, ng, bits, stream_cif_base, steps);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_viterbi(const CodewordItem* items, const CodewordPlan* plans, const int* group_nsteps,
+                          const int64_t* group_base, const int64_t* group_dec_base, int ngroups, const uint4* steps,
+                          uint2* decisions, const uint32_t* prbs_words, uint8_t* out, int record_stride,
+                          hipStream_t stream)
+{
+  if (ngroups <= 0) return hipSuccess;
+  hipLaunchKernelGGL(viterbi_kernel, dim3(ngroups), dim3(64), 0, stream, items, plans, group_nsteps, group_base,
+                     group_dec_base, steps, decisions, prbs_words, out, record_stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_fib_crc(const uint8_t* fibs, int nfib, const uint16_t* crc_tab, uint8_t* ok, hipStream_t stream)
+{
+  if (nfib <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fib_crc_kernel, dim3((nfib + 255) / 256), dim3(256), 0, stream, fibs, nfib, crc_tab, ok);
+  return hipGetLastError();
+}
+
+hipError_t launch_eti_finish(const EtiFrameMeta* meta, int nframes, const uint8_t* headers, const uint8_t* fibs,
+                             const uint16_t* crc_tab, uint8_t* eti, hipStream_t stream)
+{
+  if (nframes <= 0) return hipSuccess;
+  hipLaunchKernelGGL(eti_finish_kernel, dim3((nframes + 127) / 128), dim3(128), 0, stream, meta, nframes, headers, fibs,
+                     crc_tab, eti);
+  return hipGetLastError();
+}
+
+}  // namespace dabhip

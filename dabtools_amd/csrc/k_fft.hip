@@ -1,0 +1,219 @@
+// k_fft.hip — K2: the OFDM stage.  76 x 2048-point forward DFTs per transmission frame,
+// cu8 IQ in, fftshifted complex64 spectra out (replaces the FFTW loop of
+// input_sdr.c:115-130 incl. the u8->s8 conversion of :60-63), and K2b: differential
+// demodulation + hard QPSK demap + frequency de-interleave (input_sdr.c:132-162) into
+// bit-packed FIC / MSC symbol rows.
+//
+// K2 is the HBM-roofline stage: per TF it must read 311,296 B of IQ and write 1,245,184 B
+// of spectra (1,556,480 B algorithmic) for 8.6 MFLOP, i.e. 5.5 flop/B -- far below the
+// machine balance, no dense contraction, no MFMA.  One 256-thread workgroup transforms one
+// symbol at a time entirely in registers + LDS: radix 8 x 8 x 8 x 4 decimation in
+// frequency, three LDS exchanges with conflict-free (padded) layouts, twiddles from an
+// LDS-resident table, coalesced 2-byte loads and 512-byte-per-wave stores.
+#include <hip/hip_runtime.h>
+
+#include "dab_tables.hpp"
+#include "device_types.hpp"
+#include "kernels.hpp"
+
+namespace dabhip {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kSymPerBlock = 19;                 // 76 symbols = 4 workgroups x 19
+constexpr int kEx2Stride = 260;                  // [q] stride of exchange 2 (8*32 + 4: bank skew)
+constexpr int kEx3Stride = 520;                  // [t''] stride of exchange 3 (512 + 8)
+constexpr int kExSize = 2080;                    // float2 per exchange buffer
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // * (-i)
+
+// 8-point forward DFT in registers: v[q] <- sum_r v[r] exp(-2 pi i r q / 8)
+__device__ __forceinline__ void dft8(float2 (&v)[8])
+{
+  constexpr float h = 0.70710678118654752440f;
+  float2 a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
+  float2 a1 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
+  float2 a2 = cadd(v[2], v[6]), a6 = csub(v[2], v[6]);
+  float2 a3 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
+  a5 = make_float2(h * (a5.x + a5.y), h * (a5.y - a5.x));      // * exp(-i pi/4)
+  a6 = mul_mi(a6);                                              // * exp(-i pi/2)
+  a7 = make_float2(h * (a7.y - a7.x), -h * (a7.x + a7.y));     // * exp(-3i pi/4)
+  float2 b0 = cadd(a0, a2), b2 = csub(a0, a2), b1 = cadd(a1, a3), b3 = mul_mi(csub(a1, a3));
+  float2 b4 = cadd(a4, a6), b6 = csub(a4, a6), b5 = cadd(a5, a7), b7 = mul_mi(csub(a5, a7));
+  v[0] = cadd(b0, b1); v[4] = csub(b0, b1); v[2] = cadd(b2, b3); v[6] = csub(b2, b3);
+  v[1] = cadd(b4, b5); v[5] = csub(b4, b5); v[3] = cadd(b6, b7); v[7] = csub(b6, b7);
+}
+
+__device__ __forceinline__ void dft4(float2& x0, float2& x1, float2& x2, float2& x3)
+{
+  const float2 d0 = cadd(x0, x2), d2 = csub(x0, x2), d1 = cadd(x1, x3), d3 = mul_mi(csub(x1, x3));
+  x0 = cadd(d0, d1); x2 = csub(d0, d1); x1 = cadd(d2, d3); x3 = csub(d2, d3);
+}
+
+__device__ __forceinline__ int view_byte(const uint8_t* stream, const FrameView& v, int p)
+{
+  int i = 0;
+  while (i < v.nseg - 1 && p >= v.seg_end[i]) ++i;
+  const int64_t s = v.seg_src[i];
+  return s < 0 ? 0 : stream[s + p];
+}
+__device__ __forceinline__ float rail(int byte) { return static_cast<float>(static_cast<int8_t>(static_cast<uint8_t>(byte - 127))); }
+
+// One 2048-point transform by the whole workgroup.  v holds x[tid + 256 r] on entry.
+__device__ __forceinline__ void fft2048_store(float2 (&v)[8], float2* exA, float2* exB, const float2* tw, float2* __restrict__ out)
+{
+  const int tid = threadIdx.x;
+  // stage 1: radix 8 over r, twiddle W_2048^(t q), exchange so that each thread owns one q
+  dft8(v);
+#pragma unroll
+  for (int q = 1; q < 8; ++q) v[q] = cmul(v[q], tw[tid * q]);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) exA[q * 256 + tid] = v[q];
+  __syncthreads();
+  {
+    const int q = tid >> 5, t1 = tid & 31;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = exA[q * 256 + t1 + 32 * r];
+    dft8(v);
+#pragma unroll
+    for (int q2 = 1; q2 < 8; ++q2) v[q2] = cmul(v[q2], tw[8 * t1 * q2]);
+#pragma unroll
+    for (int q2 = 0; q2 < 8; ++q2) exB[q * kEx2Stride + q2 * 32 + t1] = v[q2];
+  }
+  __syncthreads();
+  {
+    const int q = tid & 7, t2 = (tid >> 3) & 3, q2 = tid >> 5;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = exB[q * kEx2Stride + q2 * 32 + t2 + 4 * r];
+    dft8(v);
+#pragma unroll
+    for (int q3 = 1; q3 < 8; ++q3) v[q3] = cmul(v[q3], tw[64 * t2 * q3]);
+#pragma unroll
+    for (int q3 = 0; q3 < 8; ++q3) exA[t2 * kEx3Stride + q + 8 * q2 + 64 * q3] = v[q3];
+  }
+  __syncthreads();
+  // stage 4: radix 4 over t'', output bin k = p + 512 k''', written fftshifted
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int p = tid + 256 * half;
+    float2 x0 = exA[p], x1 = exA[kEx3Stride + p], x2 = exA[2 * kEx3Stride + p], x3 = exA[3 * kEx3Stride + p];
+    dft4(x0, x1, x2, x3);
+    out[(p + 1024) & 2047] = x0;
+    out[(p + 512 + 1024) & 2047] = x1;
+    out[(p + 1024 + 1024) & 2047] = x2;
+    out[(p + 1536 + 1024) & 2047] = x3;
+  }
+  __syncthreads();   // exA is rewritten by the next symbol's stage 1
+}
+
+// grid = (4 * nframes); frame j of the launch is frames[first + j] = {stream, call}
+__global__ __launch_bounds__(kThreads) void ofdm_fft_kernel(const uint8_t* const* __restrict__ iq,
+                                                            const CallDesc* __restrict__ descs, int max_calls,
+                                                            const int2* __restrict__ frames, int first,
+                                                            float2* __restrict__ spectra,
+                                                            const float2* __restrict__ tw_global)
+{
+  __shared__ float2 tw[2048];
+  __shared__ float2 exA[kExSize];
+  __shared__ float2 exB[kExSize];
+  __shared__ FrameView view;
+  const int tid = threadIdx.x;
+  const int j = blockIdx.x >> 2, part = blockIdx.x & 3;
+  const int2 fr = frames[first + j];
+  const uint8_t* stream = iq[fr.x];
+  for (int i = tid; i < 2048; i += kThreads) tw[i] = tw_global[i];
+  if (tid == 0) view = descs[static_cast<size_t>(fr.x) * max_calls + fr.y].view;
+  __syncthreads();
+  float2* out_tf = spectra + static_cast<size_t>(j) * (kSymbolsPerTf * 2048);
+
+  for (int sym = part * kSymPerBlock; sym < (part + 1) * kSymPerBlock; ++sym) {
+    const int start = 2 * (kNullSamples + kSymSamples * sym + kCpSamples);   // byte offset in the frame buffer
+    float2 v[8];
+    if (start + 4096 <= view.seg_end[0]) {
+      const uint16_t* src = reinterpret_cast<const uint16_t*>(stream + view.seg_src[0] + start);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const unsigned s = src[tid + 256 * r];
+        v[r] = make_float2(rail(s & 0xff), rail(s >> 8));
+      }
+    } else {   // window reaches into the stale tail of the reference's frame buffer
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int p = start + 2 * (tid + 256 * r);
+        v[r] = make_float2(rail(view_byte(stream, view, p)), rail(view_byte(stream, view, p + 1)));
+      }
+    }
+    fft2048_store(v, exA, exB, tw, out_tf + static_cast<size_t>(sym) * 2048);
+  }
+}
+
+// ---- K2b ----------------------------------------------------------------------------------
+// grid = 15 * nframes: workgroup g handles data symbols 1 + 5 (g % 15) .. 5 + 5 (g % 15)
+// of frame g / 15.  Carrier c (0..1535, ascending frequency) sits at fftshifted bin
+// 256 + c (c < 768) or 257 + c.
+__global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restrict__ spectra,
+                                                         const int2* __restrict__ frames, int first,
+                                                         const int* __restrict__ frame_slot,
+                                                         const uint16_t* __restrict__ qpsk_of_carrier,
+                                                         uint32_t* __restrict__ fic_bits, uint32_t* __restrict__ msc_bits)
+{
+  __shared__ uint8_t bits[kBitsPerSym];
+  const int tid = threadIdx.x;
+  const int j = blockIdx.x / 15, grp = blockIdx.x % 15;
+  const int slot = frame_slot[first + j];                 // global TF slot of this frame
+  const float2* tf = spectra + static_cast<size_t>(j) * (kSymbolsPerTf * 2048);
+  int bin[6], qk[6];
+  float2 prev[6];
+#pragma unroll
+  for (int m = 0; m < 6; ++m) {
+    const int c = tid + 256 * m;
+    bin[m] = c < 768 ? 256 + c : 257 + c;
+    qk[m] = qpsk_of_carrier[c];
+    prev[m] = tf[(5 * grp) * 2048 + bin[m]];
+  }
+  for (int l = 5 * grp + 1; l <= 5 * grp + 5; ++l) {
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+      const float2 cur = tf[l * 2048 + bin[m]];
+      const float re = cur.x * prev[m].x + cur.y * prev[m].y;     // Re(cur conj(prev))
+      const float im = cur.x * prev[m].y - cur.y * prev[m].x;     // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
+      bits[qk[m]] = (re > 0.0f) ? 0 : 1;                          // input_sdr.c:157
+      bits[1536 + qk[m]] = (im > 0.0f) ? 1 : 0;                   // input_sdr.c:158
+      prev[m] = cur;
+    }
+    __syncthreads();
+    if (tid < 96) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int b = 0; b < 32; ++b) w |= static_cast<uint32_t>(bits[32 * tid + b]) << b;
+      if (l <= 3) fic_bits[static_cast<size_t>(slot) * 288 + (l - 1) * 96 + tid] = w;
+      else msc_bits[static_cast<size_t>(slot) * 6912 + (l - 4) * 96 + tid] = w;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+hipError_t launch_ofdm_fft(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first,
+                           int nframes, float2* spectra, const float2* tw, hipStream_t stream)
+{
+  if (nframes <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ofdm_fft_kernel, dim3(4 * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first,
+                     spectra, tw);
+  return hipGetLastError();
+}
+
+hipError_t launch_demap(const float2* spectra, const int2* frames, int first, int nframes, const int* frame_slot,
+                        const uint16_t* qpsk_of_carrier, uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream)
+{
+  if (nframes <= 0) return hipSuccess;
+  hipLaunchKernelGGL(demap_kernel, dim3(15 * nframes), dim3(kThreads), 0, stream, spectra, frames, first, frame_slot,
+                     qpsk_of_carrier, fic_bits, msc_bits);
+  return hipGetLastError();
+}
+
+}  // namespace dabhip

@@ -1,0 +1,343 @@
+// k_sync.hip — K1: per-stream synchronisation scan.
+//
+// Replaces, for every 262144-byte call of sdr_demod (input_sdr.c:27-112): the FIFO
+// bookkeeping of sdr_fifo.c:26-61 (in closed form, as views into the resident IQ stream),
+// dab_coarse_time_sync (sdr_sync.c:34-68), dab_fine_time_sync (:71-202),
+// dab_coarse_freq_sync_2 (:205-258) and dab_fine_freq_corr (:259-302).
+//
+// The chain is sequential per stream (the timing correction found in TF n positions TF
+// n+1) and independent across streams, so one 256-thread workgroup owns one stream for
+// the whole scan: no inter-workgroup traffic, B workgroups in flight.  Arithmetic is fp64
+// like the reference's FFTW calls (two 2048-point DFTs, one 1536-point and 29 128-point
+// inverse DFTs per TF); arg-max decisions use the reference's float compare, first hit wins.
+#include <hip/hip_runtime.h>
+
+#include "dab_tables.hpp"
+#include "device_types.hpp"
+#include "kernels.hpp"
+
+namespace dabhip {
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ int view_byte(const uint8_t* stream, const FrameView& v, int p)
+{
+  int i = 0;
+  while (i < v.nseg - 1 && p >= v.seg_end[i]) ++i;
+  const int64_t s = v.seg_src[i];
+  return s < 0 ? 0 : stream[s + p];
+}
+// u8 -> s8 with DC offset 127 and int8 wrap (input_sdr.c:60-63)
+__device__ __forceinline__ int rail(int byte) { return static_cast<int>(static_cast<int8_t>(static_cast<uint8_t>(byte - 127))); }
+
+__device__ __forceinline__ unsigned brev(unsigned x, int bits) { return __brev(x) >> (32 - bits); }
+
+// nbatch independent DFTs of size N = 1 << LOGN stored back to back in LDS, radix-2
+// decimation in frequency, in place; X[k] ends up at index brev(k).  sign = -1 forward.
+template <int LOGN>
+__device__ void dft_dif(double2* buf, int nbatch, double sign, const double2* __restrict__ tw2048)
+{
+  constexpr int N = 1 << LOGN;
+  for (int s = 0; s < LOGN; ++s) {
+    const int half = N >> (s + 1);
+    for (int idx = threadIdx.x; idx < nbatch * (N / 2); idx += kThreads) {
+      const int batch = idx / (N / 2), j = idx % (N / 2);
+      const int blk = j / half, k = j % half;
+      const int a = batch * N + blk * 2 * half + k, b = a + half;
+      const double2 A = buf[a], B = buf[b];
+      double2 w = tw2048[k * (1024 / half)];
+      w.y *= sign;
+      const double dr = A.x - B.x, di = A.y - B.y;
+      buf[a] = make_double2(A.x + B.x, A.y + B.y);
+      buf[b] = make_double2(dr * w.x - di * w.y, dr * w.y + di * w.x);
+    }
+    __syncthreads();
+  }
+}
+
+struct Red {
+  float fv[kThreads];
+  int iv[kThreads];
+  double dv[kThreads];
+};
+
+// arg-max with the reference's semantics (strict '>' scanning upwards: lowest index wins ties)
+__device__ void block_argmax(Red& r, float v, int idx, float* out_v, int* out_i)
+{
+  r.fv[threadIdx.x] = v;
+  r.iv[threadIdx.x] = idx;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      const float ov = r.fv[threadIdx.x + s];
+      const int oi = r.iv[threadIdx.x + s];
+      if (ov > r.fv[threadIdx.x] || (ov == r.fv[threadIdx.x] && oi < r.iv[threadIdx.x])) { r.fv[threadIdx.x] = ov; r.iv[threadIdx.x] = oi; }
+    }
+    __syncthreads();
+  }
+  *out_v = r.fv[0];
+  *out_i = r.iv[0];
+  __syncthreads();
+}
+
+__device__ int block_sum_int(Red& r, int v)
+{
+  r.iv[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) r.iv[threadIdx.x] += r.iv[threadIdx.x + s];
+    __syncthreads();
+  }
+  const int out = r.iv[0];
+  __syncthreads();
+  return out;
+}
+
+__device__ double block_sum_double(Red& r, double v)
+{
+  r.dv[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) r.dv[threadIdx.x] += r.dv[threadIdx.x + s];
+    __syncthreads();
+  }
+  const double out = r.dv[0];
+  __syncthreads();
+  return out;
+}
+
+// multiply by conj(PRS value): quarter turns q = 0..3 <-> 1, j, -1, -j
+__device__ __forceinline__ double2 mul_conj_prs(double2 x, int q)
+{
+  switch (q & 3) {
+    case 0: return x;
+    case 1: return make_double2(x.y, -x.x);
+    case 2: return make_double2(-x.x, -x.y);
+    default: return make_double2(-x.y, x.x);
+  }
+}
+
+struct Shared {
+  StreamState st;
+  Red red;
+  int status, do_sync, fifo_count;
+  int coarse_fs;
+  double fine_fs;
+};
+
+__global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* const* __restrict__ iq,
+                                                             const int64_t* __restrict__ nbytes,
+                                                             StreamState* __restrict__ states,
+                                                             CallDesc* __restrict__ descs, int max_calls, int call_begin,
+                                                             int call_end, const double2* __restrict__ tw2048,
+                                                             const double2* __restrict__ tw1536,
+                                                             const uint8_t* __restrict__ prs_q)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double2* A = reinterpret_cast<double2*>(smem);   // 2048: main DFT buffer
+  double2* Bf = A + 2048;                            // 3712: 3 x 512 or 29 x 128 batch buffer
+  Shared& sh = *reinterpret_cast<Shared*>(Bf + 29 * 128);
+  uint8_t* env = reinterpret_cast<uint8_t*>(Bf);     // 19660 bytes, coarse search only
+
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const uint8_t* stream = iq[b];
+  const int64_t total_calls = nbytes[b] / kChunkBytes;
+  const int kend = call_end < 0 ? static_cast<int>(total_calls) : min(call_end, static_cast<int>(total_calls));
+  if (tid == 0) { sh.st = states[b]; sh.fine_fs = sh.st.fine_freq_shift; }
+  __syncthreads();
+
+  for (int k = call_begin; k < kend; ++k) {
+    // ---- FIFO bookkeeping: input_sdr.c:36-55 over sdr_fifo.c:43-61 --------------------
+    if (tid == 0) {
+      StreamState& st = sh.st;
+      st.fed += kChunkBytes;
+      int64_t count = st.fed - st.consumed;
+      sh.status = 0;
+      sh.do_sync = 0;
+      sh.coarse_fs = 0;
+      if (count >= 3 * kTfSamples) {
+        const int shift = st.coarse_timeshift + st.fine_timeshift;
+        int len;
+        if (shift > 0) {
+          st.consumed += shift;
+          count -= shift;
+          len = count < kTfBytes ? static_cast<int>(count) : kTfBytes;
+        } else {
+          len = kTfBytes + shift;
+        }
+        FrameView nv;
+        int n = 1;
+        nv.seg_end[0] = len;
+        nv.seg_src[0] = st.consumed;
+        for (int i = 0; i < st.view.nseg; ++i) {
+          if (st.view.seg_end[i] > len) {
+            if (n < kMaxSeg) { nv.seg_end[n] = st.view.seg_end[i]; nv.seg_src[n] = st.view.seg_src[i]; ++n; }
+            else st.overflow = 1;
+          }
+        }
+        nv.nseg = n;
+        for (int i = n; i < kMaxSeg; ++i) { nv.seg_end[i] = kTfBytes; nv.seg_src[i] = -1; }
+        st.view = nv;
+        st.consumed += len;
+        count -= len;
+        sh.status = 1;
+        if (st.startup_delay <= 0) st.startup_delay++;   // input_sdr.c:51-55, GAIN_SETTLE_TIME 0
+        else sh.do_sync = 1;
+      }
+      sh.fifo_count = static_cast<int>(count);
+    }
+    __syncthreads();
+
+    if (sh.do_sync) {
+      const FrameView& view = sh.st.view;
+      // ---- coarse time: sdr_sync.c:34-68 ------------------------------------------------
+      int e = 0;
+      for (int n = tid; n < 266; n += kThreads) e += abs(rail(view_byte(stream, view, 20 * n)));
+      e = block_sum_int(sh.red, e);
+      int coarse = 0;
+      if (!(e < 5000 && sh.st.force_timesync == 0)) {
+        // envelope a[n] = |real[10 n]|, window sums of 266 taps, first minimum
+        constexpr int kEnv = (kTfSamples - kNullSamples) / 10 + 266;   // 19661
+        constexpr int kWin = (kTfSamples - kNullSamples) / 10;        // 19395 windows examined
+        for (int n = tid; n < kEnv; n += kThreads) env[n] = static_cast<uint8_t>(abs(rail(view_byte(stream, view, 20 * n))));
+        __syncthreads();
+        const int per = (kWin + kThreads - 1) / kThreads;
+        const int m0 = tid * per, m1 = min(m0 + per, kWin);
+        float best = 9999999.0f;
+        int bestm = 0x7fffffff;
+        if (m0 < m1) {
+          int s = 0;
+          for (int q = 0; q < 266; ++q) s += env[m0 + q];
+          for (int m = m0; m < m1; ++m) {
+            if (static_cast<float>(s) < best) { best = static_cast<float>(s); bestm = m; }
+            s += env[m + 266] - env[m];
+          }
+        }
+        // arg-min, lowest index wins ties: arg-max of the negated value
+        float bv;
+        int bi;
+        block_argmax(sh.red, -best, bestm, &bv, &bi);
+        coarse = (-bv < 9999999.0f) ? bi * 20 : 0;
+      }
+      __syncthreads();
+      if (tid == 0) { sh.st.coarse_timeshift = coarse; sh.st.force_timesync = 0; }
+      __syncthreads();
+
+      if (coarse == 0) {
+        // ---- fine time: sdr_sync.c:71-202 -------------------------------------------------
+        for (int n = tid; n < 2048; n += kThreads) {
+          const int p = 2 * (kNullSamples + kCpSamples + n);
+          A[n] = make_double2(rail(view_byte(stream, view, p)), rail(view_byte(stream, view, p + 1)));
+        }
+        __syncthreads();
+        dft_dif<11>(A, 1, -1.0, tw2048);
+        for (int i = tid; i < kCarriers; i += kThreads) {
+          const int bin = i < 768 ? i + 1280 : i - 765;
+          const double2 c = mul_conj_prs(A[brev(bin, 11)], prs_q[i]);
+          Bf[(i % 3) * 512 + i / 3] = c;       // decimate by 3 for the 3 x 512 inverse DFT
+        }
+        __syncthreads();
+        dft_dif<9>(Bf, 3, +1.0, tw2048);
+        float fv = -99999.0f;
+        int fi = 0x7fffffff;
+        for (int kk = tid; kk < kCarriers; kk += kThreads) {
+          const int r = brev(kk & 511, 9);
+          const double2 f0 = Bf[r], f1 = Bf[512 + r], f2 = Bf[1024 + r];
+          const double2 w1 = tw1536[kk], w2 = tw1536[(2 * kk) % 1536];
+          const double xr = f0.x + (f1.x * w1.x - f1.y * w1.y) + (f2.x * w2.x - f2.y * w2.y);
+          const double xi = f0.y + (f1.x * w1.y + f1.y * w1.x) + (f2.x * w2.y + f2.y * w2.x);
+          const float mag = static_cast<float>(sqrt(xr * xr + xi * xi));
+          if (mag > fv) { fv = mag; fi = kk; }     // kk ascending per thread: first maximum kept
+        }
+        float gv;
+        int gi;
+        block_argmax(sh.red, fv, fi, &gv, &gi);
+        const int fine = gi < 768 ? gi * 2 + 16 : (gi - 1536) * 2;
+        if (tid == 0) sh.st.fine_timeshift = fine;
+
+        // ---- coarse frequency: input_sdr.c:90-109, sdr_sync.c:205-258 ---------------------
+        for (int n = tid; n < 2048; n += kThreads) {
+          const int p = 2 * (kNullSamples + kCpSamples + 1 + fine + n);
+          A[n] = make_double2(rail(view_byte(stream, view, p)), rail(view_byte(stream, view, p + 1)));
+        }
+        __syncthreads();
+        dft_dif<11>(A, 1, -1.0, tw2048);
+        for (int idx = tid; idx < 29 * 128; idx += kThreads) {
+          const int kk = idx / 128 - 14, s = idx % 128;
+          const int shifted = 14 + kk + 256 + s;              // index into the fftshifted spectrum
+          const int bin = (shifted + 1024) & 2047;
+          Bf[idx] = mul_conj_prs(A[brev(bin, 11)], prs_q[14 + s]);
+        }
+        __syncthreads();
+        dft_dif<7>(Bf, 29, +1.0, tw2048);
+        // per-offset maximum |.|, then first maximum over offsets
+        float cv = -99999.0f;
+        int ci = 0x7fffffff;
+        for (int idx = tid; idx < 29 * 128; idx += kThreads) {
+          const double2 x = Bf[idx];
+          const float mag = static_cast<float>(sqrt(x.x * x.x + x.y * x.y));
+          if (mag > cv) { cv = mag; ci = idx / 128; }        // idx ascending per thread
+        }
+        float hv;
+        int hi;
+        block_argmax(sh.red, cv, ci, &hv, &hi);
+        const int cfs = hi - 14;
+        if (tid == 0) sh.coarse_fs = cfs;
+        if (abs(cfs) > 1) {
+          if (tid == 0) sh.st.force_timesync = 1;
+        } else {
+          // ---- fine frequency (estimate only): sdr_sync.c:259-302 -------------------------
+          double acc = 0;
+          for (int n = tid; n < kCpSamples; n += kThreads) {
+            const int pl = 2 * (kNullSamples + 2048 + n), pr = 2 * (kNullSamples + n);
+            const double lr = rail(view_byte(stream, view, pl)), li = rail(view_byte(stream, view, pl + 1));
+            const double rr = rail(view_byte(stream, view, pr)), ri = rail(view_byte(stream, view, pr + 1));
+            acc += atan2(-lr * ri + li * rr, lr * rr + li * ri);
+          }
+          acc = block_sum_double(sh.red, acc);
+          if (tid == 0) {
+            sh.fine_fs = acc / 504 / (2 * M_PI) * 1000;
+            sh.status = 2;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      CallDesc& d = descs[static_cast<size_t>(b) * max_calls + k];
+      d.status = sh.status;
+      d.ordinal = sh.status == 2 ? sh.st.next_ordinal++ : -1;
+      d.coarse_timeshift = sh.st.coarse_timeshift;
+      d.fine_timeshift = sh.st.fine_timeshift;
+      d.coarse_freq_shift = sh.coarse_fs;
+      d.fifo_count = sh.fifo_count;
+      d.fine_freq_shift = sh.fine_fs;
+      d.view = sh.st.view;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { sh.st.fine_freq_shift = sh.fine_fs; states[b] = sh.st; }
+}
+
+}  // namespace
+
+size_t sync_scan_lds_bytes() { return sizeof(double2) * (2048 + 29 * 128) + sizeof(Shared); }
+
+hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, StreamState* states, CallDesc* descs,
+                            int nstreams, int max_calls, int call_begin, int call_end, const double2* tw2048,
+                            const double2* tw1536, const uint8_t* prs_q, hipStream_t stream)
+{
+  static bool attr_set = false;
+  const size_t lds = sync_scan_lds_bytes();
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(sync_scan_kernel, dim3(nstreams), dim3(kThreads), lds, stream, iq, nbytes, states, descs, max_calls,
+                     call_begin, call_end, tw2048, tw1536, prs_q);
+  return hipGetLastError();
+}
+
+}  // namespace dabhip

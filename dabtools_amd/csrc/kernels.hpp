@@ -1,0 +1,43 @@
+// kernels.hpp — host-callable launchers of the HIP kernels (k_sync.hip, k_fft.hip, k_decode.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "device_types.hpp"
+
+namespace dabhip {
+
+// K1: synchronisation scan, one workgroup per stream, calls [call_begin, call_end) (call_end < 0: all)
+hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, StreamState* states, CallDesc* descs,
+                            int nstreams, int max_calls, int call_begin, int call_end, const double2* tw2048,
+                            const double2* tw1536, const uint8_t* prs_q, hipStream_t stream);
+
+// K2: 76 x 2048-point DFT of frames[first .. first+nframes) -> spectra[nframes][76][2048]
+hipError_t launch_ofdm_fft(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first,
+                           int nframes, float2* spectra, const float2* tw, hipStream_t stream);
+
+// K2b: DQPSK + demap + frequency de-interleave -> bit-packed rows at TF slot frame_slot[first + j]
+hipError_t launch_demap(const float2* spectra, const int2* frames, int first, int nframes, const int* frame_slot,
+                        const uint16_t* qpsk_of_carrier, uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream);
+
+// K3/K4a: time de-interleave + de-puncture gather into per-step bytes
+hipError_t launch_gather(bool fic, const CodewordItem* items, const CodewordPlan* plans, const int* group_n16,
+                         const int64_t* group_base, int ngroups, int max_n16, const uint32_t* bits,
+                         const int* stream_cif_base, uint4* steps, hipStream_t stream);
+
+// K3/K4b: Viterbi forward pass + chain-back + descramble + pack
+hipError_t launch_viterbi(const CodewordItem* items, const CodewordPlan* plans, const int* group_nsteps,
+                          const int64_t* group_base, const int64_t* group_dec_base, int ngroups, const uint4* steps,
+                          uint2* decisions, const uint32_t* prbs_words, uint8_t* out, int record_stride,
+                          hipStream_t stream);
+
+hipError_t launch_fib_crc(const uint8_t* fibs, int nfib, const uint16_t* crc_tab, uint8_t* ok, hipStream_t stream);
+
+// K5: ETI header/FIB copy, EOF CRC, trailer
+hipError_t launch_eti_finish(const EtiFrameMeta* meta, int nframes, const uint8_t* headers, const uint8_t* fibs,
+                             const uint16_t* crc_tab, uint8_t* eti, hipStream_t stream);
+
+}  // namespace dabhip

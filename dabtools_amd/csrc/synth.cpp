@@ -177,13 +177,16 @@ void fic_bits_of_cif(const dabhip_synth_cfg& cfg, int cif, uint8_t* bits2304)
 // in-place radix-2 complex DFT, sign = +1 for the synthesis direction
 void fft2048(double* re, double* im, int sign)
 {
-  static std::vector<double> wr, wi;
-  const int n = 2048;
-  if (wr.empty()) {
-    wr.resize(n / 2);
-    wi.resize(n / 2);
-    for (int k = 0; k < n / 2; ++k) { wr[k] = std::cos(2 * M_PI * k / n); wi[k] = std::sin(2 * M_PI * k / n); }
-  }
+  constexpr int n = 2048;
+  struct Twiddles {
+    std::vector<double> r, i;
+    Twiddles() : r(n / 2), i(n / 2)
+    {
+      for (int k = 0; k < n / 2; ++k) { r[k] = std::cos(2 * M_PI * k / n); i[k] = std::sin(2 * M_PI * k / n); }
+    }
+  };
+  static const Twiddles tw;   // thread-safe one-time initialisation
+  const std::vector<double>&wr = tw.r, &wi = tw.i;
   for (int i = 1, j = 0; i < n; ++i) {
     int bit = n >> 1;
     for (; j & bit; bit >>= 1) j ^= bit;
@@ -285,7 +288,6 @@ extern "C" int64_t dabhip_synth_generate(const dabhip_synth_cfg* cfg, int ntf, u
   static const int tmap[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
   const auto& qpsk_of_carrier = carrier_to_qpsk();
   const auto& prs = prs_quarter_turns();
-  const int ncif = ntf * 4;
   // logical CIFs -15 .. ncif-1, kept in a sliding window of 16
   std::vector<std::vector<uint8_t>> window(16, std::vector<uint8_t>(kCifBits));
   for (int r = -15; r < 0; ++r) logical_cif(*cfg, r, window[(r + 16) & 15].data());
