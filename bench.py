@@ -33,8 +33,11 @@ def make_streams(torch, dev, nstreams, ntf, ndistinct, rank):
     """ndistinct different synthetic ensembles generated on the host cores, tiled to nstreams on the device."""
     import dabtools_amd as dab
 
-    def gen(i):
-        cfg = dab.synth_preset(0, seed=1000 * 2 + 256 * rank + i, cif_count0=(97 * i) % 5000)
+    from dabtools_amd import shard
+
+    def gen(i):   # global stream index of this rank's i-th distinct ensemble -> seed rule of SURVEY.md 8(d)
+        g = rank * nstreams + i
+        cfg = dab.synth_preset(0, seed=shard.stream_seed(2, g), cif_count0=(97 * g) % 5000)
         return dab.synth_generate(cfg, ntf)
 
     with ThreadPoolExecutor(max_workers=min(8, ndistinct)) as ex:
@@ -74,6 +77,7 @@ def main():
 
     import torch
     import dabtools_amd as dab
+    from dabtools_amd import shard
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -90,10 +94,7 @@ def main():
     eng = dab.Engine(local_rank)
 
     def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        shard.barrier(dev)
 
     frames = 0
     for _ in range(args.warmup):
@@ -113,15 +114,7 @@ def main():
             stage[k] = stage.get(k, 0.0) + v
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        f = torch.tensor([frames], dtype=torch.int64, device=dev)
-        dist.all_reduce(f, op=dist.ReduceOp.SUM)
-        total_frames_per_step = int(f.item())
-    else:
-        total_frames_per_step = frames
+    elapsed, total_frames_per_step = shard.aggregate(elapsed, frames, dev)
 
     if rank == 0:
         value = total_frames_per_step * args.steps / elapsed

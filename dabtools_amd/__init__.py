@@ -74,6 +74,9 @@ _SIGNATURES = {
     "dabhip_stage_ofdm_fft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "dabhip_stage_demap": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, u8p, u8p]),
     "dabhip_stage_fic_decode": (C.c_int, [C.c_void_p, u8p, C.c_int, u8p, u8p]),
+    "dabhip_host_parse_fibs": (C.c_int, [u8p, u8p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "dabhip_host_eti_header": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), u8p, C.c_int]),
+    "dabhip_host_control_replay": (C.c_int, [u8p, u8p, C.c_int, C.POINTER(C.c_int32), u8p, C.POINTER(C.c_int32), C.c_int]),
     "dabhip_synth_preset": (C.c_int, [C.c_int, C.POINTER(SynthCfg)]),
     "dabhip_synth_bytes": (C.c_size_t, [C.POINTER(SynthCfg), C.c_int]),
     "dabhip_synth_generate": (C.c_int64, [C.POINTER(SynthCfg), C.c_int, u8p, C.c_size_t]),
@@ -156,6 +159,40 @@ def synth_fibs(cfg, cif_index):
     buf = np.zeros(96, dtype=np.uint8)
     _need(lib().dabhip_synth_fibs(C.byref(cfg), cif_index, _p(buf)) == 96, "synth_fibs")
     return buf
+
+
+# ---- host-side control plane (no GPU needed) ----------------------------------------------------
+def host_parse_fibs(fibs, crc_ok):
+    fibs = np.ascontiguousarray(fibs, dtype=np.uint8)
+    crc_ok = np.ascontiguousarray(crc_ok, dtype=np.uint8)
+    hdr = np.zeros(3, dtype=np.int32)
+    sub = np.zeros((64, 8), dtype=np.int32)
+    _need(lib().dabhip_host_parse_fibs(_p(fibs), _p(crc_ok), hdr.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       sub.ctypes.data_as(C.POINTER(C.c_int32))) == 0, "host_parse_fibs")
+    return hdr, sub
+
+
+def host_eti_header(hdr, sub):
+    hdr = np.ascontiguousarray(hdr, dtype=np.int32)
+    sub = np.ascontiguousarray(sub, dtype=np.int32)
+    out = np.zeros(272, dtype=np.uint8)
+    n = lib().dabhip_host_eti_header(hdr.ctypes.data_as(C.POINTER(C.c_int32)), sub.ctypes.data_as(C.POINTER(C.c_int32)), _p(out), out.size)
+    _need(n > 0, "host_eti_header")
+    return out[:n].copy()
+
+
+def host_control_replay(fibs, crc_ok):
+    fibs = np.ascontiguousarray(fibs, dtype=np.uint8).reshape(-1, 384)
+    crc_ok = np.ascontiguousarray(crc_ok, dtype=np.uint8).reshape(-1, 12)
+    ntf = fibs.shape[0]
+    cap = 4 * ntf + 4
+    first = np.zeros(cap, dtype=np.int32)
+    hlen = np.zeros(cap, dtype=np.int32)
+    hdrs = np.zeros((cap, 272), dtype=np.uint8)
+    n = lib().dabhip_host_control_replay(_p(fibs), _p(crc_ok), ntf, first.ctypes.data_as(C.POINTER(C.c_int32)), _p(hdrs),
+                                         hlen.ctypes.data_as(C.POINTER(C.c_int32)), cap)
+    _need(n >= 0, "host_control_replay")
+    return first[:n], [hdrs[i, :hlen[i]].copy() for i in range(n)]
 
 
 # ---- S1 -----------------------------------------------------------------------------------------

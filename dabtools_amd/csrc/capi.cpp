@@ -275,3 +275,58 @@ int dabhip_dab_process_frame(dabhip_dab* d)
 }
 
 }  // extern "C"
+
+// ---- host-side control plane without a GPU -----------------------------------------------------------
+namespace {
+void sub_to_row(const SubChannel& s, int32_t* o)
+{
+  o[0] = s.id; o[1] = s.slform; o[2] = s.uep_index; o[3] = s.start_cu;
+  o[4] = s.size_cu; o[5] = s.bitrate; o[6] = s.protlev; o[7] = s.ascty;
+}
+}  // namespace
+
+extern "C" {
+
+int dabhip_host_parse_fibs(const uint8_t* fibs, const uint8_t* crc_ok, int32_t* hdr3, int32_t* sub)
+{
+  if (!fibs || !crc_ok || !hdr3 || !sub) { set_error("host_parse_fibs: null argument"); return -1; }
+  EnsembleInfo info;
+  decode_fibs(info, fibs, crc_ok);
+  hdr3[0] = info.eid; hdr3[1] = info.cif_hi; hdr3[2] = info.cif_lo;
+  for (int i = 0; i < 64; ++i) sub_to_row(info.sub[i], sub + 8 * i);
+  return 0;
+}
+
+int dabhip_host_eti_header(const int32_t* hdr3, const int32_t* sub, uint8_t* out, int cap)
+{
+  if (!hdr3 || !sub || !out || cap < kEtiHeaderMax) { set_error("host_eti_header: bad argument"); return -1; }
+  EnsembleInfo info;
+  info.eid = static_cast<uint16_t>(hdr3[0]);
+  info.cif_hi = static_cast<uint8_t>(hdr3[1]);
+  info.cif_lo = static_cast<uint8_t>(hdr3[2]);
+  for (int i = 0; i < 64; ++i) {
+    const int32_t* r = sub + 8 * i;
+    SubChannel& s = info.sub[i];
+    s.id = r[0]; s.slform = r[1]; s.uep_index = r[2]; s.start_cu = r[3];
+    s.size_cu = r[4]; s.bitrate = r[5]; s.protlev = r[6]; s.ascty = r[7];
+  }
+  return build_eti_header(out, info);
+}
+
+int dabhip_host_control_replay(const uint8_t* fibs, const uint8_t* crc_ok, int ntf, int32_t* first_cif, uint8_t* headers,
+                               int32_t* header_len, int cap_frames)
+{
+  if (!fibs || !crc_ok || !first_cif || !headers || !header_len) { set_error("host_control_replay: null argument"); return -1; }
+  ControlPlane plane;
+  std::vector<EtiJob> jobs;
+  for (int t = 0; t < ntf; ++t) plane.on_tf(t, fibs + static_cast<size_t>(t) * 384, crc_ok + static_cast<size_t>(t) * 12, jobs);
+  const int n = static_cast<int>(jobs.size());
+  for (int i = 0; i < n && i < cap_frames; ++i) {
+    first_cif[i] = jobs[i].first_cif;
+    header_len[i] = jobs[i].header_len;
+    std::memcpy(headers + static_cast<size_t>(i) * kEtiHeaderMax, jobs[i].header, kEtiHeaderMax);
+  }
+  return n;
+}
+
+}  // extern "C"

@@ -129,6 +129,20 @@ int dabhip_stage_demap(dabhip_engine *e, const float *spectra, int nframes, uint
 /* FIC decode of nframes TFs (fic.c:160-208): 9216 demapped bytes each -> 12x32 FIB bytes + 12 flags each. */
 int dabhip_stage_fic_decode(dabhip_engine *e, const uint8_t *fic, int nframes, uint8_t *fibs, uint8_t *crc_ok);
 
+/* ---- host-side control plane, callable without a GPU (used by the CPU test-suite) ------ */
+/* FIG 0/0, 0/1, 0/2 parse of the 12 FIBs of one TF (fib_decode, fic.c:132-147).
+ * hdr3 = {EId, CIFCount_hi, CIFCount_lo}; sub = 64 rows of
+ * {id, slForm, uep_index, start_cu, size, bitrate, protlev, ASCTy}. */
+int dabhip_host_parse_fibs(const uint8_t *fibs, const uint8_t *crc_ok, int32_t *hdr3, int32_t *sub);
+/* ETI(NI) header (init_eti, misc.c:153-213) from the same table layout; returns its length. */
+int dabhip_host_eti_header(const int32_t *hdr3, const int32_t *sub, uint8_t *out, int cap);
+/* Lock FSM + 16-CIF ring + header sequence (dab_process_frame, dab.c:35-98) over ntf TFs
+ * given their decoded FIBs (ntf x 384 bytes) and CRC flags (ntf x 12).  For each ETI frame
+ * it would emit, writes first_cif[i] (linear index of the oldest CIF) and the header bytes
+ * (272-byte rows) + lengths.  Returns the number of ETI frames. */
+int dabhip_host_control_replay(const uint8_t *fibs, const uint8_t *crc_ok, int ntf, int32_t *first_cif,
+                               uint8_t *headers, int32_t *header_len, int cap_frames);
+
 /* ---- synthetic Mode-I modulator (host only) --------------------------------------------- */
 typedef struct dabhip_subch_cfg {
   int32_t id;          /* SubChId 0..63 */

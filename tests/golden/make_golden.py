@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures from the REAL reference back end.
+
+Run in the build container (needs /root/reference): builds oracle/_ref from the reference's
+own unmodified sources (oracle/Makefile), drives it through oracle/ref_harness.c and stores
+inputs + the reference's outputs as small .npz files next to this script.  The fixtures are
+data only (inputs and expected outputs); no reference source text is stored.
+
+    python tests/golden/make_golden.py
+"""
+import ctypes as C
+import hashlib
+import os
+import re
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import oracle_lib as ol  # noqa: E402
+from oracle_lib import _ptr  # noqa: E402
+
+
+def main():
+    R = ol.ref()
+    assert R is not None, "reference not available"
+    O = ol.oracle()
+    H = R.refh_new()
+    rng = np.random.default_rng(20240607)
+
+    # ---- tables --------------------------------------------------------------------------
+    rev = np.ctypeslib.as_array(R.refh_rev_freq_deint_tab(), (1536,)).copy()
+    pvec = np.frombuffer(C.string_at(R.refh_pvec(), 24 * 32), dtype=np.uint8).reshape(24, 32).copy()
+    uep = np.zeros((64, 11), np.int32)
+    for i in range(64):
+        row = (C.c_int * 11)()
+        R.refh_uep_row(i, row)
+        uep[i] = list(row)
+    # PRS phases: data extracted from the reference's constant table (values in {1,j,-1,-j} as quarter turns)
+    txt = open("/root/reference/src/sdr_prstab.c").read()
+    vals = re.findall(r"\{\s*(-?\d+)\s*,\s*(-?\d+)\s*\}", txt)
+    prs = np.array([{(1, 0): 0, (0, 1): 1, (-1, 0): 2, (0, -1): 3}[(int(a), int(b))] for a, b in vals], np.uint8)
+    assert prs.size == 1536
+    np.savez_compressed(os.path.join(HERE, "tables.npz"), rev_freq_deint_tab=rev, pvec=pvec, ueptable=uep, prs_quarter_turns=prs)
+
+    # ---- viterbi known answers (scalar viterbi.c), incl. undecodable and tie-heavy inputs --
+    kat = {}
+    cases = [(768, 0.0, 0.0), (768, 0.25, 0.06), (192, 0.5, 0.12), (1536, 0.3, 0.15), (3072, 0.45, 0.02), (96, 0.0, 0.3)]
+    for ci, (nbits, pe, pf) in enumerate(cases):
+        d = rng.integers(0, 256, nbits // 8, dtype=np.uint8)
+        s = 127 + 2 * ol.or_encode(d).astype(np.int32)
+        s = np.where(rng.random(s.size) < pf, 256 - s, s).astype(np.uint8)
+        s[rng.random(s.size) < pe] = 128
+        out = np.zeros(nbits // 8, np.uint8)
+        R.refh_viterbi(None, _ptr(s), _ptr(out), nbits)
+        kat["vit%d_sym" % ci] = s
+        kat["vit%d_out" % ci] = out
+    s = np.full(4 * (768 + 6), 128, np.uint8)      # ties everywhere
+    s[::2] = 127
+    s[1::8] = 129
+    out = np.zeros(96, np.uint8)
+    R.refh_viterbi(None, _ptr(s), _ptr(out), 768)
+    kat["vit%d_sym" % len(cases)] = s
+    kat["vit%d_out" % len(cases)] = out
+    kat["vit_count"] = np.array(len(cases) + 1)
+
+    # ---- encoder, depuncture, PRBS, CRC, time de-interleave --------------------------------
+    d = rng.integers(0, 256, 96, dtype=np.uint8)
+    enc = np.zeros(4 * (768 + 6), np.uint8)
+    R.refh_encode(_ptr(enc), _ptr(d), 96)
+    kat["enc_in"], kat["enc_out"] = d, enc
+    bits = rng.integers(0, 2, 60000, dtype=np.uint8)
+    kat["dep_in"] = bits
+    o = np.zeros(3096, np.uint8)
+    R.refh_fic_depuncture(_ptr(o), _ptr(bits))
+    kat["dep_fic"] = o
+    for idx in (0, 35, 45, 63):
+        o = np.zeros(40000, np.uint8)
+        n = R.refh_uep_depuncture(_ptr(o), _ptr(bits), idx)
+        kat["dep_uep%d" % idx] = o[:n].copy()
+    sizemul = [12, 8, 6, 4, 27, 21, 18, 15]
+    for pl in range(8):
+        nn = 1 if pl == 1 else 2                    # 2-A with n = 1 is the 8 kbit/s special case
+        size, br = sizemul[pl] * nn, nn * (32 if pl >= 4 else 8)
+        o = np.zeros(40000, np.uint8)
+        n = R.refh_eep_depuncture(_ptr(o), _ptr(bits), pl, size, br)
+        kat["dep_eep%d" % pl] = o[:n].copy()
+        kat["dep_eep%d_cfg" % pl] = np.array([pl, size, br])
+    z = np.zeros(1152, np.uint8)
+    R.refh_descramble(_ptr(z), 1152)
+    kat["prbs"] = z
+    fibs = np.zeros((6, 32), np.uint8)
+    fibs[0] = [0xff] + [0] * 29 + [0xa8, 0xa8]     # a FIB that passes (constant known from the reference's null FIB)
+    fibs[1:] = rng.integers(0, 256, (5, 32), dtype=np.uint8)
+    kat["crc_fibs"] = fibs
+    kat["crc_ok"] = np.array([R.refh_check_fib_crc(_ptr(f)) for f in fibs], np.uint8)
+    cifs = rng.integers(0, 2, (16, 55296), dtype=np.uint8)
+    td = np.zeros(55296, np.uint8)
+    R.refh_time_deinterleave(_ptr(td), _ptr(cifs), 55296)
+    kat["td_in"] = np.packbits(cifs, axis=1)
+    kat["td_out"] = np.packbits(td)
+
+    # ---- FIB parse and ETI header ---------------------------------------------------------------
+    import dabtools_amd as dab
+    cfg = dab.synth_preset(0, seed=3, cif_count0=2499)
+    tf_fibs = np.concatenate([dab.synth_fibs(cfg, c) for c in range(4)])
+    ok = np.ones(12, np.uint8)
+    ok[5] = 0
+    hdr = (C.c_int * 3)()
+    sub = (C.c_int * 512)()
+    R.refh_fib_decode(_ptr(tf_fibs), _ptr(ok), hdr, sub)
+    kat["fibdec_fibs"], kat["fibdec_ok"] = tf_fibs, ok
+    kat["fibdec_hdr"] = np.array(list(hdr), np.int32)
+    kat["fibdec_sub"] = np.array(list(sub), np.int32).reshape(64, 8)
+    sub5 = np.full((64, 5), -1, np.int32)
+    for i in range(64):
+        r = kat["fibdec_sub"][i]
+        sub5[i] = [r[0], r[1], r[3], r[5], r[6]]
+    for tag, (hi, lo) in (("a", (9, 249)), ("b", (0, 42))):
+        eti = np.zeros(300, np.uint8)
+        n = R.refh_init_eti(_ptr(eti), 0xC181, hi, lo, sub5.ctypes.data_as(C.POINTER(C.c_int)))
+        kat["etihdr_%s" % tag] = eti[:n].copy()
+        kat["etihdr_%s_cif" % tag] = np.array([hi, lo])
+    kat["etihdr_sub5"] = sub5
+    np.savez_compressed(os.path.join(HERE, "backend_kat.npz"), **kat)
+
+    # ---- back end end-to-end: demapped bits per TF -> the reference's ETI bytes -------------------
+    # 9 dB SNR: residual bit errors reach the Viterbi decoders; one TF is corrupted to force a lock loss.
+    cfg = dab.synth_preset(1, seed=606, cif_count0=4960, snr_db=9.0)
+    ntf = 34
+    iq = dab.synth_generate(cfg, ntf)
+    S = O.or_sdr_new()
+    Hd = R.refh_new()
+    fic = np.zeros(dab.FIC_BITS, np.uint8)
+    msc = np.zeros(dab.MSC_BITS, np.uint8)
+    tf_bits = []
+    k = 0
+    for off in range(0, iq.size - dab.CHUNK_BYTES + 1, dab.CHUNK_BYTES):
+        ch = iq[off:off + dab.CHUNK_BYTES]
+        if O.or_sdr_demod(S, _ptr(ch), dab.CHUNK_BYTES, _ptr(fic), _ptr(msc)):
+            if k == 18:
+                fic[:3000] ^= 1                                   # FIC destroyed: lock lost, ring dropped
+            tf_bits.append(np.packbits(np.concatenate([fic, msc])))
+            C.memmove(R.refh_tf_fic(Hd), _ptr(fic), fic.size)
+            C.memmove(R.refh_tf_msc(Hd), _ptr(msc), msc.size)
+            R.refh_process(Hd)
+            k += 1
+    n = R.refh_neti(Hd)
+    eti = np.ctypeslib.as_array(R.refh_eti(Hd), (n, 6144)).copy()
+    assert n >= 12
+    np.savez_compressed(os.path.join(HERE, "backend_e2e.npz"), tf_bits=np.array(tf_bits), eti=eti,
+                        iq_sha256=np.frombuffer(hashlib.sha256(iq.tobytes()).digest(), np.uint8),
+                        synth=np.array([1, 606, 4960, ntf]), snr_db=np.array(9.0))
+    print("golden written: %d TF, %d ETI frames" % (len(tf_bits), n))
+
+
+if __name__ == "__main__":
+    main()

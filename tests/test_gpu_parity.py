@@ -244,3 +244,44 @@ def test_seam_s3_against_real_reference_backend():
     assert n > 0 and got.shape == want.shape and np.array_equal(got, want)
     O.or_sdr_free(S)
     d.close()
+
+
+def test_seam_s3_golden_reference_eti():
+    """Committed golden fixture: demapped bits of 32 TFs (9 dB SNR, one lock loss) -> the ETI bytes
+    the real reference produced (tests/golden/make_golden.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "backend_e2e.npz"))
+    d = dab.Dab(0)
+    for row in g["tf_bits"]:
+        bits = np.unpackbits(row)
+        d.fic[:] = bits[:9216]
+        d.msc[:] = bits[9216:]
+        d.process_frame()
+    got = np.array(d.frames)
+    assert got.shape == g["eti"].shape and np.array_equal(got, g["eti"])
+    d.close()
+
+
+def test_viterbi_golden_known_answers():
+    import os
+    kat = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "backend_kat.npz"))
+    for i in range(int(kat["vit_count"])):
+        sym, want = kat["vit%d_sym" % i], kat["vit%d_out" % i]
+        assert np.array_equal(dab.viterbi(sym, want.size * 8, 1)[0], want), i
+
+
+def test_s3_long_run_slot_recycling():
+    """More TFs than the seam's 64 device slots: the slot window is recycled without changing the output."""
+    cfg = dab.synth_preset(1, seed=61)
+    iq = dab.synth_generate(cfg, 85)
+    want, _ = ol.or_replay(iq)
+    sdr, d = dab.Sdr(0), dab.Dab(0)
+    for off in range(0, iq.size - dab.CHUNK_BYTES + 1, dab.CHUNK_BYTES):
+        if sdr.demod(iq[off:off + dab.CHUNK_BYTES]):
+            d.fic[:] = sdr.fic
+            d.msc[:] = sdr.msc
+            d.process_frame()
+    got = np.array(d.frames)
+    assert len(want) == 4 * (85 - 15) and got.shape == want.shape and np.array_equal(got, want)
+    sdr.close()
+    d.close()

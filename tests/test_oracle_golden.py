@@ -1,0 +1,129 @@
+"""The CPU oracle (oracle/*.c) against the committed golden vectors, which were produced by
+the REAL reference objects (tests/golden/make_golden.py).  Runs without a GPU and without
+/root/reference."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from oracle_lib import _ptr
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def kat():
+    return np.load(os.path.join(G, "backend_kat.npz"))
+
+
+def test_tables_match_reference_arrays():
+    t = np.load(os.path.join(G, "tables.npz"))
+    O = ol.oracle()
+    assert np.array_equal(np.ctypeslib.as_array(O.or_rev_freq_deint_tab(), (1536,)), t["rev_freq_deint_tab"])
+    pm = np.ctypeslib.as_array(O.or_puncture_masks(), (24,))
+    for i in range(24):
+        assert np.array_equal((pm[i] >> np.arange(32)) & 1, t["pvec"][i])
+        assert t["pvec"][i].sum() == 8 + (i + 1)
+    assert np.array_equal(np.ctypeslib.as_array(O.or_prs_phase(), (1536,)), t["prs_quarter_turns"].astype(np.int8))
+
+    class U(C.Structure):
+        _fields_ = [(n, C.c_int) for n in ("bitrate", "size", "pl")] + [("l", C.c_int * 4), ("pi", C.c_int * 4)]
+    ut = C.cast(O.or_uep_table(), C.POINTER(U))
+    for i in range(64):
+        mine = [ut[i].bitrate, ut[i].size, ut[i].pl] + list(ut[i].l) + [p - 1 for p in ut[i].pi]
+        assert mine == list(t["ueptable"][i]), i
+
+
+def test_viterbi_known_answers(kat):
+    for i in range(int(kat["vit_count"])):
+        sym, want = kat["vit%d_sym" % i], kat["vit%d_out" % i]
+        assert np.array_equal(ol.or_viterbi(sym, want.size * 8), want), i
+
+
+def test_encoder_known_answer(kat):
+    assert np.array_equal(ol.or_encode(kat["enc_in"]), kat["enc_out"])
+
+
+def test_depuncture_known_answers(kat):
+    O = ol.oracle()
+    bits = kat["dep_in"]
+    out = np.zeros(3096, np.uint8)
+    O.or_fic_depuncture(_ptr(out), _ptr(bits))
+    assert np.array_equal(out, kat["dep_fic"])
+    for idx in (0, 35, 45, 63):
+        want = kat["dep_uep%d" % idx]
+        out = np.zeros(40000, np.uint8)
+        n = O.or_msc_depuncture(_ptr(out), _ptr(bits), C.byref(ol.SubCh(id=1, slform=0, uep_index=idx)))
+        assert n == want.size and np.array_equal(out[:n], want), idx
+    for pl in range(8):
+        want = kat["dep_eep%d" % pl]
+        _, size, br = kat["dep_eep%d_cfg" % pl]
+        out = np.zeros(40000, np.uint8)
+        n = O.or_msc_depuncture(_ptr(out), _ptr(bits), C.byref(ol.SubCh(id=1, slform=1, protlev=pl, size=int(size), bitrate=int(br))))
+        assert n == want.size and np.array_equal(out[:n], want), pl
+        assert n // 4 - 6 == 24 * int(br)
+
+
+def test_prbs_crc_time_deinterleave(kat):
+    O = ol.oracle()
+    z = np.zeros(1152, np.uint8)
+    O.or_descramble(_ptr(z), 1152)
+    assert np.array_equal(z, kat["prbs"])
+    assert z[:8].tobytes().hex() == "07be2e64129da3cf"
+    for f, ok in zip(kat["crc_fibs"], kat["crc_ok"]):
+        assert O.or_check_fib_crc(_ptr(np.ascontiguousarray(f))) == ok
+    assert kat["crc_ok"][0] == 1                             # the reference's null FIB passes (fic.c:150-155)
+    cifs = np.unpackbits(kat["td_in"], axis=1)
+    out = np.zeros(55296, np.uint8)
+    ptrs = (C.POINTER(C.c_uint8) * 16)(*[_ptr(np.ascontiguousarray(cifs[i])) for i in range(16)])
+    rows = [np.ascontiguousarray(cifs[i]) for i in range(16)]
+    ptrs = (C.POINTER(C.c_uint8) * 16)(*[_ptr(r) for r in rows])
+    O.or_time_deinterleave(_ptr(out), ptrs)
+    assert np.array_equal(out, np.unpackbits(kat["td_out"]))
+
+
+def test_fib_parse_and_eti_header(kat):
+    O = ol.oracle()
+    info = ol.EnsInfo()
+    fibs = np.ascontiguousarray(kat["fibdec_fibs"])
+    ok = np.ascontiguousarray(kat["fibdec_ok"])
+    O.or_fib_decode(C.byref(info), _ptr(fibs), _ptr(ok))
+    assert [info.eid, info.cif_hi, info.cif_lo] == list(kat["fibdec_hdr"])
+    for i in range(64):
+        s = info.sub[i]
+        want = kat["fibdec_sub"][i]
+        assert s.id == want[0], i
+        if s.id >= 0:
+            # uep_index is only meaningful for UEP, eep fields only for EEP (the reference leaves the others stale)
+            got = [s.id, s.slform, s.start_cu, s.size, s.bitrate, s.protlev]
+            assert got == [want[0], want[1], want[3], want[4], want[5], want[6]], i
+        assert s.ascty == want[7]
+    for tag in ("a", "b"):
+        hi, lo = kat["etihdr_%s_cif" % tag]
+        e = ol.EnsInfo(eid=0xC181, cif_hi=int(hi), cif_lo=int(lo))
+        for i in range(64):
+            r = kat["etihdr_sub5"][i]
+            e.sub[i] = ol.SubCh(id=int(r[0]), slform=int(r[1]), start_cu=int(r[2]), bitrate=int(r[3]), protlev=int(r[4]))
+        out = np.zeros(300, np.uint8)
+        n = O.or_init_eti(_ptr(out), C.byref(e))
+        assert np.array_equal(out[:n], kat["etihdr_%s" % tag])
+
+
+def test_backend_end_to_end_against_reference_eti():
+    """demapped bits of 32 TFs (9 dB SNR, one destroyed FIC -> lock loss) -> the reference's ETI bytes."""
+    g = np.load(os.path.join(G, "backend_e2e.npz"))
+    O = ol.oracle()
+    frames = []
+    CB = C.CFUNCTYPE(None, C.POINTER(C.c_uint8), C.c_void_p)
+    cb = CB(lambda p, u: frames.append(np.ctypeslib.as_array(p, (6144,)).copy()))
+    d = O.or_dab_new(C.cast(cb, C.c_void_p), None)
+    for row in g["tf_bits"]:
+        bits = np.unpackbits(row)
+        C.memmove(O.or_dab_tf_fic(d), _ptr(np.ascontiguousarray(bits[:9216])), 9216)
+        C.memmove(O.or_dab_tf_msc(d), _ptr(np.ascontiguousarray(bits[9216:])), 221184)
+        O.or_dab_process_frame(d)
+    O.or_dab_free(d)
+    got = np.array(frames)
+    assert got.shape == g["eti"].shape and np.array_equal(got, g["eti"])
