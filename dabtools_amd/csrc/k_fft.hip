@@ -8,8 +8,9 @@
 // of spectra (1,556,480 B algorithmic) for 8.6 MFLOP, i.e. 5.5 flop/B -- far below the
 // machine balance, no dense contraction, no MFMA.  One 256-thread workgroup transforms one
 // symbol at a time entirely in registers + LDS: radix 8 x 8 x 8 x 4 decimation in
-// frequency, three LDS exchanges with conflict-free (padded) layouts, twiddles from an
-// LDS-resident table, coalesced 2-byte loads and 512-byte-per-wave stores.
+// frequency, three LDS exchanges with conflict-free (padded) layouts, per-thread twiddles
+// kept in registers, next symbol's IQ prefetched under the current transform, coalesced
+// 2-byte global loads and 16-byte (1 KiB per wave) stores.
 #include <hip/hip_runtime.h>
 
 #include "dab_tables.hpp"
@@ -62,91 +63,141 @@ __device__ __forceinline__ int view_byte(const uint8_t* stream, const FrameView&
 }
 __device__ __forceinline__ float rail(int byte) { return static_cast<float>(static_cast<int8_t>(static_cast<uint8_t>(byte - 127))); }
 
+// Twiddles of the three inter-stage multiplications depend only on the thread index, so
+// each thread keeps its 21 factors in registers for all symbols it transforms.
+struct Twiddles {
+  float2 s1[7], s2[7], s3[7];
+};
+
 // One 2048-point transform by the whole workgroup.  v holds x[tid + 256 r] on entry.
-__device__ __forceinline__ void fft2048_store(float2 (&v)[8], float2* exA, float2* exB, const float2* tw, float2* __restrict__ out)
+// bufP / bufQ alternate roles from symbol to symbol, which removes the barrier that would
+// otherwise separate the last LDS read of one symbol from the first LDS write of the next.
+__device__ __forceinline__ void fft2048_store(float2 (&v)[8], float2* bufP, float2* bufQ, const Twiddles& tw, float2* __restrict__ out)
 {
   const int tid = threadIdx.x;
   // stage 1: radix 8 over r, twiddle W_2048^(t q), exchange so that each thread owns one q
   dft8(v);
 #pragma unroll
-  for (int q = 1; q < 8; ++q) v[q] = cmul(v[q], tw[tid * q]);
+  for (int q = 1; q < 8; ++q) v[q] = cmul(v[q], tw.s1[q - 1]);
 #pragma unroll
-  for (int q = 0; q < 8; ++q) exA[q * 256 + tid] = v[q];
+  for (int q = 0; q < 8; ++q) bufP[q * 256 + tid] = v[q];
   __syncthreads();
   {
     const int q = tid >> 5, t1 = tid & 31;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = exA[q * 256 + t1 + 32 * r];
+    for (int r = 0; r < 8; ++r) v[r] = bufP[q * 256 + t1 + 32 * r];
     dft8(v);
 #pragma unroll
-    for (int q2 = 1; q2 < 8; ++q2) v[q2] = cmul(v[q2], tw[8 * t1 * q2]);
+    for (int q2 = 1; q2 < 8; ++q2) v[q2] = cmul(v[q2], tw.s2[q2 - 1]);
 #pragma unroll
-    for (int q2 = 0; q2 < 8; ++q2) exB[q * kEx2Stride + q2 * 32 + t1] = v[q2];
+    for (int q2 = 0; q2 < 8; ++q2) bufQ[q * kEx2Stride + q2 * 32 + t1] = v[q2];
   }
   __syncthreads();
   {
     const int q = tid & 7, t2 = (tid >> 3) & 3, q2 = tid >> 5;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = exB[q * kEx2Stride + q2 * 32 + t2 + 4 * r];
+    for (int r = 0; r < 8; ++r) v[r] = bufQ[q * kEx2Stride + q2 * 32 + t2 + 4 * r];
     dft8(v);
 #pragma unroll
-    for (int q3 = 1; q3 < 8; ++q3) v[q3] = cmul(v[q3], tw[64 * t2 * q3]);
+    for (int q3 = 1; q3 < 8; ++q3) v[q3] = cmul(v[q3], tw.s3[q3 - 1]);
 #pragma unroll
-    for (int q3 = 0; q3 < 8; ++q3) exA[t2 * kEx3Stride + q + 8 * q2 + 64 * q3] = v[q3];
+    for (int q3 = 0; q3 < 8; ++q3) bufP[t2 * kEx3Stride + q + 8 * q2 + 64 * q3] = v[q3];
   }
   __syncthreads();
-  // stage 4: radix 4 over t'', output bin k = p + 512 k''', written fftshifted
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const int p = tid + 256 * half;
-    float2 x0 = exA[p], x1 = exA[kEx3Stride + p], x2 = exA[2 * kEx3Stride + p], x3 = exA[3 * kEx3Stride + p];
+  // stage 4: radix 4 over the last index t2.  Each thread takes the adjacent pair p = 2 tid,
+  // 2 tid + 1 so that bins k = p + 512 k3 leave as 16-byte stores (1 KiB per wave), fftshifted.
+  {
+    const float4* src = reinterpret_cast<const float4*>(bufP);
+    const float4 a0 = src[tid], a1 = src[kEx3Stride / 2 + tid], a2 = src[kEx3Stride + tid], a3 = src[3 * kEx3Stride / 2 + tid];
+    float2 x0 = make_float2(a0.x, a0.y), x1 = make_float2(a1.x, a1.y), x2 = make_float2(a2.x, a2.y), x3 = make_float2(a3.x, a3.y);
+    float2 y0 = make_float2(a0.z, a0.w), y1 = make_float2(a1.z, a1.w), y2 = make_float2(a2.z, a2.w), y3 = make_float2(a3.z, a3.w);
     dft4(x0, x1, x2, x3);
-    out[(p + 1024) & 2047] = x0;
-    out[(p + 512 + 1024) & 2047] = x1;
-    out[(p + 1024 + 1024) & 2047] = x2;
-    out[(p + 1536 + 1024) & 2047] = x3;
+    dft4(y0, y1, y2, y3);
+    float4* dst = reinterpret_cast<float4*>(out);          // float4 index i holds bins 2i, 2i+1
+    dst[(tid + 512) & 1023] = make_float4(x0.x, x0.y, y0.x, y0.y);          // k3 = 0: bin p       -> p + 1024
+    dst[(tid + 256 + 512) & 1023] = make_float4(x1.x, x1.y, y1.x, y1.y);    // k3 = 1: bin p + 512
+    dst[(tid + 512 + 512) & 1023] = make_float4(x2.x, x2.y, y2.x, y2.y);    // k3 = 2: bin p + 1024
+    dst[(tid + 768 + 512) & 1023] = make_float4(x3.x, x3.y, y3.x, y3.y);    // k3 = 3: bin p + 1536
   }
-  __syncthreads();   // exA is rewritten by the next symbol's stage 1
+  // no barrier here: the next symbol starts by writing the OTHER buffer (roles swap)
+}
+
+typedef const __attribute__((address_space(1))) uint16_t* GlobalU16;
+
+template <bool kFast>
+__device__ __forceinline__ void load_symbol(GlobalU16 fast_src, const uint8_t* stream, const FrameView& view, int sym, unsigned (&raw)[8])
+{
+  const int tid = threadIdx.x;
+  const int start = 2 * (kNullSamples + kSymSamples * sym + kCpSamples);   // byte offset in the frame buffer
+  if (kFast) {
+    GlobalU16 src = fast_src + (start >> 1);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) raw[r] = src[tid + 256 * r];
+  } else {   // window reaches into the stale tail of the reference's frame buffer
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int p = start + 2 * (tid + 256 * r);
+      raw[r] = static_cast<unsigned>(view_byte(stream, view, p)) | (static_cast<unsigned>(view_byte(stream, view, p + 1)) << 8);
+    }
+  }
+}
+
+template <bool kFast>
+__device__ __forceinline__ void transform_symbols(GlobalU16 fast_src, const uint8_t* stream, const FrameView& view, int sym0,
+                                                  float2* exA, float2* exB, const Twiddles& tw, float2* __restrict__ out_tf)
+{
+  unsigned raw[8];
+  load_symbol<kFast>(fast_src, stream, view, sym0, raw);
+#pragma unroll 2
+  for (int i = 0; i < kSymPerBlock; ++i) {
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = make_float2(rail(raw[r] & 0xff), rail(raw[r] >> 8));
+    if (i + 1 < kSymPerBlock) load_symbol<kFast>(fast_src, stream, view, sym0 + i + 1, raw);   // prefetch under the transform
+    if (i & 1) fft2048_store(v, exB, exA, tw, out_tf + static_cast<size_t>(sym0 + i) * 2048);
+    else fft2048_store(v, exA, exB, tw, out_tf + static_cast<size_t>(sym0 + i) * 2048);
+  }
 }
 
 // grid = (4 * nframes); frame j of the launch is frames[first + j] = {stream, call}
-__global__ __launch_bounds__(kThreads) void ofdm_fft_kernel(const uint8_t* const* __restrict__ iq,
-                                                            const CallDesc* __restrict__ descs, int max_calls,
-                                                            const int2* __restrict__ frames, int first,
-                                                            float2* __restrict__ spectra,
-                                                            const float2* __restrict__ tw_global)
+__global__ __launch_bounds__(kThreads, 4) void ofdm_fft_kernel(const uint8_t* const* __restrict__ iq,
+                                                               const CallDesc* __restrict__ descs, int max_calls,
+                                                               const int2* __restrict__ frames, int first,
+                                                               float2* __restrict__ spectra,
+                                                               const float2* __restrict__ tw_global)
 {
-  __shared__ float2 tw[2048];
-  __shared__ float2 exA[kExSize];
-  __shared__ float2 exB[kExSize];
+  __shared__ __attribute__((aligned(16))) float2 exA[kExSize];
+  __shared__ __attribute__((aligned(16))) float2 exB[kExSize];
   __shared__ FrameView view;
   const int tid = threadIdx.x;
   const int j = blockIdx.x >> 2, part = blockIdx.x & 3;
   const int2 fr = frames[first + j];
   const uint8_t* stream = iq[fr.x];
-  for (int i = tid; i < 2048; i += kThreads) tw[i] = tw_global[i];
-  if (tid == 0) view = descs[static_cast<size_t>(fr.x) * max_calls + fr.y].view;
+  const CallDesc* desc = descs + static_cast<size_t>(fr.x) * max_calls + fr.y;
+  if (tid == 0) view = desc->view;
+  const int seg_end0 = desc->view.seg_end[0];
+  const int64_t seg_src0 = desc->view.seg_src[0];
+  Twiddles tw;
+  {
+    const int t1 = tid & 31, t2 = (tid >> 3) & 3;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+      tw.s1[q - 1] = tw_global[tid * q];
+      tw.s2[q - 1] = tw_global[8 * t1 * q];
+      tw.s3[q - 1] = tw_global[64 * t2 * q];
+    }
+  }
   __syncthreads();
   float2* out_tf = spectra + static_cast<size_t>(j) * (kSymbolsPerTf * 2048);
-
-  for (int sym = part * kSymPerBlock; sym < (part + 1) * kSymPerBlock; ++sym) {
-    const int start = 2 * (kNullSamples + kSymSamples * sym + kCpSamples);   // byte offset in the frame buffer
-    float2 v[8];
-    if (start + 4096 <= view.seg_end[0]) {
-      const uint16_t* src = reinterpret_cast<const uint16_t*>(stream + view.seg_src[0] + start);
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const unsigned s = src[tid + 256 * r];
-        v[r] = make_float2(rail(s & 0xff), rail(s >> 8));
-      }
-    } else {   // window reaches into the stale tail of the reference's frame buffer
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int p = start + 2 * (tid + 256 * r);
-        v[r] = make_float2(rail(view_byte(stream, view, p)), rail(view_byte(stream, view, p + 1)));
-      }
-    }
-    fft2048_store(v, exA, exB, tw, out_tf + static_cast<size_t>(sym) * 2048);
+  const int sym0 = part * kSymPerBlock;
+  // all 19 windows inside what this call read from the stream? (always, except symbol 75 after a
+  // negative timing shift and frames right after a coarse resync)
+  const int last_end = 2 * (kNullSamples + kSymSamples * (sym0 + kSymPerBlock - 1) + kCpSamples) + 4096;
+  if (last_end <= seg_end0 && seg_src0 >= 0) {
+    GlobalU16 src = reinterpret_cast<GlobalU16>(reinterpret_cast<uintptr_t>(stream + seg_src0));
+    transform_symbols<true>(src, stream, view, sym0, exA, exB, tw, out_tf);
+  } else {
+    transform_symbols<false>(nullptr, stream, view, sym0, exA, exB, tw, out_tf);
   }
 }
 
