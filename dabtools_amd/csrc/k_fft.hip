@@ -113,11 +113,12 @@ __device__ __forceinline__ void fft2048_store(float2 (&v)[8], float2* bufP, floa
     float2 y0 = make_float2(a0.z, a0.w), y1 = make_float2(a1.z, a1.w), y2 = make_float2(a2.z, a2.w), y3 = make_float2(a3.z, a3.w);
     dft4(x0, x1, x2, x3);
     dft4(y0, y1, y2, y3);
-    float4* dst = reinterpret_cast<float4*>(out);          // float4 index i holds bins 2i, 2i+1
-    dst[(tid + 512) & 1023] = make_float4(x0.x, x0.y, y0.x, y0.y);          // k3 = 0: bin p       -> p + 1024
-    dst[(tid + 256 + 512) & 1023] = make_float4(x1.x, x1.y, y1.x, y1.y);    // k3 = 1: bin p + 512
-    dst[(tid + 512 + 512) & 1023] = make_float4(x2.x, x2.y, y2.x, y2.y);    // k3 = 2: bin p + 1024
-    dst[(tid + 768 + 512) & 1023] = make_float4(x3.x, x3.y, y3.x, y3.y);    // k3 = 3: bin p + 1536
+    typedef float __attribute__((ext_vector_type(4))) vfloat4;
+    vfloat4* dst = reinterpret_cast<vfloat4*>(out);        // element i holds bins 2i, 2i+1
+    __builtin_nontemporal_store(vfloat4{x0.x, x0.y, y0.x, y0.y}, &dst[(tid + 512) & 1023]);          // k3 = 0: bin p       -> p + 1024
+    __builtin_nontemporal_store(vfloat4{x1.x, x1.y, y1.x, y1.y}, &dst[(tid + 256 + 512) & 1023]);    // k3 = 1: bin p + 512
+    __builtin_nontemporal_store(vfloat4{x2.x, x2.y, y2.x, y2.y}, &dst[(tid + 512 + 512) & 1023]);    // k3 = 2: bin p + 1024
+    __builtin_nontemporal_store(vfloat4{x3.x, x3.y, y3.x, y3.y}, &dst[(tid + 768 + 512) & 1023]);    // k3 = 3: bin p + 1536
   }
   // no barrier here: the next symbol starts by writing the OTHER buffer (roles swap)
 }
