@@ -265,9 +265,10 @@ int dabhip_dab_process_frame(dabhip_dab* d)
   d->plane.on_tf(d->slot, d->fibs.data(), d->ok.data(), jobs);
   ++d->slot;
   if (jobs.empty()) return 0;
-  std::vector<int> job_stream(jobs.size(), 0), cif_base = {0};
+  std::vector<int> cif_base = {0};
   std::vector<const ControlPlane*> planes = {&d->plane};
-  if (!d->eng.msc_decode(job_stream, jobs, planes, cif_base)) return -1;
+  std::vector<const std::vector<EtiJob>*> job_lists = {&jobs};
+  if (!d->eng.msc_decode(job_lists, planes, cif_base)) return -1;
   if (!d->eng.read_eti(0, static_cast<int64_t>(jobs.size()), d->eti.data())) return -1;
   if (d->cb)
     for (size_t f = 0; f < jobs.size(); ++f) d->cb(d->eti.data() + f * kEtiBytes);

@@ -50,11 +50,21 @@ struct CodewordPlan {
   int32_t out_bytes;     // (nsteps - 6) / 8
 };
 
-struct CodewordItem {
-  int32_t stream;
-  int32_t cif;           // MSC: linear index of the oldest of the 16 CIFs; FIC: 4*tf + block
-  int32_t plan;          // index into the plan table
-  int32_t out_record;    // ETI frame index (MSC) or FIC block index (FIC)
+// One output record to decode into: an ETI frame (MSC) or a 96-byte FIC block.
+struct DecodeJob {
+  int32_t stream;        // MSC: selects the stream's first CIF row; FIC: unused
+  int32_t cif;           // MSC: linear index of the oldest of the 16 CIFs; FIC: 4*tf_slot + block
+};
+
+// 64 equal-length code words handled by one wave: lane l decodes job job_ids[first + l]
+// (or job first + l when there is no id list) with code word plan `plan`.
+struct WaveGroup {
+  int32_t plan;
+  int32_t first;
+  int32_t count;         // valid lanes (<= 64)
+  int32_t nsteps;
+  int64_t step_base;     // row offset into the trellis-input buffer (rows of 64 x 16 bytes)
+  int64_t dec_base;      // row offset into the decision buffer (rows of 64 x 8 bytes)
 };
 
 // Per ETI frame: what eti_finish_kernel needs besides the decoded sub-channel data.

@@ -2,10 +2,12 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 #include "dab_bits.hpp"
 #include "dab_tables.hpp"
@@ -120,61 +122,77 @@ static CodewordPlan make_plan(const PuncturePlan& pp, int start_bit, int out_off
   return p;
 }
 
-// sort code words into wave-groups of 64 with equal trellis length, longest first
-void Engine::build_batch(const std::vector<CodewordItem>& items, const std::vector<int>& item_nsteps, DecodeBatch& out)
+// wave-groups of <= 64 jobs per plan, longest code words first
+void Engine::build_batch(const std::vector<std::pair<int, const std::vector<int>*>>& plan_jobs, DecodeBatch& out)
 {
   out = DecodeBatch{};
-  std::map<int, std::vector<int>, std::greater<int>> by_len;
-  for (size_t i = 0; i < items.size(); ++i) by_len[item_nsteps[i]].push_back(static_cast<int>(i));
-  for (auto& kv : by_len) {
-    const std::vector<int>& idx = kv.second;
-    for (size_t g = 0; g < idx.size(); g += 64) {
-      for (size_t l = 0; l < 64; ++l) {
-        if (g + l < idx.size()) out.items.push_back(items[idx[g + l]]);
-        else out.items.push_back(CodewordItem{0, 0, -1, 0});
-      }
-      out.group_nsteps.push_back(kv.first);
-      out.group_n16.push_back((kv.first + 15) / 16);
+  std::vector<std::pair<int, size_t>> order;   // (nsteps, index into plan_jobs)
+  size_t total = 0;
+  for (size_t i = 0; i < plan_jobs.size(); ++i) {
+    order.emplace_back(plans_[plan_jobs[i].first].nsteps, i);
+    total += plan_jobs[i].second->size();
+  }
+  std::stable_sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+  (void)total;
+  std::map<const std::vector<int>*, int> placed;   // plans of one layout share the same job list
+  for (const auto& o : order) {
+    const int plan = plan_jobs[o.second].first;
+    const std::vector<int>& ids = *plan_jobs[o.second].second;
+    auto it = placed.find(&ids);
+    if (it == placed.end()) {
+      it = placed.emplace(&ids, static_cast<int>(out.job_ids.size())).first;
+      out.job_ids.insert(out.job_ids.end(), ids.begin(), ids.end());
     }
+    const int first = it->second;
+    for (size_t g = 0; g < ids.size(); g += 64)
+      out.groups.push_back(WaveGroup{plan, first + static_cast<int>(g), static_cast<int>(std::min<size_t>(64, ids.size() - g)), o.first, 0, 0});
   }
 }
 
 // run gather + Viterbi over a batch, in slices that bound the decision buffer
-bool Engine::run_decode_batch(const DecodeBatch& b, bool fic, const uint32_t* bits, const int* d_stream_cif_base,
-                              const uint32_t* prbs, uint8_t* out, int record_stride, float* gather_ms, float* viterbi_ms)
+bool Engine::run_decode_batch(DecodeBatch& b, bool fic, const std::vector<DecodeJob>& jobs, const uint32_t* bits,
+                              const int* d_stream_cif_base, const uint32_t* prbs, uint8_t* out, int record_stride,
+                              float* gather_ms, float* viterbi_ms)
 {
-  const int ng = b.ngroups();
+  const int ng = static_cast<int>(b.groups.size());
   if (ng == 0) return true;
-  if (!d_plans_.upload(plans_, stream_)) return false;
-  if (!d_items_.upload(b.items, stream_)) return false;
-  int g0 = 0;
-  while (g0 < ng) {
-    std::vector<int64_t> base, dec_base;
-    int64_t step_rows = 0, dec_rows = 0;
-    int g1 = g0, max_n16 = 0;
-    while (g1 < ng) {
-      const int64_t dr = (b.group_nsteps[g1] + 3) / 4 * 4;
-      if (g1 > g0 && dec_rows + dr > kMaxDecisionRows) break;
-      base.push_back(step_rows);
-      dec_base.push_back(dec_rows);
-      step_rows += b.group_n16[g1];
-      dec_rows += dr;
-      max_n16 = std::max(max_n16, b.group_n16[g1]);
-      ++g1;
+  // slices of groups whose survivor decisions fit the cap; offsets are per slice
+  std::vector<int> slice_start = {0};
+  std::vector<int64_t> slice_steps, slice_dec;
+  int64_t step_rows = 0, dec_rows = 0;
+  for (int g = 0; g < ng; ++g) {
+    const int64_t dr = (b.groups[g].nsteps + 3) / 4 * 4, sr = (b.groups[g].nsteps + 15) / 16;
+    if (g > slice_start.back() && dec_rows + dr > kMaxDecisionRows) {
+      slice_start.push_back(g);
+      slice_steps.push_back(step_rows);
+      slice_dec.push_back(dec_rows);
+      step_rows = dec_rows = 0;
     }
-    const int n = g1 - g0;
-    if (!d_group_nsteps_.upload(b.group_nsteps.data() + g0, n, stream_) || !d_group_n16_.upload(b.group_n16.data() + g0, n, stream_) ||
-        !d_group_base_.upload(base, stream_) || !d_group_dec_base_.upload(dec_base, stream_))
-      return false;
-    if (!d_steps_.reserve(static_cast<size_t>(step_rows) * 64) || !d_decisions_.reserve(static_cast<size_t>(dec_rows) * 64)) return false;
+    b.groups[g].step_base = step_rows;
+    b.groups[g].dec_base = dec_rows;
+    step_rows += sr;
+    dec_rows += dr;
+  }
+  slice_start.push_back(ng);
+  slice_steps.push_back(step_rows);
+  slice_dec.push_back(dec_rows);
+  const int64_t max_steps = *std::max_element(slice_steps.begin(), slice_steps.end());
+  const int64_t max_dec = *std::max_element(slice_dec.begin(), slice_dec.end());
+  if (!d_plans_.upload(plans_, stream_) || !d_groups_.upload(b.groups, stream_) || !d_job_ids_.upload(b.job_ids, stream_) ||
+      !d_jobs_.upload(jobs, stream_) || !d_steps_.reserve(static_cast<size_t>(max_steps) * 64) ||
+      !d_decisions_.reserve(static_cast<size_t>(max_dec) * 64))
+    return false;
+  const int* ids = b.job_ids.empty() ? nullptr : d_job_ids_.get();
+  for (size_t s = 0; s + 1 < slice_start.size(); ++s) {
+    const int g0 = slice_start[s], n = slice_start[s + 1] - g0;
+    const int max_n16 = (b.groups[g0].nsteps + 15) / 16;     // groups are sorted longest first
     (void)hipEventRecord(ev_[0], stream_);
-    if (!check(launch_gather(fic, d_items_.get() + static_cast<size_t>(g0) * 64, d_plans_.get(), d_group_n16_.get(), d_group_base_.get(), n,
-                             max_n16, bits, d_stream_cif_base, d_steps_.get(), stream_),
-               "gather launch"))
+    if (bits && !check(launch_gather(fic, d_groups_.get() + g0, n, max_n16, d_jobs_.get(), ids, d_plans_.get(), bits, d_stream_cif_base,
+                                     d_steps_.get(), stream_),
+                       "gather launch"))
       return false;
     (void)hipEventRecord(ev_[1], stream_);
-    if (!check(launch_viterbi(d_items_.get() + static_cast<size_t>(g0) * 64, d_plans_.get(), d_group_nsteps_.get(), d_group_base_.get(),
-                              d_group_dec_base_.get(), n, d_steps_.get(), d_decisions_.get(), prbs, out, record_stride, stream_),
+    if (!check(launch_viterbi(d_groups_.get() + g0, n, ids, d_plans_.get(), d_steps_.get(), d_decisions_.get(), prbs, out, record_stride, stream_),
                "viterbi launch"))
       return false;
     (void)hipEventRecord(ev_[2], stream_);
@@ -182,7 +200,6 @@ bool Engine::run_decode_batch(const DecodeBatch& b, bool fic, const uint32_t* bi
     float ms = 0;
     if (gather_ms && hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) *gather_ms += ms;
     if (viterbi_ms && hipEventElapsedTime(&ms, ev_[1], ev_[2]) == hipSuccess) *viterbi_ms += ms;
-    g0 = g1;
   }
   return true;
 }
@@ -234,21 +251,15 @@ bool Engine::unpack_tf_slot(int slot, uint8_t* fic_bytes, uint8_t* msc_bytes)
 bool Engine::fic_decode_slots(int first, int n, uint8_t* fibs_host, uint8_t* ok_host)
 {
   if (n <= 0) return true;
-  const PuncturePlan pp = fic_plan();
-  int ids[4];
-  for (int blk = 0; blk < 4; ++blk) ids[blk] = plan_id(make_plan(pp, 2304 * blk, 0));
-  std::vector<CodewordItem> items;
-  std::vector<int> lens;
-  items.reserve(static_cast<size_t>(n) * 4);
-  for (int s = first; s < first + n; ++s)
-    for (int blk = 0; blk < 4; ++blk) {
-      items.push_back(CodewordItem{0, 4 * s + blk, ids[blk], 4 * s + blk});
-      lens.push_back(plans_[ids[blk]].nsteps);
-    }
+  const int pid = plan_id(make_plan(fic_plan(), 0, 0));
+  // job i = FIC block i = (TF slot i / 4, block i % 4); jobs below `first` exist only to keep indices absolute
+  std::vector<DecodeJob> jobs(static_cast<size_t>(4) * (first + n));
+  for (size_t i = 0; i < jobs.size(); ++i) jobs[i] = DecodeJob{0, static_cast<int32_t>(i)};
   DecodeBatch batch;
-  build_batch(items, lens, batch);
+  for (int i = 4 * first; i < 4 * (first + n); i += 64)
+    batch.groups.push_back(WaveGroup{pid, i, std::min(64, 4 * (first + n) - i), plans_[pid].nsteps, 0, 0});
   float g = 0, v = 0;
-  if (!run_decode_batch(batch, true, d_fic_bits_.get(), nullptr, d_prbs_.get(), d_fibs_.get(), 96, &g, &v)) return false;
+  if (!run_decode_batch(batch, true, jobs, d_fic_bits_.get(), nullptr, d_prbs_.get(), d_fibs_.get(), 96, &g, &v)) return false;
   if (!check(launch_fib_crc(d_fibs_.get() + static_cast<size_t>(first) * 384, n * 12, d_crc_tab_.get(), d_fib_ok_.get() + static_cast<size_t>(first) * 12, stream_), "fib crc launch")) return false;
   if (!check(hipMemcpyAsync(fibs_host, d_fibs_.get() + static_cast<size_t>(first) * 384, static_cast<size_t>(n) * 384, hipMemcpyDeviceToHost, stream_), "fib download") ||
       !check(hipMemcpyAsync(ok_host, d_fib_ok_.get() + static_cast<size_t>(first) * 12, static_cast<size_t>(n) * 12, hipMemcpyDeviceToHost, stream_), "fib flag download"))
@@ -256,59 +267,80 @@ bool Engine::fic_decode_slots(int first, int n, uint8_t* fibs_host, uint8_t* ok_
   return check(hipStreamSynchronize(stream_), "fic decode");
 }
 
-bool Engine::msc_decode(const std::vector<int>& job_stream, const std::vector<EtiJob>& jobs,
-                        const std::vector<const ControlPlane*>& planes, const std::vector<int>& stream_cif_base)
+bool Engine::msc_decode(const std::vector<const std::vector<EtiJob>*>& stream_jobs, const std::vector<const ControlPlane*>& planes,
+                        const std::vector<int>& stream_cif_base)
 {
-  const size_t nf = jobs.size();
+  size_t nf = 0;
+  for (const auto* v : stream_jobs) nf += v->size();
   if (nf == 0) return true;
-  std::vector<CodewordItem> items;
-  std::vector<int> lens;
+  // An ensemble layout (the active sub-channels in SubChId order) fixes the code word plans and their offsets in
+  // the ETI frame.  Layouts are identified by content so that streams carrying the same multiplex share plans.
+  struct Layout {
+    std::vector<int> plan_ids;
+    std::vector<std::vector<int>> frames;   // frames[k]: ETI frame indices decoded with plan_ids[k] (same list for all k)
+    int mst_bytes = 0;
+  };
+  std::map<std::vector<int32_t>, int> layout_index;
+  std::vector<Layout> layouts;
+  std::vector<std::vector<int>> layout_frames;
+  std::vector<DecodeJob> jobs(nf);
   std::vector<EtiFrameMeta> meta(nf);
-  std::vector<uint8_t> headers(nf * kEtiHeaderMax, 0);
-  // plan ids per (stream, layout) are cached: the layout of an ensemble rarely changes
-  std::map<std::pair<int, int>, std::vector<int>> layout_plans;
-  std::map<std::pair<int, int>, int> layout_mst;
-  for (size_t f = 0; f < nf; ++f) {
-    const int b = job_stream[f];
-    const EtiJob& job = jobs[f];
-    const auto key = std::make_pair(b, static_cast<int>(job.layout));
-    auto it = layout_plans.find(key);
-    if (it == layout_plans.end()) {
-      std::vector<int> ids;
-      int off = job.header_len + 96;
-      for (const SubChannel& sc : planes[b]->layouts()[job.layout]) {
-        const PuncturePlan pp = puncture_plan(sc);
-        CodewordPlan cp = make_plan(pp, sc.start_cu * 64, off);
-        // misc.c:259-260: bits = len/4 - 6, obytes = ((bits/8)+7) & 0xfff8
-        const int obytes = (cp.out_bytes + 7) & 0xfff8;
-        ids.push_back(plan_id(cp));
-        off += obytes;
+  int max_header = 0;
+  for (const auto* v : stream_jobs)
+    for (const EtiJob& j : *v) max_header = std::max(max_header, j.header_len);
+  const int header_stride = (max_header + 15) & ~15;
+  std::vector<uint8_t> headers(nf * static_cast<size_t>(header_stride), 0);
+  size_t f = 0;
+  for (size_t b = 0; b < stream_jobs.size(); ++b) {
+    std::vector<int> local_to_global;       // this stream's layout index -> global layout id
+    for (const EtiJob& job : *stream_jobs[b]) {
+      if (static_cast<size_t>(job.layout) >= local_to_global.size()) local_to_global.resize(job.layout + 1, -1);
+      int gid = local_to_global[job.layout];
+      if (gid < 0) {
+        const std::vector<SubChannel>& subs = planes[b]->layouts()[job.layout];
+        std::vector<int32_t> key = {job.header_len};
+        for (const SubChannel& sc : subs) {
+          const int32_t fields[] = {sc.slform, sc.uep_index, sc.start_cu, sc.size_cu, sc.bitrate, sc.protlev};
+          key.insert(key.end(), fields, fields + 6);
+        }
+        auto it = layout_index.find(key);
+        if (it == layout_index.end()) {
+          Layout lay;
+          int off = job.header_len + 96;
+          for (const SubChannel& sc : subs) {
+            CodewordPlan cp = make_plan(puncture_plan(sc), sc.start_cu * 64, off);
+            lay.plan_ids.push_back(plan_id(cp));
+            off += (cp.out_bytes + 7) & 0xfff8;          // misc.c:259-260: obytes = ((bits/8)+7) & 0xfff8
+          }
+          lay.mst_bytes = off - job.header_len - 96;
+          if (off + 8 > kEtiBytes) { set_error("ETI frame overflow: sub-channels exceed 6144 bytes"); return false; }
+          it = layout_index.emplace(std::move(key), static_cast<int>(layouts.size())).first;
+          layouts.push_back(std::move(lay));
+          layout_frames.emplace_back();
+        }
+        gid = local_to_global[job.layout] = it->second;
       }
-      layout_mst[key] = off - job.header_len - 96;
-      it = layout_plans.emplace(key, std::move(ids)).first;
+      layout_frames[gid].push_back(static_cast<int>(f));
+      jobs[f] = DecodeJob{static_cast<int32_t>(b), job.first_cif};
+      meta[f] = EtiFrameMeta{job.header_len, layouts[gid].mst_bytes, stream_cif_base[b] + job.first_cif, 0};
+      std::memcpy(headers.data() + f * header_stride, job.header, static_cast<size_t>(job.header_len));
+      ++f;
     }
-    for (int id : it->second) {
-      items.push_back(CodewordItem{b, job.first_cif, id, static_cast<int32_t>(f)});
-      lens.push_back(plans_[id].nsteps);
-    }
-    meta[f].header_len = job.header_len;
-    meta[f].mst_bytes = layout_mst[key];
-    meta[f].fib_block = stream_cif_base[b] + job.first_cif;
-    meta[f].pad = 0;
-    if (meta[f].header_len + 96 + meta[f].mst_bytes + 8 > kEtiBytes) { set_error("ETI frame overflow: sub-channels exceed 6144 bytes"); return false; }
-    std::memcpy(headers.data() + f * kEtiHeaderMax, job.header, kEtiHeaderMax);
   }
+  std::vector<std::pair<int, const std::vector<int>*>> plan_jobs;
+  for (size_t l = 0; l < layouts.size(); ++l)
+    for (int pid : layouts[l].plan_ids) plan_jobs.emplace_back(pid, &layout_frames[l]);
   DecodeBatch batch;
-  build_batch(items, lens, batch);
+  build_batch(plan_jobs, batch);
   if (!d_eti_.reserve(nf * kEtiBytes) || !d_meta_.upload(meta, stream_) || !d_headers_.upload(headers, stream_) ||
       !d_stream_cif_base_.upload(stream_cif_base, stream_))
     return false;
   if (!check(hipMemsetAsync(d_eti_.get(), 0x55, nf * kEtiBytes, stream_), "eti memset")) return false;   // padding, misc.c:295
-  if (!run_decode_batch(batch, false, d_msc_bits_.get(), d_stream_cif_base_.get(), d_prbs_.get(), d_eti_.get(), kEtiBytes,
+  if (!run_decode_batch(batch, false, jobs, d_msc_bits_.get(), d_stream_cif_base_.get(), d_prbs_.get(), d_eti_.get(), kEtiBytes,
                         &times_.gather, &times_.viterbi))
     return false;
   (void)hipEventRecord(ev_[0], stream_);
-  if (!check(launch_eti_finish(d_meta_.get(), static_cast<int>(nf), d_headers_.get(), d_fibs_.get(), d_crc_tab_.get(), d_eti_.get(), stream_), "eti finish launch"))
+  if (!check(launch_eti_finish(d_meta_.get(), static_cast<int>(nf), d_headers_.get(), header_stride, d_fibs_.get(), d_crc_tab_.get(), d_eti_.get(), stream_), "eti finish launch"))
     return false;
   (void)hipEventRecord(ev_[1], stream_);
   if (!check(hipEventSynchronize(ev_[1]), "eti finish")) return false;
@@ -432,24 +464,37 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
     (void)hipEventElapsedTime(&times_.fic, ev_[3], end);
   }
 
-  // control plane
+  // control plane: independent per stream, spread over host threads
   const auto t0 = std::chrono::steady_clock::now();
   std::vector<ControlPlane> planes(nstreams);
+  std::vector<std::vector<EtiJob>> stream_jobs(nstreams);
+  {
+    const int nthreads = std::max(1, std::min<int>({nstreams, 16, static_cast<int>(std::thread::hardware_concurrency())}));
+    std::atomic<int> next{0};
+    auto work = [&]() {
+      for (int b = next.fetch_add(1); b < nstreams; b = next.fetch_add(1))
+        for (int s = tf_base[b]; s < tf_base[b + 1]; ++s)
+          planes[b].on_tf(s - tf_base[b], fibs.data() + static_cast<size_t>(s) * 384, ok.data() + static_cast<size_t>(s) * 12, stream_jobs[b]);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+  }
   std::vector<const ControlPlane*> plane_ptrs(nstreams);
-  std::vector<EtiJob> jobs;
-  std::vector<int> job_stream;
+  std::vector<const std::vector<EtiJob>*> job_ptrs(nstreams);
+  total_eti_ = 0;
   for (int b = 0; b < nstreams; ++b) {
     plane_ptrs[b] = &planes[b];
-    eti_base_[b] = static_cast<int64_t>(jobs.size());
-    for (int s = tf_base[b]; s < tf_base[b + 1]; ++s) planes[b].on_tf(s - tf_base[b], fibs.data() + static_cast<size_t>(s) * 384, ok.data() + static_cast<size_t>(s) * 12, jobs);
-    eti_count_[b] = static_cast<int64_t>(jobs.size()) - eti_base_[b];
-    job_stream.resize(jobs.size(), b);
+    job_ptrs[b] = &stream_jobs[b];
+    eti_base_[b] = total_eti_;
+    eti_count_[b] = static_cast<int64_t>(stream_jobs[b].size());
+    total_eti_ += eti_count_[b];
   }
-  total_eti_ = static_cast<int64_t>(jobs.size());
   times_.control = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
   // K4 + K5
-  if (!msc_decode(job_stream, jobs, plane_ptrs, cif_base)) return -1;
+  if (!msc_decode(job_ptrs, plane_ptrs, cif_base)) return -1;
   return total_eti_;
 }
 
@@ -570,21 +615,20 @@ int Engine::viterbi_batch(const uint8_t* symbols, uint8_t* data, int framebits, 
   plan.nsteps = nsteps;
   plan.out_bytes = framebits / 8;
   const int pid = plan_id(plan);
-  DecodeBatch batch;
+  std::vector<WaveGroup> groups;
+  const int64_t dr = (nsteps + 3) / 4 * 4;
   std::vector<uint4> steps(static_cast<size_t>(ngroups) * n16 * 64, make_uint4(0, 0, 0, 0));
   for (int g = 0; g < ngroups; ++g) {
-    batch.group_nsteps.push_back(nsteps);
-    batch.group_n16.push_back(n16);
+    groups.push_back(WaveGroup{pid, 64 * g, std::min(64, n - 64 * g), nsteps, static_cast<int64_t>(g) * n16, g * dr});
     for (int l = 0; l < 64; ++l) {
       const int cw = g * 64 + l;
-      batch.items.push_back(cw < n ? CodewordItem{0, 0, pid, cw} : CodewordItem{0, 0, -1, 0});
       if (cw >= n) continue;
       const uint8_t* sym = symbols + static_cast<size_t>(cw) * 4 * nsteps;
       for (int t = 0; t < nsteps; ++t) {
         unsigned byte = 0;
         for (int j = 0; j < 4; ++j) {
-          const uint8_t s = sym[4 * t + j];
-          if (s != 128) byte |= (1u << (4 + j)) | ((s > 128 ? 1u : 0u) << j);
+          const uint8_t sv = sym[4 * t + j];
+          if (sv != 128) byte |= (1u << (4 + j)) | ((sv > 128 ? 1u : 0u) << j);
         }
         uint4& u = steps[(static_cast<size_t>(g) * n16 + t / 16) * 64 + l];
         uint32_t* w = &u.x;
@@ -593,17 +637,13 @@ int Engine::viterbi_batch(const uint8_t* symbols, uint8_t* data, int framebits, 
     }
   }
   // no gather: upload the step rows directly, then run the decoder with an all-zero scrambler
-  std::vector<int64_t> base(ngroups), dec_base(ngroups);
-  const int64_t dr = (nsteps + 3) / 4 * 4;
-  for (int g = 0; g < ngroups; ++g) { base[g] = static_cast<int64_t>(g) * n16; dec_base[g] = g * dr; }
   const size_t out_bytes = static_cast<size_t>(n) * (framebits / 8);
-  if (!d_plans_.upload(plans_, stream_) || !d_items_.upload(batch.items, stream_) || !d_group_nsteps_.upload(batch.group_nsteps, stream_) ||
-      !d_group_base_.upload(base, stream_) || !d_group_dec_base_.upload(dec_base, stream_) || !d_steps_.upload(steps, stream_) ||
-      !d_decisions_.reserve(static_cast<size_t>(ngroups) * dr * 64) || !d_bytes_.reserve(out_bytes) || !d_zero_words_.reserve(1))
-    return -1;
   if (framebits / 32 > 1024) { set_error("viterbi: code word too long"); return -1; }
-  if (!check(launch_viterbi(d_items_.get(), d_plans_.get(), d_group_nsteps_.get(), d_group_base_.get(), d_group_dec_base_.get(), ngroups,
-                            d_steps_.get(), d_decisions_.get(), d_zero_words_.get(), d_bytes_.get(), framebits / 8, stream_),
+  if (!d_plans_.upload(plans_, stream_) || !d_groups_.upload(groups, stream_) || !d_steps_.upload(steps, stream_) ||
+      !d_decisions_.reserve(static_cast<size_t>(ngroups) * dr * 64) || !d_bytes_.reserve(out_bytes))
+    return -1;
+  if (!check(launch_viterbi(d_groups_.get(), ngroups, nullptr, d_plans_.get(), d_steps_.get(), d_decisions_.get(), d_zero_words_.get(),
+                            d_bytes_.get(), framebits / 8, stream_),
              "viterbi launch") ||
       !check(hipMemcpyAsync(data, d_bytes_.get(), out_bytes, hipMemcpyDeviceToHost, stream_), "decoded download") ||
       !check(hipStreamSynchronize(stream_), "viterbi"))

@@ -68,13 +68,10 @@ struct StageTimes {
   float sync = 0, fft = 0, demap = 0, fic = 0, control = 0, gather = 0, viterbi = 0, eti = 0;
 };
 
-// Work list for Viterbi launches: code words sorted into wave-groups of 64 of equal length.
+// Work list for gather + Viterbi launches: wave-groups of <= 64 equal-length code words.
 struct DecodeBatch {
-  std::vector<CodewordItem> items;        // ngroups * 64, padded with plan = -1
-  std::vector<int> group_nsteps, group_n16;
-  std::vector<int64_t> group_base;        // step buffer offsets (rows of 64 x 16 bytes)
-  std::vector<int64_t> group_dec_base;    // decision buffer offsets (rows of 64 x 8 bytes)
-  int ngroups() const { return static_cast<int>(group_nsteps.size()); }
+  std::vector<WaveGroup> groups;   // longest code words first
+  std::vector<int> job_ids;        // lanes of group g decode jobs job_ids[g.first .. g.first + g.count)
 };
 
 class Engine {
@@ -107,9 +104,9 @@ class Engine {
   bool move_tf_slots(int dst, int src, int n);
   // FIC-decode TF slots [first, first+n): FIBs and CRC flags to host
   bool fic_decode_slots(int first, int n, uint8_t* fibs_host, uint8_t* ok_host);
-  // decode the ETI frames described by jobs into the ETI buffer (frame order = job order)
-  bool msc_decode(const std::vector<int>& job_stream, const std::vector<EtiJob>& jobs,
-                  const std::vector<const ControlPlane*>& planes, const std::vector<int>& stream_cif_base);
+  // decode the ETI frames described by the per-stream job lists into the ETI buffer (stream-major order)
+  bool msc_decode(const std::vector<const std::vector<EtiJob>*>& stream_jobs, const std::vector<const ControlPlane*>& planes,
+                  const std::vector<int>& stream_cif_base);
   bool read_eti(int64_t first, int64_t n, uint8_t* dst);
   // front end on an explicit single stream (S2 seam): calls [call, call+1)
   bool scan_one_call(const uint8_t* iq_virtual_base, int64_t fed_bytes, StreamState* d_state, int call, CallDesc* out);
@@ -118,9 +115,11 @@ class Engine {
 
  private:
   bool check(hipError_t e, const char* what);
-  void build_batch(const std::vector<CodewordItem>& items, const std::vector<int>& item_nsteps, DecodeBatch& out);
-  bool run_decode_batch(const DecodeBatch& b, bool fic, const uint32_t* bits, const int* d_stream_cif_base,
-                        const uint32_t* prbs, uint8_t* out, int record_stride, float* gather_ms, float* viterbi_ms);
+  // plan_jobs[i] = (plan id, job indices decoded with that plan)
+  void build_batch(const std::vector<std::pair<int, const std::vector<int>*>>& plan_jobs, DecodeBatch& out);
+  bool run_decode_batch(DecodeBatch& b, bool fic, const std::vector<DecodeJob>& jobs, const uint32_t* bits,
+                        const int* d_stream_cif_base, const uint32_t* prbs, uint8_t* out, int record_stride, float* gather_ms,
+                        float* viterbi_ms);
   int plan_id(const CodewordPlan& p);
   bool unpack_tf_slot(int slot, uint8_t* fic_bytes, uint8_t* msc_bytes);
 
@@ -147,10 +146,10 @@ class Engine {
   DeviceBuffer<float2> d_spectra_;
   DeviceBuffer<uint32_t> d_fic_bits_, d_msc_bits_;
   DeviceBuffer<uint8_t> d_fibs_, d_fib_ok_;
-  DeviceBuffer<CodewordItem> d_items_;
+  DeviceBuffer<DecodeJob> d_jobs_;
+  DeviceBuffer<WaveGroup> d_groups_;
+  DeviceBuffer<int> d_job_ids_;
   DeviceBuffer<CodewordPlan> d_plans_;
-  DeviceBuffer<int> d_group_nsteps_, d_group_n16_;
-  DeviceBuffer<int64_t> d_group_base_, d_group_dec_base_;
   DeviceBuffer<uint4> d_steps_;
   DeviceBuffer<uint2> d_decisions_;
   DeviceBuffer<EtiFrameMeta> d_meta_;

@@ -34,22 +34,24 @@ namespace {
 // ---------------------------------------------------------------------------------------
 // gather: one thread per (item, 16 trellis steps)
 template <bool kFic>
-__global__ __launch_bounds__(256) void gather_kernel(const CodewordItem* __restrict__ items,
-                                                     const CodewordPlan* __restrict__ plans,
-                                                     const int* __restrict__ group_n16,        // per wave-group: ceil(nsteps/16)
-                                                     const int64_t* __restrict__ group_base,   // per wave-group: offset in 16-byte units
-                                                     int ngroups, const uint32_t* __restrict__ bits,
+__global__ __launch_bounds__(256) void gather_kernel(const WaveGroup* __restrict__ groups, int ngroups,
+                                                     const DecodeJob* __restrict__ jobs, const int* __restrict__ job_ids,
+                                                     const CodewordPlan* __restrict__ plans, const uint32_t* __restrict__ bits,
                                                      const int* __restrict__ stream_cif_base,   // MSC: first CIF row of each stream
                                                      uint4* __restrict__ steps)
 {
   const int group = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int t16 = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (group >= ngroups || t16 >= group_n16[group]) return;
-  const CodewordItem it = items[group * 64 + lane];
+  if (group >= ngroups) return;
+  const WaveGroup grp = groups[group];
+  if (t16 >= (grp.nsteps + 15) / 16) return;
+  const bool valid = lane < grp.count;
+  DecodeJob job{0, 0};
+  if (valid) job = jobs[job_ids ? job_ids[grp.first + lane] : grp.first + lane];
   uint32_t w[4] = {0, 0, 0, 0};
-  if (it.plan >= 0) {
-    const CodewordPlan pl = plans[it.plan];
+  if (valid) {
+    const CodewordPlan pl = plans[grp.plan];
     const int x0 = 64 * t16;                     // first mother-code bit of this thread
     // locate the segment holding x0 (segments are multiples of 128 mother bits)
     int seg_start = 0, j0 = 0, s = 0;
@@ -63,8 +65,8 @@ __global__ __launch_bounds__(256) void gather_kernel(const CodewordItem* __restr
     const bool tail = (s == 4);                  // 24 tail bits at PI 8 (depuncture.c:97-103)
     int j = j0 + ((x0 - seg_start) >> 5) * __popc(mask);
     const uint32_t* row0;
-    if (kFic) row0 = bits + static_cast<size_t>(it.cif >> 2) * 288;
-    else row0 = bits + (static_cast<size_t>(stream_cif_base[it.stream]) + it.cif) * 1728;
+    if (kFic) row0 = bits + static_cast<size_t>(job.cif) * 72;   // FIC block = 2304 bits = 72 words
+    else row0 = bits + (static_cast<size_t>(stream_cif_base[job.stream]) + job.cif) * 1728;
     for (int g = 0; g < 2; ++g) {
       uint32_t m = mask;
       if (tail) m = (g == 0) ? (puncture_mask(8) & 0x00ffffffu) : 0u;
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const CodewordItem* __restr
       }
     }
   }
-  steps[(group_base[group] + t16) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+  steps[(grp.step_base + t16) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -149,20 +151,16 @@ __device__ __forceinline__ void acs_step(unsigned sb, const int (&old)[64], int 
 }
 
 // one wave (64 lanes) per group of 64 equal-length code words
-__global__ __launch_bounds__(64) void viterbi_kernel(const CodewordItem* __restrict__ items,
-                                                     const CodewordPlan* __restrict__ plans,
-                                                     const int* __restrict__ group_nsteps,
-                                                     const int64_t* __restrict__ group_base,      // step buffer, 16-byte units
-                                                     const int64_t* __restrict__ group_dec_base,  // decision buffer, steps
-                                                     const uint4* __restrict__ steps, uint2* __restrict__ decisions,
-                                                     const uint32_t* __restrict__ prbs_words, uint8_t* __restrict__ out,
-                                                     int record_stride)
+__global__ __launch_bounds__(64) void viterbi_kernel(const WaveGroup* __restrict__ groups, const int* __restrict__ job_ids,
+                                                     const CodewordPlan* __restrict__ plans, const uint4* __restrict__ steps,
+                                                     uint2* __restrict__ decisions, const uint32_t* __restrict__ prbs_words,
+                                                     uint8_t* __restrict__ out, int record_stride)
 {
-  const int group = blockIdx.x, lane = threadIdx.x;
-  const int nsteps = group_nsteps[group];
-  const CodewordItem it = items[group * 64 + lane];
-  const uint4* my_steps = steps + group_base[group] * 64 + lane;
-  uint2* my_dec = decisions + group_dec_base[group] * 64 + lane;
+  const int lane = threadIdx.x;
+  const WaveGroup grp = groups[blockIdx.x];
+  const int nsteps = grp.nsteps;
+  const uint4* my_steps = steps + grp.step_base * 64 + lane;
+  uint2* my_dec = decisions + grp.dec_base * 64 + lane;
 
   int pm[64], pn[64];
 #pragma unroll
@@ -189,11 +187,12 @@ __global__ __launch_bounds__(64) void viterbi_kernel(const CodewordItem* __restr
       my_dec[static_cast<size_t>(t + 3) * 64] = d3;
     }
   }
-  if (it.plan < 0) return;
+  if (lane >= grp.count) return;
 
   // chain back from state 0 (viterbi.c:438-450), descramble, pack MSB first
-  const CodewordPlan pl = plans[it.plan];
-  uint32_t* dst = reinterpret_cast<uint32_t*>(out + static_cast<size_t>(it.out_record) * record_stride + pl.out_offset);
+  const CodewordPlan pl = plans[grp.plan];
+  const int record = job_ids ? job_ids[grp.first + lane] : grp.first + lane;
+  uint32_t* dst = reinterpret_cast<uint32_t*>(out + static_cast<size_t>(record) * record_stride + pl.out_offset);
   unsigned state = 0;
   uint32_t acc = 0;
   for (int t = nsteps - 1; t >= 6; --t) {
@@ -230,7 +229,7 @@ __global__ void fib_crc_kernel(const uint8_t* __restrict__ fibs, int nfib, const
 // one thread per ETI frame: header bytes (built by the host control plane, init_eti
 // misc.c:153-213), the 96 FIB bytes of the oldest CIF (misc.c:239), EOF CRC over FIC+MST,
 // RFU, TIST (misc.c:281-292).  The 0x55 padding was laid down by a memset beforehand.
-__global__ void eti_finish_kernel(const EtiFrameMeta* __restrict__ meta, int nframes, const uint8_t* __restrict__ headers,
+__global__ void eti_finish_kernel(const EtiFrameMeta* __restrict__ meta, int nframes, const uint8_t* __restrict__ headers, int header_stride,
                                   const uint8_t* __restrict__ fibs, const uint16_t* __restrict__ crc_tab,
                                   uint8_t* __restrict__ eti)
 {
@@ -238,7 +237,7 @@ __global__ void eti_finish_kernel(const EtiFrameMeta* __restrict__ meta, int nfr
   if (f >= nframes) return;
   const EtiFrameMeta m = meta[f];
   uint8_t* e = eti + static_cast<size_t>(f) * kEtiBytes;
-  const uint8_t* h = headers + static_cast<size_t>(f) * kEtiHeaderMax;
+  const uint8_t* h = headers + static_cast<size_t>(f) * header_stride;
   for (int i = 0; i < m.header_len; ++i) e[i] = h[i];
   const uint8_t* fb = fibs + static_cast<size_t>(m.fib_block) * 96;
   uint16_t crc = 0xffff;
@@ -257,9 +256,9 @@ __global__ void eti_finish_kernel(const EtiFrameMeta* __restrict__ meta, int nfr
 
 }  // namespace
 
-hipError_t launch_gather(bool fic, const CodewordItem* items, const CodewordPlan* plans, const int* group_n16,
-                         const int64_t* group_base, int ngroups, int max_n16, const uint32_t* bits,
-                         const int* stream_cif_base, uint4* steps, hipStream_t stream)
+hipError_t launch_gather(bool fic, const WaveGroup* groups, int ngroups, int max_n16, const DecodeJob* jobs, const int* job_ids,
+                         const CodewordPlan* plans, const uint32_t* bits, const int* stream_cif_base, uint4* steps,
+                         hipStream_t stream)
 {
   if (ngroups <= 0) return hipSuccess;
   // grid.y is limited to 65535: slice the groups
@@ -267,23 +266,19 @@ hipError_t launch_gather(bool fic, const CodewordItem* items, const CodewordPlan
     const int ng = min(32768, ngroups - g0);
     dim3 grid((max_n16 + 3) / 4, ng);
     if (fic)
-      hipLaunchKernelGGL(gather_kernel<true>, grid, dim3(256), 0, stream, items + static_cast<size_t>(g0) * 64, plans,
-                         group_n16 + g0, group_base + g0, ng, bits, stream_cif_base, steps);
+      hipLaunchKernelGGL(gather_kernel<true>, grid, dim3(256), 0, stream, groups + g0, ng, jobs, job_ids, plans, bits, stream_cif_base, steps);
     else
-      hipLaunchKernelGGL(gather_kernel<false>, grid, dim3(256), 0, stream, items + static_cast<size_t>(g0) * 64, plans,
-                         group_n16 + g0, group_base + g0, ng, bits, stream_cif_base, steps);
+      hipLaunchKernelGGL(gather_kernel<false>, grid, dim3(256), 0, stream, groups + g0, ng, jobs, job_ids, plans, bits, stream_cif_base, steps);
   }
   return hipGetLastError();
 }
 
-hipError_t launch_viterbi(const CodewordItem* items, const CodewordPlan* plans, const int* group_nsteps,
-                          const int64_t* group_base, const int64_t* group_dec_base, int ngroups, const uint4* steps,
-                          uint2* decisions, const uint32_t* prbs_words, uint8_t* out, int record_stride,
-                          hipStream_t stream)
+hipError_t launch_viterbi(const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans, const uint4* steps,
+                          uint2* decisions, const uint32_t* prbs_words, uint8_t* out, int record_stride, hipStream_t stream)
 {
   if (ngroups <= 0) return hipSuccess;
-  hipLaunchKernelGGL(viterbi_kernel, dim3(ngroups), dim3(64), 0, stream, items, plans, group_nsteps, group_base,
-                     group_dec_base, steps, decisions, prbs_words, out, record_stride);
+  hipLaunchKernelGGL(viterbi_kernel, dim3(ngroups), dim3(64), 0, stream, groups, job_ids, plans, steps, decisions, prbs_words, out,
+                     record_stride);
   return hipGetLastError();
 }
 
@@ -294,11 +289,11 @@ hipError_t launch_fib_crc(const uint8_t* fibs, int nfib, const uint16_t* crc_tab
   return hipGetLastError();
 }
 
-hipError_t launch_eti_finish(const EtiFrameMeta* meta, int nframes, const uint8_t* headers, const uint8_t* fibs,
+hipError_t launch_eti_finish(const EtiFrameMeta* meta, int nframes, const uint8_t* headers, int header_stride, const uint8_t* fibs,
                              const uint16_t* crc_tab, uint8_t* eti, hipStream_t stream)
 {
   if (nframes <= 0) return hipSuccess;
-  hipLaunchKernelGGL(eti_finish_kernel, dim3((nframes + 127) / 128), dim3(128), 0, stream, meta, nframes, headers, fibs,
+  hipLaunchKernelGGL(eti_finish_kernel, dim3((nframes + 127) / 128), dim3(128), 0, stream, meta, nframes, headers, header_stride, fibs,
                      crc_tab, eti);
   return hipGetLastError();
 }

@@ -143,21 +143,26 @@ __device__ __forceinline__ void load_symbol(GlobalU16 fast_src, const uint8_t* s
   }
 }
 
+// Transform symbols [sym_begin, sym_end).  `parity` tells which LDS buffer plays which role first and is
+// returned advanced, so that a fast run can be followed by a slow run without an extra barrier.
 template <bool kFast>
-__device__ __forceinline__ void transform_symbols(GlobalU16 fast_src, const uint8_t* stream, const FrameView& view, int sym0,
-                                                  float2* exA, float2* exB, const Twiddles& tw, float2* __restrict__ out_tf)
+__device__ __forceinline__ int transform_symbols(GlobalU16 fast_src, const uint8_t* stream, const FrameView& view, int sym_begin,
+                                                 int sym_end, int parity, float2* exA, float2* exB, const Twiddles& tw,
+                                                 float2* __restrict__ out_tf)
 {
+  if (sym_begin >= sym_end) return parity;
   unsigned raw[8];
-  load_symbol<kFast>(fast_src, stream, view, sym0, raw);
-#pragma unroll 2
-  for (int i = 0; i < kSymPerBlock; ++i) {
+  load_symbol<kFast>(fast_src, stream, view, sym_begin, raw);
+  for (int sym = sym_begin; sym < sym_end; ++sym) {
     float2 v[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = make_float2(rail(raw[r] & 0xff), rail(raw[r] >> 8));
-    if (i + 1 < kSymPerBlock) load_symbol<kFast>(fast_src, stream, view, sym0 + i + 1, raw);   // prefetch under the transform
-    if (i & 1) fft2048_store(v, exB, exA, tw, out_tf + static_cast<size_t>(sym0 + i) * 2048);
-    else fft2048_store(v, exA, exB, tw, out_tf + static_cast<size_t>(sym0 + i) * 2048);
+    if (sym + 1 < sym_end) load_symbol<kFast>(fast_src, stream, view, sym + 1, raw);   // prefetch under the transform
+    if (parity) fft2048_store(v, exB, exA, tw, out_tf + static_cast<size_t>(sym) * 2048);
+    else fft2048_store(v, exA, exB, tw, out_tf + static_cast<size_t>(sym) * 2048);
+    parity ^= 1;
   }
+  return parity;
 }
 
 // grid = (4 * nframes); frame j of the launch is frames[first + j] = {stream, call}
@@ -191,15 +196,18 @@ __global__ __launch_bounds__(kThreads, 4) void ofdm_fft_kernel(const uint8_t* co
   __syncthreads();
   float2* out_tf = spectra + static_cast<size_t>(j) * (kSymbolsPerTf * 2048);
   const int sym0 = part * kSymPerBlock;
-  // all 19 windows inside what this call read from the stream? (always, except symbol 75 after a
-  // negative timing shift and frames right after a coarse resync)
-  const int last_end = 2 * (kNullSamples + kSymSamples * (sym0 + kSymPerBlock - 1) + kCpSamples) + 4096;
-  if (last_end <= seg_end0 && seg_src0 >= 0) {
-    GlobalU16 src = reinterpret_cast<GlobalU16>(reinterpret_cast<uintptr_t>(stream + seg_src0));
-    transform_symbols<true>(src, stream, view, sym0, exA, exB, tw, out_tf);
-  } else {
-    transform_symbols<false>(nullptr, stream, view, sym0, exA, exB, tw, out_tf);
+  // Symbols whose window lies inside what this call read from the stream take the contiguous path; the
+  // rest (symbol 75 after a negative timing shift, frames right after a coarse resync) read through the view.
+  const int sym_end = sym0 + kSymPerBlock;
+  int nfast = 0;
+  if (seg_src0 >= 0) {
+    const int avail = (seg_end0 - 4096) / 2 - kNullSamples - kCpSamples;      // start sample of the last fitting window, relative
+    if (seg_end0 >= 4096 && avail >= 0) nfast = min(kSymbolsPerTf, avail / kSymSamples + 1);
   }
+  const int fast_end = max(sym0, min(sym_end, nfast));
+  GlobalU16 src = reinterpret_cast<GlobalU16>(reinterpret_cast<uintptr_t>(stream + (seg_src0 >= 0 ? seg_src0 : 0)));
+  int parity = transform_symbols<true>(src, stream, view, sym0, fast_end, 0, exA, exB, tw, out_tf);
+  transform_symbols<false>(nullptr, stream, view, fast_end, sym_end, parity, exA, exB, tw, out_tf);
 }
 
 // ---- K2b ----------------------------------------------------------------------------------

@@ -24,20 +24,18 @@ hipError_t launch_demap(const float2* spectra, const int2* frames, int first, in
                         const uint16_t* qpsk_of_carrier, uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream);
 
 // K3/K4a: time de-interleave + de-puncture gather into per-step bytes
-hipError_t launch_gather(bool fic, const CodewordItem* items, const CodewordPlan* plans, const int* group_n16,
-                         const int64_t* group_base, int ngroups, int max_n16, const uint32_t* bits,
-                         const int* stream_cif_base, uint4* steps, hipStream_t stream);
+hipError_t launch_gather(bool fic, const WaveGroup* groups, int ngroups, int max_n16, const DecodeJob* jobs, const int* job_ids,
+                         const CodewordPlan* plans, const uint32_t* bits, const int* stream_cif_base, uint4* steps,
+                         hipStream_t stream);
 
 // K3/K4b: Viterbi forward pass + chain-back + descramble + pack
-hipError_t launch_viterbi(const CodewordItem* items, const CodewordPlan* plans, const int* group_nsteps,
-                          const int64_t* group_base, const int64_t* group_dec_base, int ngroups, const uint4* steps,
-                          uint2* decisions, const uint32_t* prbs_words, uint8_t* out, int record_stride,
-                          hipStream_t stream);
+hipError_t launch_viterbi(const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans, const uint4* steps,
+                          uint2* decisions, const uint32_t* prbs_words, uint8_t* out, int record_stride, hipStream_t stream);
 
 hipError_t launch_fib_crc(const uint8_t* fibs, int nfib, const uint16_t* crc_tab, uint8_t* ok, hipStream_t stream);
 
 // K5: ETI header/FIB copy, EOF CRC, trailer
-hipError_t launch_eti_finish(const EtiFrameMeta* meta, int nframes, const uint8_t* headers, const uint8_t* fibs,
+hipError_t launch_eti_finish(const EtiFrameMeta* meta, int nframes, const uint8_t* headers, int header_stride, const uint8_t* fibs,
                              const uint16_t* crc_tab, uint8_t* eti, hipStream_t stream);
 
 }  // namespace dabhip
