@@ -6,9 +6,9 @@
 //                  (4 received bits + 4 "was transmitted" flags).
 //  viterbi_kernel  K=7 rate-1/4 maximum-likelihood decoder with the decisions of the
 //                  reference's scalar viterbi() (viterbi.c:352-451): one LANE per code word,
-//                  all 64 path metrics of that code word live in the lane's VGPRs, so the
-//                  add-compare-select needs no cross-lane traffic; 64 code words of equal
-//                  length per wave.  Followed in the same kernel by the chain-back,
+//                  all 64 path metrics of that code word live in the lane's VGPRs (32 packed
+//                  int16 pairs), so the add-compare-select is packed VALU work with no
+//                  cross-lane traffic; 64 code words of equal length per wave.  Followed in the same kernel by the chain-back,
 //                  energy-dispersal descrambling (misc.c:41-58) and MSB-first byte packing.
 //  eti_finish_kernel  header + FIBs + EOF CRC + trailer of each ETI frame (misc.c:218-296).
 //
@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void gather_kernel(const WaveGroup* __restrict
 
 // ---------------------------------------------------------------------------------------
 // branch code words: bit j of code(i) = parity(i & poly_j), i = 7-bit register with the
-// low predecessor's oldest bit 0 (viterbi.c:373-381).  poly 0 == poly 3, so bit 3 == bit 0.
+// low predecessor's oldest bit 0 (viterbi.c:373-381).  poly 0 == poly 3, so bit 3 == bit 0
+// and only 8 distinct code words exist; code(i ^ 1) = code(i) ^ 7 on the three distinct bits.
 __host__ __device__ constexpr unsigned parity_u(unsigned x)
 {
   x ^= x >> 4;
@@ -111,82 +112,165 @@ __host__ __device__ constexpr unsigned branch_code3(unsigned i)   // bits 0..2 o
   return parity_u(i & 0x6d) | (parity_u(i & 0x4f) << 1) | (parity_u(i & 0x53) << 2);
 }
 
-template <int kJ>
-__device__ __forceinline__ void butterfly(const int (&old)[64], int (&nw)[64], const int (&bm)[8], int ntx, uint32_t& dlo,
-                                          uint32_t& dhi)
+// Path metrics are agreement counts held as packed int16 pairs: 32 VGPRs for the 64 states.
+// In layout L(tau) (tau = 0..3, delta = 1 << tau) register r (0..15) holds states (k, k ^ delta) for the
+// r-th k < 32 whose bit tau is clear, register 16 + r the same pair + 32.  With both members of a
+// pair in one register, the butterflies of k and k ^ delta run as ONE packed add/max each:
+//   E = max(X + B[c], Y + B[c^7])   -> new states (2k, 2(k^delta))      (pair difference 2 delta)
+//   O = max(X + B[c^7], Y + B[c])   -> new states (2k+1, 2(k^delta)+1)
+// so a step in L(tau) leaves its results in L(tau+1) with no data movement; after tau = 3 the
+// registers are re-paired to L(0) with one v_perm_b32 each.  Four steps = one 32-bit word of
+// trellis input.
+typedef short __attribute__((ext_vector_type(2))) pk16;
+typedef unsigned short __attribute__((ext_vector_type(2))) upk16;
+
+__device__ __forceinline__ pk16 as_pk(uint32_t x) { return __builtin_bit_cast(pk16, x); }
+__device__ __forceinline__ uint32_t as_u32(pk16 x) { return __builtin_bit_cast(uint32_t, x); }
+
+__host__ __device__ constexpr int expand_bit(int r, int tau) { return ((r >> tau) << (tau + 1)) | (r & ((1 << tau) - 1)); }
+__host__ __device__ constexpr int compress_bit(int k, int tau) { return ((k >> (tau + 1)) << tau) | (k & ((1 << tau) - 1)); }
+
+// where the survivor decision of new state s lands in the 64-bit word of a step of type tau
+__host__ __device__ constexpr int decision_bit(int tau, int s)
 {
-  constexpr unsigned c = branch_code3(2 * kJ);
-  const int b1 = bm[c], b2 = ntx - b1;
-  const int lo = old[kJ], hi = old[kJ + 32];
-  const int e0 = lo + b1, e1 = hi + b2;       // into state 2j   (viterbi.c:404-414)
-  const int o0 = lo + b2, o1 = hi + b1;       // into state 2j+1 (viterbi.c:415-421)
-  nw[2 * kJ] = max(e0, e1);
-  nw[2 * kJ + 1] = max(o0, o1);
-  constexpr int be = 2 * kJ, bo = 2 * kJ + 1;
-  if (be < 32) { dlo |= (e1 > e0 ? 1u : 0u) << be; dlo |= (o1 > o0 ? 1u : 0u) << bo; }
-  else { dhi |= (e1 > e0 ? 1u : 0u) << (be - 32); dhi |= (o1 > o0 ? 1u : 0u) << (bo - 32); }
+  const int b = s & 1, jj = s >> 1, delta = 1 << tau;
+  const int half = (jj >> tau) & 1;
+  const int j = half ? (jj ^ delta) : jj;
+  const int idx = 2 * compress_bit(j, tau) + b;          // D register index 0..31
+  return (idx >> 4) * 32 + (idx & 15) + 16 * half;
 }
 
-template <int... kJs>
-__device__ __forceinline__ void all_butterflies(const int (&old)[64], int (&nw)[64], const int (&bm)[8], int ntx,
-                                                uint32_t& dlo, uint32_t& dhi, std::integer_sequence<int, kJs...>)
+template <int kTau, int kR>
+__device__ __forceinline__ void butterfly_pair(const pk16 (&p)[32], pk16 (&n)[32], const pk16 (&bb)[8], uint32_t& d0, uint32_t& d1)
 {
-  (butterfly<kJs>(old, nw, bm, ntx, dlo, dhi), ...);
+  constexpr int j = expand_bit(kR, kTau);                 // butterfly index of the low half; high half is j ^ delta
+  constexpr unsigned c = branch_code3(2 * j);
+  const pk16 x = p[kR], y = p[16 + kR];
+  const pk16 t0 = x + bb[c], t1 = y + bb[c ^ 7];          // into states 2j, 2j'      (viterbi.c:404-414)
+  const pk16 t2 = x + bb[c ^ 7], t3 = y + bb[c];          // into states 2j+1, 2j'+1  (viterbi.c:415-421)
+  const pk16 e = __builtin_elementwise_max(t0, t1), o = __builtin_elementwise_max(t2, t3);
+  // decision = 1 iff the high predecessor is strictly better: sign of (low - high)
+  // (bit 0 and bit 16 of de / dd after the logical shift; shifted into their slots of the decision word)
+  const uint32_t de = as_u32(__builtin_bit_cast(pk16, __builtin_bit_cast(upk16, t0 - t1) >> 15));
+  const uint32_t dd = as_u32(__builtin_bit_cast(pk16, __builtin_bit_cast(upk16, t2 - t3) >> 15));
+  constexpr int ie = 2 * kR, io = 2 * kR + 1;
+  if (ie < 16) { d0 |= de << (ie & 15); d0 |= dd << (io & 15); } else { d1 |= de << (ie & 15); d1 |= dd << (io & 15); }
+  // results already form the pairs of the next layout
+  constexpr int k_e = 2 * j, k_o = 2 * j + 1;
+  if (kTau < 3) {
+    n[(k_e >= 32 ? 16 : 0) + compress_bit(k_e & 31, kTau + 1)] = e;
+    n[(k_o >= 32 ? 16 : 0) + compress_bit(k_o & 31, kTau + 1)] = o;
+  } else {                                                // delta = 8 -> pairs (k, k ^ 16): park as L(4)
+    n[(k_e >= 32 ? 16 : 0) + (k_e & 15)] = e;
+    n[(k_o >= 32 ? 16 : 0) + (k_o & 15)] = o;
+  }
 }
 
-__device__ __forceinline__ void acs_step(unsigned sb, const int (&old)[64], int (&nw)[64], uint2& dec)
+template <int kTau, int... kRs>
+__device__ __forceinline__ void all_pairs(const pk16 (&p)[32], pk16 (&n)[32], const pk16 (&bb)[8], uint32_t& d0, uint32_t& d1,
+                                          std::integer_sequence<int, kRs...>)
+{
+  (butterfly_pair<kTau, kRs>(p, n, bb, d0, d1), ...);
+}
+
+template <int kTau>
+__device__ __forceinline__ void acs_step(unsigned sb, const pk16 (&p)[32], pk16 (&n)[32], uint2& dec)
 {
   const unsigned v = sb & 15u, m = (sb >> 4) & 15u;
   // agreement count of the 8 distinct code words (bit3 = bit0) with the received nibble
+  const int ntx = __popc(m);
   int bm[8];
 #pragma unroll
-  for (unsigned c = 0; c < 8; ++c) {
+  for (unsigned c = 0; c < 4; ++c) {
     const unsigned cw = c | ((c & 1u) << 3);
     bm[c] = __popc(~(v ^ cw) & m);
+    bm[c ^ 7] = ntx - bm[c];
   }
-  const int ntx = __popc(m);
-  uint32_t dlo = 0, dhi = 0;
-  all_butterflies(old, nw, bm, ntx, dlo, dhi, std::make_integer_sequence<int, 32>{});
-  dec = make_uint2(dlo, dhi);
+  constexpr unsigned gamma = branch_code3(2u << kTau);    // code difference between the two members of a pair
+  pk16 bb[8];
+#pragma unroll
+  for (unsigned c = 0; c < 8; ++c) bb[c] = as_pk(static_cast<uint32_t>(bm[c]) | (static_cast<uint32_t>(bm[c ^ gamma]) << 16));
+  uint32_t d0 = 0, d1 = 0;
+  all_pairs<kTau>(p, n, bb, d0, d1, std::make_integer_sequence<int, 16>{});
+  dec = make_uint2(d0, d1);
 }
 
-// one wave (64 lanes) per group of 64 equal-length code words
+// L(4) (pairs (k, k^16)) -> L(0) (pairs (k, k^1)): one byte permute per register
+__device__ __forceinline__ void repair_layout(const pk16 (&n)[32], pk16 (&p)[32])
+{
+#pragma unroll
+  for (int side = 0; side < 2; ++side)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int a = side * 16 + ((2 * q) & 15);           // register holding state 2q (low half if 2q < 16)
+      const uint32_t sel = (2 * q < 16) ? 0x05040100u : 0x07060302u;
+      p[side * 16 + q] = as_pk(__builtin_amdgcn_perm(as_u32(n[a + 1]), as_u32(n[a]), sel));
+    }
+}
+
+struct DecisionTable {
+  uint8_t pos[4][64];
+};
+__host__ __device__ constexpr DecisionTable make_decision_table()
+{
+  DecisionTable t{};
+  for (int tau = 0; tau < 4; ++tau)
+    for (int s = 0; s < 64; ++s) t.pos[tau][s] = static_cast<uint8_t>(decision_bit(tau, s));
+  return t;
+}
+__constant__ DecisionTable kDecisionTable = make_decision_table();
+
+// one wave (64 lanes) per group of <= 64 equal-length code words
 __global__ __launch_bounds__(64) void viterbi_kernel(const WaveGroup* __restrict__ groups, const int* __restrict__ job_ids,
                                                      const CodewordPlan* __restrict__ plans, const uint4* __restrict__ steps,
                                                      uint2* __restrict__ decisions, const uint32_t* __restrict__ prbs_words,
                                                      uint8_t* __restrict__ out, int record_stride)
 {
+  __shared__ uint8_t dec_pos[4 * 64];
   const int lane = threadIdx.x;
   const WaveGroup grp = groups[blockIdx.x];
   const int nsteps = grp.nsteps;
   const uint4* my_steps = steps + grp.step_base * 64 + lane;
   uint2* my_dec = decisions + grp.dec_base * 64 + lane;
+  for (int i = lane; i < 256; i += 64) dec_pos[i] = kDecisionTable.pos[i >> 6][i & 63];
 
-  int pm[64], pn[64];
+  // L(0): register r = states (2r, 2r+1), register 16 + r = states (32 + 2r, 33 + 2r); state 0 starts at 0,
+  // every other state "unreachable" (viterbi.c:387-389, scaled to agreement counts)
+  pk16 pm[32], pn[32], pl4[32];
 #pragma unroll
-  for (int i = 0; i < 64; ++i) pm[i] = -1024;   // "unreachable" (viterbi.c:387-389, scaled)
-  pm[0] = 0;
+  for (int r = 0; r < 32; ++r) pm[r] = as_pk(0xfc00fc00u);       // (-1024, -1024)
+  pm[0] = as_pk(0xfc000000u);                                      // (0, -1024)
 
   const int n16 = (nsteps + 15) >> 4;
   for (int t16 = 0; t16 < n16; ++t16) {
     const uint4 pack = my_steps[static_cast<size_t>(t16) * 64];
     const uint32_t w[4] = {pack.x, pack.y, pack.z, pack.w};
-#pragma unroll
+#pragma unroll 1
     for (int q = 0; q < 4; ++q) {
       const int t = 16 * t16 + 4 * q;
       if (t >= nsteps) break;
+      const uint32_t ww = (q == 0) ? w[0] : (q == 1) ? w[1] : (q == 2) ? w[2] : w[3];
       uint2 d0, d1, d2, d3;
-      acs_step(w[q] & 0xff, pm, pn, d0);
-      acs_step((w[q] >> 8) & 0xff, pn, pm, d1);
-      acs_step((w[q] >> 16) & 0xff, pm, pn, d2);
-      acs_step(w[q] >> 24, pn, pm, d3);
+      acs_step<0>(ww & 0xff, pm, pn, d0);
+      acs_step<1>((ww >> 8) & 0xff, pn, pm, d1);
+      acs_step<2>((ww >> 16) & 0xff, pm, pn, d2);
+      acs_step<3>(ww >> 24, pn, pl4, d3);
+      repair_layout(pl4, pm);
       // steps past nsteps (only in the last word) write into slack space of the buffer
       my_dec[static_cast<size_t>(t) * 64] = d0;
       my_dec[static_cast<size_t>(t + 1) * 64] = d1;
       my_dec[static_cast<size_t>(t + 2) * 64] = d2;
       my_dec[static_cast<size_t>(t + 3) * 64] = d3;
     }
+    // agreement counts grow by <= 4 per step: re-base on state 0 long before int16 could overflow
+    if ((t16 & 127) == 127) {
+      const uint32_t s0 = as_u32(pm[0]) & 0xffffu;
+      const pk16 base = as_pk(s0 | (s0 << 16));
+#pragma unroll
+      for (int r = 0; r < 32; ++r) pm[r] = pm[r] - base;
+    }
   }
+  __syncthreads();
   if (lane >= grp.count) return;
 
   // chain back from state 0 (viterbi.c:438-450), descramble, pack MSB first
@@ -197,7 +281,8 @@ __global__ __launch_bounds__(64) void viterbi_kernel(const WaveGroup* __restrict
   uint32_t acc = 0;
   for (int t = nsteps - 1; t >= 6; --t) {
     const uint2 d = my_dec[static_cast<size_t>(t) * 64];
-    const unsigned bit = ((state & 32u) ? (d.y >> (state & 31u)) : (d.x >> state)) & 1u;
+    const unsigned pos = dec_pos[(t & 3) * 64 + state];
+    const unsigned bit = ((pos & 32u) ? (d.y >> (pos & 31u)) : (d.x >> pos)) & 1u;
     state = (state | (bit << 6)) >> 1;
     const int i = t - 6;                               // data bit index
     acc |= bit << (8 * ((i >> 3) & 3) + (7 - (i & 7)));
