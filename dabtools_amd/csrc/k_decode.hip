@@ -242,8 +242,11 @@ __global__ __launch_bounds__(64) void viterbi_kernel(const WaveGroup* __restrict
   pm[0] = as_pk(0xfc000000u);                                      // (0, -1024)
 
   const int n16 = (nsteps + 15) >> 4;
+  uint4 pack = my_steps[0];
   for (int t16 = 0; t16 < n16; ++t16) {
-    const uint4 pack = my_steps[static_cast<size_t>(t16) * 64];
+    // fetch the next 16 steps before this block's decision stores are issued: the wait for it then
+    // does not have to drain those stores (loads and stores retire in order on one counter)
+    const uint4 next = my_steps[static_cast<size_t>(min(t16 + 1, n16 - 1)) * 64];
     const uint32_t w[4] = {pack.x, pack.y, pack.z, pack.w};
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
@@ -269,6 +272,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(const WaveGroup* __restrict
 #pragma unroll
       for (int r = 0; r < 32; ++r) pm[r] = pm[r] - base;
     }
+    pack = next;
   }
   __syncthreads();
   if (lane >= grp.count) return;
@@ -279,16 +283,24 @@ __global__ __launch_bounds__(64) void viterbi_kernel(const WaveGroup* __restrict
   uint32_t* dst = reinterpret_cast<uint32_t*>(out + static_cast<size_t>(record) * record_stride + pl.out_offset);
   unsigned state = 0;
   uint32_t acc = 0;
-  for (int t = nsteps - 1; t >= 6; --t) {
-    const uint2 d = my_dec[static_cast<size_t>(t) * 64];
-    const unsigned pos = dec_pos[(t & 3) * 64 + state];
-    const unsigned bit = ((pos & 32u) ? (d.y >> (pos & 31u)) : (d.x >> pos)) & 1u;
-    state = (state | (bit << 6)) >> 1;
-    const int i = t - 6;                               // data bit index
-    acc |= bit << (8 * ((i >> 3) & 3) + (7 - (i & 7)));
-    if ((i & 31) == 0) {
-      dst[i >> 5] = acc ^ prbs_words[i >> 5];
-      acc = 0;
+  // decision words are fetched 8 steps at a time (their addresses do not depend on the path)
+  for (int t_hi = nsteps - 1; t_hi >= 6; t_hi -= 8) {
+    uint2 d[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) d[u] = my_dec[static_cast<size_t>(max(t_hi - u, 0)) * 64];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = t_hi - u;
+      if (t < 6) break;
+      const unsigned pos = dec_pos[(t & 3) * 64 + state];
+      const unsigned bit = ((pos & 32u) ? (d[u].y >> (pos & 31u)) : (d[u].x >> pos)) & 1u;
+      state = (state | (bit << 6)) >> 1;
+      const int i = t - 6;                               // data bit index
+      acc |= bit << (8 * ((i >> 3) & 3) + (7 - (i & 7)));
+      if ((i & 31) == 0) {
+        dst[i >> 5] = acc ^ prbs_words[i >> 5];
+        acc = 0;
+      }
     }
   }
 }
