@@ -254,7 +254,7 @@ int dabhip_dab_process_frame(dabhip_dab* d)
 {
   if (!d) { set_error("dab_process_frame: null handle"); return -1; }
   if (d->slot == kDabSlots) {        // keep the 4 most recent TFs (16 CIFs of interleaver history)
-    if (!d->eng.move_tf_slots(0, kDabSlots - 4, 4)) return -1;
+    if (!d->eng.recycle_tf_slots(kDabSlots, 4)) return -1;
     d->plane.rebase(4 * (kDabSlots - 4));
     d->dropped += kDabSlots - 4;
     d->slot = 4;
@@ -265,10 +265,10 @@ int dabhip_dab_process_frame(dabhip_dab* d)
   d->plane.on_tf(d->slot, d->fibs.data(), d->ok.data(), jobs);
   ++d->slot;
   if (jobs.empty()) return 0;
-  std::vector<int> cif_base = {0};
+  std::vector<int> row_base = {15}, fib_base = {0};   // single stream: CIF 0 at logical row 15 (Engine::store_tf_bytes)
   std::vector<const ControlPlane*> planes = {&d->plane};
   std::vector<const std::vector<EtiJob>*> job_lists = {&jobs};
-  if (!d->eng.msc_decode(job_lists, planes, cif_base)) return -1;
+  if (!d->eng.msc_decode(job_lists, planes, row_base, fib_base)) return -1;
   if (!d->eng.read_eti(0, static_cast<int64_t>(jobs.size()), d->eti.data())) return -1;
   if (d->cb)
     for (size_t f = 0; f < jobs.size(); ++f) d->cb(d->eti.data() + f * kEtiBytes);

@@ -20,6 +20,8 @@ constexpr int kFftChunkTfs = 1024;                        // spectra buffer: 102
 constexpr int64_t kMaxDecisionRows = int64_t(12) << 20;   // x 512 B = 6 GiB of survivor decisions per launch
 constexpr int kFicWords = kFicBits / 32;                  // 288
 constexpr int kMscWords = kMscBits / 32;                  // 6912
+constexpr int kCifWords = kCifBits / 32;                  // 1728 words per (logical) CIF row
+constexpr int kRowLead = 15;                              // logical rows before a stream's CIF 0 (interleaver depth - 1)
 
 StreamState initial_state()
 {
@@ -205,38 +207,59 @@ bool Engine::run_decode_batch(DecodeBatch& b, bool fic, const std::vector<Decode
 }
 
 // ---------------------------------------------------------------------------------------------
-bool Engine::reserve_tf_slots(int nslots)
+bool Engine::reserve_tf_slots(int nslots, int msc_rows)
 {
-  if (nslots <= tf_slots_) return true;
+  if (msc_rows < 0) msc_rows = 4 * nslots + kRowLead + 1;
   // growth discards contents: callers reserve before filling
-  if (!d_fic_bits_.reserve(static_cast<size_t>(nslots) * kFicWords) || !d_msc_bits_.reserve(static_cast<size_t>(nslots) * kMscWords) ||
-      !d_fibs_.reserve(static_cast<size_t>(nslots) * 384) || !d_fib_ok_.reserve(static_cast<size_t>(nslots) * 12))
-    return false;
-  tf_slots_ = nslots;
+  if (nslots > tf_slots_) {
+    if (!d_fic_bits_.reserve(static_cast<size_t>(nslots) * kFicWords) || !d_fibs_.reserve(static_cast<size_t>(nslots) * 384) ||
+        !d_fib_ok_.reserve(static_cast<size_t>(nslots) * 12))
+      return false;
+    tf_slots_ = nslots;
+  }
+  if (msc_rows > msc_rows_) {
+    if (!d_msc_bits_.reserve(static_cast<size_t>(msc_rows) * kCifWords)) return false;
+    msc_rows_ = msc_rows;
+  }
   return true;
 }
 
+// S3: host 0/1 bytes of one TF -> FIC row of `slot`, MSC scattered into the planar logical rows (single stream,
+// CIF 0 at row kRowLead), the same layout demap_kernel<true> produces
 bool Engine::store_tf_bytes(int slot, const uint8_t* fic_bytes, const uint8_t* msc_bytes)
 {
-  std::vector<uint32_t> f(kFicWords), m(kMscWords);
+  static const int tmap[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+  std::vector<uint32_t> f(kFicWords), plane(108);
   pack_bits(fic_bytes, kFicBits, f.data());
-  pack_bits(msc_bytes, kMscBits, m.data());
-  return check(hipMemcpy(d_fic_bits_.get() + static_cast<size_t>(slot) * kFicWords, f.data(), f.size() * 4, hipMemcpyHostToDevice), "fic upload") &&
-         check(hipMemcpy(d_msc_bits_.get() + static_cast<size_t>(slot) * kMscWords, m.data(), m.size() * 4, hipMemcpyHostToDevice), "msc upload");
+  if (!check(hipMemcpy(d_fic_bits_.get() + static_cast<size_t>(slot) * kFicWords, f.data(), f.size() * 4, hipMemcpyHostToDevice), "fic upload")) return false;
+  for (int q = 0; q < 4; ++q) {
+    const uint8_t* cif = msc_bytes + static_cast<size_t>(q) * kCifBits;
+    for (int r = 0; r < 16; ++r) {
+      std::fill(plane.begin(), plane.end(), 0u);
+      for (int u = 0; u < kCifBits / 16; ++u) plane[u >> 5] |= static_cast<uint32_t>(cif[16 * u + r] & 1u) << (u & 31);
+      const size_t row = static_cast<size_t>(kRowLead + 4 * slot + q - tmap[r]);
+      if (!check(hipMemcpy(d_msc_bits_.get() + (row * 16 + r) * 108, plane.data(), 108 * 4, hipMemcpyHostToDevice), "msc upload")) return false;
+    }
+  }
+  return true;
 }
 
-bool Engine::move_tf_slots(int dst, int src, int n)
+bool Engine::recycle_tf_slots(int used_slots, int keep_slots)
 {
-  // ranges may overlap only when dst < src; stage through the spectra scratch
-  if (!d_bytes_.reserve(static_cast<size_t>(n) * kMscWords * 4)) return false;
-  auto mv = [&](void* base, size_t slot_bytes) {
+  // FIC rows / FIB records: the newest keep_slots; logical CIF rows: everything from 15 rows before the oldest kept CIF
+  const int src_slot = used_slots - keep_slots;
+  const size_t row_src = static_cast<size_t>(4 * src_slot), nrows = static_cast<size_t>(4 * keep_slots + kRowLead);
+  if (!d_bytes_.reserve(std::max(nrows * kCifWords * 4, static_cast<size_t>(keep_slots) * kFicWords * 4))) return false;
+  auto mv = [&](void* base, size_t unit, size_t src, size_t n) {
     uint8_t* b = static_cast<uint8_t*>(base);
-    return check(hipMemcpy(d_bytes_.get(), b + src * slot_bytes, n * slot_bytes, hipMemcpyDeviceToDevice), "slot move") &&
-           check(hipMemcpy(b + dst * slot_bytes, d_bytes_.get(), n * slot_bytes, hipMemcpyDeviceToDevice), "slot move");
+    return check(hipMemcpy(d_bytes_.get(), b + src * unit, n * unit, hipMemcpyDeviceToDevice), "slot move") &&
+           check(hipMemcpy(b, d_bytes_.get(), n * unit, hipMemcpyDeviceToDevice), "slot move");
   };
-  return mv(d_fic_bits_.get(), kFicWords * 4) && mv(d_msc_bits_.get(), kMscWords * 4) && mv(d_fibs_.get(), 384) && mv(d_fib_ok_.get(), 12);
+  return mv(d_fic_bits_.get(), kFicWords * 4, src_slot, keep_slots) && mv(d_fibs_.get(), 384, src_slot, keep_slots) &&
+         mv(d_fib_ok_.get(), 12, src_slot, keep_slots) && mv(d_msc_bits_.get(), kCifWords * 4, row_src, nrows);
 }
 
+// S2 / stage_demap: the TF was demapped in NATURAL order (demap_kernel<false>) into FIC slot `slot`, CIF rows 4*slot..
 bool Engine::unpack_tf_slot(int slot, uint8_t* fic_bytes, uint8_t* msc_bytes)
 {
   std::vector<uint32_t> f(kFicWords), m(kMscWords);
@@ -268,7 +291,7 @@ bool Engine::fic_decode_slots(int first, int n, uint8_t* fibs_host, uint8_t* ok_
 }
 
 bool Engine::msc_decode(const std::vector<const std::vector<EtiJob>*>& stream_jobs, const std::vector<const ControlPlane*>& planes,
-                        const std::vector<int>& stream_cif_base)
+                        const std::vector<int>& stream_row_base, const std::vector<int>& stream_fib_base)
 {
   size_t nf = 0;
   for (const auto* v : stream_jobs) nf += v->size();
@@ -322,7 +345,7 @@ bool Engine::msc_decode(const std::vector<const std::vector<EtiJob>*>& stream_jo
       }
       layout_frames[gid].push_back(static_cast<int>(f));
       jobs[f] = DecodeJob{static_cast<int32_t>(b), job.first_cif};
-      meta[f] = EtiFrameMeta{job.header_len, layouts[gid].mst_bytes, stream_cif_base[b] + job.first_cif, 0};
+      meta[f] = EtiFrameMeta{job.header_len, layouts[gid].mst_bytes, stream_fib_base[b] + job.first_cif, 0};
       std::memcpy(headers.data() + f * header_stride, job.header, static_cast<size_t>(job.header_len));
       ++f;
     }
@@ -333,7 +356,7 @@ bool Engine::msc_decode(const std::vector<const std::vector<EtiJob>*>& stream_jo
   DecodeBatch batch;
   build_batch(plan_jobs, batch);
   if (!d_eti_.reserve(nf * kEtiBytes) || !d_meta_.upload(meta, stream_) || !d_headers_.upload(headers, stream_) ||
-      !d_stream_cif_base_.upload(stream_cif_base, stream_))
+      !d_stream_cif_base_.upload(stream_row_base, stream_))
     return false;
   if (!check(hipMemsetAsync(d_eti_.get(), 0x55, nf * kEtiBytes, stream_), "eti memset")) return false;   // padding, misc.c:295
   if (!run_decode_batch(batch, false, jobs, d_msc_bits_.get(), d_stream_cif_base_.get(), d_prbs_.get(), d_eti_.get(), kEtiBytes,
@@ -412,7 +435,8 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
 
   // frame list: demodulated TFs, stream-major
   std::vector<int2> frames;
-  std::vector<int> frame_slot, tf_base(nstreams + 1, 0), cif_base(nstreams);
+  std::vector<int> frame_slot, frame_cif_row, tf_base(nstreams + 1, 0), row_base(nstreams), fib_base(nstreams);
+  int next_row = 0;
   for (int b = 0; b < nstreams; ++b) {
     int n = 0;
     const int ncalls = static_cast<int>(nbytes[b] / kChunkBytes);
@@ -421,15 +445,20 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
       if (d.status == 2) {
         frames.push_back(make_int2(b, k));
         frame_slot.push_back(tf_base[b] + d.ordinal);
+        frame_cif_row.push_back(next_row + kRowLead + 4 * d.ordinal);
         ++n;
       }
     }
     tf_base[b + 1] = tf_base[b] + n;
-    cif_base[b] = 4 * tf_base[b];
+    fib_base[b] = 4 * tf_base[b];
+    row_base[b] = next_row + kRowLead;      // each stream gets 15 lead-in rows for the scatter of its first CIFs
+    next_row += kRowLead + 4 * n;
   }
   const int ntf = static_cast<int>(frames.size());
   if (ntf == 0) return 0;
-  if (!reserve_tf_slots(ntf) || !d_frames_.upload(frames, stream_) || !d_frame_slot_.upload(frame_slot, stream_)) return -1;
+  if (!reserve_tf_slots(ntf, next_row + 1) || !d_frames_.upload(frames, stream_) || !d_frame_slot_.upload(frame_slot, stream_) ||
+      !d_frame_cif_row_.upload(frame_cif_row, stream_))
+    return -1;
 
   // K2 + K2b in chunks
   const int chunk = std::min(ntf, kFftChunkTfs);
@@ -439,7 +468,7 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
     (void)hipEventRecord(ev_[0], stream_);
     if (!check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(), stream_), "fft launch")) return -1;
     (void)hipEventRecord(ev_[1], stream_);
-    if (!check(launch_demap(d_spectra_.get(), d_frames_.get(), first, n, d_frame_slot_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch")) return -1;
+    if (!check(launch_demap(true, d_spectra_.get(), first, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch")) return -1;
     (void)hipEventRecord(ev_[2], stream_);
     if (!check(hipEventSynchronize(ev_[2]), "fft/demap")) return -1;
     float a = 0, c = 0;
@@ -494,7 +523,7 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
   times_.control = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
   // K4 + K5
-  if (!msc_decode(job_ptrs, plane_ptrs, cif_base)) return -1;
+  if (!msc_decode(job_ptrs, plane_ptrs, row_base, fib_base)) return -1;
   return total_eti_;
 }
 
@@ -578,12 +607,11 @@ int Engine::stage_demap(const float* spectra, int nframes, uint8_t* fic, uint8_t
   if (!ok_) { set_error("engine not initialised (no GPU?)"); return -1; }
   if (nframes <= 0) return 0;
   const size_t nspec = static_cast<size_t>(nframes) * kSymbolsPerTf * 2048;
-  std::vector<int2> list(nframes);
-  std::vector<int> slots(nframes);
-  for (int j = 0; j < nframes; ++j) { list[j] = make_int2(0, j); slots[j] = j; }
-  if (!reserve_tf_slots(nframes) || !d_spectra_.reserve(nspec) || !d_frames_.upload(list, stream_) || !d_frame_slot_.upload(slots, stream_)) return -1;
+  std::vector<int> slots(nframes), rows(nframes);
+  for (int j = 0; j < nframes; ++j) { slots[j] = j; rows[j] = 4 * j; }
+  if (!reserve_tf_slots(nframes) || !d_spectra_.reserve(nspec) || !d_frame_slot_.upload(slots, stream_) || !d_frame_cif_row_.upload(rows, stream_)) return -1;
   if (!check(hipMemcpyAsync(d_spectra_.get(), spectra, nspec * sizeof(float2), hipMemcpyHostToDevice, stream_), "spectra upload")) return -1;
-  if (!check(launch_demap(d_spectra_.get(), d_frames_.get(), 0, nframes, d_frame_slot_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch") ||
+  if (!check(launch_demap(false, d_spectra_.get(), 0, nframes, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch") ||
       !check(hipStreamSynchronize(stream_), "demap"))
     return -1;
   for (int j = 0; j < nframes; ++j)
@@ -674,10 +702,11 @@ bool Engine::demod_one_frame(const uint8_t* iq_virtual_base, const CallDesc& des
   std::vector<int> slots = {0};
   std::vector<CallDesc> d = {desc};
   if (!reserve_tf_slots(1) || !d_iq_ptrs_.upload(ptrs, stream_) || !d_descs_.upload(d, stream_) || !d_frames_.upload(list, stream_) ||
-      !d_frame_slot_.upload(slots, stream_) || !d_spectra_.reserve(static_cast<size_t>(kSymbolsPerTf) * 2048))
+      !d_frame_slot_.upload(slots, stream_) || !d_frame_cif_row_.upload(slots, stream_) ||
+      !d_spectra_.reserve(static_cast<size_t>(kSymbolsPerTf) * 2048))
     return false;
   if (!check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), 1, d_frames_.get(), 0, 1, d_spectra_.get(), d_twf_.get(), stream_), "fft launch") ||
-      !check(launch_demap(d_spectra_.get(), d_frames_.get(), 0, 1, d_frame_slot_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch") ||
+      !check(launch_demap(false, d_spectra_.get(), 0, 1, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch") ||
       !check(hipStreamSynchronize(stream_), "demod"))
     return false;
   return unpack_tf_slot(0, fic_bytes, msc_bytes);

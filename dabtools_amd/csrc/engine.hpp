@@ -98,15 +98,18 @@ class Engine {
   int viterbi_batch(const uint8_t* symbols, uint8_t* data, int framebits, int n);
 
   // -- building blocks shared with the streaming seams (capi.cpp) ------------------------------
-  bool reserve_tf_slots(int nslots);
+  // FIC rows / FIB records for nslots TFs and msc_rows logical CIF rows (default 4 per slot + 15 lead-in + 1)
+  bool reserve_tf_slots(int nslots, int msc_rows = -1);
   // host 0/1 bytes of one demapped TF -> bit rows of TF slot `slot`
   bool store_tf_bytes(int slot, const uint8_t* fic_bytes, const uint8_t* msc_bytes);
-  bool move_tf_slots(int dst, int src, int n);
+  // S3 recycling: keep the newest `keep_slots` TF slots (and the logical CIF rows still being filled) at the front
+  bool recycle_tf_slots(int used_slots, int keep_slots);
   // FIC-decode TF slots [first, first+n): FIBs and CRC flags to host
   bool fic_decode_slots(int first, int n, uint8_t* fibs_host, uint8_t* ok_host);
   // decode the ETI frames described by the per-stream job lists into the ETI buffer (stream-major order)
+  // stream_row_base[b]: logical CIF row of stream b's CIF 0; stream_fib_base[b]: FIB block (4 per TF slot) of its CIF 0
   bool msc_decode(const std::vector<const std::vector<EtiJob>*>& stream_jobs, const std::vector<const ControlPlane*>& planes,
-                  const std::vector<int>& stream_cif_base);
+                  const std::vector<int>& stream_row_base, const std::vector<int>& stream_fib_base);
   bool read_eti(int64_t first, int64_t n, uint8_t* dst);
   // front end on an explicit single stream (S2 seam): calls [call, call+1)
   bool scan_one_call(const uint8_t* iq_virtual_base, int64_t fed_bytes, StreamState* d_state, int call, CallDesc* out);
@@ -142,7 +145,7 @@ class Engine {
   DeviceBuffer<StreamState> d_states_;
   DeviceBuffer<CallDesc> d_descs_;
   DeviceBuffer<int2> d_frames_;
-  DeviceBuffer<int> d_frame_slot_, d_stream_cif_base_;
+  DeviceBuffer<int> d_frame_slot_, d_frame_cif_row_, d_stream_cif_base_;
   DeviceBuffer<float2> d_spectra_;
   DeviceBuffer<uint32_t> d_fic_bits_, d_msc_bits_;
   DeviceBuffer<uint8_t> d_fibs_, d_fib_ok_;
@@ -154,7 +157,7 @@ class Engine {
   DeviceBuffer<uint2> d_decisions_;
   DeviceBuffer<EtiFrameMeta> d_meta_;
   DeviceBuffer<uint8_t> d_headers_, d_eti_, d_bytes_;
-  int tf_slots_ = 0;
+  int tf_slots_ = 0, msc_rows_ = 0;
 
   std::vector<CodewordPlan> plans_;
   std::map<std::vector<int32_t>, int> plan_index_;

@@ -1,9 +1,9 @@
 // k_decode.hip — K3/K4: channel decoding of the FIC and of every MSC sub-channel, and K5:
 // ETI frame completion.
 //
-//  gather_kernel   time de-interleave (misc.c:29-39) + de-puncture (depuncture.c:45-132)
-//                  fused into one gather: demapped bit rows -> one byte per trellis step
-//                  (4 received bits + 4 "was transmitted" flags).
+//  gather_kernel   de-puncture (depuncture.c:45-132) of the time-de-interleaved logical CIF rows
+//                  that demap_kernel laid out (misc.c:29-39 is folded into that scatter):
+//                  bit rows -> one byte per trellis step (4 received bits + 4 "was transmitted" flags).
 //  viterbi_kernel  K=7 rate-1/4 maximum-likelihood decoder with the decisions of the
 //                  reference's scalar viterbi() (viterbi.c:352-451): one LANE per code word,
 //                  all 64 path metrics of that code word live in the lane's VGPRs (32 packed
@@ -37,63 +37,65 @@ template <bool kFic>
 __global__ __launch_bounds__(256) void gather_kernel(const WaveGroup* __restrict__ groups, int ngroups,
                                                      const DecodeJob* __restrict__ jobs, const int* __restrict__ job_ids,
                                                      const CodewordPlan* __restrict__ plans, const uint32_t* __restrict__ bits,
-                                                     const int* __restrict__ stream_cif_base,   // MSC: first CIF row of each stream
+                                                     const int* __restrict__ stream_cif_base,   // MSC: logical row of each stream's CIF 0
                                                      uint4* __restrict__ steps)
 {
+  // Lanes run along the code word (64 consecutive 16-step chunks), so a wave reads one contiguous stretch of
+  // ~2200 received bits (a few cache lines per plane).  Each wave walks 16 of the group's 64 code words.
   const int group = blockIdx.y;
-  const int lane = threadIdx.x & 63;
-  const int t16 = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (group >= ngroups) return;
   const WaveGroup grp = groups[group];
+  const int t16 = blockIdx.x * 64 + (threadIdx.x & 63);
   if (t16 >= (grp.nsteps + 15) / 16) return;
-  const bool valid = lane < grp.count;
-  DecodeJob job{0, 0};
-  if (valid) job = jobs[job_ids ? job_ids[grp.first + lane] : grp.first + lane];
-  uint32_t w[4] = {0, 0, 0, 0};
-  if (valid) {
-    const CodewordPlan pl = plans[grp.plan];
-    const int x0 = 64 * t16;                     // first mother-code bit of this thread
-    // locate the segment holding x0 (segments are multiples of 128 mother bits)
-    int seg_start = 0, j0 = 0, s = 0;
-    uint32_t mask = 0;
-    for (; s < 4; ++s) {
-      const int seg_bits = 128 * pl.blocks[s];
-      if (x0 < seg_start + seg_bits) { mask = pl.mask[s]; break; }
-      j0 += pl.blocks[s] * 4 * __popc(pl.mask[s]);
-      seg_start += seg_bits;
-    }
-    const bool tail = (s == 4);                  // 24 tail bits at PI 8 (depuncture.c:97-103)
-    int j = j0 + ((x0 - seg_start) >> 5) * __popc(mask);
-    const uint32_t* row0;
-    if (kFic) row0 = bits + static_cast<size_t>(job.cif) * 72;   // FIC block = 2304 bits = 72 words
-    else row0 = bits + (static_cast<size_t>(stream_cif_base[job.stream]) + job.cif) * 1728;
-    for (int g = 0; g < 2; ++g) {
-      uint32_t m = mask;
-      if (tail) m = (g == 0) ? (puncture_mask(8) & 0x00ffffffu) : 0u;
-      uint32_t val = 0;
-      for (int u = 0; u < 32; ++u) {
-        if ((m >> u) & 1u) {
-          const int i = pl.start_bit + j++;
-          uint32_t word;
-          if (kFic) {
-            word = row0[i >> 5];
-          } else {
-            // out[i] = cifs[map[i & 15]][i], map = bit reversal of 4 bits (misc.c:32)
-            const int r = static_cast<int>(__brev(static_cast<unsigned>(i & 15)) >> 28);
-            word = row0[static_cast<size_t>(r) * 1728 + (i >> 5)];
+  const CodewordPlan pl = plans[grp.plan];
+  const int x0 = 64 * t16;                       // first mother-code bit of this thread
+  // locate the segment holding x0 (segments are multiples of 128 mother bits)
+  int seg_start = 0, j0 = 0, s = 0;
+  uint32_t mask = 0;
+  for (; s < 4; ++s) {
+    const int seg_bits = 128 * pl.blocks[s];
+    if (x0 < seg_start + seg_bits) { mask = pl.mask[s]; break; }
+    j0 += pl.blocks[s] * 4 * __popc(pl.mask[s]);
+    seg_start += seg_bits;
+  }
+  const bool tail = (s == 4);                    // 24 tail bits at PI 8 (depuncture.c:97-103)
+  const int jbase = pl.start_bit + j0 + ((x0 - seg_start) >> 5) * __popc(mask);
+  const uint32_t m0 = tail ? (puncture_mask(8) & 0x00ffffffu) : mask, m1 = tail ? 0u : mask;
+
+  for (int k = 0; k < 16; ++k) {
+    const int lane = (threadIdx.x >> 6) * 16 + k;          // code word within the group
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (lane < grp.count) {
+      const DecodeJob job = jobs[job_ids ? job_ids[grp.first + lane] : grp.first + lane];
+      const uint32_t* row0;
+      if (kFic) row0 = bits + static_cast<size_t>(job.cif) * 72;   // FIC block = 2304 bits = 72 words
+      else row0 = bits + (static_cast<size_t>(stream_cif_base[job.stream]) + job.cif) * 1728;
+      int i = jbase;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const uint32_t m = g ? m1 : m0;
+        uint32_t val = 0;
+        for (int u = 0; u < 32; ++u) {
+          if ((m >> u) & 1u) {
+            if (kFic) {
+              val |= ((row0[i >> 5] >> (i & 31)) & 1u) << u;
+            } else {
+              // time de-interleaved bit i = plane (i & 15), bit (i >> 4) of the logical row (demap_kernel)
+              val |= ((row0[(i & 15) * 108 + (i >> 9)] >> ((i >> 4) & 31)) & 1u) << u;
+            }
+            ++i;
           }
-          val |= ((word >> (i & 31)) & 1u) << u;
+        }
+        // 8 steps: byte = value nibble | mask nibble << 4
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const uint32_t byte = ((val >> (4 * q)) & 15u) | (((m >> (4 * q)) & 15u) << 4);
+          w[2 * g + (q >> 2)] |= byte << (8 * (q & 3));
         }
       }
-      // 8 steps: byte = value nibble | mask nibble << 4
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const uint32_t byte = ((val >> (4 * q)) & 15u) | (((m >> (4 * q)) & 15u) << 4);
-        w[2 * g + (q >> 2)] |= byte << (8 * (q & 3));
-      }
     }
+    steps[(grp.step_base + t16) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
   }
-  steps[(grp.step_base + t16) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -361,7 +363,7 @@ hipError_t launch_gather(bool fic, const WaveGroup* groups, int ngroups, int max
   // grid.y is limited to 65535: slice the groups
   for (int g0 = 0; g0 < ngroups; g0 += 32768) {
     const int ng = min(32768, ngroups - g0);
-    dim3 grid((max_n16 + 3) / 4, ng);
+    dim3 grid((max_n16 + 63) / 64, ng);
     if (fic)
       hipLaunchKernelGGL(gather_kernel<true>, grid, dim3(256), 0, stream, groups + g0, ng, jobs, job_ids, plans, bits, stream_cif_base, steps);
     else

@@ -214,16 +214,25 @@ __global__ __launch_bounds__(kThreads, 4) void ofdm_fft_kernel(const uint8_t* co
 // grid = 15 * nframes: workgroup g handles data symbols 1 + 5 (g % 15) .. 5 + 5 (g % 15)
 // of frame g / 15.  Carrier c (0..1535, ascending frequency) sits at fftshifted bin
 // 256 + c (c < 768) or 257 + c.
-__global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restrict__ spectra,
-                                                         const int2* __restrict__ frames, int first,
+//
+// MSC output layout (kPlanar): the time de-interleaver (misc.c:29-39) reads bit i of the CIF
+// that lies map[i & 15] CIFs after the oldest one.  Instead of gathering from 16 rows later,
+// every transmitted CIF n is scattered here: its bits with i & 15 == r form "plane r" of
+// LOGICAL row n - map[r], stored contiguously (3456 bits = 108 words).  A complete logical
+// row (16 planes) is then exactly the reference's cif_time_deinterleaved, plane-major:
+// out[i] = row[(i & 15) * 108 words][bit i >> 4].
+template <bool kPlanar>
+__global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restrict__ spectra, int first,
                                                          const int* __restrict__ frame_slot,
+                                                         const int* __restrict__ frame_cif_row,
                                                          const uint16_t* __restrict__ qpsk_of_carrier,
                                                          uint32_t* __restrict__ fic_bits, uint32_t* __restrict__ msc_bits)
 {
   __shared__ uint8_t bits[kBitsPerSym];
   const int tid = threadIdx.x;
   const int j = blockIdx.x / 15, grp = blockIdx.x % 15;
-  const int slot = frame_slot[first + j];                 // global TF slot of this frame
+  const int slot = frame_slot[first + j];                 // TF slot (FIC rows, FIB records)
+  const int cif_row = frame_cif_row[first + j];           // row of this TF's first CIF
   const float2* tf = spectra + static_cast<size_t>(j) * (kSymbolsPerTf * 2048);
   int bin[6], qk[6];
   float2 prev[6];
@@ -246,11 +255,21 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
     }
     __syncthreads();
     if (tid < 96) {
-      uint32_t w = 0;
+      if (l <= 3 || !kPlanar) {
+        uint32_t w = 0;
 #pragma unroll
-      for (int b = 0; b < 32; ++b) w |= static_cast<uint32_t>(bits[32 * tid + b]) << b;
-      if (l <= 3) fic_bits[static_cast<size_t>(slot) * 288 + (l - 1) * 96 + tid] = w;
-      else msc_bits[static_cast<size_t>(slot) * 6912 + (l - 4) * 96 + tid] = w;
+        for (int b = 0; b < 32; ++b) w |= static_cast<uint32_t>(bits[32 * tid + b]) << b;
+        if (l <= 3) fic_bits[static_cast<size_t>(slot) * 288 + (l - 1) * 96 + tid] = w;
+        else msc_bits[static_cast<size_t>(cif_row) * 1728 + (l - 4) * 96 + tid] = w;
+      } else {
+        const int q = (l - 4) / 18, sidx = (l - 4) % 18;          // CIF within the TF, symbol within the CIF
+        const int r = tid / 6, wq = tid % 6;                      // plane (i & 15) and word within this symbol's 192 bits
+        uint32_t w = 0;
+#pragma unroll
+        for (int b = 0; b < 32; ++b) w |= static_cast<uint32_t>(bits[16 * (32 * wq + b) + r]) << b;
+        const int delay = static_cast<int>(__brev(static_cast<unsigned>(r)) >> 28);   // map[r], misc.c:32
+        msc_bits[(static_cast<size_t>(cif_row + q - delay) * 16 + r) * 108 + sidx * 6 + wq] = w;
+      }
     }
     __syncthreads();
   }
@@ -267,12 +286,16 @@ hipError_t launch_ofdm_fft(const uint8_t* const* iq, const CallDesc* descs, int 
   return hipGetLastError();
 }
 
-hipError_t launch_demap(const float2* spectra, const int2* frames, int first, int nframes, const int* frame_slot,
+hipError_t launch_demap(bool planar, const float2* spectra, int first, int nframes, const int* frame_slot, const int* frame_cif_row,
                         const uint16_t* qpsk_of_carrier, uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream)
 {
   if (nframes <= 0) return hipSuccess;
-  hipLaunchKernelGGL(demap_kernel, dim3(15 * nframes), dim3(kThreads), 0, stream, spectra, frames, first, frame_slot,
-                     qpsk_of_carrier, fic_bits, msc_bits);
+  if (planar)
+    hipLaunchKernelGGL(demap_kernel<true>, dim3(15 * nframes), dim3(kThreads), 0, stream, spectra, first, frame_slot, frame_cif_row,
+                       qpsk_of_carrier, fic_bits, msc_bits);
+  else
+    hipLaunchKernelGGL(demap_kernel<false>, dim3(15 * nframes), dim3(kThreads), 0, stream, spectra, first, frame_slot, frame_cif_row,
+                       qpsk_of_carrier, fic_bits, msc_bits);
   return hipGetLastError();
 }
 

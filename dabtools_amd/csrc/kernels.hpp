@@ -19,8 +19,10 @@ hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, Str
 hipError_t launch_ofdm_fft(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first,
                            int nframes, float2* spectra, const float2* tw, hipStream_t stream);
 
-// K2b: DQPSK + demap + frequency de-interleave -> bit-packed rows at TF slot frame_slot[first + j]
-hipError_t launch_demap(const float2* spectra, const int2* frames, int first, int nframes, const int* frame_slot,
+// K2b: DQPSK + demap + frequency de-interleave -> bit-packed rows.  FIC rows at TF slot frame_slot[first + j];
+// MSC rows start at CIF row frame_cif_row[first + j]: planar = scattered into time-de-interleaved logical rows
+// (see k_fft.hip), else the four transmitted CIFs of the TF in natural bit order.
+hipError_t launch_demap(bool planar, const float2* spectra, int first, int nframes, const int* frame_slot, const int* frame_cif_row,
                         const uint16_t* qpsk_of_carrier, uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream);
 
 // K3/K4a: time de-interleave + de-puncture gather into per-step bytes
