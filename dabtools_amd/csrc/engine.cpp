@@ -142,6 +142,7 @@ void Engine::build_batch(const std::vector<std::pair<int, const std::vector<int>
     const std::vector<int>& ids = *plan_jobs[o.second].second;
     auto it = placed.find(&ids);
     if (it == placed.end()) {
+      out.job_ids.resize((out.job_ids.size() + 63) / 64 * 64, -1);        // lists start on a tile of 64 (regroup_kernel)
       it = placed.emplace(&ids, static_cast<int>(out.job_ids.size())).first;
       out.job_ids.insert(out.job_ids.end(), ids.begin(), ids.end());
     }
@@ -163,7 +164,7 @@ bool Engine::run_decode_batch(DecodeBatch& b, bool fic, const std::vector<Decode
   std::vector<int64_t> slice_steps, slice_dec;
   int64_t step_rows = 0, dec_rows = 0;
   for (int g = 0; g < ng; ++g) {
-    const int64_t dr = (b.groups[g].nsteps + 3) / 4 * 4, sr = (b.groups[g].nsteps + 15) / 16;
+    const int64_t dr = (b.groups[g].nsteps + 7) / 8 * 8, sr = fic ? (b.groups[g].nsteps + 15) / 16 : 0;
     if (g > slice_start.back() && dec_rows + dr > kMaxDecisionRows) {
       slice_start.push_back(g);
       slice_steps.push_back(step_rows);
@@ -185,16 +186,30 @@ bool Engine::run_decode_batch(DecodeBatch& b, bool fic, const std::vector<Decode
       !d_decisions_.reserve(static_cast<size_t>(max_dec) * 64))
     return false;
   const int* ids = b.job_ids.empty() ? nullptr : d_job_ids_.get();
+  if (!fic) {
+    b.job_ids.resize((b.job_ids.size() + 63) / 64 * 64, -1);
+    const int ntiles = static_cast<int>(b.job_ids.size() / 64);
+    if (!d_job_ids_.upload(b.job_ids, stream_) || !d_grouped_.reserve(static_cast<size_t>(ntiles) * kCifWords * 64)) return false;
+    ids = d_job_ids_.get();
+    (void)hipEventRecord(ev_[0], stream_);
+    if (!check(launch_regroup(ids, ntiles, d_jobs_.get(), d_stream_cif_base, bits, d_grouped_.get(), stream_), "regroup launch")) return false;
+    (void)hipEventRecord(ev_[1], stream_);
+    if (!check(hipEventSynchronize(ev_[1]), "regroup")) return false;
+    float ms = 0;
+    if (gather_ms && hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) *gather_ms += ms;
+  }
   for (size_t s = 0; s + 1 < slice_start.size(); ++s) {
     const int g0 = slice_start[s], n = slice_start[s + 1] - g0;
     const int max_n16 = (b.groups[g0].nsteps + 15) / 16;     // groups are sorted longest first
     (void)hipEventRecord(ev_[0], stream_);
-    if (bits && !check(launch_gather(fic, d_groups_.get() + g0, n, max_n16, d_jobs_.get(), ids, d_plans_.get(), bits, d_stream_cif_base,
-                                     d_steps_.get(), stream_),
-                       "gather launch"))
+    if (fic && !check(launch_gather(true, d_groups_.get() + g0, n, max_n16, d_jobs_.get(), ids, d_plans_.get(), bits, d_stream_cif_base,
+                                    d_steps_.get(), stream_),
+                      "gather launch"))
       return false;
     (void)hipEventRecord(ev_[1], stream_);
-    if (!check(launch_viterbi(d_groups_.get() + g0, n, ids, d_plans_.get(), d_steps_.get(), d_decisions_.get(), prbs, out, record_stride, stream_),
+    if (!check(fic ? launch_viterbi(d_groups_.get() + g0, n, ids, d_plans_.get(), d_steps_.get(), d_decisions_.get(), prbs, out, record_stride, stream_)
+                   : launch_viterbi_msc(d_groups_.get() + g0, n, ids, d_plans_.get(), d_grouped_.get(), d_decisions_.get(), prbs, out,
+                                        record_stride, stream_),
                "viterbi launch"))
       return false;
     (void)hipEventRecord(ev_[2], stream_);
@@ -238,7 +253,8 @@ bool Engine::store_tf_bytes(int slot, const uint8_t* fic_bytes, const uint8_t* m
       std::fill(plane.begin(), plane.end(), 0u);
       for (int u = 0; u < kCifBits / 16; ++u) plane[u >> 5] |= static_cast<uint32_t>(cif[16 * u + r] & 1u) << (u & 31);
       const size_t row = static_cast<size_t>(kRowLead + 4 * slot + q - tmap[r]);
-      if (!check(hipMemcpy(d_msc_bits_.get() + (row * 16 + r) * 108, plane.data(), 108 * 4, hipMemcpyHostToDevice), "msc upload")) return false;
+      // plane r occupies every 16th word of the logical row (layout of demap_kernel<true>)
+      if (!check(hipMemcpy2D(d_msc_bits_.get() + row * kCifWords + r, 16 * 4, plane.data(), 4, 4, 108, hipMemcpyHostToDevice), "msc upload")) return false;
     }
   }
   return true;
@@ -644,7 +660,7 @@ int Engine::viterbi_batch(const uint8_t* symbols, uint8_t* data, int framebits, 
   plan.out_bytes = framebits / 8;
   const int pid = plan_id(plan);
   std::vector<WaveGroup> groups;
-  const int64_t dr = (nsteps + 3) / 4 * 4;
+  const int64_t dr = (nsteps + 7) / 8 * 8;
   std::vector<uint4> steps(static_cast<size_t>(ngroups) * n16 * 64, make_uint4(0, 0, 0, 0));
   for (int g = 0; g < ngroups; ++g) {
     groups.push_back(WaveGroup{pid, 64 * g, std::min(64, n - 64 * g), nsteps, static_cast<int64_t>(g) * n16, g * dr});

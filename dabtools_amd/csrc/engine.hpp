@@ -120,6 +120,7 @@ class Engine {
   bool check(hipError_t e, const char* what);
   // plan_jobs[i] = (plan id, job indices decoded with that plan)
   void build_batch(const std::vector<std::pair<int, const std::vector<int>*>>& plan_jobs, DecodeBatch& out);
+  // fic = true: gather from FIC rows + step-byte Viterbi; fic = false: regroup logical CIF rows + fused Viterbi
   bool run_decode_batch(DecodeBatch& b, bool fic, const std::vector<DecodeJob>& jobs, const uint32_t* bits,
                         const int* d_stream_cif_base, const uint32_t* prbs, uint8_t* out, int record_stride, float* gather_ms,
                         float* viterbi_ms);
@@ -154,6 +155,7 @@ class Engine {
   DeviceBuffer<int> d_job_ids_;
   DeviceBuffer<CodewordPlan> d_plans_;
   DeviceBuffer<uint4> d_steps_;
+  DeviceBuffer<uint32_t> d_grouped_;
   DeviceBuffer<uint2> d_decisions_;
   DeviceBuffer<EtiFrameMeta> d_meta_;
   DeviceBuffer<uint8_t> d_headers_, d_eti_, d_bytes_;

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const WaveGroup* __restrict
               val |= ((row0[i >> 5] >> (i & 31)) & 1u) << u;
             } else {
               // time de-interleaved bit i = plane (i & 15), bit (i >> 4) of the logical row (demap_kernel)
-              val |= ((row0[(i & 15) * 108 + (i >> 9)] >> ((i >> 4) & 31)) & 1u) << u;
+              val |= ((row0[(i >> 9) * 16 + (i & 15)] >> ((i >> 4) & 31)) & 1u) << u;
             }
             ++i;
           }
@@ -222,67 +222,63 @@ __host__ __device__ constexpr DecisionTable make_decision_table()
 }
 __constant__ DecisionTable kDecisionTable = make_decision_table();
 
-// one wave (64 lanes) per group of <= 64 equal-length code words
-__global__ __launch_bounds__(64) void viterbi_kernel(const WaveGroup* __restrict__ groups, const int* __restrict__ job_ids,
-                                                     const CodewordPlan* __restrict__ plans, const uint4* __restrict__ steps,
-                                                     uint2* __restrict__ decisions, const uint32_t* __restrict__ prbs_words,
-                                                     uint8_t* __restrict__ out, int record_stride)
+// ---------------------------------------------------------------------------------------
+// regroup: logical CIF rows (planes interleaved word by word, one row per ETI frame) ->
+// de-interleaved natural bit order, 64 frames interleaved word by word:
+//   grouped[(tile * 1728 + w) * 64 + lane] = bits 32 w .. 32 w + 31 of cif_time_deinterleaved
+// of frame job_ids[64 tile + lane].  The Viterbi kernel (lane = frame) then reads its received
+// bits with fully coalesced 256-byte loads.  Thread = (frame lane, block of 16 output words):
+// one 64-byte line in, 16 words out.
+__global__ __launch_bounds__(256) void regroup_kernel(const int* __restrict__ job_ids, const DecodeJob* __restrict__ jobs,
+                                                      const int* __restrict__ stream_cif_base, const uint32_t* __restrict__ rows,
+                                                      uint32_t* __restrict__ grouped)
 {
-  __shared__ uint8_t dec_pos[4 * 64];
-  const int lane = threadIdx.x;
-  const WaveGroup grp = groups[blockIdx.x];
-  const int nsteps = grp.nsteps;
-  const uint4* my_steps = steps + grp.step_base * 64 + lane;
-  uint2* my_dec = decisions + grp.dec_base * 64 + lane;
-  for (int i = lane; i < 256; i += 64) dec_pos[i] = kDecisionTable.pos[i >> 6][i & 63];
-
-  // L(0): register r = states (2r, 2r+1), register 16 + r = states (32 + 2r, 33 + 2r); state 0 starts at 0,
-  // every other state "unreachable" (viterbi.c:387-389, scaled to agreement counts)
-  pk16 pm[32], pn[32], pl4[32];
+  const int tile = blockIdx.y, lane = threadIdx.x & 63;
+  const int wb = blockIdx.x * 4 + (threadIdx.x >> 6);          // 0..107: block of 16 output words
+  if (wb >= 108) return;
+  const int jid = job_ids[tile * 64 + lane];
+  if (jid < 0) return;
+  const DecodeJob job = jobs[jid];
+  const uint4* src = reinterpret_cast<const uint4*>(rows + (static_cast<size_t>(stream_cif_base[job.stream]) + job.cif) * 1728 + wb * 16);
+  uint32_t pw[16];
 #pragma unroll
-  for (int r = 0; r < 32; ++r) pm[r] = as_pk(0xfc00fc00u);       // (-1024, -1024)
-  pm[0] = as_pk(0xfc000000u);                                      // (0, -1024)
-
-  const int n16 = (nsteps + 15) >> 4;
-  uint4 pack = my_steps[0];
-  for (int t16 = 0; t16 < n16; ++t16) {
-    // fetch the next 16 steps before this block's decision stores are issued: the wait for it then
-    // does not have to drain those stores (loads and stores retire in order on one counter)
-    const uint4 next = my_steps[static_cast<size_t>(min(t16 + 1, n16 - 1)) * 64];
-    const uint32_t w[4] = {pack.x, pack.y, pack.z, pack.w};
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-      const int t = 16 * t16 + 4 * q;
-      if (t >= nsteps) break;
-      const uint32_t ww = (q == 0) ? w[0] : (q == 1) ? w[1] : (q == 2) ? w[2] : w[3];
-      uint2 d0, d1, d2, d3;
-      acs_step<0>(ww & 0xff, pm, pn, d0);
-      acs_step<1>((ww >> 8) & 0xff, pn, pm, d1);
-      acs_step<2>((ww >> 16) & 0xff, pm, pn, d2);
-      acs_step<3>(ww >> 24, pn, pl4, d3);
-      repair_layout(pl4, pm);
-      // steps past nsteps (only in the last word) write into slack space of the buffer
-      my_dec[static_cast<size_t>(t) * 64] = d0;
-      my_dec[static_cast<size_t>(t + 1) * 64] = d1;
-      my_dec[static_cast<size_t>(t + 2) * 64] = d2;
-      my_dec[static_cast<size_t>(t + 3) * 64] = d3;
-    }
-    // agreement counts grow by <= 4 per step: re-base on state 0 long before int16 could overflow
-    if ((t16 & 127) == 127) {
-      const uint32_t s0 = as_u32(pm[0]) & 0xffffu;
-      const pk16 base = as_pk(s0 | (s0 << 16));
-#pragma unroll
-      for (int r = 0; r < 32; ++r) pm[r] = pm[r] - base;
-    }
-    pack = next;
+  for (int k = 0; k < 4; ++k) {
+    const uint4 v = src[k];
+    pw[4 * k] = v.x; pw[4 * k + 1] = v.y; pw[4 * k + 2] = v.z; pw[4 * k + 3] = v.w;
   }
-  __syncthreads();
-  if (lane >= grp.count) return;
+  uint32_t* dst = grouped + (static_cast<size_t>(tile) * 1728 + wb * 16) * 64 + lane;
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {           // output word o: bits k -> plane k & 15, bit 2 o + (k >> 4) of that plane's word
+    uint32_t w = 0;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const uint32_t two = (pw[p] >> (2 * o)) & 3u;
+      w |= ((two & 1u) << p) | ((two >> 1) << (16 + p));
+    }
+    dst[static_cast<size_t>(o) * 64] = w;
+  }
+}
 
-  // chain back from state 0 (viterbi.c:438-450), descramble, pack MSB first
-  const CodewordPlan pl = plans[grp.plan];
-  const int record = job_ids ? job_ids[grp.first + lane] : grp.first + lane;
-  uint32_t* dst = reinterpret_cast<uint32_t*>(out + static_cast<size_t>(record) * record_stride + pl.out_offset);
+// ---------------------------------------------------------------------------------------
+// shared by both Viterbi kernels: 4 trellis steps = one pass through the register layouts
+__device__ __forceinline__ void acs4(uint32_t ww, pk16 (&pm)[32], pk16 (&pn)[32], pk16 (&pl4)[32], uint2* dec_rows)
+{
+  uint2 d0, d1, d2, d3;
+  acs_step<0>(ww & 0xff, pm, pn, d0);
+  acs_step<1>((ww >> 8) & 0xff, pn, pm, d1);
+  acs_step<2>((ww >> 16) & 0xff, pm, pn, d2);
+  acs_step<3>(ww >> 24, pn, pl4, d3);
+  repair_layout(pl4, pm);
+  dec_rows[0] = d0;
+  dec_rows[64] = d1;
+  dec_rows[128] = d2;
+  dec_rows[192] = d3;
+}
+
+// chain back from state 0 (viterbi.c:438-450), descramble (misc.c:41-58), pack MSB first
+__device__ __forceinline__ void chain_back(const uint2* my_dec, int nsteps, const uint8_t* dec_pos, const uint32_t* __restrict__ prbs_words,
+                                           uint32_t* dst)
+{
   unsigned state = 0;
   uint32_t acc = 0;
   // decision words are fetched 8 steps at a time (their addresses do not depend on the path)
@@ -305,6 +301,129 @@ __global__ __launch_bounds__(64) void viterbi_kernel(const WaveGroup* __restrict
       }
     }
   }
+}
+
+__device__ __forceinline__ void init_metrics(pk16 (&pm)[32])
+{
+  // L(0): register r = states (2r, 2r+1), register 16 + r = states (32 + 2r, 33 + 2r); state 0 starts at 0,
+  // every other state "unreachable" (viterbi.c:387-389, scaled to agreement counts)
+#pragma unroll
+  for (int r = 0; r < 32; ++r) pm[r] = as_pk(0xfc00fc00u);       // (-1024, -1024)
+  pm[0] = as_pk(0xfc000000u);                                      // (0, -1024)
+}
+
+// agreement counts grow by <= 4 per step: re-base on state 0 long before int16 could overflow
+__device__ __forceinline__ void rebase_metrics(pk16 (&pm)[32])
+{
+  const uint32_t s0 = as_u32(pm[0]) & 0xffffu;
+  const pk16 base = as_pk(s0 | (s0 << 16));
+#pragma unroll
+  for (int r = 0; r < 32; ++r) pm[r] = pm[r] - base;
+}
+
+// one wave (64 lanes) per group of <= 64 equal-length code words; trellis input = one byte per step (gather_kernel)
+__global__ __launch_bounds__(64) void viterbi_kernel(const WaveGroup* __restrict__ groups, const int* __restrict__ job_ids,
+                                                     const CodewordPlan* __restrict__ plans, const uint4* __restrict__ steps,
+                                                     uint2* __restrict__ decisions, const uint32_t* __restrict__ prbs_words,
+                                                     uint8_t* __restrict__ out, int record_stride)
+{
+  __shared__ uint8_t dec_pos[4 * 64];
+  const int lane = threadIdx.x;
+  const WaveGroup grp = groups[blockIdx.x];
+  const int nsteps = grp.nsteps;
+  const uint4* my_steps = steps + grp.step_base * 64 + lane;
+  uint2* my_dec = decisions + grp.dec_base * 64 + lane;
+  for (int i = lane; i < 256; i += 64) dec_pos[i] = kDecisionTable.pos[i >> 6][i & 63];
+
+  pk16 pm[32], pn[32], pl4[32];
+  init_metrics(pm);
+  const int n16 = (nsteps + 15) >> 4;
+  uint4 pack = my_steps[0];
+  for (int t16 = 0; t16 < n16; ++t16) {
+    // fetch the next 16 steps before this block's decision stores are issued: the wait for it then
+    // does not have to drain those stores (loads and stores retire in order on one counter)
+    const uint4 next = my_steps[static_cast<size_t>(min(t16 + 1, n16 - 1)) * 64];
+    const uint32_t w[4] = {pack.x, pack.y, pack.z, pack.w};
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+      const int t = 16 * t16 + 4 * q;
+      if (t >= nsteps) break;
+      const uint32_t ww = (q == 0) ? w[0] : (q == 1) ? w[1] : (q == 2) ? w[2] : w[3];
+      acs4(ww, pm, pn, pl4, my_dec + static_cast<size_t>(t) * 64);   // steps past nsteps land in slack rows
+    }
+    if ((t16 & 127) == 127) rebase_metrics(pm);
+    pack = next;
+  }
+  __syncthreads();
+  if (lane >= grp.count) return;
+  const CodewordPlan pl = plans[grp.plan];
+  const int record = job_ids ? job_ids[grp.first + lane] : grp.first + lane;
+  chain_back(my_dec, nsteps, dec_pos, prbs_words,
+             reinterpret_cast<uint32_t*>(out + static_cast<size_t>(record) * record_stride + pl.out_offset));
+}
+
+// MSC variant with the de-puncturing fused into the load (depuncture.c:84-132): lane = ETI frame,
+// received bits come from regroup_kernel's lane-interleaved rows, 32 bits per coalesced load.
+// Puncturing vectors keep the FIRST n bits of every group of four (n = 1..4), so a step's input is
+// simply the next n bits of the stream; n is wave-uniform.
+__global__ __launch_bounds__(64) void viterbi_msc_kernel(const WaveGroup* __restrict__ groups, const int* __restrict__ job_ids,
+                                                         const CodewordPlan* __restrict__ plans,
+                                                         const uint32_t* __restrict__ grouped, uint2* __restrict__ decisions,
+                                                         const uint32_t* __restrict__ prbs_words, uint8_t* __restrict__ out,
+                                                         int record_stride)
+{
+  __shared__ uint8_t dec_pos[4 * 64];
+  const int lane = threadIdx.x;
+  const WaveGroup grp = groups[blockIdx.x];
+  const CodewordPlan pl = plans[grp.plan];
+  uint2* my_dec = decisions + grp.dec_base * 64 + lane;
+  for (int i = lane; i < 256; i += 64) dec_pos[i] = kDecisionTable.pos[i >> 6][i & 63];
+
+  // received words of this lane's frame: tile = grp.first / 64 (job lists are padded to tiles of 64)
+  const uint32_t* src = grouped + (static_cast<size_t>(grp.first >> 6) * 1728 + (pl.start_bit >> 5)) * 64 + lane;
+  uint64_t fifo = 0;
+  int have = 0;                              // wave-uniform number of valid bits in fifo
+  uint32_t nextw = src[0];
+  int widx = 1;
+
+  pk16 pm[32], pn[32], pl4[32];
+  init_metrics(pm);
+  int t = 0;
+  for (int seg = 0; seg < 5; ++seg) {
+    const uint32_t mask = seg < 4 ? pl.mask[seg] : (puncture_mask(8) & 0x00ffffffu);
+    const int units = seg < 4 ? 4 * pl.blocks[seg] : 1;     // units of 8 trellis steps (= 32 mother-code bits)
+    const int need = __popc(mask);
+    // bits taken by each of the 8 steps of a unit, 3 bits per step
+    uint32_t counts = 0;
+    for (int g = 0; g < 8; ++g) counts |= static_cast<uint32_t>(__popc((mask >> (4 * g)) & 15u)) << (3 * g);
+    for (int u = 0; u < units; ++u) {
+      if (have < need) {                     // at most one refill per unit: need <= 32
+        fifo |= static_cast<uint64_t>(nextw) << have;
+        have += 32;
+        nextw = src[static_cast<size_t>(min(widx, 1727 - (pl.start_bit >> 5))) * 64];
+        ++widx;
+      }
+      uint32_t ww[2] = {0, 0};
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int n = (counts >> (3 * g)) & 7;
+        const uint32_t m = (1u << n) - 1u;
+        const uint32_t sb = (static_cast<uint32_t>(fifo) & m) | (m << 4);
+        fifo >>= n;
+        ww[g >> 2] |= sb << (8 * (g & 3));
+      }
+      have -= need;
+      acs4(ww[0], pm, pn, pl4, my_dec + static_cast<size_t>(t) * 64);
+      acs4(ww[1], pm, pn, pl4, my_dec + static_cast<size_t>(t + 4) * 64);
+      t += 8;
+      if ((t & 2047) == 0) rebase_metrics(pm);
+    }
+  }
+  __syncthreads();
+  if (lane >= grp.count) return;
+  const int record = job_ids[grp.first + lane];
+  chain_back(my_dec, grp.nsteps, dec_pos, prbs_words,
+             reinterpret_cast<uint32_t*>(out + static_cast<size_t>(record) * record_stride + pl.out_offset));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -377,6 +496,28 @@ hipError_t launch_viterbi(const WaveGroup* groups, int ngroups, const int* job_i
 {
   if (ngroups <= 0) return hipSuccess;
   hipLaunchKernelGGL(viterbi_kernel, dim3(ngroups), dim3(64), 0, stream, groups, job_ids, plans, steps, decisions, prbs_words, out,
+                     record_stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_regroup(const int* job_ids, int ntiles, const DecodeJob* jobs, const int* stream_cif_base, const uint32_t* rows,
+                          uint32_t* grouped, hipStream_t stream)
+{
+  if (ntiles <= 0) return hipSuccess;
+  for (int t0 = 0; t0 < ntiles; t0 += 32768) {
+    const int nt = min(32768, ntiles - t0);
+    hipLaunchKernelGGL(regroup_kernel, dim3(27, nt), dim3(256), 0, stream, job_ids + static_cast<size_t>(t0) * 64, jobs, stream_cif_base, rows,
+                       grouped + static_cast<size_t>(t0) * 1728 * 64);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_viterbi_msc(const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans,
+                              const uint32_t* grouped, uint2* decisions, const uint32_t* prbs_words, uint8_t* out, int record_stride,
+                              hipStream_t stream)
+{
+  if (ngroups <= 0) return hipSuccess;
+  hipLaunchKernelGGL(viterbi_msc_kernel, dim3(ngroups), dim3(64), 0, stream, groups, job_ids, plans, grouped, decisions, prbs_words, out,
                      record_stride);
   return hipGetLastError();
 }

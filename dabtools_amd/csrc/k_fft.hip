@@ -218,9 +218,9 @@ __global__ __launch_bounds__(kThreads, 4) void ofdm_fft_kernel(const uint8_t* co
 // MSC output layout (kPlanar): the time de-interleaver (misc.c:29-39) reads bit i of the CIF
 // that lies map[i & 15] CIFs after the oldest one.  Instead of gathering from 16 rows later,
 // every transmitted CIF n is scattered here: its bits with i & 15 == r form "plane r" of
-// LOGICAL row n - map[r], stored contiguously (3456 bits = 108 words).  A complete logical
-// row (16 planes) is then exactly the reference's cif_time_deinterleaved, plane-major:
-// out[i] = row[(i & 15) * 108 words][bit i >> 4].
+// LOGICAL row n - map[r] (3456 bits = 108 words per plane, the 16 planes interleaved word by
+// word).  A complete logical row is then exactly the reference's cif_time_deinterleaved:
+// out[i] = bit ((i >> 4) & 31) of row word ((i >> 9) * 16 + (i & 15)).
 template <bool kPlanar>
 __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restrict__ spectra, int first,
                                                          const int* __restrict__ frame_slot,
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
 #pragma unroll
         for (int b = 0; b < 32; ++b) w |= static_cast<uint32_t>(bits[16 * (32 * wq + b) + r]) << b;
         const int delay = static_cast<int>(__brev(static_cast<unsigned>(r)) >> 28);   // map[r], misc.c:32
-        msc_bits[(static_cast<size_t>(cif_row + q - delay) * 16 + r) * 108 + sidx * 6 + wq] = w;
+        msc_bits[static_cast<size_t>(cif_row + q - delay) * 1728 + (sidx * 6 + wq) * 16 + r] = w;
       }
     }
     __syncthreads();

@@ -34,6 +34,13 @@ hipError_t launch_gather(bool fic, const WaveGroup* groups, int ngroups, int max
 hipError_t launch_viterbi(const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans, const uint4* steps,
                           uint2* decisions, const uint32_t* prbs_words, uint8_t* out, int record_stride, hipStream_t stream);
 
+// K4 (MSC): regroup logical rows 64 frames at a time, then Viterbi with fused de-puncturing
+hipError_t launch_regroup(const int* job_ids, int ntiles, const DecodeJob* jobs, const int* stream_cif_base, const uint32_t* rows,
+                          uint32_t* grouped, hipStream_t stream);
+hipError_t launch_viterbi_msc(const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans,
+                              const uint32_t* grouped, uint2* decisions, const uint32_t* prbs_words, uint8_t* out, int record_stride,
+                              hipStream_t stream);
+
 hipError_t launch_fib_crc(const uint8_t* fibs, int nfib, const uint16_t* crc_tab, uint8_t* ok, hipStream_t stream);
 
 // K5: ETI header/FIB copy, EOF CRC, trailer
