@@ -148,15 +148,18 @@ __device__ __forceinline__ void butterfly_pair(const pk16 (&p)[32], pk16 (&n)[32
   constexpr int j = expand_bit(kR, kTau);                 // butterfly index of the low half; high half is j ^ delta
   constexpr unsigned c = branch_code3(2 * j);
   const pk16 x = p[kR], y = p[16 + kR];
-  const pk16 t0 = x + bb[c], t1 = y + bb[c ^ 7];          // into states 2j, 2j'      (viterbi.c:404-414)
-  const pk16 t2 = x + bb[c ^ 7], t3 = y + bb[c];          // into states 2j+1, 2j'+1  (viterbi.c:415-421)
+  // Metrics are kept non-negative and < 2^15, so the two halves of a register can be advanced by ONE 32-bit
+  // add without a carry crossing over (v_add_u32 issues at twice the rate of the packed 16-bit forms on gfx950).
+  const pk16 t0 = as_pk(as_u32(x) + as_u32(bb[c])), t1 = as_pk(as_u32(y) + as_u32(bb[c ^ 7]));      // into states 2j, 2j'      (viterbi.c:404-414)
+  const pk16 t2 = as_pk(as_u32(x) + as_u32(bb[c ^ 7])), t3 = as_pk(as_u32(y) + as_u32(bb[c]));      // into states 2j+1, 2j'+1  (viterbi.c:415-421)
   const pk16 e = __builtin_elementwise_max(t0, t1), o = __builtin_elementwise_max(t2, t3);
-  // decision = 1 iff the high predecessor is strictly better: sign of (low - high)
-  // (bit 0 and bit 16 of de / dd after the logical shift; shifted into their slots of the decision word)
-  const uint32_t de = as_u32(__builtin_bit_cast(pk16, __builtin_bit_cast(upk16, t0 - t1) >> 15));
-  const uint32_t dd = as_u32(__builtin_bit_cast(pk16, __builtin_bit_cast(upk16, t2 - t3) >> 15));
+  // decision = 1 iff the high predecessor is strictly better: sign bits (15 and 31) of (low - high), moved to
+  // bit i and bit 16 + i of the decision word with 32-bit shift/and/or (full-rate encodings)
+  const uint32_t de = as_u32(t0 - t1), dd = as_u32(t2 - t3);
   constexpr int ie = 2 * kR, io = 2 * kR + 1;
-  if (ie < 16) { d0 |= de << (ie & 15); d0 |= dd << (io & 15); } else { d1 |= de << (ie & 15); d1 |= dd << (io & 15); }
+  constexpr uint32_t ke = 0x00010001u << (ie & 15), ko = 0x00010001u << (io & 15);
+  if (ie < 16) { d0 |= (de >> (15 - (ie & 15))) & ke; d0 |= (dd >> (15 - (io & 15))) & ko; }
+  else { d1 |= (de >> (15 - (ie & 15))) & ke; d1 |= (dd >> (15 - (io & 15))) & ko; }
   // results already form the pairs of the next layout
   constexpr int k_e = 2 * j, k_o = 2 * j + 1;
   if (kTau < 3) {
@@ -305,17 +308,18 @@ __device__ __forceinline__ void chain_back(const uint2* my_dec, int nsteps, cons
 
 __device__ __forceinline__ void init_metrics(pk16 (&pm)[32])
 {
-  // L(0): register r = states (2r, 2r+1), register 16 + r = states (32 + 2r, 33 + 2r); state 0 starts at 0,
-  // every other state "unreachable" (viterbi.c:387-389, scaled to agreement counts)
+  // L(0): register r = states (2r, 2r+1), register 16 + r = states (32 + 2r, 33 + 2r).  State 0 starts 1024
+  // above every other ("unreachable") state (viterbi.c:387-389: 0 vs -999999, scaled to agreement counts: the
+  // gap only has to exceed the 24 agreements six steps can collect); all values stay non-negative.
 #pragma unroll
-  for (int r = 0; r < 32; ++r) pm[r] = as_pk(0xfc00fc00u);       // (-1024, -1024)
-  pm[0] = as_pk(0xfc000000u);                                      // (0, -1024)
+  for (int r = 0; r < 32; ++r) pm[r] = as_pk(0u);
+  pm[0] = as_pk(0x00000400u);                                      // (1024, 0)
 }
 
 // agreement counts grow by <= 4 per step: re-base on state 0 long before int16 could overflow
 __device__ __forceinline__ void rebase_metrics(pk16 (&pm)[32])
 {
-  const uint32_t s0 = as_u32(pm[0]) & 0xffffu;
+  const uint32_t s0 = (as_u32(pm[0]) & 0xffffu) - 1024u;          // keep state 0 at 1024: all states stay within +-24 of it
   const pk16 base = as_pk(s0 | (s0 << 16));
 #pragma unroll
   for (int r = 0; r < 32; ++r) pm[r] = pm[r] - base;
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(const WaveGroup* __restrict
 // received bits come from regroup_kernel's lane-interleaved rows, 32 bits per coalesced load.
 // Puncturing vectors keep the FIRST n bits of every group of four (n = 1..4), so a step's input is
 // simply the next n bits of the stream; n is wave-uniform.
-__global__ __launch_bounds__(64) void viterbi_msc_kernel(const WaveGroup* __restrict__ groups, const int* __restrict__ job_ids,
+__global__ __launch_bounds__(64, 5) void viterbi_msc_kernel(const WaveGroup* __restrict__ groups, const int* __restrict__ job_ids,
                                                          const CodewordPlan* __restrict__ plans,
                                                          const uint32_t* __restrict__ grouped, uint2* __restrict__ decisions,
                                                          const uint32_t* __restrict__ prbs_words, uint8_t* __restrict__ out,

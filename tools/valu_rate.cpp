@@ -20,7 +20,30 @@ __global__ void k(unsigned* out, int iters)
     if (OP == 6) BODY("v_pk_lshrrev_b16");
     if (OP == 7) BODY("v_and_b32");
     if (OP == 8) BODY("v_max_f32");
-    if (OP == 9) BODY("v_pk_add_f32");   // note: 64-bit operands; register pairs overlap here, rate only indicative
+#define BODY3(ins) asm volatile(REP16(ins " %0, %0, %8, %1\n" ins " %1, %1, %8, %2\n" ins " %2, %2, %8, %3\n" ins " %3, %3, %8, %4\n" ins " %4, %4, %8, %5\n" ins " %5, %5, %8, %6\n" ins " %6, %6, %8, %7\n" ins " %7, %7, %8, %0\n") \
+                       : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b))
+    if (OP == 10) BODY("v_lshrrev_b32");
+    if (OP == 11) BODY3("v_and_or_b32");
+    if (OP == 12) BODY3("v_lshl_or_b32");
+    if (OP == 13) BODY3("v_or3_b32");
+    if (OP == 14) BODY3("v_perm_b32");
+    if (OP == 15) BODY3("v_bfi_b32");
+    if (OP == 16) BODY("v_bcnt_u32_b32");
+    if (OP == 17) BODY("v_sub_u32");
+    if (OP == 18) BODY("v_xor_b32");
+    if (OP == 19) BODY3("v_alignbit_b32");
+    if (OP == 20) BODY("v_mul_u32_u24");
+    if (OP == 21) BODY3("v_bfe_u32");
+    if (OP == 22) BODY3("v_lshl_add_u32");
+    if (OP == 23) BODY3("v_add3_u32");
+    if (OP == 24) BODY("v_pk_ashrrev_i16");
+    if (OP == 25) BODY3("v_xad_u32");
+    if (OP == 26) BODY3("v_sad_u8");
+    if (OP == 27) BODY("v_min_u32");
+    if (OP == 28) BODY3("v_max3_i32");
+    if (OP == 29) BODY3("v_pk_mad_u16");
+    if (OP == 30) BODY("v_max_i16");
+    if (OP == 31) BODY("v_add_u16");
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
 }
@@ -46,5 +69,10 @@ int main()
   unsigned* d; hipMalloc(&d, 256 * 8 * 256 * 4);
   run<0>("v_add_u32", d); run<1>("v_pk_add_u16", d); run<2>("v_pk_max_i16", d); run<3>("v_max_i32", d); run<4>("v_add_f32", d);
   run<5>("v_pk_sub_i16", d); run<6>("v_pk_lshrrev_b16", d); run<7>("v_and_b32", d); run<8>("v_max_f32", d);
+  run<10>("v_lshrrev_b32", d); run<11>("v_and_or_b32", d); run<12>("v_lshl_or_b32", d); run<13>("v_or3_b32", d); run<14>("v_perm_b32", d);
+  run<15>("v_bfi_b32", d); run<16>("v_bcnt_u32_b32", d); run<17>("v_sub_u32", d); run<18>("v_xor_b32", d); run<19>("v_alignbit_b32", d);
+  run<20>("v_mul_u32_u24", d); run<21>("v_bfe_u32", d); run<22>("v_lshl_add_u32", d); run<23>("v_add3_u32", d); run<24>("v_pk_ashrrev_i16", d);
+  run<25>("v_xad_u32", d); run<26>("v_sad_u8", d); run<27>("v_min_u32", d); run<28>("v_max3_i32", d); run<29>("v_pk_mad_u16", d);
+  run<30>("v_max_i16", d); run<31>("v_add_u16", d);
   return 0;
 }
