@@ -324,9 +324,9 @@ class Engine:
         return ints[:n], ffs[:n]
 
     def stage_ms(self):
-        names = (C.c_char_p * 8)()
-        ms = (C.c_float * 8)()
-        n = lib().dabhip_engine_stage_ms(self._h, names, ms, 8)
+        names = (C.c_char_p * 12)()
+        ms = (C.c_float * 12)()
+        n = lib().dabhip_engine_stage_ms(self._h, names, ms, 12)
         return {names[i].decode(): ms[i] for i in range(n)}
 
     def fft_stats(self):

@@ -88,11 +88,11 @@ int dabhip_engine_trace(const dabhip_engine* e, int stream, int32_t* ints6, doub
 int dabhip_engine_stage_ms(const dabhip_engine* e, const char** names, float* ms, int cap)
 {
   if (!e) return -1;
-  static const char* kNames[8] = {"sync", "fft", "demap", "fic", "control", "gather", "viterbi", "eti"};
+  static const char* kNames[12] = {"sync", "fft", "demap", "fic", "control", "gather", "viterbi", "eti", "host_setup", "host_frames", "host_worklist", "wall"};
   const StageTimes& t = e->eng.stage_times();
-  const float v[8] = {t.sync, t.fft, t.demap, t.fic, t.control, t.gather, t.viterbi, t.eti};
+  const float v[12] = {t.sync, t.fft, t.demap, t.fic, t.control, t.gather, t.viterbi, t.eti, t.setup, t.frames, t.worklist, t.wall};
   int n = 0;
-  for (; n < 8 && n < cap; ++n) {
+  for (; n < 12 && n < cap; ++n) {
     if (names) names[n] = kNames[n];
     if (ms) ms[n] = v[n];
   }

@@ -89,6 +89,8 @@ Engine::Engine(int device) : device_(device)
       !d_prbs_.upload(prbs, stream_) || !d_zero_words_.upload(zeros, stream_))
     return;
   if (!check(hipStreamSynchronize(stream_), "table upload")) return;
+  const int hw = static_cast<int>(std::thread::hardware_concurrency());
+  pool_.reset(new ThreadPool(std::max(0, std::min(hw / 2, 24) - 1)));
   ok_ = true;
 }
 
@@ -316,7 +318,6 @@ bool Engine::msc_decode(const std::vector<const std::vector<EtiJob>*>& stream_jo
   // the ETI frame.  Layouts are identified by content so that streams carrying the same multiplex share plans.
   struct Layout {
     std::vector<int> plan_ids;
-    std::vector<std::vector<int>> frames;   // frames[k]: ETI frame indices decoded with plan_ids[k] (same list for all k)
     int mst_bytes = 0;
   };
   std::map<std::vector<int32_t>, int> layout_index;
@@ -329,43 +330,65 @@ bool Engine::msc_decode(const std::vector<const std::vector<EtiJob>*>& stream_jo
     for (const EtiJob& j : *v) max_header = std::max(max_header, j.header_len);
   const int header_stride = (max_header + 15) & ~15;
   std::vector<uint8_t> headers(nf * static_cast<size_t>(header_stride), 0);
-  size_t f = 0;
-  for (size_t b = 0; b < stream_jobs.size(); ++b) {
-    std::vector<int> local_to_global;       // this stream's layout index -> global layout id
+  // pass 1 (serial, cheap): global layout id of every (stream, local layout)
+  const size_t nstreams = stream_jobs.size();
+  std::vector<std::vector<int>> local_to_global(nstreams);
+  std::vector<size_t> frame_base(nstreams + 1, 0);
+  for (size_t b = 0; b < nstreams; ++b) {
+    frame_base[b + 1] = frame_base[b] + stream_jobs[b]->size();
+    if (stream_jobs[b]->empty()) continue;
+    const auto& lays = planes[b]->layouts();
+    local_to_global[b].assign(lays.size(), -1);
+    int prev = -1;
     for (const EtiJob& job : *stream_jobs[b]) {
-      if (static_cast<size_t>(job.layout) >= local_to_global.size()) local_to_global.resize(job.layout + 1, -1);
-      int gid = local_to_global[job.layout];
-      if (gid < 0) {
-        const std::vector<SubChannel>& subs = planes[b]->layouts()[job.layout];
-        std::vector<int32_t> key = {job.header_len};
-        for (const SubChannel& sc : subs) {
-          const int32_t fields[] = {sc.slform, sc.uep_index, sc.start_cu, sc.size_cu, sc.bitrate, sc.protlev};
-          key.insert(key.end(), fields, fields + 6);
-        }
-        auto it = layout_index.find(key);
-        if (it == layout_index.end()) {
-          Layout lay;
-          int off = job.header_len + 96;
-          for (const SubChannel& sc : subs) {
-            CodewordPlan cp = make_plan(puncture_plan(sc), sc.start_cu * 64, off);
-            lay.plan_ids.push_back(plan_id(cp));
-            off += (cp.out_bytes + 7) & 0xfff8;          // misc.c:259-260: obytes = ((bits/8)+7) & 0xfff8
-          }
-          lay.mst_bytes = off - job.header_len - 96;
-          if (off + 8 > kEtiBytes) { set_error("ETI frame overflow: sub-channels exceed 6144 bytes"); return false; }
-          it = layout_index.emplace(std::move(key), static_cast<int>(layouts.size())).first;
-          layouts.push_back(std::move(lay));
-          layout_frames.emplace_back();
-        }
-        gid = local_to_global[job.layout] = it->second;
+      if (job.layout == prev) continue;       // layouts change rarely: one lookup per run
+      prev = job.layout;
+      if (local_to_global[b][job.layout] >= 0) continue;
+      const std::vector<SubChannel>& subs = lays[job.layout];
+      std::vector<int32_t> key = {job.header_len};
+      for (const SubChannel& sc : subs) {
+        const int32_t fields[] = {sc.slform, sc.uep_index, sc.start_cu, sc.size_cu, sc.bitrate, sc.protlev};
+        key.insert(key.end(), fields, fields + 6);
       }
-      layout_frames[gid].push_back(static_cast<int>(f));
+      auto it = layout_index.find(key);
+      if (it == layout_index.end()) {
+        Layout lay;
+        int off = job.header_len + 96;
+        for (const SubChannel& sc : subs) {
+          CodewordPlan cp = make_plan(puncture_plan(sc), sc.start_cu * 64, off);
+          lay.plan_ids.push_back(plan_id(cp));
+          off += (cp.out_bytes + 7) & 0xfff8;          // misc.c:259-260: obytes = ((bits/8)+7) & 0xfff8
+        }
+        lay.mst_bytes = off - job.header_len - 96;
+        if (off + 8 > kEtiBytes) { set_error("ETI frame overflow: sub-channels exceed 6144 bytes"); return false; }
+        it = layout_index.emplace(std::move(key), static_cast<int>(layouts.size())).first;
+        layouts.push_back(std::move(lay));
+        layout_frames.emplace_back();
+      }
+      local_to_global[b][job.layout] = it->second;
+    }
+  }
+  // pass 2 (parallel over streams): per-frame records
+  std::vector<std::vector<std::pair<int, std::pair<int, int>>>> runs(nstreams);   // per stream: (layout, [first, last) frame)
+  pool_->parallel_for(static_cast<int>(nstreams), [&](int b) {
+    size_t f = frame_base[b];
+    int run_gid = -1;
+    for (const EtiJob& job : *stream_jobs[b]) {
+      const int gid = local_to_global[b][job.layout];
+      if (gid != run_gid) {
+        runs[b].push_back({gid, {static_cast<int>(f), static_cast<int>(f)}});
+        run_gid = gid;
+      }
+      runs[b].back().second.second = static_cast<int>(f) + 1;
       jobs[f] = DecodeJob{static_cast<int32_t>(b), job.first_cif};
       meta[f] = EtiFrameMeta{job.header_len, layouts[gid].mst_bytes, stream_fib_base[b] + job.first_cif, 0};
       std::memcpy(headers.data() + f * header_stride, job.header, static_cast<size_t>(job.header_len));
       ++f;
     }
-  }
+  });
+  for (size_t b = 0; b < nstreams; ++b)
+    for (const auto& r : runs[b])
+      for (int f = r.second.first; f < r.second.second; ++f) layout_frames[r.first].push_back(f);
   std::vector<std::pair<int, const std::vector<int>*>> plan_jobs;
   for (size_t l = 0; l < layouts.size(); ++l)
     for (int pid : layouts[l].plan_ids) plan_jobs.emplace_back(pid, &layout_frames[l]);
@@ -400,6 +423,8 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
   if (!ok_) { set_error("engine not initialised (no GPU?)"); return -1; }
   if (nstreams <= 0) { set_error("decode: no streams"); return -1; }
   if (!check(hipSetDevice(device_), "hipSetDevice")) return -1;
+  const auto wall0 = std::chrono::steady_clock::now();
+  auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - a).count(); };
   times_ = StageTimes{};
   fft_launches_ = fft_tfs_ = 0;
   fft_ms_ = 0;
@@ -433,6 +458,7 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
   if (!d_iq_ptrs_.upload(ptrs, stream_) || !d_nbytes_.upload(nb, stream_) || !d_states_.upload(states, stream_) || !d_descs_.reserve(ndesc)) return -1;
   if (!check(hipMemsetAsync(d_descs_.get(), 0, ndesc * sizeof(CallDesc), stream_), "desc memset")) return -1;
 
+  times_.setup = since(wall0);
   // K1
   (void)hipEventRecord(ev_[0], stream_);
   if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), nstreams, max_calls_, 0, -1,
@@ -450,6 +476,7 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
     if (st.overflow) { set_error("sync scan: stale-tail bookkeeping overflow (more than kMaxSeg nested short reads)"); return -1; }
 
   // frame list: demodulated TFs, stream-major
+  const auto tfr = std::chrono::steady_clock::now();
   std::vector<int2> frames;
   std::vector<int> frame_slot, frame_cif_row, tf_base(nstreams + 1, 0), row_base(nstreams), fib_base(nstreams);
   int next_row = 0;
@@ -476,6 +503,7 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
       !d_frame_cif_row_.upload(frame_cif_row, stream_))
     return -1;
 
+  times_.frames = since(tfr);
   // K2 + K2b in chunks
   const int chunk = std::min(ntf, kFftChunkTfs);
   if (!d_spectra_.reserve(static_cast<size_t>(chunk) * kSymbolsPerTf * 2048)) return -1;
@@ -513,19 +541,11 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
   const auto t0 = std::chrono::steady_clock::now();
   std::vector<ControlPlane> planes(nstreams);
   std::vector<std::vector<EtiJob>> stream_jobs(nstreams);
-  {
-    const int nthreads = std::max(1, std::min<int>({nstreams, 16, static_cast<int>(std::thread::hardware_concurrency())}));
-    std::atomic<int> next{0};
-    auto work = [&]() {
-      for (int b = next.fetch_add(1); b < nstreams; b = next.fetch_add(1))
-        for (int s = tf_base[b]; s < tf_base[b + 1]; ++s)
-          planes[b].on_tf(s - tf_base[b], fibs.data() + static_cast<size_t>(s) * 384, ok.data() + static_cast<size_t>(s) * 12, stream_jobs[b]);
-    };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nthreads; ++t) pool.emplace_back(work);
-    work();
-    for (auto& th : pool) th.join();
-  }
+  pool_->parallel_for(nstreams, [&](int b) {
+    stream_jobs[b].reserve(static_cast<size_t>(4) * (tf_base[b + 1] - tf_base[b]));
+    for (int s = tf_base[b]; s < tf_base[b + 1]; ++s)
+      planes[b].on_tf(s - tf_base[b], fibs.data() + static_cast<size_t>(s) * 384, ok.data() + static_cast<size_t>(s) * 12, stream_jobs[b]);
+  });
   std::vector<const ControlPlane*> plane_ptrs(nstreams);
   std::vector<const std::vector<EtiJob>*> job_ptrs(nstreams);
   total_eti_ = 0;
@@ -539,7 +559,10 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
   times_.control = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
   // K4 + K5
+  const auto twl = std::chrono::steady_clock::now();
   if (!msc_decode(job_ptrs, plane_ptrs, row_base, fib_base)) return -1;
+  times_.worklist = since(twl) - times_.gather - times_.viterbi - times_.eti;
+  times_.wall = since(wall0);
   return total_eti_;
 }
 

@@ -14,11 +14,13 @@
 
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "control_plane.hpp"
 #include "device_types.hpp"
+#include "thread_pool.hpp"
 
 namespace dabhip {
 
@@ -66,6 +68,7 @@ class DeviceBuffer {
 
 struct StageTimes {
   float sync = 0, fft = 0, demap = 0, fic = 0, control = 0, gather = 0, viterbi = 0, eti = 0;
+  float setup = 0, frames = 0, worklist = 0, wall = 0;   // host-side phases (wall clock)
 };
 
 // Work list for gather + Viterbi launches: wave-groups of <= 64 equal-length code words.
@@ -128,6 +131,7 @@ class Engine {
   bool unpack_tf_slot(int slot, uint8_t* fic_bytes, uint8_t* msc_bytes);
 
   bool ok_ = false;
+  std::unique_ptr<ThreadPool> pool_;   // host threads for per-stream control-plane work
   int device_ = 0;
   hipStream_t stream_ = nullptr;
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -109,8 +109,8 @@ const void *dabhip_engine_eti_device_ptr(const dabhip_engine *e, int64_t *nframe
 int dabhip_engine_trace(const dabhip_engine *e, int stream, int32_t *ints6, double *ffs, int cap_calls);
 
 /* Timing of the stages of the last decode (milliseconds, HIP events on the engine's stream).
- * names: "sync", "fft", "demap", "fic", "control", "gather", "viterbi", "eti".  Returns
- * number of entries written. */
+ * names: "sync", "fft", "demap", "fic", "control", "gather", "viterbi", "eti", then host wall-clock
+ * phases "host_setup", "host_frames", "host_worklist" and the total "wall".  Returns number of entries written. */
 int dabhip_engine_stage_ms(const dabhip_engine *e, const char **names, float *ms, int cap);
 /* Per-launch statistics of the OFDM FFT kernel in the last decode: number of launches,
  * transmission frames transformed, total kernel milliseconds (HIP events). */
