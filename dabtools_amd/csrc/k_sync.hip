@@ -19,7 +19,7 @@
 namespace dabhip {
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;   // one workgroup per stream: more threads = shorter butterfly stages
 
 __device__ __forceinline__ int view_byte(const uint8_t* stream, const FrameView& v, int p)
 {
@@ -27,6 +27,16 @@ __device__ __forceinline__ int view_byte(const uint8_t* stream, const FrameView&
   while (i < v.nseg - 1 && p >= v.seg_end[i]) ++i;
   const int64_t s = v.seg_src[i];
   return s < 0 ? 0 : stream[s + p];
+}
+// one IQ sample (I at the even byte p, Q at p + 1): segment boundaries and sources are even, so both bytes
+// come from the same segment and one 2-byte load fetches them
+__device__ __forceinline__ double2 view_sample(const uint8_t* stream, const FrameView& v, int p)
+{
+  int i = 0;
+  while (i < v.nseg - 1 && p >= v.seg_end[i]) ++i;
+  const int64_t s = v.seg_src[i];
+  const unsigned w = s < 0 ? 0u : *reinterpret_cast<const uint16_t*>(stream + s + p);
+  return make_double2(static_cast<int8_t>(static_cast<uint8_t>((w & 0xff) - 127)), static_cast<int8_t>(static_cast<uint8_t>((w >> 8) - 127)));
 }
 // u8 -> s8 with DC offset 127 and int8 wrap (input_sdr.c:60-63)
 __device__ __forceinline__ int rail(int byte) { return static_cast<int>(static_cast<int8_t>(static_cast<uint8_t>(byte - 127))); }
@@ -36,7 +46,7 @@ __device__ __forceinline__ unsigned brev(unsigned x, int bits) { return __brev(x
 // nbatch independent DFTs of size N = 1 << LOGN stored back to back in LDS, radix-2
 // decimation in frequency, in place; X[k] ends up at index brev(k).  sign = -1 forward.
 template <int LOGN>
-__device__ void dft_dif(double2* buf, int nbatch, double sign, const double2* __restrict__ tw2048)
+__device__ void dft_dif(double2* buf, int nbatch, double sign, const double2* tw2048)
 {
   constexpr int N = 1 << LOGN;
   for (int s = 0; s < LOGN; ++s) {
@@ -56,53 +66,60 @@ __device__ void dft_dif(double2* buf, int nbatch, double sign, const double2* __
   }
 }
 
+constexpr int kWaves = kThreads / 64;
 struct Red {
-  float fv[kThreads];
-  int iv[kThreads];
-  double dv[kThreads];
+  float fv[kWaves];
+  int iv[kWaves];
+  double dv[kWaves];
 };
 
-// arg-max with the reference's semantics (strict '>' scanning upwards: lowest index wins ties)
+// arg-max with the reference's semantics (strict '>' scanning upwards: lowest index wins ties);
+// wave shuffles first, one LDS round across the waves
 __device__ void block_argmax(Red& r, float v, int idx, float* out_v, int* out_i)
 {
-  r.fv[threadIdx.x] = v;
-  r.iv[threadIdx.x] = idx;
-  __syncthreads();
-  for (int s = kThreads / 2; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-      const float ov = r.fv[threadIdx.x + s];
-      const int oi = r.iv[threadIdx.x + s];
-      if (ov > r.fv[threadIdx.x] || (ov == r.fv[threadIdx.x] && oi < r.iv[threadIdx.x])) { r.fv[threadIdx.x] = ov; r.iv[threadIdx.x] = oi; }
-    }
-    __syncthreads();
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    const float ov = __shfl_xor(v, m);
+    const int oi = __shfl_xor(idx, m);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
   }
-  *out_v = r.fv[0];
-  *out_i = r.iv[0];
+  if ((threadIdx.x & 63) == 0) { r.fv[threadIdx.x >> 6] = v; r.iv[threadIdx.x >> 6] = idx; }
+  __syncthreads();
+  float bv = r.fv[0];
+  int bi = r.iv[0];
+#pragma unroll
+  for (int w = 1; w < kWaves; ++w) {
+    const float ov = r.fv[w];
+    const int oi = r.iv[w];
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  *out_v = bv;
+  *out_i = bi;
   __syncthreads();
 }
 
 __device__ int block_sum_int(Red& r, int v)
 {
-  r.iv[threadIdx.x] = v;
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+  if ((threadIdx.x & 63) == 0) r.iv[threadIdx.x >> 6] = v;
   __syncthreads();
-  for (int s = kThreads / 2; s > 0; s >>= 1) {
-    if (threadIdx.x < s) r.iv[threadIdx.x] += r.iv[threadIdx.x + s];
-    __syncthreads();
-  }
-  const int out = r.iv[0];
+  int out = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) out += r.iv[w];
   __syncthreads();
   return out;
 }
 
 __device__ double block_sum_double(Red& r, double v)
 {
-  r.dv[threadIdx.x] = v;
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+  if ((threadIdx.x & 63) == 0) r.dv[threadIdx.x >> 6] = v;
   __syncthreads();
-  for (int s = kThreads / 2; s > 0; s >>= 1) {
-    if (threadIdx.x < s) r.dv[threadIdx.x] += r.dv[threadIdx.x + s];
-    __syncthreads();
-  }
-  const double out = r.dv[0];
+  double out = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) out += r.dv[w];
   __syncthreads();
   return out;
 }
@@ -137,7 +154,8 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double2* A = reinterpret_cast<double2*>(smem);   // 2048: main DFT buffer
   double2* Bf = A + 2048;                            // 3712: 3 x 512 or 29 x 128 batch buffer
-  Shared& sh = *reinterpret_cast<Shared*>(Bf + 29 * 128);
+  double2* tw = Bf + 29 * 128;                       // 1024: exp(2 pi i k / 2048), LDS copy of the twiddle table
+  Shared& sh = *reinterpret_cast<Shared*>(tw + 1024);
   uint8_t* env = reinterpret_cast<uint8_t*>(Bf);     // 19660 bytes, coarse search only
 
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -145,6 +163,7 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
   const int64_t total_calls = nbytes[b] / kChunkBytes;
   const int kend = call_end < 0 ? static_cast<int>(total_calls) : min(call_end, static_cast<int>(total_calls));
   if (tid == 0) { sh.st = states[b]; sh.fine_fs = sh.st.fine_freq_shift; }
+  for (int i = tid; i < 1024; i += kThreads) tw[i] = tw2048[i];
   __syncthreads();
 
   for (int k = call_begin; k < kend; ++k) {
@@ -228,17 +247,17 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
         // ---- fine time: sdr_sync.c:71-202 -------------------------------------------------
         for (int n = tid; n < 2048; n += kThreads) {
           const int p = 2 * (kNullSamples + kCpSamples + n);
-          A[n] = make_double2(rail(view_byte(stream, view, p)), rail(view_byte(stream, view, p + 1)));
+          A[n] = view_sample(stream, view, p);
         }
         __syncthreads();
-        dft_dif<11>(A, 1, -1.0, tw2048);
+        dft_dif<11>(A, 1, -1.0, tw);
         for (int i = tid; i < kCarriers; i += kThreads) {
           const int bin = i < 768 ? i + 1280 : i - 765;
           const double2 c = mul_conj_prs(A[brev(bin, 11)], prs_q[i]);
           Bf[(i % 3) * 512 + i / 3] = c;       // decimate by 3 for the 3 x 512 inverse DFT
         }
         __syncthreads();
-        dft_dif<9>(Bf, 3, +1.0, tw2048);
+        dft_dif<9>(Bf, 3, +1.0, tw);
         float fv = -99999.0f;
         int fi = 0x7fffffff;
         for (int kk = tid; kk < kCarriers; kk += kThreads) {
@@ -259,10 +278,10 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
         // ---- coarse frequency: input_sdr.c:90-109, sdr_sync.c:205-258 ---------------------
         for (int n = tid; n < 2048; n += kThreads) {
           const int p = 2 * (kNullSamples + kCpSamples + 1 + fine + n);
-          A[n] = make_double2(rail(view_byte(stream, view, p)), rail(view_byte(stream, view, p + 1)));
+          A[n] = view_sample(stream, view, p);
         }
         __syncthreads();
-        dft_dif<11>(A, 1, -1.0, tw2048);
+        dft_dif<11>(A, 1, -1.0, tw);
         for (int idx = tid; idx < 29 * 128; idx += kThreads) {
           const int kk = idx / 128 - 14, s = idx % 128;
           const int shifted = 14 + kk + 256 + s;              // index into the fftshifted spectrum
@@ -270,7 +289,7 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
           Bf[idx] = mul_conj_prs(A[brev(bin, 11)], prs_q[14 + s]);
         }
         __syncthreads();
-        dft_dif<7>(Bf, 29, +1.0, tw2048);
+        dft_dif<7>(Bf, 29, +1.0, tw);
         // per-offset maximum |.|, then first maximum over offsets
         float cv = -99999.0f;
         int ci = 0x7fffffff;
@@ -291,8 +310,8 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
           double acc = 0;
           for (int n = tid; n < kCpSamples; n += kThreads) {
             const int pl = 2 * (kNullSamples + 2048 + n), pr = 2 * (kNullSamples + n);
-            const double lr = rail(view_byte(stream, view, pl)), li = rail(view_byte(stream, view, pl + 1));
-            const double rr = rail(view_byte(stream, view, pr)), ri = rail(view_byte(stream, view, pr + 1));
+            const double2 l = view_sample(stream, view, pl), r = view_sample(stream, view, pr);
+            const double lr = l.x, li = l.y, rr = r.x, ri = r.y;
             acc += atan2(-lr * ri + li * rr, lr * rr + li * ri);
           }
           acc = block_sum_double(sh.red, acc);
@@ -322,7 +341,7 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
 
 }  // namespace
 
-size_t sync_scan_lds_bytes() { return sizeof(double2) * (2048 + 29 * 128) + sizeof(Shared); }
+size_t sync_scan_lds_bytes() { return sizeof(double2) * (2048 + 29 * 128 + 1024) + sizeof(Shared); }
 
 hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, StreamState* states, CallDesc* descs,
                             int nstreams, int max_calls, int call_begin, int call_end, const double2* tw2048,
