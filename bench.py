@@ -26,6 +26,10 @@ sys.path.insert(0, ROOT)
 
 FFT_BYTES_PER_TF = 311296 + 1245184        # cu8 read + complex64 spectra written
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8.0 TB/s spec
+# HBM bytes per TF of ofdm_fft_kernel from rocprofv3 PMC passes (profiles/r01_k2_pmc_traffic.csv):
+# (2 x FETCH_SIZE + WRITE_SIZE) KiB per 1024-TF launch = 2 x 165.8k + 1259.5k, FETCH_SIZE doubled as the
+# gfx950 note in MI355X_MICROARCH.md (HBM) prescribes.  PMC counters cannot be read from inside this script.
+FFT_PMC_BYTES_PER_TF = (2 * 165800 + 1259500) * 1024 // 1024   # KiB per 1024 TF == bytes per TF: 1,591,100
 REALTIME_FPS = 1000.0 / 24.0
 
 
@@ -48,8 +52,11 @@ def make_streams(torch, dev, nstreams, ntf, ndistinct, rank):
 
 
 def cpu_baseline(host_stream, ntf):
-    """The CPU restatement (oracle/, kind 'port') timed on one host core on a bounded sample
-    of the same workload.  Checker code used only as the reported baseline."""
+    """The CPU restatement (oracle/, kind 'port') timed on one host core on a bounded sample of the same
+    workload, plus -- when oracle/_ref was built -- the REAL reference back end (dab_process_frame with the
+    scalar viterbi.c and with ENABLE_SPIRAL_VITERBI) on the same demapped frames.  Checker code, used here
+    only as the reported baseline."""
+    import ctypes as C
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     sample_tf = min(ntf, 40)
@@ -57,17 +64,51 @@ def cpu_baseline(host_stream, ntf):
     t0 = time.perf_counter()
     eti, _ = oracle_lib.or_replay(iq)
     dt = time.perf_counter() - t0
-    return {
+    out = {
         "value": len(eti) / dt, "unit": "ETI frames/s", "cores": 1, "kind": "port",
         "sample": "oracle/or_replay (scalar viterbi.c semantics, own fp64 DFT: libfftw3 absent) on 1 stream x %d TF of the same "
                   "ensemble: %d ETI frames in %.2f s on 1 of %d host cores" % (sample_tf, len(eti), dt, os.cpu_count()),
     }
+    # the reference's own back end (the front end needs libfftw3 and cannot be built): demapped TFs are produced
+    # untimed by the oracle front end, then dab_process_frame of the real objects is timed
+    O = oracle_lib.oracle()
+    S = O.or_sdr_new()
+    fic = np.zeros(9216, np.uint8)
+    msc = np.zeros(221184, np.uint8)
+    tfs = []
+    for off in range(0, iq.size - 262144 + 1, 262144):
+        if O.or_sdr_demod(S, oracle_lib._ptr(iq[off:off + 262144]), 262144, oracle_lib._ptr(fic), oracle_lib._ptr(msc)):
+            tfs.append((fic.copy(), msc.copy()))
+    O.or_sdr_free(S)
+    for key, sse in (("reference_backend_scalar", False), ("reference_backend_sse", True)):
+        R = oracle_lib.ref(sse=sse)
+        if R is None:
+            continue
+        devnull, saved = os.open(os.devnull, os.O_WRONLY), os.dup(2)
+        os.dup2(devnull, 2)                 # the reference prints its ensemble table to stderr
+        try:
+            H = R.refh_new()
+            t0 = time.perf_counter()
+            for f, m in tfs:
+                C.memmove(R.refh_tf_fic(H), oracle_lib._ptr(f), f.size)
+                C.memmove(R.refh_tf_msc(H), oracle_lib._ptr(m), m.size)
+                R.refh_process(H)
+            dt = time.perf_counter() - t0
+            n = R.refh_neti(H)
+        finally:
+            os.dup2(saved, 2)
+            os.close(devnull)
+            os.close(saved)
+        out[key] = {"value": n / dt, "unit": "ETI frames/s", "cores": 1,
+                    "sample": "real reference dab_process_frame (%s) on %d demapped TF: %d ETI frames in %.2f s; back end only"
+                              % ("viterbi_spiral SSE2" if sse else "scalar viterbi.c", len(tfs), n, dt)}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
     ap.add_argument("--tfs", type=int, default=64, help="transmission frames per stream")
@@ -130,7 +171,11 @@ def main():
                        "streams_per_gpu": args.streams, "tf_per_stream": args.tfs, "eti_frames_per_step": total_frames_per_step,
                        "sharding": "independent ensembles, %d per GPU, no collective" % args.streams},
             "roofline": {"bound": "hbm", "kernel": "ofdm_fft_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": FFT_PMC_BYTES_PER_TF * fft_tfs / max(fft_launches, 1),
+                         "traffic_note": "bytes per launch; per-TF HBM bytes from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                         "(profiles/r01_k2_pmc_traffic.csv, FETCH_SIZE x2 gfx950 correction) x TFs per launch",
+                         "achieved_vs_measured_copy_ceiling": achieved / 6290.0,
                          "launches": fft_launches, "tf_per_launch": fft_tfs / max(fft_launches, 1),
                          "avg_launch_ms": fft_ms / max(fft_launches, 1), "algorithmic_bytes_per_tf": FFT_BYTES_PER_TF},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},

@@ -17,7 +17,7 @@ namespace dabhip {
 
 namespace {
 constexpr int kFftChunkTfs = 1024;                        // spectra buffer: 1024 TF x 1.19 MiB = 1.2 GiB
-constexpr int64_t kMaxDecisionRows = int64_t(12) << 20;   // x 512 B = 6 GiB of survivor decisions per launch
+constexpr int64_t kMaxDecisionRows = int64_t(48) << 20;   // x 512 B = 24 GiB of survivor decisions per launch
 constexpr int kFicWords = kFicBits / 32;                  // 288
 constexpr int kMscWords = kMscBits / 32;                  // 6912
 constexpr int kCifWords = kCifBits / 32;                  // 1728 words per (logical) CIF row
