@@ -206,8 +206,26 @@ __global__ __launch_bounds__(kThreads, 4) void ofdm_fft_kernel(const uint8_t* co
   }
   const int fast_end = max(sym0, min(sym_end, nfast));
   GlobalU16 src = reinterpret_cast<GlobalU16>(reinterpret_cast<uintptr_t>(stream + (seg_src0 >= 0 ? seg_src0 : 0)));
-  int parity = transform_symbols<true>(src, stream, view, sym0, fast_end, 0, exA, exB, tw, out_tf);
-  transform_symbols<false>(nullptr, stream, view, fast_end, sym_end, parity, exA, exB, tw, out_tf);
+  int done = sym0, parity0 = 0;
+  if (fast_end - sym0 >= kSymPerBlock - 1) {
+    // the common case gets a compile-time trip count (18: even, so the buffer roles end where they started):
+    // fully unrolled, prefetches hoisted.  The 19th symbol is the only one that can straddle the stale tail.
+    constexpr int kFixed = kSymPerBlock - 1;
+    unsigned raw[8];
+    load_symbol<true>(src, stream, view, sym0, raw);
+#pragma unroll
+    for (int i = 0; i < kFixed; ++i) {
+      float2 v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = make_float2(rail(raw[r] & 0xff), rail(raw[r] >> 8));
+      if (i + 1 < kFixed) load_symbol<true>(src, stream, view, sym0 + i + 1, raw);
+      if (i & 1) fft2048_store(v, exB, exA, tw, out_tf + static_cast<size_t>(sym0 + i) * 2048);
+      else fft2048_store(v, exA, exB, tw, out_tf + static_cast<size_t>(sym0 + i) * 2048);
+    }
+    done = sym0 + kFixed;
+  }
+  const int parity = transform_symbols<true>(src, stream, view, done, max(done, fast_end), parity0, exA, exB, tw, out_tf);
+  transform_symbols<false>(nullptr, stream, view, max(done, fast_end), sym_end, parity, exA, exB, tw, out_tf);
 }
 
 // ---- K2b ----------------------------------------------------------------------------------
