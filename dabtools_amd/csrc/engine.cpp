@@ -75,6 +75,20 @@ Engine::Engine(int device) : device_(device)
     const uint8_t b = static_cast<uint8_t>(v);
     crc[v] = crc16_ccitt(&b, 1, 0);
   }
+  // CRC shift operators: column b of operator i = CRC register after feeding 2^i zero bytes starting from 1 << b
+  std::vector<uint16_t> crc_shift(14 * 16);
+  for (int i = 0; i < 14; ++i)
+    for (int bit = 0; bit < 16; ++bit) {
+      if (i == 0) {
+        const uint8_t zero = 0;
+        crc_shift[bit] = crc16_ccitt(&zero, 1, static_cast<uint16_t>(1u << bit));
+      } else {                               // square the previous operator
+        uint16_t v = crc_shift[(i - 1) * 16 + bit], y = 0;
+        for (int b = 0; b < 16; ++b)
+          if ((v >> b) & 1) y ^= crc_shift[(i - 1) * 16 + b];
+        crc_shift[i * 16 + bit] = y;
+      }
+    }
   std::vector<uint32_t> prbs(1024), zeros(1024, 0u);     // 4096 bytes >= the largest sub-channel (1152 bytes per CIF at 384 kbit/s)
   {
     Prbs g;
@@ -85,7 +99,7 @@ Engine::Engine(int device) : device_(device)
     }
   }
   if (!d_tw2048_.upload(tw2048, stream_) || !d_tw1536_.upload(tw1536, stream_) || !d_twf_.upload(twf, stream_) ||
-      !d_prs_.upload(prs, stream_) || !d_qpsk_.upload(qpsk, stream_) || !d_crc_tab_.upload(crc, stream_) ||
+      !d_prs_.upload(prs, stream_) || !d_qpsk_.upload(qpsk, stream_) || !d_crc_tab_.upload(crc, stream_) || !d_crc_shift_.upload(crc_shift, stream_) ||
       !d_prbs_.upload(prbs, stream_) || !d_zero_words_.upload(zeros, stream_))
     return;
   if (!check(hipStreamSynchronize(stream_), "table upload")) return;
@@ -402,7 +416,7 @@ bool Engine::msc_decode(const std::vector<const std::vector<EtiJob>*>& stream_jo
                         &times_.gather, &times_.viterbi))
     return false;
   (void)hipEventRecord(ev_[0], stream_);
-  if (!check(launch_eti_finish(d_meta_.get(), static_cast<int>(nf), d_headers_.get(), header_stride, d_fibs_.get(), d_crc_tab_.get(), d_eti_.get(), stream_), "eti finish launch"))
+  if (!check(launch_eti_finish(d_meta_.get(), static_cast<int>(nf), d_headers_.get(), header_stride, d_fibs_.get(), d_crc_tab_.get(), d_crc_shift_.get(), d_eti_.get(), stream_), "eti finish launch"))
     return false;
   (void)hipEventRecord(ev_[1], stream_);
   if (!check(hipEventSynchronize(ev_[1]), "eti finish")) return false;

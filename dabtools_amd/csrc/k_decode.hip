@@ -448,32 +448,55 @@ __global__ void fib_crc_kernel(const uint8_t* __restrict__ fibs, int nfib, const
   ok[i] = crc == 0x1d0f;
 }
 
-// one thread per ETI frame: header bytes (built by the host control plane, init_eti
-// misc.c:153-213), the 96 FIB bytes of the oldest CIF (misc.c:239), EOF CRC over FIC+MST,
-// RFU, TIST (misc.c:281-292).  The 0x55 padding was laid down by a memset beforehand.
-__global__ void eti_finish_kernel(const EtiFrameMeta* __restrict__ meta, int nframes, const uint8_t* __restrict__ headers, int header_stride,
-                                  const uint8_t* __restrict__ fibs, const uint16_t* __restrict__ crc_tab,
-                                  uint8_t* __restrict__ eti)
+// CRC-16/CCITT is linear over GF(2): crc(A || B) = shift(crc(A), |B|) xor crc_0(B), where shift multiplies by
+// x^(8 |B|) modulo the polynomial.  shift_cols[i][b] = image of bit b under a shift by 2^i bytes.
+__device__ __forceinline__ uint16_t crc_shift(uint16_t crc, int nbytes, const uint16_t* __restrict__ shift_cols)
 {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = 0; nbytes; ++i, nbytes >>= 1) {
+    if (nbytes & 1) {
+      uint16_t y = 0;
+#pragma unroll
+      for (int bit = 0; bit < 16; ++bit)
+        if ((crc >> bit) & 1) y ^= shift_cols[i * 16 + bit];
+      crc = y;
+    }
+  }
+  return crc;
+}
+
+// one WAVE per ETI frame: header bytes (built by the host control plane, init_eti misc.c:153-213), the 96 FIB
+// bytes of the oldest CIF (misc.c:239), EOF CRC over FIC+MST, RFU, TIST (misc.c:281-292).  Each lane takes a
+// slice of the CRC range; the partial CRCs are combined with crc_shift.  The 0x55 padding was laid down by a
+// memset beforehand.
+__global__ __launch_bounds__(256) void eti_finish_kernel(const EtiFrameMeta* __restrict__ meta, int nframes,
+                                                         const uint8_t* __restrict__ headers, int header_stride,
+                                                         const uint8_t* __restrict__ fibs, const uint16_t* __restrict__ crc_tab,
+                                                         const uint16_t* __restrict__ shift_cols, uint8_t* __restrict__ eti)
+{
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (f >= nframes) return;
   const EtiFrameMeta m = meta[f];
   uint8_t* e = eti + static_cast<size_t>(f) * kEtiBytes;
   const uint8_t* h = headers + static_cast<size_t>(f) * header_stride;
-  for (int i = 0; i < m.header_len; ++i) e[i] = h[i];
   const uint8_t* fb = fibs + static_cast<size_t>(m.fib_block) * 96;
-  uint16_t crc = 0xffff;
-  for (int i = 0; i < 96; ++i) {
-    e[m.header_len + i] = fb[i];
-    crc = crc16_step(crc, fb[i], crc_tab);
+  for (int i = lane; i < m.header_len; i += 64) e[i] = h[i];
+  for (int i = lane; i < 96; i += 64) e[m.header_len + i] = fb[i];
+  const int n = 96 + m.mst_bytes;                       // CRC range: FIBs then the decoded sub-channel data
+  const int chunk = (n + 63) / 64;
+  const int lo = min(n, lane * chunk), hi = min(n, lo + chunk);
+  uint16_t crc = lane == 0 ? 0xffff : 0;
+  const uint8_t* mst = e + m.header_len;                // MST bytes were written by the Viterbi kernel
+  for (int i = lo; i < hi; ++i) crc = crc16_step(crc, i < 96 ? fb[i] : mst[i], crc_tab);
+  unsigned acc = crc_shift(crc, n - hi, shift_cols);
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) acc ^= __shfl_xor(acc, s);
+  if (lane == 0) {
+    int pos = m.header_len + n;
+    const uint16_t out = static_cast<uint16_t>(~acc);
+    e[pos++] = static_cast<uint8_t>(out >> 8);
+    e[pos++] = static_cast<uint8_t>(out & 0xff);
+    for (int i = 0; i < 6; ++i) e[pos++] = 0xff;
   }
-  int pos = m.header_len + 96;
-  for (int i = 0; i < m.mst_bytes; ++i) crc = crc16_step(crc, e[pos + i], crc_tab);
-  pos += m.mst_bytes;
-  crc = static_cast<uint16_t>(~crc);
-  e[pos++] = static_cast<uint8_t>(crc >> 8);
-  e[pos++] = static_cast<uint8_t>(crc & 0xff);
-  for (int i = 0; i < 6; ++i) e[pos++] = 0xff;
 }
 
 }  // namespace
@@ -534,11 +557,11 @@ hipError_t launch_fib_crc(const uint8_t* fibs, int nfib, const uint16_t* crc_tab
 }
 
 hipError_t launch_eti_finish(const EtiFrameMeta* meta, int nframes, const uint8_t* headers, int header_stride, const uint8_t* fibs,
-                             const uint16_t* crc_tab, uint8_t* eti, hipStream_t stream)
+                             const uint16_t* crc_tab, const uint16_t* shift_cols, uint8_t* eti, hipStream_t stream)
 {
   if (nframes <= 0) return hipSuccess;
-  hipLaunchKernelGGL(eti_finish_kernel, dim3((nframes + 127) / 128), dim3(128), 0, stream, meta, nframes, headers, header_stride, fibs,
-                     crc_tab, eti);
+  hipLaunchKernelGGL(eti_finish_kernel, dim3((nframes + 3) / 4), dim3(256), 0, stream, meta, nframes, headers, header_stride, fibs,
+                     crc_tab, shift_cols, eti);
   return hipGetLastError();
 }
 

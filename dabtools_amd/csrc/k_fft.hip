@@ -25,6 +25,8 @@ constexpr int kSymPerBlock = 19;                 // 76 symbols = 4 workgroups x 
 constexpr int kEx2Stride = 260;                  // [q] stride of exchange 2 (8*32 + 4: bank skew)
 constexpr int kEx3Stride = 520;                  // [t''] stride of exchange 3 (512 + 8)
 constexpr int kExSize = 2080;                    // float2 per exchange buffer
+constexpr int kDemapSyms = 5;                    // data symbols per demap workgroup (75 = 5 x 15)
+constexpr int kDemapGroups = 75 / kDemapSyms;
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -229,8 +231,8 @@ __global__ __launch_bounds__(kThreads, 4) void ofdm_fft_kernel(const uint8_t* co
 }
 
 // ---- K2b ----------------------------------------------------------------------------------
-// grid = 15 * nframes: workgroup g handles data symbols 1 + 5 (g % 15) .. 5 + 5 (g % 15)
-// of frame g / 15.  Carrier c (0..1535, ascending frequency) sits at fftshifted bin
+// grid = kDemapGroups * nframes: workgroup g handles kDemapSyms consecutive data symbols of frame g / kDemapGroups
+// (it re-reads one previous symbol as the differential reference).  Carrier c (0..1535, ascending frequency) sits at fftshifted bin
 // 256 + c (c < 768) or 257 + c.
 //
 // MSC output layout (kPlanar): the time de-interleaver (misc.c:29-39) reads bit i of the CIF
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
 {
   __shared__ uint8_t bits[kBitsPerSym];
   const int tid = threadIdx.x;
-  const int j = blockIdx.x / 15, grp = blockIdx.x % 15;
+  const int j = blockIdx.x / kDemapGroups, grp = blockIdx.x % kDemapGroups;
   const int slot = frame_slot[first + j];                 // TF slot (FIC rows, FIB records)
   const int cif_row = frame_cif_row[first + j];           // row of this TF's first CIF
   const float2* tf = spectra + static_cast<size_t>(j) * (kSymbolsPerTf * 2048);
@@ -259,9 +261,9 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
     const int c = tid + 256 * m;
     bin[m] = c < 768 ? 256 + c : 257 + c;
     qk[m] = qpsk_of_carrier[c];
-    prev[m] = tf[(5 * grp) * 2048 + bin[m]];
+    prev[m] = tf[(kDemapSyms * grp) * 2048 + bin[m]];
   }
-  for (int l = 5 * grp + 1; l <= 5 * grp + 5; ++l) {
+  for (int l = kDemapSyms * grp + 1; l <= kDemapSyms * grp + kDemapSyms; ++l) {
 #pragma unroll
     for (int m = 0; m < 6; ++m) {
       const float2 cur = tf[l * 2048 + bin[m]];
@@ -309,10 +311,10 @@ hipError_t launch_demap(bool planar, const float2* spectra, int first, int nfram
 {
   if (nframes <= 0) return hipSuccess;
   if (planar)
-    hipLaunchKernelGGL(demap_kernel<true>, dim3(15 * nframes), dim3(kThreads), 0, stream, spectra, first, frame_slot, frame_cif_row,
+    hipLaunchKernelGGL(demap_kernel<true>, dim3(kDemapGroups * nframes), dim3(kThreads), 0, stream, spectra, first, frame_slot, frame_cif_row,
                        qpsk_of_carrier, fic_bits, msc_bits);
   else
-    hipLaunchKernelGGL(demap_kernel<false>, dim3(15 * nframes), dim3(kThreads), 0, stream, spectra, first, frame_slot, frame_cif_row,
+    hipLaunchKernelGGL(demap_kernel<false>, dim3(kDemapGroups * nframes), dim3(kThreads), 0, stream, spectra, first, frame_slot, frame_cif_row,
                        qpsk_of_carrier, fic_bits, msc_bits);
   return hipGetLastError();
 }

@@ -45,6 +45,6 @@ hipError_t launch_fib_crc(const uint8_t* fibs, int nfib, const uint16_t* crc_tab
 
 // K5: ETI header/FIB copy, EOF CRC, trailer
 hipError_t launch_eti_finish(const EtiFrameMeta* meta, int nframes, const uint8_t* headers, int header_stride, const uint8_t* fibs,
-                             const uint16_t* crc_tab, uint8_t* eti, hipStream_t stream);
+                             const uint16_t* crc_tab, const uint16_t* shift_cols, uint8_t* eti, hipStream_t stream);
 
 }  // namespace dabhip
