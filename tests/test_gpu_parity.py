@@ -321,3 +321,62 @@ def test_engine_e2e_low_snr_lock_loss(engine):
         assert [tuple(r[:5]) for r in ints] == [(t.ok, t.read_frame, t.coarse_timeshift, t.fine_timeshift, t.coarse_freq_shift) for t in trace]
         unlocked += int(len(want) < 4 * (40 - 15))
     assert unlocked >= 1          # at least one stream actually lost frames at this SNR
+
+
+def test_engine_edge_inputs(engine):
+    """Ragged / degenerate inputs: shorter than one call, no signal at all, clipped full-scale noise, a stream that
+    ends right after lock.  Traces and (empty or short) ETI outputs must equal the oracle's."""
+    rng = np.random.default_rng(5)
+    good = dab.synth_generate(dab.synth_preset(1, seed=91), 16)            # exactly 4 ETI frames
+    streams = [
+        np.full(100000, 127, np.uint8),                                     # < one 262144-byte call: nothing happens
+        np.full(3 * dab.TF_BYTES, 127, np.uint8),                           # silence: in "sync", FIBs never pass
+        rng.integers(0, 256, 4 * dab.TF_BYTES, dtype=np.uint8),             # full-scale noise incl. 255 -> int8 wrap
+        good,
+        good[: 14 * dab.TF_BYTES],                                          # ends before the first frame is due
+        np.concatenate([good[:5 * dab.TF_BYTES], rng.integers(100, 156, 2 * dab.TF_BYTES, dtype=np.uint8), good[5 * dab.TF_BYTES:]]),
+    ]
+    total = engine.decode(streams)
+    n = 0
+    for b, iq in enumerate(streams):
+        want, trace = ol.or_replay(iq)
+        got = engine.eti(b)
+        assert got.shape == want.shape and np.array_equal(got, want), b
+        ints, _ = engine.trace(b, max(len(trace), 1))
+        for k, t in enumerate(trace):
+            assert tuple(ints[k]) == (t.ok, t.read_frame, t.coarse_timeshift, t.fine_timeshift, t.coarse_freq_shift, t.fifo_count), (b, k)
+        n += len(want)
+    assert total == n and engine.eti_count(3) == 4 and engine.eti_count(0) == 0
+
+
+def test_engine_many_subchannels_and_uep_eep_mix(engine):
+    """A dense custom multiplex: 20 sub-channels incl. the smallest and largest code words the tables allow here."""
+    cfg = dab.synth_preset(0, seed=95)
+    cfg.nsub = 0
+    cu = 0
+    def add(slform, idx_or_lev, size=0):
+        nonlocal cu
+        k = cfg.nsub
+        cfg.sub[k].id = 3 * k + 1
+        cfg.sub[k].start_cu = cu
+        cfg.sub[k].slform = slform
+        if slform == 0:
+            cfg.sub[k].uep_index = idx_or_lev
+            cu += [16, 21, 24, 29, 35, 24, 29, 35, 42, 52, 29, 35, 42, 52, 32, 42, 48, 58, 70, 40][idx_or_lev] if idx_or_lev < 20 else 0
+        else:
+            cfg.sub[k].eep_protlev = idx_or_lev
+            cfg.sub[k].size_cu = size
+            cu += size
+        cfg.nsub += 1
+    for idx in (0, 4, 5, 9, 14, 18):       # UEP 32k PL5, 32k PL1, 48k PL5, 48k PL1, 64k PL5, 64k PL1
+        add(0, idx)
+    for lev, size in ((0, 12), (1, 8), (2, 6), (3, 4), (4, 27), (5, 21), (6, 18), (7, 15), (0, 96), (3, 64), (1, 16), (2, 12), (3, 8), (7, 30)):
+        add(1, lev, size)
+    assert cfg.nsub == 20 and cu <= 864
+    iq = dab.synth_generate(cfg, 18)
+    assert engine.decode([iq]) == 12
+    want, _ = ol.or_replay(iq)
+    got = engine.eti(0)
+    assert np.array_equal(got, want)
+    e = got[0].astype(int)
+    assert (e[5] & 0x7f) == 20
