@@ -1,11 +1,14 @@
 // capi.cpp — the C ABI of libdabhip.so (include/dabhip.h): the three reference seams
 // (S1 viterbi, S2 sdr_demod, S3 dab_process_frame) as single-stream shims over the same
 // HIP kernels the batch engine uses, plus the batch and stage entry points.
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dabhip.h"
@@ -13,9 +16,61 @@
 
 using namespace dabhip;
 
+// The batch engine behind the C ABI: one or two lanes (each a complete Engine with its own HIP stream, buffers and
+// host thread).  With two lanes the streams are split in halves; while one lane runs a GPU-saturating phase the other
+// does its sync scan or its host-side control plane, so those no longer leave the GPU idle.
 struct dabhip_engine {
-  Engine eng;
-  explicit dabhip_engine(int device) : eng(device) {}
+  std::vector<std::unique_ptr<Engine>> lanes;
+  std::mutex heavy;
+  std::vector<int> lane_of, local_of;        // per stream of the last decode
+  std::vector<int64_t> lane_frames;
+  DeviceBuffer<uint8_t> combined;            // all ETI frames, stream-major, when more than one lane produced them
+  float wall_ms = 0;
+  int device = 0;
+
+  explicit dabhip_engine(int dev) : device(dev)
+  {
+    int nl = 1;   // measured on MI355X: splitting the batch costs more (two shorter Viterbi launches, two scans) than the overlap wins
+    if (const char* env = std::getenv("DABHIP_LANES")) nl = std::max(1, std::min(4, std::atoi(env)));
+    for (int l = 0; l < nl; ++l) {
+      lanes.emplace_back(new Engine(dev));
+      if (!lanes.back()->ok()) break;
+    }
+    for (auto& l : lanes) l->set_heavy_lock(lanes.size() > 1 ? &heavy : nullptr);
+  }
+  bool ok() const { return !lanes.empty() && lanes.back()->ok(); }
+  Engine& first() { return *lanes[0]; }
+
+  int64_t decode(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device)
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int nl = nstreams >= 64 ? static_cast<int>(lanes.size()) : 1;   // small batches: the split does not pay
+    lane_of.assign(nstreams, 0);
+    local_of.assign(nstreams, 0);
+    lane_frames.assign(lanes.size(), 0);
+    std::vector<int> begin(nl + 1, 0);
+    for (int l = 0; l < nl; ++l) begin[l + 1] = begin[l] + nstreams / nl + (l < nstreams % nl ? 1 : 0);
+    for (int l = 0; l < nl; ++l)
+      for (int b = begin[l]; b < begin[l + 1]; ++b) { lane_of[b] = l; local_of[b] = b - begin[l]; }
+    std::vector<int64_t> result(nl, 0);
+    std::vector<std::string> errors(nl);
+    auto run = [&](int l) {
+      result[l] = lanes[l]->decode(iq + begin[l], nbytes + begin[l], begin[l + 1] - begin[l], on_device);
+      if (result[l] < 0) errors[l] = dabhip_last_error();
+    };
+    std::vector<std::thread> threads;
+    for (int l = 1; l < nl; ++l) threads.emplace_back(run, l);
+    run(0);
+    for (auto& t : threads) t.join();
+    int64_t total = 0;
+    for (int l = 0; l < nl; ++l) {
+      if (result[l] < 0) { set_error(errors[l]); return -1; }
+      lane_frames[l] = result[l];
+      total += result[l];
+    }
+    wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return total;
+  }
 };
 
 namespace {
@@ -48,7 +103,7 @@ int dabhip_device_count(void)
 dabhip_engine* dabhip_engine_create(int device)
 {
   dabhip_engine* e = new (std::nothrow) dabhip_engine(device);
-  if (e && !e->eng.ok()) { delete e; return nullptr; }
+  if (e && !e->ok()) { delete e; return nullptr; }
   return e;
 }
 void dabhip_engine_destroy(dabhip_engine* e) { delete e; }
@@ -56,41 +111,77 @@ void dabhip_engine_destroy(dabhip_engine* e) { delete e; }
 int64_t dabhip_engine_decode(dabhip_engine* e, const uint8_t* const* iq, const size_t* nbytes, int nstreams, int on_device)
 {
   if (!e || !iq || !nbytes) { set_error("engine_decode: null argument"); return -1; }
-  return e->eng.decode(iq, nbytes, nstreams, on_device != 0);
+  if (nstreams <= 0) { set_error("engine_decode: no streams"); return -1; }
+  return e->decode(iq, nbytes, nstreams, on_device != 0);
 }
-int64_t dabhip_engine_eti_count(const dabhip_engine* e, int stream) { return e ? e->eng.eti_count(stream) : -1; }
+int64_t dabhip_engine_eti_count(const dabhip_engine* e, int stream)
+{
+  if (!e || stream < 0 || stream >= static_cast<int>(e->lane_of.size())) return -1;
+  return e->lanes[e->lane_of[stream]]->eti_count(e->local_of[stream]);
+}
 int64_t dabhip_engine_eti_read(dabhip_engine* e, int stream, uint8_t* dst, int64_t cap_frames)
 {
   if (!e || !dst) { set_error("eti_read: null argument"); return -1; }
-  return e->eng.eti_read(stream, dst, cap_frames);
+  if (stream < 0 || stream >= static_cast<int>(e->lane_of.size())) { set_error("eti_read: bad stream"); return -1; }
+  return e->lanes[e->lane_of[stream]]->eti_read(e->local_of[stream], dst, cap_frames);
 }
 int64_t dabhip_engine_eti_drain(dabhip_engine* e, dabhip_eti_sink sink, void* user)
 {
   if (!e || !sink) { set_error("eti_drain: null argument"); return -1; }
   int64_t total = 0;
   std::vector<uint8_t> buf;
-  for (int b = 0;; ++b) {
-    const int64_t n = e->eng.eti_count(b);
-    if (n < 0) break;
+  for (int b = 0; b < static_cast<int>(e->lane_of.size()); ++b) {
+    const int64_t n = dabhip_engine_eti_count(e, b);
+    if (n < 0) return -1;
     buf.resize(static_cast<size_t>(n) * DABHIP_ETI_BYTES);
-    if (e->eng.eti_read(b, buf.data(), n) != n) return -1;
+    if (dabhip_engine_eti_read(e, b, buf.data(), n) != n) return -1;
     for (int64_t f = 0; f < n; ++f) sink(buf.data() + f * DABHIP_ETI_BYTES, b, user);
     total += n;
   }
   return total;
 }
-const void* dabhip_engine_eti_device_ptr(const dabhip_engine* e, int64_t* nframes) { return e ? e->eng.eti_device(nframes) : nullptr; }
+const void* dabhip_engine_eti_device_ptr(const dabhip_engine* ce, int64_t* nframes)
+{
+  if (!ce) return nullptr;
+  dabhip_engine* e = const_cast<dabhip_engine*>(ce);
+  int64_t total = 0, used = 0;
+  for (size_t l = 0; l < e->lanes.size(); ++l) { total += e->lane_frames.empty() ? 0 : e->lane_frames[l]; used += (!e->lane_frames.empty() && e->lane_frames[l] > 0) ? 1 : 0; }
+  if (nframes) *nframes = total;
+  if (used <= 1) {
+    for (size_t l = 0; l < e->lanes.size(); ++l)
+      if (!e->lane_frames.empty() && e->lane_frames[l] > 0) return e->lanes[l]->eti_buffer();
+    return e->lanes[0]->eti_buffer();
+  }
+  // several lanes produced frames: concatenate them (lane order = stream order)
+  if (!e->combined.reserve(static_cast<size_t>(total) * DABHIP_ETI_BYTES)) return nullptr;
+  size_t off = 0;
+  for (size_t l = 0; l < e->lanes.size(); ++l) {
+    const size_t bytes = static_cast<size_t>(e->lane_frames[l]) * DABHIP_ETI_BYTES;
+    if (bytes && hipMemcpy(e->combined.get() + off, e->lanes[l]->eti_buffer(), bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
+      set_error("eti_device_ptr: concatenation failed");
+      return nullptr;
+    }
+    off += bytes;
+  }
+  return e->combined.get();
+}
 int dabhip_engine_trace(const dabhip_engine* e, int stream, int32_t* ints6, double* ffs, int cap_calls)
 {
-  if (!e || !ints6) return -1;
-  return e->eng.trace(stream, ints6, ffs, cap_calls);
+  if (!e || !ints6 || stream < 0 || stream >= static_cast<int>(e->lane_of.size())) return -1;
+  return e->lanes[e->lane_of[stream]]->trace(e->local_of[stream], ints6, ffs, cap_calls);
 }
 int dabhip_engine_stage_ms(const dabhip_engine* e, const char** names, float* ms, int cap)
 {
   if (!e) return -1;
   static const char* kNames[12] = {"sync", "fft", "demap", "fic", "control", "gather", "viterbi", "eti", "host_setup", "host_frames", "host_worklist", "wall"};
-  const StageTimes& t = e->eng.stage_times();
-  const float v[12] = {t.sync, t.fft, t.demap, t.fic, t.control, t.gather, t.viterbi, t.eti, t.setup, t.frames, t.worklist, t.wall};
+  float v[12] = {0};
+  for (size_t l = 0; l < e->lanes.size(); ++l) {
+    if (e->lane_frames.empty() || (l > 0 && e->lane_frames[l] == 0 && e->lane_of.size() < 64)) continue;
+    const StageTimes& t = e->lanes[l]->stage_times();
+    const float x[11] = {t.sync, t.fft, t.demap, t.fic, t.control, t.gather, t.viterbi, t.eti, t.setup, t.frames, t.worklist};
+    for (int i = 0; i < 11; ++i) v[i] += x[i];     // lanes overlap in time: the sum is device/host work, not wall time
+  }
+  v[11] = e->wall_ms;
   int n = 0;
   for (; n < 12 && n < cap; ++n) {
     if (names) names[n] = kNames[n];
@@ -101,7 +192,18 @@ int dabhip_engine_stage_ms(const dabhip_engine* e, const char** names, float* ms
 int dabhip_engine_fft_stats(const dabhip_engine* e, int64_t* launches, int64_t* tfs, double* ms)
 {
   if (!e) return -1;
-  e->eng.fft_stats(launches, tfs, ms);
+  int64_t a = 0, b = 0;
+  double c = 0;
+  const int nl = e->lane_of.size() >= 64 ? static_cast<int>(e->lanes.size()) : 1;
+  for (int l = 0; l < nl; ++l) {
+    int64_t x = 0, y = 0;
+    double z = 0;
+    e->lanes[l]->fft_stats(&x, &y, &z);
+    a += x; b += y; c += z;
+  }
+  if (launches) *launches = a;
+  if (tfs) *tfs = b;
+  if (ms) *ms = c;
   return 0;
 }
 
@@ -109,17 +211,17 @@ int dabhip_engine_fft_stats(const dabhip_engine* e, int64_t* launches, int64_t* 
 int dabhip_stage_ofdm_fft(dabhip_engine* e, const uint8_t* frames, int nframes, float* spectra, int on_device, int reps, float* kernel_ms)
 {
   if (!e || !frames) { set_error("stage_ofdm_fft: null argument"); return -1; }
-  return e->eng.stage_ofdm_fft(frames, nframes, spectra, on_device != 0, reps, kernel_ms);
+  return e->first().stage_ofdm_fft(frames, nframes, spectra, on_device != 0, reps, kernel_ms);
 }
 int dabhip_stage_demap(dabhip_engine* e, const float* spectra, int nframes, uint8_t* fic, uint8_t* msc)
 {
   if (!e || !spectra || !fic || !msc) { set_error("stage_demap: null argument"); return -1; }
-  return e->eng.stage_demap(spectra, nframes, fic, msc);
+  return e->first().stage_demap(spectra, nframes, fic, msc);
 }
 int dabhip_stage_fic_decode(dabhip_engine* e, const uint8_t* fic, int nframes, uint8_t* fibs, uint8_t* crc_ok)
 {
   if (!e || !fic || !fibs || !crc_ok) { set_error("stage_fic_decode: null argument"); return -1; }
-  return e->eng.stage_fic_decode(fic, nframes, fibs, crc_ok);
+  return e->first().stage_fic_decode(fic, nframes, fibs, crc_ok);
 }
 
 // ---- S1: decoder seam ---------------------------------------------------------------------------

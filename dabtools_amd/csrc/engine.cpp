@@ -408,6 +408,8 @@ bool Engine::msc_decode(const std::vector<const std::vector<EtiJob>*>& stream_jo
     for (int pid : layouts[l].plan_ids) plan_jobs.emplace_back(pid, &layout_frames[l]);
   DecodeBatch batch;
   build_batch(plan_jobs, batch);
+  std::unique_lock<std::mutex> heavy;
+  if (heavy_mu_) heavy = std::unique_lock<std::mutex>(*heavy_mu_);
   if (!d_eti_.reserve(nf * kEtiBytes) || !d_meta_.upload(meta, stream_) || !d_headers_.upload(headers, stream_) ||
       !d_stream_cif_base_.upload(stream_row_base, stream_))
     return false;
@@ -518,7 +520,9 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
     return -1;
 
   times_.frames = since(tfr);
-  // K2 + K2b in chunks
+  // K2 + K2b in chunks, then K3: one GPU-saturating phase
+  std::unique_lock<std::mutex> heavy;
+  if (heavy_mu_) heavy = std::unique_lock<std::mutex>(*heavy_mu_);
   const int chunk = std::min(ntf, kFftChunkTfs);
   if (!d_spectra_.reserve(static_cast<size_t>(chunk) * kSymbolsPerTf * 2048)) return -1;
   for (int first = 0; first < ntf; first += chunk) {
@@ -551,6 +555,8 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
     (void)hipEventElapsedTime(&times_.fic, ev_[3], end);
   }
 
+  if (heavy.owns_lock()) heavy.unlock();
+
   // control plane: independent per stream, spread over host threads
   const auto t0 = std::chrono::steady_clock::now();
   std::vector<ControlPlane> planes(nstreams);
@@ -575,7 +581,7 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
   // K4 + K5
   const auto twl = std::chrono::steady_clock::now();
   if (!msc_decode(job_ptrs, plane_ptrs, row_base, fib_base)) return -1;
-  times_.worklist = since(twl) - times_.gather - times_.viterbi - times_.eti;
+  times_.worklist = std::max(0.0f, since(twl) - times_.gather - times_.viterbi - times_.eti);
   times_.wall = since(wall0);
   return total_eti_;
 }

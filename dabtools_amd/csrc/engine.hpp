@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -84,6 +85,10 @@ class Engine {
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
   bool ok() const { return ok_; }
+  // Lanes of one batch engine share this lock around their GPU-saturating phases (FFT/demap/FIC and MSC decode), so
+  // those never overlap each other; only the light phases (sync scan, host control plane) run beside them.
+  void set_heavy_lock(std::mutex* m) { heavy_mu_ = m; }
+  const uint8_t* eti_buffer() const { return d_eti_.get(); }
 
   // -- batch path ---------------------------------------------------------------------------
   int64_t decode(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device);
@@ -131,6 +136,7 @@ class Engine {
   bool unpack_tf_slot(int slot, uint8_t* fic_bytes, uint8_t* msc_bytes);
 
   bool ok_ = false;
+  std::mutex* heavy_mu_ = nullptr;
   std::unique_ptr<ThreadPool> pool_;   // host threads for per-stream control-plane work
   int device_ = 0;
   hipStream_t stream_ = nullptr;
