@@ -5,12 +5,14 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <numeric>
 #include <thread>
 
 #include "dab_bits.hpp"
 #include "dab_tables.hpp"
+#include "../../include/dabhip.h"
 #include "kernels.hpp"
 
 namespace dabhip {
@@ -322,11 +324,13 @@ bool Engine::fic_decode_slots(int first, int n, uint8_t* fibs_host, uint8_t* ok_
   return check(hipStreamSynchronize(stream_), "fic decode");
 }
 
-bool Engine::msc_decode(const std::vector<const std::vector<EtiJob>*>& stream_jobs, const std::vector<const ControlPlane*>& planes,
-                        const std::vector<int>& stream_row_base, const std::vector<int>& stream_fib_base)
+bool Engine::msc_prepare(const std::vector<const std::vector<EtiJob>*>& stream_jobs, const std::vector<const ControlPlane*>& planes,
+                         const std::vector<int>& stream_row_base, const std::vector<int>& stream_fib_base, MscWork& out)
 {
   size_t nf = 0;
   for (const auto* v : stream_jobs) nf += v->size();
+  out.nframes = nf;
+  out.stream_row_base = stream_row_base;
   if (nf == 0) return true;
   // An ensemble layout (the active sub-channels in SubChId order) fixes the code word plans and their offsets in
   // the ETI frame.  Layouts are identified by content so that streams carrying the same multiplex share plans.
@@ -337,13 +341,17 @@ bool Engine::msc_decode(const std::vector<const std::vector<EtiJob>*>& stream_jo
   std::map<std::vector<int32_t>, int> layout_index;
   std::vector<Layout> layouts;
   std::vector<std::vector<int>> layout_frames;
-  std::vector<DecodeJob> jobs(nf);
-  std::vector<EtiFrameMeta> meta(nf);
+  std::vector<DecodeJob>& jobs = out.jobs;
+  std::vector<EtiFrameMeta>& meta = out.meta;
+  jobs.assign(nf, DecodeJob{0, 0});
+  meta.assign(nf, EtiFrameMeta{0, 0, 0, 0});
   int max_header = 0;
   for (const auto* v : stream_jobs)
     for (const EtiJob& j : *v) max_header = std::max(max_header, j.header_len);
   const int header_stride = (max_header + 15) & ~15;
-  std::vector<uint8_t> headers(nf * static_cast<size_t>(header_stride), 0);
+  out.header_stride = header_stride;
+  std::vector<uint8_t>& headers = out.headers;
+  headers.assign(nf * static_cast<size_t>(header_stride), 0);
   // pass 1 (serial, cheap): global layout id of every (stream, local layout)
   const size_t nstreams = stream_jobs.size();
   std::vector<std::vector<int>> local_to_global(nstreams);
@@ -406,12 +414,21 @@ bool Engine::msc_decode(const std::vector<const std::vector<EtiJob>*>& stream_jo
   std::vector<std::pair<int, const std::vector<int>*>> plan_jobs;
   for (size_t l = 0; l < layouts.size(); ++l)
     for (int pid : layouts[l].plan_ids) plan_jobs.emplace_back(pid, &layout_frames[l]);
-  DecodeBatch batch;
-  build_batch(plan_jobs, batch);
+  build_batch(plan_jobs, out.batch);
+  return true;
+}
+
+bool Engine::msc_run(MscWork& w)
+{
+  const size_t nf = w.nframes;
+  if (nf == 0) return true;
   std::unique_lock<std::mutex> heavy;
   if (heavy_mu_) heavy = std::unique_lock<std::mutex>(*heavy_mu_);
-  if (!d_eti_.reserve(nf * kEtiBytes) || !d_meta_.upload(meta, stream_) || !d_headers_.upload(headers, stream_) ||
-      !d_stream_cif_base_.upload(stream_row_base, stream_))
+  const std::vector<DecodeJob>& jobs = w.jobs;
+  DecodeBatch& batch = w.batch;
+  const int header_stride = w.header_stride;
+  if (!d_eti_.reserve(nf * kEtiBytes) || !d_meta_.upload(w.meta, stream_) || !d_headers_.upload(w.headers, stream_) ||
+      !d_stream_cif_base_.upload(w.stream_row_base, stream_))
     return false;
   if (!check(hipMemsetAsync(d_eti_.get(), 0x55, nf * kEtiBytes, stream_), "eti memset")) return false;   // padding, misc.c:295
   if (!run_decode_batch(batch, false, jobs, d_msc_bits_.get(), d_stream_cif_base_.get(), d_prbs_.get(), d_eti_.get(), kEtiBytes,
@@ -520,19 +537,70 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
     return -1;
 
   times_.frames = since(tfr);
-  // K2 + K2b in chunks, then K3: one GPU-saturating phase
+  // K3 first: a pre-pass transforms only symbols 0..3 of every TF, so the FIC is decoded -- and the host control
+  // plane can run -- while the full OFDM stage (K2 + K2b) still occupies the GPU.
   std::unique_lock<std::mutex> heavy;
   if (heavy_mu_) heavy = std::unique_lock<std::mutex>(*heavy_mu_);
   const int chunk = std::min(ntf, kFftChunkTfs);
   if (!d_spectra_.reserve(static_cast<size_t>(chunk) * kSymbolsPerTf * 2048)) return -1;
-  for (int first = 0; first < ntf; first += chunk) {
+  std::vector<uint8_t> fibs(static_cast<size_t>(ntf) * 384), ok(static_cast<size_t>(ntf) * 12);
+  (void)hipEventRecord(ev_[3], stream_);
+  for (int first = 0; first < ntf; first += chunk * 19) {       // 4 of 76 symbols: 19 x as many TFs fit the spectra buffer
+    const int n = std::min(chunk * 19, ntf - first);
+    if (!check(launch_fic_prepass(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(),
+                                  d_frame_slot_.get(), d_qpsk_.get(), d_fic_bits_.get(), stream_),
+               "fic pre-pass launch"))
+      return -1;
+  }
+  if (!fic_decode_slots(0, ntf, fibs.data(), ok.data())) return -1;
+  {
+    hipEvent_t end = ev_[0];
+    (void)hipEventRecord(end, stream_);
+    (void)hipEventSynchronize(end);
+    (void)hipEventElapsedTime(&times_.fic, ev_[3], end);
+  }
+
+  // control plane + work lists on a host thread, hidden behind K2 + K2b
+  std::vector<ControlPlane> planes(nstreams);
+  std::vector<std::vector<EtiJob>> stream_jobs(nstreams);
+  MscWork work;
+  bool host_ok = true;
+  std::string host_error;
+  std::thread host([&]() {
+    const auto t0 = std::chrono::steady_clock::now();
+    pool_->parallel_for(nstreams, [&](int b) {
+      stream_jobs[b].reserve(static_cast<size_t>(4) * (tf_base[b + 1] - tf_base[b]));
+      for (int s = tf_base[b]; s < tf_base[b + 1]; ++s)
+        planes[b].on_tf(s - tf_base[b], fibs.data() + static_cast<size_t>(s) * 384, ok.data() + static_cast<size_t>(s) * 12, stream_jobs[b]);
+    });
+    std::vector<const ControlPlane*> plane_ptrs(nstreams);
+    std::vector<const std::vector<EtiJob>*> job_ptrs(nstreams);
+    total_eti_ = 0;
+    for (int b = 0; b < nstreams; ++b) {
+      plane_ptrs[b] = &planes[b];
+      job_ptrs[b] = &stream_jobs[b];
+      eti_base_[b] = total_eti_;
+      eti_count_[b] = static_cast<int64_t>(stream_jobs[b].size());
+      total_eti_ += eti_count_[b];
+    }
+    times_.control = since(t0);
+    const auto t1 = std::chrono::steady_clock::now();
+    host_ok = msc_prepare(job_ptrs, plane_ptrs, row_base, fib_base, work);
+    if (!host_ok) host_error = dabhip_last_error();
+    times_.worklist = since(t1);
+  });
+
+  // K2 + K2b in chunks
+  bool gpu_ok = true;
+  for (int first = 0; first < ntf && gpu_ok; first += chunk) {
     const int n = std::min(chunk, ntf - first);
     (void)hipEventRecord(ev_[0], stream_);
-    if (!check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(), stream_), "fft launch")) return -1;
+    gpu_ok = check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(), stream_), "fft launch");
     (void)hipEventRecord(ev_[1], stream_);
-    if (!check(launch_demap(true, d_spectra_.get(), first, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch")) return -1;
+    gpu_ok = gpu_ok && check(launch_demap(true, d_spectra_.get(), first, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch");
     (void)hipEventRecord(ev_[2], stream_);
-    if (!check(hipEventSynchronize(ev_[2]), "fft/demap")) return -1;
+    gpu_ok = gpu_ok && check(hipEventSynchronize(ev_[2]), "fft/demap");
+    if (!gpu_ok) break;
     float a = 0, c = 0;
     (void)hipEventElapsedTime(&a, ev_[0], ev_[1]);
     (void)hipEventElapsedTime(&c, ev_[1], ev_[2]);
@@ -542,46 +610,13 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
     fft_launches_ += 1;
     fft_tfs_ += n;
   }
-
-  // K3
-  std::vector<uint8_t> fibs(static_cast<size_t>(ntf) * 384), ok(static_cast<size_t>(ntf) * 12);
-  (void)hipEventRecord(ev_[3], stream_);
-  if (!fic_decode_slots(0, ntf, fibs.data(), ok.data())) return -1;
-  {
-    // ev_[0..2] were reused inside; time FIC by wall clock of the stream segment
-    hipEvent_t end = ev_[0];
-    (void)hipEventRecord(end, stream_);
-    (void)hipEventSynchronize(end);
-    (void)hipEventElapsedTime(&times_.fic, ev_[3], end);
-  }
-
   if (heavy.owns_lock()) heavy.unlock();
-
-  // control plane: independent per stream, spread over host threads
-  const auto t0 = std::chrono::steady_clock::now();
-  std::vector<ControlPlane> planes(nstreams);
-  std::vector<std::vector<EtiJob>> stream_jobs(nstreams);
-  pool_->parallel_for(nstreams, [&](int b) {
-    stream_jobs[b].reserve(static_cast<size_t>(4) * (tf_base[b + 1] - tf_base[b]));
-    for (int s = tf_base[b]; s < tf_base[b + 1]; ++s)
-      planes[b].on_tf(s - tf_base[b], fibs.data() + static_cast<size_t>(s) * 384, ok.data() + static_cast<size_t>(s) * 12, stream_jobs[b]);
-  });
-  std::vector<const ControlPlane*> plane_ptrs(nstreams);
-  std::vector<const std::vector<EtiJob>*> job_ptrs(nstreams);
-  total_eti_ = 0;
-  for (int b = 0; b < nstreams; ++b) {
-    plane_ptrs[b] = &planes[b];
-    job_ptrs[b] = &stream_jobs[b];
-    eti_base_[b] = total_eti_;
-    eti_count_[b] = static_cast<int64_t>(stream_jobs[b].size());
-    total_eti_ += eti_count_[b];
-  }
-  times_.control = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  host.join();
+  if (!gpu_ok) return -1;
+  if (!host_ok) { set_error(host_error); return -1; }
 
   // K4 + K5
-  const auto twl = std::chrono::steady_clock::now();
-  if (!msc_decode(job_ptrs, plane_ptrs, row_base, fib_base)) return -1;
-  times_.worklist = std::max(0.0f, since(twl) - times_.gather - times_.viterbi - times_.eti);
+  if (!msc_run(work)) return -1;
   times_.wall = since(wall0);
   return total_eti_;
 }

@@ -78,6 +78,17 @@ struct DecodeBatch {
   std::vector<int> job_ids;        // lanes of group g decode jobs job_ids[g.first .. g.first + g.count)
 };
 
+// Everything the MSC decode of a set of ETI frames needs, prepared on the host (no GPU work)
+struct MscWork {
+  std::vector<DecodeJob> jobs;
+  std::vector<EtiFrameMeta> meta;
+  std::vector<uint8_t> headers;
+  int header_stride = 0;
+  DecodeBatch batch;
+  std::vector<int> stream_row_base;
+  size_t nframes = 0;
+};
+
 class Engine {
  public:
   explicit Engine(int device);
@@ -117,7 +128,15 @@ class Engine {
   // decode the ETI frames described by the per-stream job lists into the ETI buffer (stream-major order)
   // stream_row_base[b]: logical CIF row of stream b's CIF 0; stream_fib_base[b]: FIB block (4 per TF slot) of its CIF 0
   bool msc_decode(const std::vector<const std::vector<EtiJob>*>& stream_jobs, const std::vector<const ControlPlane*>& planes,
-                  const std::vector<int>& stream_row_base, const std::vector<int>& stream_fib_base);
+                  const std::vector<int>& stream_row_base, const std::vector<int>& stream_fib_base)
+  {
+    MscWork w;
+    return msc_prepare(stream_jobs, planes, stream_row_base, stream_fib_base, w) && msc_run(w);
+  }
+  // host half (work lists, headers, plans) and GPU half (regroup, Viterbi, ETI finish) of msc_decode
+  bool msc_prepare(const std::vector<const std::vector<EtiJob>*>& stream_jobs, const std::vector<const ControlPlane*>& planes,
+                   const std::vector<int>& stream_row_base, const std::vector<int>& stream_fib_base, MscWork& out);
+  bool msc_run(MscWork& w);
   bool read_eti(int64_t first, int64_t n, uint8_t* dst);
   // front end on an explicit single stream (S2 seam): calls [call, call+1)
   bool scan_one_call(const uint8_t* iq_virtual_base, int64_t fed_bytes, StreamState* d_state, int call, CallDesc* out);

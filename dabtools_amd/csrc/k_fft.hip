@@ -68,7 +68,8 @@ __device__ __forceinline__ float rail(int byte) { return static_cast<float>(stat
 // Twiddles of the three inter-stage multiplications depend only on the thread index, so
 // each thread keeps its 21 factors in registers for all symbols it transforms.
 struct Twiddles {
-  float2 s1[7], s2[7], s3[7];
+  float2 s1[7], s2[7];
+  const float2* s3;      // stage-3 factors W_32^(t2 q3) depend on 2 bits of the thread index only: a 4 x 8 table in LDS
 };
 
 // One 2048-point transform by the whole workgroup.  v holds x[tid + 256 r] on entry.
@@ -101,7 +102,7 @@ __device__ __forceinline__ void fft2048_store(float2 (&v)[8], float2* bufP, floa
     for (int r = 0; r < 8; ++r) v[r] = bufQ[q * kEx2Stride + q2 * 32 + t2 + 4 * r];
     dft8(v);
 #pragma unroll
-    for (int q3 = 1; q3 < 8; ++q3) v[q3] = cmul(v[q3], tw.s3[q3 - 1]);
+    for (int q3 = 1; q3 < 8; ++q3) v[q3] = cmul(v[q3], tw.s3[q3]);
 #pragma unroll
     for (int q3 = 0; q3 < 8; ++q3) bufP[t2 * kEx3Stride + q + 8 * q2 + 64 * q3] = v[q3];
   }
@@ -167,24 +168,15 @@ __device__ __forceinline__ int transform_symbols(GlobalU16 fast_src, const uint8
   return parity;
 }
 
-// grid = (4 * nframes); frame j of the launch is frames[first + j] = {stream, call}
-__global__ __launch_bounds__(kThreads, 4) void ofdm_fft_kernel(const uint8_t* const* __restrict__ iq,
-                                                               const CallDesc* __restrict__ descs, int max_calls,
-                                                               const int2* __restrict__ frames, int first,
-                                                               float2* __restrict__ spectra,
-                                                               const float2* __restrict__ tw_global)
+// One workgroup: kSyms consecutive OFDM symbols (sym0 ..) of one transmission frame -> out_tf[sym * 2048 ..].
+template <int kSyms>
+__device__ __forceinline__ void fft_block(const uint8_t* stream, const FrameView& view, const int seg_end0, const int64_t seg_src0,
+                                          const int sym0, float2* __restrict__ out_tf, const float2* __restrict__ tw_global,
+                                          float2* exA, float2* exB)
 {
-  __shared__ __attribute__((aligned(16))) float2 exA[kExSize];
-  __shared__ __attribute__((aligned(16))) float2 exB[kExSize];
-  __shared__ FrameView view;
   const int tid = threadIdx.x;
-  const int j = blockIdx.x >> 2, part = blockIdx.x & 3;
-  const int2 fr = frames[first + j];
-  const uint8_t* stream = iq[fr.x];
-  const CallDesc* desc = descs + static_cast<size_t>(fr.x) * max_calls + fr.y;
-  if (tid == 0) view = desc->view;
-  const int seg_end0 = desc->view.seg_end[0];
-  const int64_t seg_src0 = desc->view.seg_src[0];
+  __shared__ float2 tw3[4 * 8];
+  if (tid < 32) tw3[tid] = tw_global[64 * (tid >> 3) * (tid & 7)];
   Twiddles tw;
   {
     const int t1 = tid & 31, t2 = (tid >> 3) & 3;
@@ -192,15 +184,13 @@ __global__ __launch_bounds__(kThreads, 4) void ofdm_fft_kernel(const uint8_t* co
     for (int q = 1; q < 8; ++q) {
       tw.s1[q - 1] = tw_global[tid * q];
       tw.s2[q - 1] = tw_global[8 * t1 * q];
-      tw.s3[q - 1] = tw_global[64 * t2 * q];
     }
+    tw.s3 = tw3 + 8 * t2;
   }
   __syncthreads();
-  float2* out_tf = spectra + static_cast<size_t>(j) * (kSymbolsPerTf * 2048);
-  const int sym0 = part * kSymPerBlock;
   // Symbols whose window lies inside what this call read from the stream take the contiguous path; the
   // rest (symbol 75 after a negative timing shift, frames right after a coarse resync) read through the view.
-  const int sym_end = sym0 + kSymPerBlock;
+  const int sym_end = sym0 + kSyms;
   int nfast = 0;
   if (seg_src0 >= 0) {
     const int avail = (seg_end0 - 4096) / 2 - kNullSamples - kCpSamples;      // start sample of the last fitting window, relative
@@ -208,11 +198,11 @@ __global__ __launch_bounds__(kThreads, 4) void ofdm_fft_kernel(const uint8_t* co
   }
   const int fast_end = max(sym0, min(sym_end, nfast));
   GlobalU16 src = reinterpret_cast<GlobalU16>(reinterpret_cast<uintptr_t>(stream + (seg_src0 >= 0 ? seg_src0 : 0)));
-  int done = sym0, parity0 = 0;
-  if (fast_end - sym0 >= kSymPerBlock - 1) {
-    // the common case gets a compile-time trip count (18: even, so the buffer roles end where they started):
-    // fully unrolled, prefetches hoisted.  The 19th symbol is the only one that can straddle the stale tail.
-    constexpr int kFixed = kSymPerBlock - 1;
+  // the common case gets a compile-time, EVEN trip count (buffer roles end where they started): fully unrolled,
+  // prefetches hoisted.  For 19 symbols that is 18; the 19th is the only one that can straddle the stale tail.
+  constexpr int kFixed = kSyms & ~1;
+  int done = sym0;
+  if (fast_end - sym0 >= kFixed) {
     unsigned raw[8];
     load_symbol<true>(src, stream, view, sym0, raw);
 #pragma unroll
@@ -226,8 +216,46 @@ __global__ __launch_bounds__(kThreads, 4) void ofdm_fft_kernel(const uint8_t* co
     }
     done = sym0 + kFixed;
   }
-  const int parity = transform_symbols<true>(src, stream, view, done, max(done, fast_end), parity0, exA, exB, tw, out_tf);
+  const int parity = transform_symbols<true>(src, stream, view, done, max(done, fast_end), 0, exA, exB, tw, out_tf);
   transform_symbols<false>(nullptr, stream, view, max(done, fast_end), sym_end, parity, exA, exB, tw, out_tf);
+}
+
+// grid = (4 * nframes); frame j of the launch is frames[first + j] = {stream, call}
+__global__ __launch_bounds__(kThreads, 4) void ofdm_fft_kernel(const uint8_t* const* __restrict__ iq,
+                                                               const CallDesc* __restrict__ descs, int max_calls,
+                                                               const int2* __restrict__ frames, int first,
+                                                               float2* __restrict__ spectra,
+                                                               const float2* __restrict__ tw_global)
+{
+  __shared__ __attribute__((aligned(16))) float2 exA[kExSize];
+  __shared__ __attribute__((aligned(16))) float2 exB[kExSize];
+  __shared__ FrameView view;
+  const int j = blockIdx.x >> 2, part = blockIdx.x & 3;
+  const int2 fr = frames[first + j];
+  const CallDesc* desc = descs + static_cast<size_t>(fr.x) * max_calls + fr.y;
+  if (threadIdx.x == 0) view = desc->view;
+  fft_block<kSymPerBlock>(iq[fr.x], view, desc->view.seg_end[0], desc->view.seg_src[0], part * kSymPerBlock,
+                          spectra + static_cast<size_t>(j) * (kSymbolsPerTf * 2048), tw_global, exA, exB);
+}
+
+// FIC pre-pass: only the phase reference symbol and the three FIC symbols (0..3) of every frame, so that the FIC
+// can be decoded -- and the host control plane run -- while the full OFDM stage is still on the GPU.
+// grid = nframes; output [frame][4][2048].
+__global__ __launch_bounds__(kThreads, 4) void fic_fft_kernel(const uint8_t* const* __restrict__ iq,
+                                                              const CallDesc* __restrict__ descs, int max_calls,
+                                                              const int2* __restrict__ frames, int first,
+                                                              float2* __restrict__ spectra4,
+                                                              const float2* __restrict__ tw_global)
+{
+  __shared__ __attribute__((aligned(16))) float2 exA[kExSize];
+  __shared__ __attribute__((aligned(16))) float2 exB[kExSize];
+  __shared__ FrameView view;
+  const int j = blockIdx.x;
+  const int2 fr = frames[first + j];
+  const CallDesc* desc = descs + static_cast<size_t>(fr.x) * max_calls + fr.y;
+  if (threadIdx.x == 0) view = desc->view;
+  fft_block<4>(iq[fr.x], view, desc->view.seg_end[0], desc->view.seg_src[0], 0, spectra4 + static_cast<size_t>(j) * (4 * 2048), tw_global,
+               exA, exB);
 }
 
 // ---- K2b ----------------------------------------------------------------------------------
@@ -242,7 +270,8 @@ __global__ __launch_bounds__(kThreads, 4) void ofdm_fft_kernel(const uint8_t* co
 // word).  A complete logical row is then exactly the reference's cif_time_deinterleaved:
 // out[i] = bit ((i >> 4) & 31) of row word ((i >> 9) * 16 + (i & 15)).
 template <bool kPlanar>
-__global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restrict__ spectra, int first,
+__global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restrict__ spectra, int syms_per_tf, int group_syms,
+                                                         int groups_per_tf, int first,
                                                          const int* __restrict__ frame_slot,
                                                          const int* __restrict__ frame_cif_row,
                                                          const uint16_t* __restrict__ qpsk_of_carrier,
@@ -250,10 +279,10 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
 {
   __shared__ uint8_t bits[kBitsPerSym];
   const int tid = threadIdx.x;
-  const int j = blockIdx.x / kDemapGroups, grp = blockIdx.x % kDemapGroups;
+  const int j = blockIdx.x / groups_per_tf, grp = blockIdx.x % groups_per_tf;
   const int slot = frame_slot[first + j];                 // TF slot (FIC rows, FIB records)
   const int cif_row = frame_cif_row[first + j];           // row of this TF's first CIF
-  const float2* tf = spectra + static_cast<size_t>(j) * (kSymbolsPerTf * 2048);
+  const float2* tf = spectra + static_cast<size_t>(j) * (syms_per_tf * 2048);
   int bin[6], qk[6];
   float2 prev[6];
 #pragma unroll
@@ -261,9 +290,9 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
     const int c = tid + 256 * m;
     bin[m] = c < 768 ? 256 + c : 257 + c;
     qk[m] = qpsk_of_carrier[c];
-    prev[m] = tf[(kDemapSyms * grp) * 2048 + bin[m]];
+    prev[m] = tf[(group_syms * grp) * 2048 + bin[m]];
   }
-  for (int l = kDemapSyms * grp + 1; l <= kDemapSyms * grp + kDemapSyms; ++l) {
+  for (int l = group_syms * grp + 1; l <= group_syms * grp + group_syms; ++l) {
 #pragma unroll
     for (int m = 0; m < 6; ++m) {
       const float2 cur = tf[l * 2048 + bin[m]];
@@ -311,11 +340,23 @@ hipError_t launch_demap(bool planar, const float2* spectra, int first, int nfram
 {
   if (nframes <= 0) return hipSuccess;
   if (planar)
-    hipLaunchKernelGGL(demap_kernel<true>, dim3(kDemapGroups * nframes), dim3(kThreads), 0, stream, spectra, first, frame_slot, frame_cif_row,
-                       qpsk_of_carrier, fic_bits, msc_bits);
+    hipLaunchKernelGGL(demap_kernel<true>, dim3(kDemapGroups * nframes), dim3(kThreads), 0, stream, spectra, kSymbolsPerTf, kDemapSyms,
+                       kDemapGroups, first, frame_slot, frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits);
   else
-    hipLaunchKernelGGL(demap_kernel<false>, dim3(kDemapGroups * nframes), dim3(kThreads), 0, stream, spectra, first, frame_slot, frame_cif_row,
-                       qpsk_of_carrier, fic_bits, msc_bits);
+    hipLaunchKernelGGL(demap_kernel<false>, dim3(kDemapGroups * nframes), dim3(kThreads), 0, stream, spectra, kSymbolsPerTf, kDemapSyms,
+                       kDemapGroups, first, frame_slot, frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits);
+  return hipGetLastError();
+}
+
+// FIC pre-pass: 4-symbol spectra -> FIC bit rows only
+hipError_t launch_fic_prepass(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
+                              float2* spectra4, const float2* tw, const int* frame_slot, const uint16_t* qpsk_of_carrier,
+                              uint32_t* fic_bits, hipStream_t stream)
+{
+  if (nframes <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fic_fft_kernel, dim3(nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, spectra4, tw);
+  hipLaunchKernelGGL(demap_kernel<false>, dim3(nframes), dim3(kThreads), 0, stream, spectra4, 4, 3, 1, first, frame_slot, frame_slot,
+                     qpsk_of_carrier, fic_bits, static_cast<uint32_t*>(nullptr));
   return hipGetLastError();
 }
 

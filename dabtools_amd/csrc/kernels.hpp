@@ -25,6 +25,11 @@ hipError_t launch_ofdm_fft(const uint8_t* const* iq, const CallDesc* descs, int 
 hipError_t launch_demap(bool planar, const float2* spectra, int first, int nframes, const int* frame_slot, const int* frame_cif_row,
                         const uint16_t* qpsk_of_carrier, uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream);
 
+// FIC pre-pass: DFT of symbols 0..3 of every frame + demap of the three FIC symbols (spectra4: [nframes][4][2048])
+hipError_t launch_fic_prepass(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
+                              float2* spectra4, const float2* tw, const int* frame_slot, const uint16_t* qpsk_of_carrier,
+                              uint32_t* fic_bits, hipStream_t stream);
+
 // K3/K4a: time de-interleave + de-puncture gather into per-step bytes
 hipError_t launch_gather(bool fic, const WaveGroup* groups, int ngroups, int max_n16, const DecodeJob* jobs, const int* job_ids,
                          const CodewordPlan* plans, const uint32_t* bits, const int* stream_cif_base, uint4* steps,
