@@ -249,7 +249,6 @@ struct dabhip_sdr {
   DeviceBuffer<StreamState> state;
   int64_t base = 0;                  // stream offset of window[0]
   int64_t fed = 0;                   // bytes received so far
-  int64_t carry = 0;                 // bytes of a partial 262144-byte call not yet scanned
   int call = 0;
   CallDesc last{};
   explicit dabhip_sdr(int device) : eng(device) {}

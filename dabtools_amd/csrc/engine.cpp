@@ -220,8 +220,7 @@ bool Engine::run_decode_batch(DecodeBatch& b, bool fic, const std::vector<Decode
     const int g0 = slice_start[s], n = slice_start[s + 1] - g0;
     const int max_n16 = (b.groups[g0].nsteps + 15) / 16;     // groups are sorted longest first
     (void)hipEventRecord(ev_[0], stream_);
-    if (fic && !check(launch_gather(true, d_groups_.get() + g0, n, max_n16, d_jobs_.get(), ids, d_plans_.get(), bits, d_stream_cif_base,
-                                    d_steps_.get(), stream_),
+    if (fic && !check(launch_fic_gather(d_groups_.get() + g0, n, max_n16, d_jobs_.get(), ids, d_plans_.get(), bits, d_steps_.get(), stream_),
                       "gather launch"))
       return false;
     (void)hipEventRecord(ev_[1], stream_);

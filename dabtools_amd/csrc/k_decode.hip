@@ -1,9 +1,10 @@
 // k_decode.hip — K3/K4: channel decoding of the FIC and of every MSC sub-channel, and K5:
 // ETI frame completion.
 //
-//  gather_kernel   de-puncture (depuncture.c:45-132) of the time-de-interleaved logical CIF rows
-//                  that demap_kernel laid out (misc.c:29-39 is folded into that scatter):
-//                  bit rows -> one byte per trellis step (4 received bits + 4 "was transmitted" flags).
+//  fic_gather_kernel  FIC de-puncture (depuncture.c:45-82): FIC bit rows -> one byte per trellis
+//                  step (4 received bits + 4 "was transmitted" flags) for viterbi_kernel.
+//  regroup_kernel  logical CIF rows (demap_kernel folded misc.c:29-39 into its scatter) -> natural
+//                  bit order, 64 ETI frames interleaved, for viterbi_msc_kernel.
 //  viterbi_kernel  K=7 rate-1/4 maximum-likelihood decoder with the decisions of the
 //                  reference's scalar viterbi() (viterbi.c:352-451): one LANE per code word,
 //                  all 64 path metrics of that code word live in the lane's VGPRs (32 packed
@@ -33,15 +34,13 @@ namespace {
 
 // ---------------------------------------------------------------------------------------
 // gather: one thread per (item, 16 trellis steps)
-template <bool kFic>
-__global__ __launch_bounds__(256) void gather_kernel(const WaveGroup* __restrict__ groups, int ngroups,
-                                                     const DecodeJob* __restrict__ jobs, const int* __restrict__ job_ids,
-                                                     const CodewordPlan* __restrict__ plans, const uint32_t* __restrict__ bits,
-                                                     const int* __restrict__ stream_cif_base,   // MSC: logical row of each stream's CIF 0
-                                                     uint4* __restrict__ steps)
+__global__ __launch_bounds__(256) void fic_gather_kernel(const WaveGroup* __restrict__ groups, int ngroups,
+                                                         const DecodeJob* __restrict__ jobs, const int* __restrict__ job_ids,
+                                                         const CodewordPlan* __restrict__ plans, const uint32_t* __restrict__ bits,
+                                                         uint4* __restrict__ steps)
 {
   // Lanes run along the code word (64 consecutive 16-step chunks), so a wave reads one contiguous stretch of
-  // ~2200 received bits (a few cache lines per plane).  Each wave walks 16 of the group's 64 code words.
+  // received bits.  Each wave walks 16 of the group's 64 code words.
   const int group = blockIdx.y;
   if (group >= ngroups) return;
   const WaveGroup grp = groups[group];
@@ -58,7 +57,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const WaveGroup* __restrict
     j0 += pl.blocks[s] * 4 * __popc(pl.mask[s]);
     seg_start += seg_bits;
   }
-  const bool tail = (s == 4);                    // 24 tail bits at PI 8 (depuncture.c:97-103)
+  const bool tail = (s == 4);                    // 24 tail bits at PI 8 (depuncture.c:74-80)
   const int jbase = pl.start_bit + j0 + ((x0 - seg_start) >> 5) * __popc(mask);
   const uint32_t m0 = tail ? (puncture_mask(8) & 0x00ffffffu) : mask, m1 = tail ? 0u : mask;
 
@@ -67,9 +66,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const WaveGroup* __restrict
     uint32_t w[4] = {0, 0, 0, 0};
     if (lane < grp.count) {
       const DecodeJob job = jobs[job_ids ? job_ids[grp.first + lane] : grp.first + lane];
-      const uint32_t* row0;
-      if (kFic) row0 = bits + static_cast<size_t>(job.cif) * 72;   // FIC block = 2304 bits = 72 words
-      else row0 = bits + (static_cast<size_t>(stream_cif_base[job.stream]) + job.cif) * 1728;
+      const uint32_t* row0 = bits + static_cast<size_t>(job.cif) * 72;   // FIC block = 2304 bits = 72 words
       int i = jbase;
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
@@ -77,12 +74,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const WaveGroup* __restrict
         uint32_t val = 0;
         for (int u = 0; u < 32; ++u) {
           if ((m >> u) & 1u) {
-            if (kFic) {
-              val |= ((row0[i >> 5] >> (i & 31)) & 1u) << u;
-            } else {
-              // time de-interleaved bit i = plane (i & 15), bit (i >> 4) of the logical row (demap_kernel)
-              val |= ((row0[(i >> 9) * 16 + (i & 15)] >> ((i >> 4) & 31)) & 1u) << u;
-            }
+            val |= ((row0[i >> 5] >> (i & 31)) & 1u) << u;
             ++i;
           }
         }
@@ -501,19 +493,14 @@ __global__ __launch_bounds__(256) void eti_finish_kernel(const EtiFrameMeta* __r
 
 }  // namespace
 
-hipError_t launch_gather(bool fic, const WaveGroup* groups, int ngroups, int max_n16, const DecodeJob* jobs, const int* job_ids,
-                         const CodewordPlan* plans, const uint32_t* bits, const int* stream_cif_base, uint4* steps,
-                         hipStream_t stream)
+hipError_t launch_fic_gather(const WaveGroup* groups, int ngroups, int max_n16, const DecodeJob* jobs, const int* job_ids,
+                             const CodewordPlan* plans, const uint32_t* bits, uint4* steps, hipStream_t stream)
 {
   if (ngroups <= 0) return hipSuccess;
-  // grid.y is limited to 65535: slice the groups
-  for (int g0 = 0; g0 < ngroups; g0 += 32768) {
+  for (int g0 = 0; g0 < ngroups; g0 += 32768) {     // grid.y is limited to 65535
     const int ng = min(32768, ngroups - g0);
-    dim3 grid((max_n16 + 63) / 64, ng);
-    if (fic)
-      hipLaunchKernelGGL(gather_kernel<true>, grid, dim3(256), 0, stream, groups + g0, ng, jobs, job_ids, plans, bits, stream_cif_base, steps);
-    else
-      hipLaunchKernelGGL(gather_kernel<false>, grid, dim3(256), 0, stream, groups + g0, ng, jobs, job_ids, plans, bits, stream_cif_base, steps);
+    hipLaunchKernelGGL(fic_gather_kernel, dim3((max_n16 + 63) / 64, ng), dim3(256), 0, stream, groups + g0, ng, jobs, job_ids, plans, bits,
+                       steps);
   }
   return hipGetLastError();
 }

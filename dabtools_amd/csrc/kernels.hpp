@@ -30,10 +30,9 @@ hipError_t launch_fic_prepass(const uint8_t* const* iq, const CallDesc* descs, i
                               float2* spectra4, const float2* tw, const int* frame_slot, const uint16_t* qpsk_of_carrier,
                               uint32_t* fic_bits, hipStream_t stream);
 
-// K3/K4a: time de-interleave + de-puncture gather into per-step bytes
-hipError_t launch_gather(bool fic, const WaveGroup* groups, int ngroups, int max_n16, const DecodeJob* jobs, const int* job_ids,
-                         const CodewordPlan* plans, const uint32_t* bits, const int* stream_cif_base, uint4* steps,
-                         hipStream_t stream);
+// K3: FIC de-puncture gather into per-step bytes
+hipError_t launch_fic_gather(const WaveGroup* groups, int ngroups, int max_n16, const DecodeJob* jobs, const int* job_ids,
+                             const CodewordPlan* plans, const uint32_t* bits, uint4* steps, hipStream_t stream);
 
 // K3/K4b: Viterbi forward pass + chain-back + descramble + pack
 hipError_t launch_viterbi(const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans, const uint4* steps,

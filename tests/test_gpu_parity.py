@@ -380,3 +380,38 @@ def test_engine_many_subchannels_and_uep_eep_mix(engine):
     assert np.array_equal(got, want)
     e = got[0].astype(int)
     assert (e[5] & 0x7f) == 20
+
+
+def test_full_size_batch_properties():
+    """BASELINE configs[2] size (256 streams x 64 TF, 12 sub-channels): size-independent properties.
+    (a) every ETI frame of sampled streams is well formed (HCRC, EOF CRC, FL, FSYNC/FCT, padding);
+    (b) encode -> modulate -> decode returns the payload;  (c) identical inputs give identical outputs;
+    (d) one stream is compared byte for byte with the CPU oracle."""
+    import torch
+    import eti_check
+    ntf, distinct, nstreams = 64, 8, 256
+    cfgs = [dab.synth_preset(0, seed=300 + i, cif_count0=(611 * i) % 5000) for i in range(distinct)]
+    host = [dab.synth_generate(c, ntf) for c in cfgs]
+    base = [torch.from_numpy(h).cuda() for h in host]
+    tensors = [base[i % distinct] if i < distinct else base[i % distinct].clone() for i in range(nstreams)]
+    eng = dab.Engine(0)
+    total = eng.decode_device([t.data_ptr() for t in tensors], [t.numel() for t in tensors])
+    assert total == nstreams * 4 * (ntf - 15)
+    ref = {}
+    for b in list(range(distinct)) + [distinct + 3, 100, 255]:
+        eti = eng.eti(b)
+        assert eti.shape == (4 * (ntf - 15), 6144)
+        if b < distinct:
+            ref[b] = eti
+            assert eti_check.check_sequence(eti) == 196                       # (a)
+            for f in (0, 77, 195):                                            # (b)
+                p = eti_check.parse(eti[f])
+                cif = 40 + f
+                assert np.array_equal(p["fic"], dab.synth_fibs(cfgs[b], cif))
+                for k, data in enumerate(p["subch"]):
+                    assert np.array_equal(data, dab.synth_payload(cfgs[b], cif, k)), (b, f, k)
+        else:
+            assert np.array_equal(eti, ref[b % distinct])                     # (c)
+    want, _ = ol.or_replay(host[5])                                           # (d)
+    assert np.array_equal(ref[5], want)
+    eng.close()

@@ -127,3 +127,16 @@ def test_backend_end_to_end_against_reference_eti():
     O.or_dab_free(d)
     got = np.array(frames)
     assert got.shape == g["eti"].shape and np.array_equal(got, g["eti"])
+
+
+def test_reference_eti_frames_parse_with_the_validator():
+    """tests/eti_check.py (used by the full-size GPU property test) accepts the frames the real reference emitted."""
+    import eti_check
+    g = np.load(os.path.join(G, "backend_e2e.npz"))
+    assert eti_check.check_sequence(g["eti"]) == len(g["eti"])
+    p = eti_check.parse(g["eti"][0])
+    assert p["nst"] == 4 and [s[0] for s in p["stc"]] == [1, 2, 5, 9]
+    bad = g["eti"][0].copy()
+    bad[200] ^= 1
+    with pytest.raises(AssertionError):
+        eti_check.parse(bad)
