@@ -35,7 +35,7 @@ class SubChCfg(C.Structure):
 class SynthCfg(C.Structure):
     _fields_ = [("eid", C.c_uint32), ("nsub", C.c_int32), ("sub", SubChCfg * 64), ("seed", C.c_uint64),
                 ("cif_count0", C.c_int32), ("skip_samples", C.c_int32), ("amplitude", C.c_double),
-                ("snr_db", C.c_double)]
+                ("snr_db", C.c_double), ("cfo_hz", C.c_double)]
 
 
 ETI_CALLBACK = C.CFUNCTYPE(None, u8p)
@@ -68,6 +68,7 @@ _SIGNATURES = {
     "dabhip_engine_eti_read": (C.c_int64, [C.c_void_p, C.c_int, u8p, C.c_int64]),
     "dabhip_engine_eti_drain": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dabhip_engine_eti_device_ptr": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "dabhip_engine_set_afc": (C.c_int, [C.c_void_p, C.c_int]),
     "dabhip_engine_trace": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int]),
     "dabhip_engine_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
     "dabhip_engine_fft_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -129,7 +130,7 @@ def _need(cond, what):
 
 
 # ---- synthetic modulator --------------------------------------------------------------------
-def synth_preset(preset=0, seed=1, cif_count0=0, skip_samples=0, snr_db=1000.0, amplitude=1.0):
+def synth_preset(preset=0, seed=1, cif_count0=0, skip_samples=0, snr_db=1000.0, amplitude=1.0, cfo_hz=0.0):
     cfg = SynthCfg()
     _need(lib().dabhip_synth_preset(preset, C.byref(cfg)) == 0, "synth_preset")
     cfg.seed = seed
@@ -137,6 +138,7 @@ def synth_preset(preset=0, seed=1, cif_count0=0, skip_samples=0, snr_db=1000.0, 
     cfg.skip_samples = skip_samples
     cfg.snr_db = snr_db
     cfg.amplitude = amplitude
+    cfg.cfo_hz = cfo_hz
     return cfg
 
 
@@ -279,6 +281,10 @@ class Engine:
         self._h = lib().dabhip_engine_create(device)
         _need(self._h, "engine_create")
         self.nstreams = 0
+
+    def set_afc(self, enable):
+        """Software AFC (NCO per stream steered by the reference's tuner rule); off = parity mode."""
+        _need(lib().dabhip_engine_set_afc(self._h, 1 if enable else 0) == 0, "set_afc")
 
     def decode(self, streams):
         """streams: list of numpy uint8 arrays (host) -> total ETI frames."""

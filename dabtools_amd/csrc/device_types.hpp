@@ -24,6 +24,8 @@ struct CallDesc {
   int32_t ordinal;       // dense index of this TF among the demodulated TFs of the stream
   int32_t coarse_timeshift, fine_timeshift, coarse_freq_shift, fifo_count;
   double fine_freq_shift;
+  int32_t nco_hz;        // software AFC: frequency the samples of this frame were de-rotated by (0 in parity mode)
+  int32_t pad;
   FrameView view;
 };
 
@@ -36,6 +38,8 @@ struct StreamState {
   int32_t next_ordinal;
   int32_t overflow;      // set if the stale-tail bookkeeping exceeded kMaxSeg
   double fine_freq_shift;
+  int32_t tuner_hz;      // software AFC: accumulated re-tuning, the NCO's frequency (sdr->frequency - nominal, dab2eti.c:76-103)
+  uint32_t rng;          // state of the generator standing in for rand() at dab2eti.c:90-93
   FrameView view;
 };
 

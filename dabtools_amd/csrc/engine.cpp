@@ -29,6 +29,7 @@ StreamState initial_state()
 {
   StreamState st;
   std::memset(&st, 0, sizeof st);
+  st.rng = 1;
   st.view.nseg = 1;                                       // the calloc'ed frame buffer: all zero bytes
   for (int i = 0; i < kMaxSeg; ++i) { st.view.seg_end[i] = kTfBytes; st.view.seg_src[i] = -1; }
   return st;
@@ -494,7 +495,7 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
   // K1
   (void)hipEventRecord(ev_[0], stream_);
   if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), nstreams, max_calls_, 0, -1,
-                              d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), stream_),
+                              d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), afc_ ? 1 : 0, stream_),
              "sync scan launch"))
     return -1;
   (void)hipEventRecord(ev_[1], stream_);
@@ -781,7 +782,7 @@ bool Engine::scan_one_call(const uint8_t* iq_virtual_base, int64_t fed_bytes, St
   if (!d_iq_ptrs_.upload(ptrs, stream_) || !d_nbytes_.upload(nb, stream_) || !d_descs_.reserve(1)) return false;
   // the kernel indexes descs[stream * max_calls + call]; with max_calls = 0 and the pointer moved back by `call` it hits slot 0
   if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_state, d_descs_.get() - call, 1, 0, call, call + 1, d_tw2048_.get(),
-                              d_tw1536_.get(), d_prs_.get(), stream_),
+                              d_tw1536_.get(), d_prs_.get(), 0, stream_),
              "sync scan launch"))
     return false;
   return check(hipMemcpyAsync(out, d_descs_.get(), sizeof(CallDesc), hipMemcpyDeviceToHost, stream_), "desc download") &&

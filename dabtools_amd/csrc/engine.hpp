@@ -100,6 +100,8 @@ class Engine {
   // those never overlap each other; only the light phases (sync scan, host control plane) run beside them.
   void set_heavy_lock(std::mutex* m) { heavy_mu_ = m; }
   const uint8_t* eti_buffer() const { return d_eti_.get(); }
+  // software AFC: an NCO per stream steered by the reference's tuner rule; off = parity mode
+  void set_afc(bool on) { afc_ = on; }
 
   // -- batch path ---------------------------------------------------------------------------
   int64_t decode(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device);
@@ -155,6 +157,7 @@ class Engine {
   bool unpack_tf_slot(int slot, uint8_t* fic_bytes, uint8_t* msc_bytes);
 
   bool ok_ = false;
+  bool afc_ = false;
   std::mutex* heavy_mu_ = nullptr;
   std::unique_ptr<ThreadPool> pool_;   // host threads for per-stream control-plane work
   int device_ = 0;

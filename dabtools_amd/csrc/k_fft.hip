@@ -65,6 +65,19 @@ __device__ __forceinline__ int view_byte(const uint8_t* stream, const FrameView&
 }
 __device__ __forceinline__ float rail(int byte) { return static_cast<float>(static_cast<int8_t>(static_cast<uint8_t>(byte - 127))); }
 
+// software AFC: de-rotate the 8 samples of this thread by exp(-2 pi i nco n / fs); phase kept as a 32-bit fraction of a
+// turn (inc = nco / fs * 2^32 per sample), so it never loses precision over the 196,608 samples of a frame
+__device__ __forceinline__ void derotate(float2 (&v)[8], uint32_t inc, int first_sample)
+{
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const uint32_t turns = 0u - inc * static_cast<uint32_t>(first_sample + 256 * r);
+    float sn, cs;
+    sincospif(static_cast<float>(static_cast<int32_t>(turns)) * (1.0f / 2147483648.0f), &sn, &cs);   // angle = pi * turns / 2^31
+    v[r] = make_float2(v[r].x * cs - v[r].y * sn, v[r].x * sn + v[r].y * cs);
+  }
+}
+
 // Twiddles of the three inter-stage multiplications depend only on the thread index, so
 // each thread keeps its 21 factors in registers for all symbols it transforms.
 struct Twiddles {
@@ -151,7 +164,7 @@ __device__ __forceinline__ void load_symbol(GlobalU16 fast_src, const uint8_t* s
 template <bool kFast>
 __device__ __forceinline__ int transform_symbols(GlobalU16 fast_src, const uint8_t* stream, const FrameView& view, int sym_begin,
                                                  int sym_end, int parity, float2* exA, float2* exB, const Twiddles& tw,
-                                                 float2* __restrict__ out_tf)
+                                                 float2* __restrict__ out_tf, uint32_t nco_inc)
 {
   if (sym_begin >= sym_end) return parity;
   unsigned raw[8];
@@ -160,6 +173,7 @@ __device__ __forceinline__ int transform_symbols(GlobalU16 fast_src, const uint8
     float2 v[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = make_float2(rail(raw[r] & 0xff), rail(raw[r] >> 8));
+    if (nco_inc) derotate(v, nco_inc, kNullSamples + kSymSamples * sym + kCpSamples + static_cast<int>(threadIdx.x));
     if (sym + 1 < sym_end) load_symbol<kFast>(fast_src, stream, view, sym + 1, raw);   // prefetch under the transform
     if (parity) fft2048_store(v, exB, exA, tw, out_tf + static_cast<size_t>(sym) * 2048);
     else fft2048_store(v, exA, exB, tw, out_tf + static_cast<size_t>(sym) * 2048);
@@ -172,7 +186,7 @@ __device__ __forceinline__ int transform_symbols(GlobalU16 fast_src, const uint8
 template <int kSyms>
 __device__ __forceinline__ void fft_block(const uint8_t* stream, const FrameView& view, const int seg_end0, const int64_t seg_src0,
                                           const int sym0, float2* __restrict__ out_tf, const float2* __restrict__ tw_global,
-                                          float2* exA, float2* exB)
+                                          float2* exA, float2* exB, const int nco_hz)
 {
   const int tid = threadIdx.x;
   __shared__ float2 tw3[4 * 8];
@@ -202,7 +216,9 @@ __device__ __forceinline__ void fft_block(const uint8_t* stream, const FrameView
   // prefetches hoisted.  For 19 symbols that is 18; the 19th is the only one that can straddle the stale tail.
   constexpr int kFixed = kSyms & ~1;
   int done = sym0;
-  if (fast_end - sym0 >= kFixed) {
+  // software AFC (off in parity mode: nco_hz == 0): per-sample phase step as a 32-bit fraction of a turn
+  const uint32_t nco_inc = nco_hz ? static_cast<uint32_t>(static_cast<int64_t>(llrint(nco_hz * (4294967296.0 / 2048000.0)))) : 0u;
+  if (nco_inc == 0 && fast_end - sym0 >= kFixed) {
     unsigned raw[8];
     load_symbol<true>(src, stream, view, sym0, raw);
 #pragma unroll
@@ -216,8 +232,8 @@ __device__ __forceinline__ void fft_block(const uint8_t* stream, const FrameView
     }
     done = sym0 + kFixed;
   }
-  const int parity = transform_symbols<true>(src, stream, view, done, max(done, fast_end), 0, exA, exB, tw, out_tf);
-  transform_symbols<false>(nullptr, stream, view, max(done, fast_end), sym_end, parity, exA, exB, tw, out_tf);
+  const int parity = transform_symbols<true>(src, stream, view, done, max(done, fast_end), 0, exA, exB, tw, out_tf, nco_inc);
+  transform_symbols<false>(nullptr, stream, view, max(done, fast_end), sym_end, parity, exA, exB, tw, out_tf, nco_inc);
 }
 
 // grid = (4 * nframes); frame j of the launch is frames[first + j] = {stream, call}
@@ -235,7 +251,7 @@ __global__ __launch_bounds__(kThreads, 4) void ofdm_fft_kernel(const uint8_t* co
   const CallDesc* desc = descs + static_cast<size_t>(fr.x) * max_calls + fr.y;
   if (threadIdx.x == 0) view = desc->view;
   fft_block<kSymPerBlock>(iq[fr.x], view, desc->view.seg_end[0], desc->view.seg_src[0], part * kSymPerBlock,
-                          spectra + static_cast<size_t>(j) * (kSymbolsPerTf * 2048), tw_global, exA, exB);
+                          spectra + static_cast<size_t>(j) * (kSymbolsPerTf * 2048), tw_global, exA, exB, desc->nco_hz);
 }
 
 // FIC pre-pass: only the phase reference symbol and the three FIC symbols (0..3) of every frame, so that the FIC
@@ -255,7 +271,7 @@ __global__ __launch_bounds__(kThreads, 4) void fic_fft_kernel(const uint8_t* con
   const CallDesc* desc = descs + static_cast<size_t>(fr.x) * max_calls + fr.y;
   if (threadIdx.x == 0) view = desc->view;
   fft_block<4>(iq[fr.x], view, desc->view.seg_end[0], desc->view.seg_src[0], 0, spectra4 + static_cast<size_t>(j) * (4 * 2048), tw_global,
-               exA, exB);
+               exA, exB, desc->nco_hz);
 }
 
 // ---- K2b ----------------------------------------------------------------------------------

@@ -30,13 +30,18 @@ __device__ __forceinline__ int view_byte(const uint8_t* stream, const FrameView&
 }
 // one IQ sample (I at the even byte p, Q at p + 1): segment boundaries and sources are even, so both bytes
 // come from the same segment and one 2-byte load fetches them
-__device__ __forceinline__ double2 view_sample(const uint8_t* stream, const FrameView& v, int p)
+// nco_hz != 0 (software AFC only): the sample is de-rotated by exp(-2 pi i nco n / fs), n = sample index in the frame
+__device__ __forceinline__ double2 view_sample(const uint8_t* stream, const FrameView& v, int p, int nco_hz)
 {
   int i = 0;
   while (i < v.nseg - 1 && p >= v.seg_end[i]) ++i;
   const int64_t s = v.seg_src[i];
   const unsigned w = s < 0 ? 0u : *reinterpret_cast<const uint16_t*>(stream + s + p);
-  return make_double2(static_cast<int8_t>(static_cast<uint8_t>((w & 0xff) - 127)), static_cast<int8_t>(static_cast<uint8_t>((w >> 8) - 127)));
+  const double2 x = make_double2(static_cast<int8_t>(static_cast<uint8_t>((w & 0xff) - 127)), static_cast<int8_t>(static_cast<uint8_t>((w >> 8) - 127)));
+  if (nco_hz == 0) return x;
+  double sn, cs;
+  sincospi(-2.0 * nco_hz * (p >> 1) / 2048000.0, &sn, &cs);
+  return make_double2(x.x * cs - x.y * sn, x.x * sn + x.y * cs);
 }
 // u8 -> s8 with DC offset 127 and int8 wrap (input_sdr.c:60-63)
 __device__ __forceinline__ int rail(int byte) { return static_cast<int>(static_cast<int8_t>(static_cast<uint8_t>(byte - 127))); }
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
                                                              CallDesc* __restrict__ descs, int max_calls, int call_begin,
                                                              int call_end, const double2* __restrict__ tw2048,
                                                              const double2* __restrict__ tw1536,
-                                                             const uint8_t* __restrict__ prs_q)
+                                                             const uint8_t* __restrict__ prs_q, int afc)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double2* A = reinterpret_cast<double2*>(smem);   // 2048: main DFT buffer
@@ -208,6 +213,7 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
     }
     __syncthreads();
 
+    const int nco = afc ? sh.st.tuner_hz : 0;
     if (sh.do_sync) {
       const FrameView& view = sh.st.view;
       // ---- coarse time: sdr_sync.c:34-68 ------------------------------------------------
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
         // ---- fine time: sdr_sync.c:71-202 -------------------------------------------------
         for (int n = tid; n < 2048; n += kThreads) {
           const int p = 2 * (kNullSamples + kCpSamples + n);
-          A[n] = view_sample(stream, view, p);
+          A[n] = view_sample(stream, view, p, nco);
         }
         __syncthreads();
         dft_dif<11>(A, 1, -1.0, tw);
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
         // ---- coarse frequency: input_sdr.c:90-109, sdr_sync.c:205-258 ---------------------
         for (int n = tid; n < 2048; n += kThreads) {
           const int p = 2 * (kNullSamples + kCpSamples + 1 + fine + n);
-          A[n] = view_sample(stream, view, p);
+          A[n] = view_sample(stream, view, p, nco);
         }
         __syncthreads();
         dft_dif<11>(A, 1, -1.0, tw);
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
           double acc = 0;
           for (int n = tid; n < kCpSamples; n += kThreads) {
             const int pl = 2 * (kNullSamples + 2048 + n), pr = 2 * (kNullSamples + n);
-            const double2 l = view_sample(stream, view, pl), r = view_sample(stream, view, pr);
+            const double2 l = view_sample(stream, view, pl, nco), r = view_sample(stream, view, pr, nco);
             const double lr = l.x, li = l.y, rr = r.x, ri = r.y;
             acc += atan2(-lr * ri + li * rr, lr * rr + li * ri);
           }
@@ -332,7 +338,21 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
       d.coarse_freq_shift = sh.coarse_fs;
       d.fifo_count = sh.fifo_count;
       d.fine_freq_shift = sh.fine_fs;
+      d.nco_hz = nco;
       d.view = sh.st.view;
+      if (afc) {
+        // the tuner feedback of demod_thread_fn (dab2eti.c:76-103), applied to the NCO instead of the tuner; it runs
+        // after EVERY call, also those that produced no frame (coarse 0, fine estimate stale), exactly as there
+        StreamState& st = sh.st;
+        const int c = sh.coarse_fs;
+        if (abs(c) > 1) st.tuner_hz += c < 0 ? -1000 : 1000;
+        if (abs(c) == 1) {
+          st.rng = st.rng * 1103515245u + 12345u;
+          const int step = static_cast<int>((st.rng >> 16) % 1000u);
+          st.tuner_hz += c < 0 ? -step : step;
+        }
+        if (c == 0 && fabs(sh.fine_fs) > 50) st.tuner_hz += static_cast<int>(sh.fine_fs / 3);
+      }
     }
     __syncthreads();
   }
@@ -345,7 +365,7 @@ size_t sync_scan_lds_bytes() { return sizeof(double2) * (2048 + 29 * 128 + 1024)
 
 hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, StreamState* states, CallDesc* descs,
                             int nstreams, int max_calls, int call_begin, int call_end, const double2* tw2048,
-                            const double2* tw1536, const uint8_t* prs_q, hipStream_t stream)
+                            const double2* tw1536, const uint8_t* prs_q, int afc, hipStream_t stream)
 {
   static bool attr_set = false;
   const size_t lds = sync_scan_lds_bytes();
@@ -355,7 +375,7 @@ hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, Str
     attr_set = true;
   }
   hipLaunchKernelGGL(sync_scan_kernel, dim3(nstreams), dim3(kThreads), lds, stream, iq, nbytes, states, descs, max_calls,
-                     call_begin, call_end, tw2048, tw1536, prs_q);
+                     call_begin, call_end, tw2048, tw1536, prs_q, afc);
   return hipGetLastError();
 }
 

@@ -13,7 +13,7 @@ namespace dabhip {
 // K1: synchronisation scan, one workgroup per stream, calls [call_begin, call_end) (call_end < 0: all)
 hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, StreamState* states, CallDesc* descs,
                             int nstreams, int max_calls, int call_begin, int call_end, const double2* tw2048,
-                            const double2* tw1536, const uint8_t* prs_q, hipStream_t stream);
+                            const double2* tw1536, const uint8_t* prs_q, int afc, hipStream_t stream);
 
 // K2: 76 x 2048-point DFT of frames[first .. first+nframes) -> spectra[nframes][76][2048]
 hipError_t launch_ofdm_fft(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first,

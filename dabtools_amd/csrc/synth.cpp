@@ -303,7 +303,14 @@ extern "C" int64_t dabhip_synth_generate(const dabhip_synth_cfg* cfg, int ntf, u
   static const double s8[8] = {0, M_SQRT1_2, 1, M_SQRT1_2, 0, -M_SQRT1_2, -1, -M_SQRT1_2};
   size_t outpos = 0;
   long long sample_index = 0;
+  const double cfo_turns = cfg->cfo_hz / 2048000.0;       // turns per sample
   auto emit = [&](double xr, double xi) {
+    if (cfo_turns != 0.0) {
+      const double ph = 2 * M_PI * std::fmod(cfo_turns * static_cast<double>(sample_index), 1.0);
+      const double c = std::cos(ph), s = std::sin(ph), r = xr * c - xi * s;
+      xi = xr * s + xi * c;
+      xr = r;
+    }
     if (sample_index++ < cfg->skip_samples) return;
     if (noise_rms_rail > 0) { xr += noise_rms_rail * gauss.next(); xi += noise_rms_rail * gauss.next(); }
     double a = std::floor(127.0 + xr + 0.5), b = std::floor(127.0 + xi + 0.5);

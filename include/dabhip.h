@@ -103,6 +103,12 @@ int64_t dabhip_engine_eti_read(dabhip_engine *e, int stream, uint8_t *dst, int64
 int64_t dabhip_engine_eti_drain(dabhip_engine *e, dabhip_eti_sink sink, void *user);
 const void *dabhip_engine_eti_device_ptr(const dabhip_engine *e, int64_t *nframes); /* all frames, stream-major */
 
+/* Software AFC (beyond the reference's file-less operation): when enabled every stream gets an NCO
+ * steered by the tuner feedback rule of dab2eti.c:76-103 (coarse offset > 1 carrier: +-1000 Hz; = 1: a random step
+ * below 1000 Hz; else fine estimate / 3 when above 50 Hz), so captures with a carrier frequency offset decode without a
+ * tuner.  Default off = parity mode (samples untouched, results identical to the reference). */
+int dabhip_engine_set_afc(dabhip_engine *e, int enable);
+
 /* Per sdr_demod call trace of one stream, for parity with the reference's state after each
  * call: {ok, frame_read, coarse_timeshift, fine_timeshift, coarse_freq_shift, fifo_count}
  * as int32[6] per call plus fine_freq_shift as double per call. */
@@ -162,6 +168,7 @@ typedef struct dabhip_synth_cfg {
   int32_t skip_samples;   /* drop this many samples from the start (0..196607): unaligned capture */
   double amplitude;       /* LSB per unit carrier of the unnormalised IDFT (1.0 -> ~28 LSB rms per rail) */
   double snr_db;          /* signal/noise power over the 2.048 MHz band; >= 100 -> no noise */
+  double cfo_hz;          /* carrier frequency offset applied to the whole capture (0 = none) */
 } dabhip_synth_cfg;
 
 /* preset 0: 12 sub-channels, 1136 kbit/s, 862 CU (the benchmark mix); 1: 4 light sub-channels. */

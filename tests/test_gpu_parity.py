@@ -415,3 +415,31 @@ def test_full_size_batch_properties():
     want, _ = ol.or_replay(host[5])                                           # (d)
     assert np.array_equal(ref[5], want)
     eng.close()
+
+
+def test_software_afc_decodes_offset_captures():
+    """SURVEY 8(f) rank 1 (beyond the reference, which needs a tuner): with the NCO steered by the reference's AFC rule,
+    captures with a carrier offset lock and return the transmitted payload; in parity mode (default) large offsets
+    never lock, exactly like the reference without its tuner."""
+    import eti_check
+    ntf = 70
+    cfgs = [dab.synth_preset(1, seed=400 + i, cfo_hz=cfo, snr_db=20.0) for i, cfo in enumerate((3400.0, -1700.0, 260.0, 0.0))]
+    streams = [dab.synth_generate(c, ntf) for c in cfgs]
+    eng = dab.Engine(0)
+    eng.decode(streams)
+    assert eng.eti_count(0) == 0 and eng.eti_count(1) == 0            # parity mode: > 1 carrier off -> never demodulated
+    assert eng.eti_count(3) == 4 * (ntf - 15)
+    eng.set_afc(True)
+    eng.decode(streams)
+    for b, cfg in enumerate(cfgs):
+        eti = eng.eti(b)
+        assert len(eti) >= 4 * (ntf - 15) - 4 * 14, (b, len(eti))      # at most a few TFs spent pulling in
+        ints, ffs = eng.trace(b, 3 * ntf // 2)
+        assert abs(ffs[len(ints) - 1]) < 60.0                         # residual offset inside the rule's dead band
+        # frames are well formed and carry the payload of the CIF their FIC announces
+        for f in (0, len(eti) // 2, len(eti) - 1):
+            p = eti_check.parse(eti[f])
+            cif = next(c for c in range(4 * ntf) if np.array_equal(dab.synth_fibs(cfg, c), p["fic"]))
+            for k, data in enumerate(p["subch"]):
+                assert np.array_equal(data, dab.synth_payload(cfg, cif, k)), (b, f, k)
+    eng.close()
