@@ -152,3 +152,19 @@ def test_oracle_replay_roundtrip_on_cpu():
         p = dab.synth_payload(cfg, cif, k)
         assert np.array_equal(eti[0][pos:pos + p.size], p)
         pos += p.size
+
+
+def test_eti2mpa_extracts_subchannel_from_reference_eti(tmp_path):
+    """The eti2mpa counterpart (eti2mpa.c:16-68) on the ETI frames the real reference produced (golden fixture)."""
+    import subprocess
+    import eti_check
+    exe = os.path.join(os.path.dirname(dab.LIB_PATH), "eti2mpa")
+    assert os.path.exists(exe), "eti2mpa not built"
+    g = np.load(os.path.join(G, "backend_e2e.npz"))
+    eti = g["eti"]
+    for scid in (1, 5, 9):
+        out = subprocess.run([exe, str(scid)], input=eti.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+        want = b"".join(bytes(p["subch"][[s[0] for s in p["stc"]].index(scid)]) for p in map(eti_check.parse, eti))
+        assert out == want
+    r = subprocess.run([exe, "33"], input=eti.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 4 and r.stdout == b""
