@@ -69,6 +69,7 @@ _SIGNATURES = {
     "dabhip_engine_eti_drain": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dabhip_engine_eti_device_ptr": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_int64)]),
     "dabhip_engine_set_afc": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_engine_set_soft": (C.c_int, [C.c_void_p, C.c_int]),
     "dabhip_engine_trace": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int]),
     "dabhip_engine_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
     "dabhip_engine_fft_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -285,6 +286,10 @@ class Engine:
     def set_afc(self, enable):
         """Software AFC (NCO per stream steered by the reference's tuner rule); off = parity mode."""
         _need(lib().dabhip_engine_set_afc(self._h, 1 if enable else 0) == 0, "set_afc")
+
+    def set_soft(self, enable):
+        """Soft-decision decoding (4-bit soft values into the Viterbi metrics); off = parity mode."""
+        _need(lib().dabhip_engine_set_soft(self._h, 1 if enable else 0) == 0, "set_soft")
 
     def decode(self, streams):
         """streams: list of numpy uint8 arrays (host) -> total ETI frames."""

@@ -183,7 +183,7 @@ bool Engine::run_decode_batch(DecodeBatch& b, bool fic, const std::vector<Decode
   std::vector<int64_t> slice_steps, slice_dec;
   int64_t step_rows = 0, dec_rows = 0;
   for (int g = 0; g < ng; ++g) {
-    const int64_t dr = (b.groups[g].nsteps + 7) / 8 * 8, sr = fic ? (b.groups[g].nsteps + 15) / 16 : 0;
+    const int64_t dr = (b.groups[g].nsteps + 7) / 8 * 8, sr = 0;
     if (g > slice_start.back() && dec_rows + dr > kMaxDecisionRows) {
       slice_start.push_back(g);
       slice_steps.push_back(step_rows);
@@ -205,13 +205,14 @@ bool Engine::run_decode_batch(DecodeBatch& b, bool fic, const std::vector<Decode
       !d_decisions_.reserve(static_cast<size_t>(max_dec) * 64))
     return false;
   const int* ids = b.job_ids.empty() ? nullptr : d_job_ids_.get();
-  if (!fic) {
+  const int row_words = kCifWords * (soft_bits_ ? 4 : 1);
+  {
     b.job_ids.resize((b.job_ids.size() + 63) / 64 * 64, -1);
     const int ntiles = static_cast<int>(b.job_ids.size() / 64);
-    if (!d_job_ids_.upload(b.job_ids, stream_) || !d_grouped_.reserve(static_cast<size_t>(ntiles) * kCifWords * 64)) return false;
+    if (!d_job_ids_.upload(b.job_ids, stream_) || !d_grouped_.reserve(static_cast<size_t>(ntiles) * row_words * 64)) return false;
     ids = d_job_ids_.get();
     (void)hipEventRecord(ev_[0], stream_);
-    if (!check(launch_regroup(ids, ntiles, d_jobs_.get(), d_stream_cif_base, bits, d_grouped_.get(), stream_), "regroup launch")) return false;
+    if (!check(launch_regroup(soft_bits_, ids, ntiles, d_jobs_.get(), d_stream_cif_base, bits, d_grouped_.get(), stream_), "regroup launch")) return false;
     (void)hipEventRecord(ev_[1], stream_);
     if (!check(hipEventSynchronize(ev_[1]), "regroup")) return false;
     float ms = 0;
@@ -219,15 +220,10 @@ bool Engine::run_decode_batch(DecodeBatch& b, bool fic, const std::vector<Decode
   }
   for (size_t s = 0; s + 1 < slice_start.size(); ++s) {
     const int g0 = slice_start[s], n = slice_start[s + 1] - g0;
-    const int max_n16 = (b.groups[g0].nsteps + 15) / 16;     // groups are sorted longest first
     (void)hipEventRecord(ev_[0], stream_);
-    if (fic && !check(launch_fic_gather(d_groups_.get() + g0, n, max_n16, d_jobs_.get(), ids, d_plans_.get(), bits, d_steps_.get(), stream_),
-                      "gather launch"))
-      return false;
     (void)hipEventRecord(ev_[1], stream_);
-    if (!check(fic ? launch_viterbi(d_groups_.get() + g0, n, ids, d_plans_.get(), d_steps_.get(), d_decisions_.get(), prbs, out, record_stride, stream_)
-                   : launch_viterbi_msc(d_groups_.get() + g0, n, ids, d_plans_.get(), d_grouped_.get(), d_decisions_.get(), prbs, out,
-                                        record_stride, stream_),
+    if (!check(launch_viterbi_fused(soft_bits_, d_groups_.get() + g0, n, ids, d_plans_.get(), d_grouped_.get(), row_words, d_decisions_.get(), prbs,
+                                    out, record_stride, stream_),
                "viterbi launch"))
       return false;
     (void)hipEventRecord(ev_[2], stream_);
@@ -244,14 +240,15 @@ bool Engine::reserve_tf_slots(int nslots, int msc_rows)
 {
   if (msc_rows < 0) msc_rows = 4 * nslots + kRowLead + 1;
   // growth discards contents: callers reserve before filling
+  const size_t bits = soft_bits_ ? 4 : 1;
   if (nslots > tf_slots_) {
-    if (!d_fic_bits_.reserve(static_cast<size_t>(nslots) * kFicWords) || !d_fibs_.reserve(static_cast<size_t>(nslots) * 384) ||
+    if (!d_fic_bits_.reserve(static_cast<size_t>(nslots) * kFicWords * bits) || !d_fibs_.reserve(static_cast<size_t>(nslots) * 384) ||
         !d_fib_ok_.reserve(static_cast<size_t>(nslots) * 12))
       return false;
     tf_slots_ = nslots;
   }
   if (msc_rows > msc_rows_) {
-    if (!d_msc_bits_.reserve(static_cast<size_t>(msc_rows) * kCifWords)) return false;
+    if (!d_msc_bits_.reserve(static_cast<size_t>(msc_rows) * kCifWords * bits)) return false;
     msc_rows_ = msc_rows;
   }
   return true;
@@ -308,15 +305,23 @@ bool Engine::unpack_tf_slot(int slot, uint8_t* fic_bytes, uint8_t* msc_bytes)
 bool Engine::fic_decode_slots(int first, int n, uint8_t* fibs_host, uint8_t* ok_host)
 {
   if (n <= 0) return true;
+  const int bits = soft_bits_ ? 4 : 1;
   const int pid = plan_id(make_plan(fic_plan(), 0, 0));
-  // job i = FIC block i = (TF slot i / 4, block i % 4); jobs below `first` exist only to keep indices absolute
-  std::vector<DecodeJob> jobs(static_cast<size_t>(4) * (first + n));
-  for (size_t i = 0; i < jobs.size(); ++i) jobs[i] = DecodeJob{0, static_cast<int32_t>(i)};
-  DecodeBatch batch;
-  for (int i = 4 * first; i < 4 * (first + n); i += 64)
-    batch.groups.push_back(WaveGroup{pid, i, std::min(64, 4 * (first + n) - i), plans_[pid].nsteps, 0, 0});
-  float g = 0, v = 0;
-  if (!run_decode_batch(batch, true, jobs, d_fic_bits_.get(), nullptr, d_prbs_.get(), d_fibs_.get(), 96, &g, &v)) return false;
+  // record i of this call = FIC block 4 * first + i; 64 blocks per wave, interleaved word by word by fic_group_kernel
+  const int nblocks = 4 * n, ntiles = (nblocks + 63) / 64, block_words = 72 * bits;
+  std::vector<int> ids(static_cast<size_t>(ntiles) * 64, -1);
+  for (int i = 0; i < nblocks; ++i) ids[i] = 4 * first + i;
+  std::vector<WaveGroup> groups;
+  const int64_t dr = (plans_[pid].nsteps + 7) / 8 * 8;
+  for (int g = 0; g < ntiles; ++g) groups.push_back(WaveGroup{pid, 64 * g, std::min(64, nblocks - 64 * g), plans_[pid].nsteps, 0, g * dr});
+  if (!d_plans_.upload(plans_, stream_) || !d_groups_.upload(groups, stream_) || !d_job_ids_.upload(ids, stream_) ||
+      !d_grouped_.reserve(static_cast<size_t>(ntiles) * block_words * 64) || !d_decisions_.reserve(static_cast<size_t>(ntiles) * dr * 64))
+    return false;
+  if (!check(launch_fic_group(d_fic_bits_.get(), 4 * first, nblocks, block_words, d_grouped_.get(), stream_), "fic group launch") ||
+      !check(launch_viterbi_fused(soft_bits_, d_groups_.get(), ntiles, d_job_ids_.get(), d_plans_.get(), d_grouped_.get(), block_words,
+                                  d_decisions_.get(), d_prbs_.get(), d_fibs_.get(), 96, stream_),
+             "fic viterbi launch"))
+    return false;
   if (!check(launch_fib_crc(d_fibs_.get() + static_cast<size_t>(first) * 384, n * 12, d_crc_tab_.get(), d_fib_ok_.get() + static_cast<size_t>(first) * 12, stream_), "fib crc launch")) return false;
   if (!check(hipMemcpyAsync(fibs_host, d_fibs_.get() + static_cast<size_t>(first) * 384, static_cast<size_t>(n) * 384, hipMemcpyDeviceToHost, stream_), "fib download") ||
       !check(hipMemcpyAsync(ok_host, d_fib_ok_.get() + static_cast<size_t>(first) * 12, static_cast<size_t>(n) * 12, hipMemcpyDeviceToHost, stream_), "fib flag download"))
@@ -547,7 +552,7 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
   (void)hipEventRecord(ev_[3], stream_);
   for (int first = 0; first < ntf; first += chunk * 19) {       // 4 of 76 symbols: 19 x as many TFs fit the spectra buffer
     const int n = std::min(chunk * 19, ntf - first);
-    if (!check(launch_fic_prepass(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(),
+    if (!check(launch_fic_prepass(soft_bits_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(),
                                   d_frame_slot_.get(), d_qpsk_.get(), d_fic_bits_.get(), stream_),
                "fic pre-pass launch"))
       return -1;
@@ -597,7 +602,7 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
     (void)hipEventRecord(ev_[0], stream_);
     gpu_ok = check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(), stream_), "fft launch");
     (void)hipEventRecord(ev_[1], stream_);
-    gpu_ok = gpu_ok && check(launch_demap(true, d_spectra_.get(), first, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch");
+    gpu_ok = gpu_ok && check(launch_demap(true, soft_bits_, d_spectra_.get(), first, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch");
     (void)hipEventRecord(ev_[2], stream_);
     gpu_ok = gpu_ok && check(hipEventSynchronize(ev_[2]), "fft/demap");
     if (!gpu_ok) break;
@@ -705,7 +710,7 @@ int Engine::stage_demap(const float* spectra, int nframes, uint8_t* fic, uint8_t
   for (int j = 0; j < nframes; ++j) { slots[j] = j; rows[j] = 4 * j; }
   if (!reserve_tf_slots(nframes) || !d_spectra_.reserve(nspec) || !d_frame_slot_.upload(slots, stream_) || !d_frame_cif_row_.upload(rows, stream_)) return -1;
   if (!check(hipMemcpyAsync(d_spectra_.get(), spectra, nspec * sizeof(float2), hipMemcpyHostToDevice, stream_), "spectra upload")) return -1;
-  if (!check(launch_demap(false, d_spectra_.get(), 0, nframes, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch") ||
+  if (!check(launch_demap(false, 0, d_spectra_.get(), 0, nframes, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch") ||
       !check(hipStreamSynchronize(stream_), "demap"))
     return -1;
   for (int j = 0; j < nframes; ++j)
@@ -800,7 +805,7 @@ bool Engine::demod_one_frame(const uint8_t* iq_virtual_base, const CallDesc& des
       !d_spectra_.reserve(static_cast<size_t>(kSymbolsPerTf) * 2048))
     return false;
   if (!check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), 1, d_frames_.get(), 0, 1, d_spectra_.get(), d_twf_.get(), stream_), "fft launch") ||
-      !check(launch_demap(false, d_spectra_.get(), 0, 1, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch") ||
+      !check(launch_demap(false, 0, d_spectra_.get(), 0, 1, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch") ||
       !check(hipStreamSynchronize(stream_), "demod"))
     return false;
   return unpack_tf_slot(0, fic_bytes, msc_bytes);

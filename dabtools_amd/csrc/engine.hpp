@@ -102,6 +102,9 @@ class Engine {
   const uint8_t* eti_buffer() const { return d_eti_.get(); }
   // software AFC: an NCO per stream steered by the reference's tuner rule; off = parity mode
   void set_afc(bool on) { afc_ = on; }
+  // soft-decision decoding (not in the reference): 4-bit soft values from the demapper through
+  // de-interleaving and de-puncturing into the Viterbi branch metrics.  Batch path only; off = parity mode.
+  void set_soft(bool on) { soft_bits_ = on ? 4 : 0; tf_slots_ = 0; msc_rows_ = 0; }
 
   // -- batch path ---------------------------------------------------------------------------
   int64_t decode(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device);
@@ -158,6 +161,7 @@ class Engine {
 
   bool ok_ = false;
   bool afc_ = false;
+  int soft_bits_ = 0;
   std::mutex* heavy_mu_ = nullptr;
   std::unique_ptr<ThreadPool> pool_;   // host threads for per-stream control-plane work
   int device_ = 0;

@@ -1,10 +1,10 @@
 // k_decode.hip — K3/K4: channel decoding of the FIC and of every MSC sub-channel, and K5:
 // ETI frame completion.
 //
-//  fic_gather_kernel  FIC de-puncture (depuncture.c:45-82): FIC bit rows -> one byte per trellis
-//                  step (4 received bits + 4 "was transmitted" flags) for viterbi_kernel.
-//  regroup_kernel  logical CIF rows (demap_kernel folded misc.c:29-39 into its scatter) -> natural
-//                  bit order, 64 ETI frames interleaved, for viterbi_msc_kernel.
+//  regroup_kernel / fic_group_kernel  logical CIF rows (demap_kernel folded misc.c:29-39 into its scatter)
+//                  resp. FIC blocks -> natural bit order, 64 records interleaved word by word.
+//  viterbi_fused_kernel  FIC and MSC decoder with the de-puncturing (depuncture.c:45-132) fused into its load.
+//  viterbi_kernel  the same decoder fed with explicit per-step symbols: the S1 seam (dabhip_viterbi_batch).
 //  viterbi_kernel  K=7 rate-1/4 maximum-likelihood decoder with the decisions of the
 //                  reference's scalar viterbi() (viterbi.c:352-451): one LANE per code word,
 //                  all 64 path metrics of that code word live in the lane's VGPRs (32 packed
@@ -31,64 +31,6 @@
 
 namespace dabhip {
 namespace {
-
-// ---------------------------------------------------------------------------------------
-// gather: one thread per (item, 16 trellis steps)
-__global__ __launch_bounds__(256) void fic_gather_kernel(const WaveGroup* __restrict__ groups, int ngroups,
-                                                         const DecodeJob* __restrict__ jobs, const int* __restrict__ job_ids,
-                                                         const CodewordPlan* __restrict__ plans, const uint32_t* __restrict__ bits,
-                                                         uint4* __restrict__ steps)
-{
-  // Lanes run along the code word (64 consecutive 16-step chunks), so a wave reads one contiguous stretch of
-  // received bits.  Each wave walks 16 of the group's 64 code words.
-  const int group = blockIdx.y;
-  if (group >= ngroups) return;
-  const WaveGroup grp = groups[group];
-  const int t16 = blockIdx.x * 64 + (threadIdx.x & 63);
-  if (t16 >= (grp.nsteps + 15) / 16) return;
-  const CodewordPlan pl = plans[grp.plan];
-  const int x0 = 64 * t16;                       // first mother-code bit of this thread
-  // locate the segment holding x0 (segments are multiples of 128 mother bits)
-  int seg_start = 0, j0 = 0, s = 0;
-  uint32_t mask = 0;
-  for (; s < 4; ++s) {
-    const int seg_bits = 128 * pl.blocks[s];
-    if (x0 < seg_start + seg_bits) { mask = pl.mask[s]; break; }
-    j0 += pl.blocks[s] * 4 * __popc(pl.mask[s]);
-    seg_start += seg_bits;
-  }
-  const bool tail = (s == 4);                    // 24 tail bits at PI 8 (depuncture.c:74-80)
-  const int jbase = pl.start_bit + j0 + ((x0 - seg_start) >> 5) * __popc(mask);
-  const uint32_t m0 = tail ? (puncture_mask(8) & 0x00ffffffu) : mask, m1 = tail ? 0u : mask;
-
-  for (int k = 0; k < 16; ++k) {
-    const int lane = (threadIdx.x >> 6) * 16 + k;          // code word within the group
-    uint32_t w[4] = {0, 0, 0, 0};
-    if (lane < grp.count) {
-      const DecodeJob job = jobs[job_ids ? job_ids[grp.first + lane] : grp.first + lane];
-      const uint32_t* row0 = bits + static_cast<size_t>(job.cif) * 72;   // FIC block = 2304 bits = 72 words
-      int i = jbase;
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        const uint32_t m = g ? m1 : m0;
-        uint32_t val = 0;
-        for (int u = 0; u < 32; ++u) {
-          if ((m >> u) & 1u) {
-            val |= ((row0[i >> 5] >> (i & 31)) & 1u) << u;
-            ++i;
-          }
-        }
-        // 8 steps: byte = value nibble | mask nibble << 4
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const uint32_t byte = ((val >> (4 * q)) & 15u) | (((m >> (4 * q)) & 15u) << 4);
-          w[2 * g + (q >> 2)] |= byte << (8 * (q & 3));
-        }
-      }
-    }
-    steps[(grp.step_base + t16) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
-  }
-}
 
 // ---------------------------------------------------------------------------------------
 // branch code words: bit j of code(i) = parity(i & poly_j), i = 7-bit register with the
@@ -170,19 +112,37 @@ __device__ __forceinline__ void all_pairs(const pk16 (&p)[32], pk16 (&n)[32], co
   (butterfly_pair<kTau, kRs>(p, n, bb, d0, d1), ...);
 }
 
-template <int kTau>
-__device__ __forceinline__ void acs_step(unsigned sb, const pk16 (&p)[32], pk16 (&n)[32], uint2& dec)
+// branch metrics of the 8 distinct code words (bit3 = bit0) for one trellis step
+// hard decisions: agreement count with the received nibble v under the "transmitted" mask m (sb = v | m << 4)
+__device__ __forceinline__ void branch_metrics_hard(unsigned sb, int (&bm)[8])
 {
   const unsigned v = sb & 15u, m = (sb >> 4) & 15u;
-  // agreement count of the 8 distinct code words (bit3 = bit0) with the received nibble
   const int ntx = __popc(m);
-  int bm[8];
 #pragma unroll
   for (unsigned c = 0; c < 4; ++c) {
     const unsigned cw = c | ((c & 1u) << 3);
     bm[c] = __popc(~(v ^ cw) & m);
     bm[c ^ 7] = ntx - bm[c];
   }
+}
+// soft decisions (extension): four signed 4-bit values s_j (> 0: bit 0 more likely, 0: punctured);
+// metric = 28 + sum_j (c_j ? -s_j : +s_j), so that it stays non-negative
+__device__ __forceinline__ void branch_metrics_soft(unsigned nib16, int (&bm)[8])
+{
+  const int s0 = static_cast<int>(nib16 << 28) >> 28, s1 = static_cast<int>(nib16 << 24) >> 28;
+  const int s2 = static_cast<int>(nib16 << 20) >> 28, s3 = static_cast<int>(nib16 << 16) >> 28;
+  const int a = s0 + s3, rest = s1 + s2, diff = s2 - s1;
+  const int corr[4] = {a + rest, rest - a, a + diff, diff - a};   // code words 0..3: bit0 flips s0,s3; bit1 flips s1
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    bm[c] = 28 + corr[c];
+    bm[c ^ 7] = 28 - corr[c];
+  }
+}
+
+template <int kTau>
+__device__ __forceinline__ void acs_step_bm(const int (&bm)[8], const pk16 (&p)[32], pk16 (&n)[32], uint2& dec)
+{
   constexpr unsigned gamma = branch_code3(2u << kTau);    // code difference between the two members of a pair
   pk16 bb[8];
 #pragma unroll
@@ -190,6 +150,22 @@ __device__ __forceinline__ void acs_step(unsigned sb, const pk16 (&p)[32], pk16 
   uint32_t d0 = 0, d1 = 0;
   all_pairs<kTau>(p, n, bb, d0, d1, std::make_integer_sequence<int, 16>{});
   dec = make_uint2(d0, d1);
+}
+
+template <int kTau>
+__device__ __forceinline__ void acs_step(unsigned sb, const pk16 (&p)[32], pk16 (&n)[32], uint2& dec)
+{
+  int bm[8];
+  branch_metrics_hard(sb, bm);
+  acs_step_bm<kTau>(bm, p, n, dec);
+}
+
+template <int kTau>
+__device__ __forceinline__ void acs_step_soft(unsigned nib16, const pk16 (&p)[32], pk16 (&n)[32], uint2& dec)
+{
+  int bm[8];
+  branch_metrics_soft(nib16, bm);
+  acs_step_bm<kTau>(bm, p, n, dec);
 }
 
 // L(4) (pairs (k, k^16)) -> L(0) (pairs (k, k^1)): one byte permute per register
@@ -224,34 +200,52 @@ __constant__ DecisionTable kDecisionTable = make_decision_table();
 // of frame job_ids[64 tile + lane].  The Viterbi kernel (lane = frame) then reads its received
 // bits with fully coalesced 256-byte loads.  Thread = (frame lane, block of 16 output words):
 // one 64-byte line in, 16 words out.
+template <int kBits>
 __global__ __launch_bounds__(256) void regroup_kernel(const int* __restrict__ job_ids, const DecodeJob* __restrict__ jobs,
                                                       const int* __restrict__ stream_cif_base, const uint32_t* __restrict__ rows,
                                                       uint32_t* __restrict__ grouped)
 {
+  constexpr int kRowWords = 1728 * kBits, kBlocks = 108 * kBits;   // blocks of 16 words (one word of each plane)
   const int tile = blockIdx.y, lane = threadIdx.x & 63;
-  const int wb = blockIdx.x * 4 + (threadIdx.x >> 6);          // 0..107: block of 16 output words
-  if (wb >= 108) return;
+  const int wb = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wb >= kBlocks) return;
   const int jid = job_ids[tile * 64 + lane];
   if (jid < 0) return;
   const DecodeJob job = jobs[jid];
-  const uint4* src = reinterpret_cast<const uint4*>(rows + (static_cast<size_t>(stream_cif_base[job.stream]) + job.cif) * 1728 + wb * 16);
+  const uint4* src = reinterpret_cast<const uint4*>(rows + (static_cast<size_t>(stream_cif_base[job.stream]) + job.cif) * kRowWords + wb * 16);
   uint32_t pw[16];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const uint4 v = src[k];
     pw[4 * k] = v.x; pw[4 * k + 1] = v.y; pw[4 * k + 2] = v.z; pw[4 * k + 3] = v.w;
   }
-  uint32_t* dst = grouped + (static_cast<size_t>(tile) * 1728 + wb * 16) * 64 + lane;
+  uint32_t* dst = grouped + (static_cast<size_t>(tile) * kRowWords + wb * 16) * 64 + lane;
 #pragma unroll
-  for (int o = 0; o < 16; ++o) {           // output word o: bits k -> plane k & 15, bit 2 o + (k >> 4) of that plane's word
+  for (int o = 0; o < 16; ++o) {
     uint32_t w = 0;
+    if (kBits == 1) {        // output word o: bit k <- plane k & 15, bit 2 o + (k >> 4) of that plane's word
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
-      const uint32_t two = (pw[p] >> (2 * o)) & 3u;
-      w |= ((two & 1u) << p) | ((two >> 1) << (16 + p));
+      for (int p = 0; p < 16; ++p) {
+        const uint32_t two = (pw[p] >> (2 * o)) & 3u;
+        w |= ((two & 1u) << p) | ((two >> 1) << (16 + p));
+      }
+    } else {                 // 4-bit soft values: output word o = values of planes 8 (o & 1) .. + 7 at index o >> 1 of their words
+#pragma unroll
+      for (int k = 0; k < 8; ++k) w |= ((pw[8 * (o & 1) + k] >> (4 * (o >> 1))) & 15u) << (4 * k);
     }
     dst[static_cast<size_t>(o) * 64] = w;
   }
+}
+
+// FIC blocks are already in natural order: only interleave 64 of them word by word for the fused decoder
+__global__ __launch_bounds__(256) void fic_group_kernel(const uint32_t* __restrict__ fic_rows, int first_block, int nblocks, int block_words,
+                                                        uint32_t* __restrict__ grouped)
+{
+  const int tile = blockIdx.y, lane = threadIdx.x & 63;
+  const int b = tile * 64 + lane;
+  if (b >= nblocks) return;
+  for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < block_words; w += gridDim.x * 4)
+    grouped[(static_cast<size_t>(tile) * block_words + w) * 64 + lane] = fic_rows[static_cast<size_t>(first_block + b) * block_words + w];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -263,6 +257,20 @@ __device__ __forceinline__ void acs4(uint32_t ww, pk16 (&pm)[32], pk16 (&pn)[32]
   acs_step<1>((ww >> 8) & 0xff, pn, pm, d1);
   acs_step<2>((ww >> 16) & 0xff, pm, pn, d2);
   acs_step<3>(ww >> 24, pn, pl4, d3);
+  repair_layout(pl4, pm);
+  dec_rows[0] = d0;
+  dec_rows[64] = d1;
+  dec_rows[128] = d2;
+  dec_rows[192] = d3;
+}
+
+__device__ __forceinline__ void acs4_soft(uint64_t nibs, pk16 (&pm)[32], pk16 (&pn)[32], pk16 (&pl4)[32], uint2* dec_rows)
+{
+  uint2 d0, d1, d2, d3;
+  acs_step_soft<0>(static_cast<unsigned>(nibs) & 0xffffu, pm, pn, d0);
+  acs_step_soft<1>(static_cast<unsigned>(nibs >> 16) & 0xffffu, pn, pm, d1);
+  acs_step_soft<2>(static_cast<unsigned>(nibs >> 32) & 0xffffu, pm, pn, d2);
+  acs_step_soft<3>(static_cast<unsigned>(nibs >> 48), pn, pl4, d3);
   repair_layout(pl4, pm);
   dec_rows[0] = d0;
   dec_rows[64] = d1;
@@ -358,15 +366,17 @@ __global__ __launch_bounds__(64) void viterbi_kernel(const WaveGroup* __restrict
              reinterpret_cast<uint32_t*>(out + static_cast<size_t>(record) * record_stride + pl.out_offset));
 }
 
-// MSC variant with the de-puncturing fused into the load (depuncture.c:84-132): lane = ETI frame,
-// received bits come from regroup_kernel's lane-interleaved rows, 32 bits per coalesced load.
-// Puncturing vectors keep the FIRST n bits of every group of four (n = 1..4), so a step's input is
-// simply the next n bits of the stream; n is wave-uniform.
-__global__ __launch_bounds__(64, 5) void viterbi_msc_kernel(const WaveGroup* __restrict__ groups, const int* __restrict__ job_ids,
-                                                         const CodewordPlan* __restrict__ plans,
-                                                         const uint32_t* __restrict__ grouped, uint2* __restrict__ decisions,
-                                                         const uint32_t* __restrict__ prbs_words, uint8_t* __restrict__ out,
-                                                         int record_stride)
+// Decoder with the de-puncturing fused into the load (depuncture.c:45-132): lane = output record (ETI frame or FIC
+// block), received bits come from lane-interleaved rows (regroup_kernel / fic_group_kernel), 32 bits per coalesced load.
+// Puncturing vectors keep the FIRST n bits of every group of four (n = 1..4), so a step's input is simply the next n
+// received values of the stream; n is wave-uniform.  kBits = 1: hard bits (the reference's behaviour);
+// kBits = 4: signed 4-bit soft values (extension).
+template <int kBits>
+__global__ __launch_bounds__(64, 5) void viterbi_fused_kernel(const WaveGroup* __restrict__ groups, const int* __restrict__ job_ids,
+                                                              const CodewordPlan* __restrict__ plans,
+                                                              const uint32_t* __restrict__ grouped, int row_words,
+                                                              uint2* __restrict__ decisions, const uint32_t* __restrict__ prbs_words,
+                                                              uint8_t* __restrict__ out, int record_stride)
 {
   __shared__ uint8_t dec_pos[4 * 64];
   const int lane = threadIdx.x;
@@ -375,12 +385,20 @@ __global__ __launch_bounds__(64, 5) void viterbi_msc_kernel(const WaveGroup* __r
   uint2* my_dec = decisions + grp.dec_base * 64 + lane;
   for (int i = lane; i < 256; i += 64) dec_pos[i] = kDecisionTable.pos[i >> 6][i & 63];
 
-  // received words of this lane's frame: tile = grp.first / 64 (job lists are padded to tiles of 64)
-  const uint32_t* src = grouped + (static_cast<size_t>(grp.first >> 6) * 1728 + (pl.start_bit >> 5)) * 64 + lane;
+  // received words of this lane's record: tile = grp.first / 64 (job lists are padded to tiles of 64)
+  const int word0 = (pl.start_bit * kBits) >> 5;
+  const uint32_t* src = grouped + (static_cast<size_t>(grp.first >> 6) * row_words + word0) * 64 + lane;
+  const int last_word = row_words - 1 - word0;
   uint64_t fifo = 0;
   int have = 0;                              // wave-uniform number of valid bits in fifo
   uint32_t nextw = src[0];
   int widx = 1;
+  auto refill = [&]() {
+    fifo |= static_cast<uint64_t>(nextw) << have;
+    have += 32;
+    nextw = src[static_cast<size_t>(min(widx, last_word)) * 64];
+    ++widx;
+  };
 
   pk16 pm[32], pn[32], pl4[32];
   init_metrics(pm);
@@ -389,35 +407,48 @@ __global__ __launch_bounds__(64, 5) void viterbi_msc_kernel(const WaveGroup* __r
     const uint32_t mask = seg < 4 ? pl.mask[seg] : (puncture_mask(8) & 0x00ffffffu);
     const int units = seg < 4 ? 4 * pl.blocks[seg] : 1;     // units of 8 trellis steps (= 32 mother-code bits)
     const int need = __popc(mask);
-    // bits taken by each of the 8 steps of a unit, 3 bits per step
+    // values taken by each of the 8 steps of a unit, 3 bits per step
     uint32_t counts = 0;
     for (int g = 0; g < 8; ++g) counts |= static_cast<uint32_t>(__popc((mask >> (4 * g)) & 15u)) << (3 * g);
     for (int u = 0; u < units; ++u) {
-      if (have < need) {                     // at most one refill per unit: need <= 32
-        fifo |= static_cast<uint64_t>(nextw) << have;
-        have += 32;
-        nextw = src[static_cast<size_t>(min(widx, 1727 - (pl.start_bit >> 5))) * 64];
-        ++widx;
-      }
-      uint32_t ww[2] = {0, 0};
+      if (kBits == 1) {
+        if (have < need) refill();           // at most one refill per unit: need <= 32
+        uint32_t ww[2] = {0, 0};
 #pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        const int n = (counts >> (3 * g)) & 7;
-        const uint32_t m = (1u << n) - 1u;
-        const uint32_t sb = (static_cast<uint32_t>(fifo) & m) | (m << 4);
-        fifo >>= n;
-        ww[g >> 2] |= sb << (8 * (g & 3));
+        for (int g = 0; g < 8; ++g) {
+          const int n = (counts >> (3 * g)) & 7;
+          const uint32_t m = (1u << n) - 1u;
+          const uint32_t sb = (static_cast<uint32_t>(fifo) & m) | (m << 4);
+          fifo >>= n;
+          ww[g >> 2] |= sb << (8 * (g & 3));
+        }
+        have -= need;
+        acs4(ww[0], pm, pn, pl4, my_dec + static_cast<size_t>(t) * 64);
+        acs4(ww[1], pm, pn, pl4, my_dec + static_cast<size_t>(t + 4) * 64);
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          uint64_t nibs = 0;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int nb = 4 * ((counts >> (3 * (4 * h + g))) & 7);      // bits of this step: 4 per received value
+            if (have < nb) refill();
+            const uint64_t v = fifo & ((1ull << nb) - 1ull);
+            fifo >>= nb;
+            have -= nb;
+            nibs |= v << (16 * g);
+          }
+          acs4_soft(nibs, pm, pn, pl4, my_dec + static_cast<size_t>(t + 4 * h) * 64);
+        }
       }
-      have -= need;
-      acs4(ww[0], pm, pn, pl4, my_dec + static_cast<size_t>(t) * 64);
-      acs4(ww[1], pm, pn, pl4, my_dec + static_cast<size_t>(t + 4) * 64);
       t += 8;
-      if ((t & 2047) == 0) rebase_metrics(pm);
+      // metrics grow by <= 4 (hard) / <= 56 (soft) per step: re-base long before int16 could overflow
+      if ((t & (kBits == 1 ? 2047 : 127)) == 0) rebase_metrics(pm);
     }
   }
   __syncthreads();
   if (lane >= grp.count) return;
-  const int record = job_ids[grp.first + lane];
+  const int record = job_ids ? job_ids[grp.first + lane] : grp.first + lane;
   chain_back(my_dec, grp.nsteps, dec_pos, prbs_words,
              reinterpret_cast<uint32_t*>(out + static_cast<size_t>(record) * record_stride + pl.out_offset));
 }
@@ -493,18 +524,6 @@ __global__ __launch_bounds__(256) void eti_finish_kernel(const EtiFrameMeta* __r
 
 }  // namespace
 
-hipError_t launch_fic_gather(const WaveGroup* groups, int ngroups, int max_n16, const DecodeJob* jobs, const int* job_ids,
-                             const CodewordPlan* plans, const uint32_t* bits, uint4* steps, hipStream_t stream)
-{
-  if (ngroups <= 0) return hipSuccess;
-  for (int g0 = 0; g0 < ngroups; g0 += 32768) {     // grid.y is limited to 65535
-    const int ng = min(32768, ngroups - g0);
-    hipLaunchKernelGGL(fic_gather_kernel, dim3((max_n16 + 63) / 64, ng), dim3(256), 0, stream, groups + g0, ng, jobs, job_ids, plans, bits,
-                       steps);
-  }
-  return hipGetLastError();
-}
-
 hipError_t launch_viterbi(const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans, const uint4* steps,
                           uint2* decisions, const uint32_t* prbs_words, uint8_t* out, int record_stride, hipStream_t stream)
 {
@@ -514,25 +533,44 @@ hipError_t launch_viterbi(const WaveGroup* groups, int ngroups, const int* job_i
   return hipGetLastError();
 }
 
-hipError_t launch_regroup(const int* job_ids, int ntiles, const DecodeJob* jobs, const int* stream_cif_base, const uint32_t* rows,
-                          uint32_t* grouped, hipStream_t stream)
+hipError_t launch_regroup(int soft_bits, const int* job_ids, int ntiles, const DecodeJob* jobs, const int* stream_cif_base,
+                          const uint32_t* rows, uint32_t* grouped, hipStream_t stream)
 {
   if (ntiles <= 0) return hipSuccess;
+  const int bits = soft_bits ? 4 : 1;
   for (int t0 = 0; t0 < ntiles; t0 += 32768) {
     const int nt = min(32768, ntiles - t0);
-    hipLaunchKernelGGL(regroup_kernel, dim3(27, nt), dim3(256), 0, stream, job_ids + static_cast<size_t>(t0) * 64, jobs, stream_cif_base, rows,
-                       grouped + static_cast<size_t>(t0) * 1728 * 64);
+    const dim3 grid(27 * bits, nt);
+    uint32_t* dst = grouped + static_cast<size_t>(t0) * 1728 * bits * 64;
+    if (soft_bits) hipLaunchKernelGGL(regroup_kernel<4>, grid, dim3(256), 0, stream, job_ids + static_cast<size_t>(t0) * 64, jobs, stream_cif_base, rows, dst);
+    else hipLaunchKernelGGL(regroup_kernel<1>, grid, dim3(256), 0, stream, job_ids + static_cast<size_t>(t0) * 64, jobs, stream_cif_base, rows, dst);
   }
   return hipGetLastError();
 }
 
-hipError_t launch_viterbi_msc(const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans,
-                              const uint32_t* grouped, uint2* decisions, const uint32_t* prbs_words, uint8_t* out, int record_stride,
-                              hipStream_t stream)
+hipError_t launch_fic_group(const uint32_t* fic_rows, int first_block, int nblocks, int block_words, uint32_t* grouped, hipStream_t stream)
+{
+  if (nblocks <= 0) return hipSuccess;
+  const int ntiles = (nblocks + 63) / 64;
+  for (int t0 = 0; t0 < ntiles; t0 += 32768) {
+    const int nt = min(32768, ntiles - t0);
+    hipLaunchKernelGGL(fic_group_kernel, dim3(8, nt), dim3(256), 0, stream, fic_rows, first_block + t0 * 64, nblocks - t0 * 64, block_words,
+                       grouped + static_cast<size_t>(t0) * block_words * 64);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_viterbi_fused(int soft_bits, const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans,
+                                const uint32_t* grouped, int row_words, uint2* decisions, const uint32_t* prbs_words, uint8_t* out,
+                                int record_stride, hipStream_t stream)
 {
   if (ngroups <= 0) return hipSuccess;
-  hipLaunchKernelGGL(viterbi_msc_kernel, dim3(ngroups), dim3(64), 0, stream, groups, job_ids, plans, grouped, decisions, prbs_words, out,
-                     record_stride);
+  if (soft_bits)
+    hipLaunchKernelGGL(viterbi_fused_kernel<4>, dim3(ngroups), dim3(64), 0, stream, groups, job_ids, plans, grouped, row_words, decisions,
+                       prbs_words, out, record_stride);
+  else
+    hipLaunchKernelGGL(viterbi_fused_kernel<1>, dim3(ngroups), dim3(64), 0, stream, groups, job_ids, plans, grouped, row_words, decisions,
+                       prbs_words, out, record_stride);
   return hipGetLastError();
 }
 

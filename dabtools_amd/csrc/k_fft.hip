@@ -285,7 +285,10 @@ __global__ __launch_bounds__(kThreads, 4) void fic_fft_kernel(const uint8_t* con
 // LOGICAL row n - map[r] (3456 bits = 108 words per plane, the 16 planes interleaved word by
 // word).  A complete logical row is then exactly the reference's cif_time_deinterleaved:
 // out[i] = bit ((i >> 4) & 31) of row word ((i >> 9) * 16 + (i & 15)).
-template <bool kPlanar>
+// kBits = 1: hard decisions (the reference); kBits = 4: signed 4-bit soft values (extension):
+// value = round(4.5 x / mean|x|) clamped to +-7 with x = Re(cur conj(prev)) for the first bit and Im(cur conj(prev)) for
+// the second, i.e. positive = "bit 0"; the mean is taken over the 3072 components of the OFDM symbol.
+template <bool kPlanar, int kBits>
 __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restrict__ spectra, int syms_per_tf, int group_syms,
                                                          int groups_per_tf, int first,
                                                          const int* __restrict__ frame_slot,
@@ -294,6 +297,7 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
                                                          uint32_t* __restrict__ fic_bits, uint32_t* __restrict__ msc_bits)
 {
   __shared__ uint8_t bits[kBitsPerSym];
+  __shared__ float wave_sum[kThreads / 64];
   const int tid = threadIdx.x;
   const int j = blockIdx.x / groups_per_tf, grp = blockIdx.x % groups_per_tf;
   const int slot = frame_slot[first + j];                 // TF slot (FIC rows, FIB records)
@@ -309,31 +313,57 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
     prev[m] = tf[(group_syms * grp) * 2048 + bin[m]];
   }
   for (int l = group_syms * grp + 1; l <= group_syms * grp + group_syms; ++l) {
+    float re[6], im[6];
 #pragma unroll
     for (int m = 0; m < 6; ++m) {
       const float2 cur = tf[l * 2048 + bin[m]];
-      const float re = cur.x * prev[m].x + cur.y * prev[m].y;     // Re(cur conj(prev))
-      const float im = cur.x * prev[m].y - cur.y * prev[m].x;     // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
-      bits[qk[m]] = (re > 0.0f) ? 0 : 1;                          // input_sdr.c:157
-      bits[1536 + qk[m]] = (im > 0.0f) ? 1 : 0;                   // input_sdr.c:158
+      re[m] = cur.x * prev[m].x + cur.y * prev[m].y;     // Re(cur conj(prev))
+      im[m] = cur.x * prev[m].y - cur.y * prev[m].x;     // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
       prev[m] = cur;
     }
+    if (kBits == 1) {
+#pragma unroll
+      for (int m = 0; m < 6; ++m) {
+        bits[qk[m]] = (re[m] > 0.0f) ? 0 : 1;            // input_sdr.c:157
+        bits[1536 + qk[m]] = (im[m] > 0.0f) ? 1 : 0;     // input_sdr.c:158
+      }
+    } else {
+      float acc = 0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) acc += fabsf(re[m]) + fabsf(im[m]);
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
+      if ((tid & 63) == 0) wave_sum[tid >> 6] = acc;
+      __syncthreads();
+      float total = 0;
+#pragma unroll
+      for (int w = 0; w < kThreads / 64; ++w) total += wave_sum[w];
+      const float scale = total > 0.0f ? 4.5f * 3072.0f / total : 0.0f;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) {
+        const int q0 = max(-7, min(7, __float2int_rn(re[m] * scale)));     // > 0: first bit is 0
+        const int q1 = max(-7, min(7, __float2int_rn(-im[m] * scale)));    // stored im > 0 means bit 1
+        bits[qk[m]] = static_cast<uint8_t>(q0 & 15);
+        bits[1536 + qk[m]] = static_cast<uint8_t>(q1 & 15);
+      }
+    }
     __syncthreads();
-    if (tid < 96) {
+    constexpr int kPer = 32 / kBits;                      // received values per 32-bit word
+    for (int t = tid; t < 96 * kBits; t += kThreads) {
       if (l <= 3 || !kPlanar) {
         uint32_t w = 0;
 #pragma unroll
-        for (int b = 0; b < 32; ++b) w |= static_cast<uint32_t>(bits[32 * tid + b]) << b;
-        if (l <= 3) fic_bits[static_cast<size_t>(slot) * 288 + (l - 1) * 96 + tid] = w;
-        else msc_bits[static_cast<size_t>(cif_row) * 1728 + (l - 4) * 96 + tid] = w;
+        for (int b = 0; b < kPer; ++b) w |= static_cast<uint32_t>(bits[kPer * t + b]) << (kBits * b);
+        if (l <= 3) fic_bits[static_cast<size_t>(slot) * (288 * kBits) + (l - 1) * (96 * kBits) + t] = w;
+        else msc_bits[static_cast<size_t>(cif_row) * (1728 * kBits) + (l - 4) * (96 * kBits) + t] = w;
       } else {
         const int q = (l - 4) / 18, sidx = (l - 4) % 18;          // CIF within the TF, symbol within the CIF
-        const int r = tid / 6, wq = tid % 6;                      // plane (i & 15) and word within this symbol's 192 bits
+        const int r = t / (6 * kBits), wq = t % (6 * kBits);      // plane (i & 15) and word within this symbol's 192 values
         uint32_t w = 0;
 #pragma unroll
-        for (int b = 0; b < 32; ++b) w |= static_cast<uint32_t>(bits[16 * (32 * wq + b) + r]) << b;
+        for (int b = 0; b < kPer; ++b) w |= static_cast<uint32_t>(bits[16 * (kPer * wq + b) + r]) << (kBits * b);
         const int delay = static_cast<int>(__brev(static_cast<unsigned>(r)) >> 28);   // map[r], misc.c:32
-        msc_bits[static_cast<size_t>(cif_row + q - delay) * 1728 + (sidx * 6 + wq) * 16 + r] = w;
+        msc_bits[static_cast<size_t>(cif_row + q - delay) * (1728 * kBits) + (sidx * 6 * kBits + wq) * 16 + r] = w;
       }
     }
     __syncthreads();
@@ -351,28 +381,37 @@ hipError_t launch_ofdm_fft(const uint8_t* const* iq, const CallDesc* descs, int 
   return hipGetLastError();
 }
 
-hipError_t launch_demap(bool planar, const float2* spectra, int first, int nframes, const int* frame_slot, const int* frame_cif_row,
-                        const uint16_t* qpsk_of_carrier, uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream)
+hipError_t launch_demap(bool planar, int soft_bits, const float2* spectra, int first, int nframes, const int* frame_slot,
+                        const int* frame_cif_row, const uint16_t* qpsk_of_carrier, uint32_t* fic_bits, uint32_t* msc_bits,
+                        hipStream_t stream)
 {
   if (nframes <= 0) return hipSuccess;
-  if (planar)
-    hipLaunchKernelGGL(demap_kernel<true>, dim3(kDemapGroups * nframes), dim3(kThreads), 0, stream, spectra, kSymbolsPerTf, kDemapSyms,
-                       kDemapGroups, first, frame_slot, frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits);
+  const dim3 grid(kDemapGroups * nframes), block(kThreads);
+  if (planar && soft_bits)
+    hipLaunchKernelGGL((demap_kernel<true, 4>), grid, block, 0, stream, spectra, kSymbolsPerTf, kDemapSyms, kDemapGroups, first, frame_slot,
+                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits);
+  else if (planar)
+    hipLaunchKernelGGL((demap_kernel<true, 1>), grid, block, 0, stream, spectra, kSymbolsPerTf, kDemapSyms, kDemapGroups, first, frame_slot,
+                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits);
   else
-    hipLaunchKernelGGL(demap_kernel<false>, dim3(kDemapGroups * nframes), dim3(kThreads), 0, stream, spectra, kSymbolsPerTf, kDemapSyms,
-                       kDemapGroups, first, frame_slot, frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits);
+    hipLaunchKernelGGL((demap_kernel<false, 1>), grid, block, 0, stream, spectra, kSymbolsPerTf, kDemapSyms, kDemapGroups, first, frame_slot,
+                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits);
   return hipGetLastError();
 }
 
-// FIC pre-pass: 4-symbol spectra -> FIC bit rows only
-hipError_t launch_fic_prepass(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
-                              float2* spectra4, const float2* tw, const int* frame_slot, const uint16_t* qpsk_of_carrier,
+// FIC pre-pass: 4-symbol spectra -> FIC rows only
+hipError_t launch_fic_prepass(int soft_bits, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first,
+                              int nframes, float2* spectra4, const float2* tw, const int* frame_slot, const uint16_t* qpsk_of_carrier,
                               uint32_t* fic_bits, hipStream_t stream)
 {
   if (nframes <= 0) return hipSuccess;
   hipLaunchKernelGGL(fic_fft_kernel, dim3(nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, spectra4, tw);
-  hipLaunchKernelGGL(demap_kernel<false>, dim3(nframes), dim3(kThreads), 0, stream, spectra4, 4, 3, 1, first, frame_slot, frame_slot,
-                     qpsk_of_carrier, fic_bits, static_cast<uint32_t*>(nullptr));
+  if (soft_bits)
+    hipLaunchKernelGGL((demap_kernel<false, 4>), dim3(nframes), dim3(kThreads), 0, stream, spectra4, 4, 3, 1, first, frame_slot, frame_slot,
+                       qpsk_of_carrier, fic_bits, static_cast<uint32_t*>(nullptr));
+  else
+    hipLaunchKernelGGL((demap_kernel<false, 1>), dim3(nframes), dim3(kThreads), 0, stream, spectra4, 4, 3, 1, first, frame_slot, frame_slot,
+                       qpsk_of_carrier, fic_bits, static_cast<uint32_t*>(nullptr));
   return hipGetLastError();
 }
 

@@ -22,28 +22,27 @@ hipError_t launch_ofdm_fft(const uint8_t* const* iq, const CallDesc* descs, int 
 // K2b: DQPSK + demap + frequency de-interleave -> bit-packed rows.  FIC rows at TF slot frame_slot[first + j];
 // MSC rows start at CIF row frame_cif_row[first + j]: planar = scattered into time-de-interleaved logical rows
 // (see k_fft.hip), else the four transmitted CIFs of the TF in natural bit order.
-hipError_t launch_demap(bool planar, const float2* spectra, int first, int nframes, const int* frame_slot, const int* frame_cif_row,
-                        const uint16_t* qpsk_of_carrier, uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream);
+hipError_t launch_demap(bool planar, int soft_bits, const float2* spectra, int first, int nframes, const int* frame_slot,
+                        const int* frame_cif_row, const uint16_t* qpsk_of_carrier, uint32_t* fic_bits, uint32_t* msc_bits,
+                        hipStream_t stream);
 
 // FIC pre-pass: DFT of symbols 0..3 of every frame + demap of the three FIC symbols (spectra4: [nframes][4][2048])
-hipError_t launch_fic_prepass(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
-                              float2* spectra4, const float2* tw, const int* frame_slot, const uint16_t* qpsk_of_carrier,
+hipError_t launch_fic_prepass(int soft_bits, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first,
+                              int nframes, float2* spectra4, const float2* tw, const int* frame_slot, const uint16_t* qpsk_of_carrier,
                               uint32_t* fic_bits, hipStream_t stream);
 
-// K3: FIC de-puncture gather into per-step bytes
-hipError_t launch_fic_gather(const WaveGroup* groups, int ngroups, int max_n16, const DecodeJob* jobs, const int* job_ids,
-                             const CodewordPlan* plans, const uint32_t* bits, uint4* steps, hipStream_t stream);
-
-// K3/K4b: Viterbi forward pass + chain-back + descramble + pack
+// S1 seam: Viterbi on explicit per-step symbol bytes (forward pass + chain-back + pack)
 hipError_t launch_viterbi(const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans, const uint4* steps,
                           uint2* decisions, const uint32_t* prbs_words, uint8_t* out, int record_stride, hipStream_t stream);
 
-// K4 (MSC): regroup logical rows 64 frames at a time, then Viterbi with fused de-puncturing
-hipError_t launch_regroup(const int* job_ids, int ntiles, const DecodeJob* jobs, const int* stream_cif_base, const uint32_t* rows,
-                          uint32_t* grouped, hipStream_t stream);
-hipError_t launch_viterbi_msc(const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans,
-                              const uint32_t* grouped, uint2* decisions, const uint32_t* prbs_words, uint8_t* out, int record_stride,
-                              hipStream_t stream);
+// K3/K4: lane-interleave the received rows 64 records at a time (soft_bits: 0 = hard bits, 4 = 4-bit soft values),
+// then Viterbi with fused de-puncturing
+hipError_t launch_regroup(int soft_bits, const int* job_ids, int ntiles, const DecodeJob* jobs, const int* stream_cif_base,
+                          const uint32_t* rows, uint32_t* grouped, hipStream_t stream);
+hipError_t launch_fic_group(const uint32_t* fic_rows, int first_block, int nblocks, int block_words, uint32_t* grouped, hipStream_t stream);
+hipError_t launch_viterbi_fused(int soft_bits, const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans,
+                                const uint32_t* grouped, int row_words, uint2* decisions, const uint32_t* prbs_words, uint8_t* out,
+                                int record_stride, hipStream_t stream);
 
 hipError_t launch_fib_crc(const uint8_t* fibs, int nfib, const uint16_t* crc_tab, uint8_t* ok, hipStream_t stream);
 

@@ -109,6 +109,13 @@ const void *dabhip_engine_eti_device_ptr(const dabhip_engine *e, int64_t *nframe
  * tuner.  Default off = parity mode (samples untouched, results identical to the reference). */
 int dabhip_engine_set_afc(dabhip_engine *e, int enable);
 
+/* Soft-decision decoding (BASELINE config 5; the reference decodes hard decisions only,
+ * input_sdr.c:157-158, depuncture.c:36-43): the demapper emits signed 4-bit values that travel through time
+ * de-interleaving and de-puncturing into the Viterbi branch metrics of FIC and MSC.  Batch engine only.  Default off =
+ * parity mode (bit-exact with the reference).  With soft decisions the output equals the reference's wherever that decodes
+ * without errors and is better (lower BER) at low SNR. */
+int dabhip_engine_set_soft(dabhip_engine *e, int enable);
+
 /* Per sdr_demod call trace of one stream, for parity with the reference's state after each
  * call: {ok, frame_read, coarse_timeshift, fine_timeshift, coarse_freq_shift, fifo_count}
  * as int32[6] per call plus fine_freq_shift as double per call. */

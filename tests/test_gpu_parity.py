@@ -443,3 +443,56 @@ def test_software_afc_decodes_offset_captures():
             for k, data in enumerate(p["subch"]):
                 assert np.array_equal(data, dab.synth_payload(cfg, cif, k)), (b, f, k)
     eng.close()
+
+
+def _payload_errors(eti, cfg, ntf):
+    """(frames, frames whose MST differs from what was sent, wrong payload bits, payload bits) over the decoded frames"""
+    import eti_check
+    frames = bad = werr = bits = 0
+    for e in eti:
+        try:
+            p = eti_check.parse(e)
+        except AssertionError:
+            frames += 1
+            bad += 1
+            continue
+        cif = next((c for c in range(4 * ntf) if np.array_equal(dab.synth_fibs(cfg, c), p["fic"])), None)
+        frames += 1
+        if cif is None:
+            bad += 1
+            continue
+        wrong = 0
+        for k, data in enumerate(p["subch"]):
+            want = dab.synth_payload(cfg, cif, k)
+            wrong += int(np.unpackbits(np.bitwise_xor(data, want)).sum())
+            bits += 8 * want.size
+        werr += wrong
+        bad += int(wrong > 0)
+    return frames, bad, werr, bits
+
+
+def test_soft_decision_mode():
+    """SURVEY 8(f) rank 2 / BASELINE config 5 (extension: the reference has hard decisions only).
+    (a) clean and 20 dB input: soft decoding returns exactly the bytes of the reference semantics;
+    (b) 6.0 - 7.5 dB SNR: soft decoding delivers more frames and fewer payload bit errors than hard decoding."""
+    ntf = 40
+    eng = dab.Engine(0)
+    eng.set_soft(True)
+    clean = [dab.synth_generate(dab.synth_preset(1, seed=500 + i, snr_db=snr, skip_samples=sk), 24) for i, (snr, sk) in enumerate(((1000.0, 0), (20.0, 31000)))]
+    eng.decode(clean)
+    for b, iq in enumerate(clean):
+        want, _ = ol.or_replay(iq)
+        assert np.array_equal(eng.eti(b), want), b                     # (a)
+    cfgs = [dab.synth_preset(1, seed=510 + i, snr_db=snr) for i, snr in enumerate((7.5, 7.0, 6.5, 6.0))]
+    noisy = [dab.synth_generate(c, ntf) for c in cfgs]
+    eng.decode(noisy)
+    soft = [_payload_errors(eng.eti(b), cfgs[b], ntf) for b in range(len(noisy))]
+    eng.set_soft(False)
+    eng.decode(noisy)
+    hard = [_payload_errors(eng.eti(b), cfgs[b], ntf) for b in range(len(noisy))]
+    good_soft = sum(f - bad for f, bad, _, _ in soft)
+    good_hard = sum(f - bad for f, bad, _, _ in hard)
+    print("error-free frames soft/hard:", good_soft, good_hard, "detail", soft, hard)
+    assert good_soft > good_hard                                        # (b)
+    assert sum(s[0] for s in soft) >= sum(h[0] for h in hard)          # soft FIC keeps lock at least as long
+    eng.close()
