@@ -33,7 +33,7 @@ FFT_PMC_BYTES_PER_TF = (2 * 165800 + 1259500) * 1024 // 1024   # KiB per 1024 TF
 REALTIME_FPS = 1000.0 / 24.0
 
 
-def make_streams(torch, dev, nstreams, ntf, ndistinct, rank):
+def make_streams(torch, dev, nstreams, ntf, ndistinct, rank, snr_db=1000.0):
     """ndistinct different synthetic ensembles generated on the host cores, tiled to nstreams on the device."""
     import dabtools_amd as dab
 
@@ -41,7 +41,7 @@ def make_streams(torch, dev, nstreams, ntf, ndistinct, rank):
 
     def gen(i):   # global stream index of this rank's i-th distinct ensemble -> seed rule of SURVEY.md 8(d)
         g = rank * nstreams + i
-        cfg = dab.synth_preset(0, seed=shard.stream_seed(2, g), cif_count0=(97 * g) % 5000)
+        cfg = dab.synth_preset(0, seed=shard.stream_seed(2, g), cif_count0=(97 * g) % 5000, snr_db=snr_db)
         return dab.synth_generate(cfg, ntf)
 
     with ThreadPoolExecutor(max_workers=min(8, ndistinct)) as ex:
@@ -49,6 +49,35 @@ def make_streams(torch, dev, nstreams, ntf, ndistinct, rank):
     base = [torch.from_numpy(h).to(dev) for h in host]
     tensors = [base[i] if i < ndistinct else base[i % ndistinct].clone() for i in range(nstreams)]
     return host, tensors
+
+
+def payload_stats(dab, eng, first_global_stream, nstreams, ntf):
+    """Decoded payload vs what the modulator sent, over the distinct streams of this rank (noisy configs)."""
+    from dabtools_amd import shard
+    frames = good = bit_err = bits = 0
+    expected = nstreams * 4 * (ntf - 15)
+    for b in range(nstreams):
+        g = first_global_stream + b
+        cfg = dab.synth_preset(0, seed=shard.stream_seed(2, g), cif_count0=(97 * g) % 5000)
+        fib_index = {dab.synth_fibs(cfg, c).tobytes(): c for c in range(4 * ntf)}
+        for e in eng.eti(b):
+            frames += 1
+            nst = int(e[5]) & 0x7f
+            pos = 12 + 4 * nst
+            cif = fib_index.get(e[pos:pos + 96].tobytes())
+            if cif is None or nst != cfg.nsub:
+                continue
+            pos += 96
+            wrong = 0
+            for k in range(nst):
+                want = dab.synth_payload(cfg, cif, k)
+                wrong += int(np.unpackbits(np.bitwise_xor(e[pos:pos + want.size], want)).sum())
+                bits += 8 * want.size
+                pos += want.size
+            bit_err += wrong
+            good += int(wrong == 0)
+    return {"streams_checked": nstreams, "frames_expected_if_locked": expected, "frames_out": frames, "error_free_frames": good,
+            "payload_ber": (bit_err / bits) if bits else None}
 
 
 def cpu_baseline(host_stream, ntf):
@@ -114,6 +143,8 @@ def main():
     ap.add_argument("--tfs", type=int, default=64, help="transmission frames per stream")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic ensembles generated on the host")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--snr", type=float, default=1000.0, help="AWGN SNR in dB over the 2.048 MHz band (BASELINE config 5: 5 dB); default: clean")
+    ap.add_argument("--soft", action="store_true", help="soft-decision decoding (extension; default: hard = reference semantics)")
     args = ap.parse_args()
 
     import torch
@@ -129,10 +160,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    host, tensors = make_streams(torch, dev, args.streams, args.tfs, min(args.distinct, args.streams), rank)
+    host, tensors = make_streams(torch, dev, args.streams, args.tfs, min(args.distinct, args.streams), rank, args.snr)
     ptrs = [t.data_ptr() for t in tensors]
     sizes = [t.numel() for t in tensors]
     eng = dab.Engine(local_rank)
+    if args.soft:
+        eng.set_soft(True)
 
     def barrier():
         shard.barrier(dev)
@@ -180,6 +213,10 @@ def main():
                          "avg_launch_ms": fft_ms / max(fft_launches, 1), "algorithmic_bytes_per_tf": FFT_BYTES_PER_TF},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
         }
+        if args.snr < 100.0:
+            out["config"]["snr_db"] = args.snr
+            out["config"]["decisions"] = "soft (4-bit)" if args.soft else "hard"
+            out["payload"] = payload_stats(dab, eng, rank * args.streams, min(args.distinct, args.streams), args.tfs)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host[0], args.tfs)
         print(json.dumps(out))
