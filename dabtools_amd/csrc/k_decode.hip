@@ -372,7 +372,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(const WaveGroup* __restrict
 // received values of the stream; n is wave-uniform.  kBits = 1: hard bits (the reference's behaviour);
 // kBits = 4: signed 4-bit soft values (extension).
 template <int kBits>
-__global__ __launch_bounds__(64, 5) void viterbi_fused_kernel(const WaveGroup* __restrict__ groups, const int* __restrict__ job_ids,
+__global__ __launch_bounds__(64, 4) void viterbi_fused_kernel(const WaveGroup* __restrict__ groups, const int* __restrict__ job_ids,
                                                               const CodewordPlan* __restrict__ plans,
                                                               const uint32_t* __restrict__ grouped, int row_words,
                                                               uint2* __restrict__ decisions, const uint32_t* __restrict__ prbs_words,
