@@ -80,7 +80,7 @@ def payload_stats(dab, eng, first_global_stream, nstreams, ntf):
             "payload_ber": (bit_err / bits) if bits else None}
 
 
-def cpu_baseline(host_stream, ntf):
+def cpu_baseline(host_streams, ntf, nsample=10):
     """The CPU restatement (oracle/, kind 'port') timed on one host core on a bounded sample of the same
     workload, plus -- when oracle/_ref was built -- the REAL reference back end (dab_process_frame with the
     scalar viterbi.c and with ENABLE_SPIRAL_VITERBI) on the same demapped frames.  Checker code, used here
@@ -88,27 +88,30 @@ def cpu_baseline(host_stream, ntf):
     import ctypes as C
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
-    sample_tf = min(ntf, 40)
-    iq = host_stream[: sample_tf * 393216]
-    t0 = time.perf_counter()
-    eti, _ = oracle_lib.or_replay(iq)
+    sample = [h[: ntf * 393216] for h in host_streams[:nsample]]     # ~10 s of scalar work at the default sizes
+    neti, t0 = 0, time.perf_counter()
+    for iq in sample:
+        neti += len(oracle_lib.or_replay(iq)[0])
     dt = time.perf_counter() - t0
     out = {
-        "value": len(eti) / dt, "unit": "ETI frames/s", "cores": 1, "kind": "port",
-        "sample": "oracle/or_replay (scalar viterbi.c semantics, own fp64 DFT: libfftw3 absent) on 1 stream x %d TF of the same "
-                  "ensemble: %d ETI frames in %.2f s on 1 of %d host cores" % (sample_tf, len(eti), dt, os.cpu_count()),
+        "value": neti / dt, "unit": "ETI frames/s", "cores": 1, "kind": "port",
+        "sample": "oracle/or_replay (scalar viterbi.c semantics, own fp64 DFT: libfftw3 absent) on %d streams x %d TF of the same "
+                  "workload: %d ETI frames in %.2f s on 1 of %d host cores" % (len(sample), ntf, neti, dt, os.cpu_count()),
     }
     # the reference's own back end (the front end needs libfftw3 and cannot be built): demapped TFs are produced
     # untimed by the oracle front end, then dab_process_frame of the real objects is timed
     O = oracle_lib.oracle()
-    S = O.or_sdr_new()
     fic = np.zeros(9216, np.uint8)
     msc = np.zeros(221184, np.uint8)
-    tfs = []
-    for off in range(0, iq.size - 262144 + 1, 262144):
-        if O.or_sdr_demod(S, oracle_lib._ptr(iq[off:off + 262144]), 262144, oracle_lib._ptr(fic), oracle_lib._ptr(msc)):
-            tfs.append((fic.copy(), msc.copy()))
-    O.or_sdr_free(S)
+    streams_tfs = []
+    for iq in sample:
+        S, tfs = O.or_sdr_new(), []
+        for off in range(0, iq.size - 262144 + 1, 262144):
+            if O.or_sdr_demod(S, oracle_lib._ptr(iq[off:off + 262144]), 262144, oracle_lib._ptr(fic), oracle_lib._ptr(msc)):
+                tfs.append((fic.copy(), msc.copy()))
+        O.or_sdr_free(S)
+        streams_tfs.append(tfs)
+    ntfs = sum(len(t) for t in streams_tfs)
     for key, sse in (("reference_backend_scalar", False), ("reference_backend_sse", True)):
         R = oracle_lib.ref(sse=sse)
         if R is None:
@@ -116,21 +119,23 @@ def cpu_baseline(host_stream, ntf):
         devnull, saved = os.open(os.devnull, os.O_WRONLY), os.dup(2)
         os.dup2(devnull, 2)                 # the reference prints its ensemble table to stderr
         try:
-            H = R.refh_new()
-            t0 = time.perf_counter()
-            for f, m in tfs:
-                C.memmove(R.refh_tf_fic(H), oracle_lib._ptr(f), f.size)
-                C.memmove(R.refh_tf_msc(H), oracle_lib._ptr(m), m.size)
-                R.refh_process(H)
-            dt = time.perf_counter() - t0
-            n = R.refh_neti(H)
+            n, dt = 0, 0.0
+            for tfs in streams_tfs:
+                H = R.refh_new()
+                t0 = time.perf_counter()
+                for f, m in tfs:
+                    C.memmove(R.refh_tf_fic(H), oracle_lib._ptr(f), f.size)
+                    C.memmove(R.refh_tf_msc(H), oracle_lib._ptr(m), m.size)
+                    R.refh_process(H)
+                dt += time.perf_counter() - t0
+                n += R.refh_neti(H)
         finally:
             os.dup2(saved, 2)
             os.close(devnull)
             os.close(saved)
         out[key] = {"value": n / dt, "unit": "ETI frames/s", "cores": 1,
                     "sample": "real reference dab_process_frame (%s) on %d demapped TF: %d ETI frames in %.2f s; back end only"
-                              % ("viterbi_spiral SSE2" if sse else "scalar viterbi.c", len(tfs), n, dt)}
+                              % ("viterbi_spiral SSE2" if sse else "scalar viterbi.c", ntfs, n, dt)}
     return out
 
 
@@ -218,7 +223,7 @@ def main():
             out["config"]["decisions"] = "soft (4-bit)" if args.soft else "hard"
             out["payload"] = payload_stats(dab, eng, rank * args.streams, min(args.distinct, args.streams), args.tfs)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host[0], args.tfs)
+            out["cpu_baseline"] = cpu_baseline(host, args.tfs)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
