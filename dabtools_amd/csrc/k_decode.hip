@@ -21,6 +21,14 @@
 // agreement counts.  The kernel therefore accumulates agreement counts (0..4 per step);
 // decisions, ties (strict '>' keeps the low predecessor) and the start condition (state 0
 // reachable, others far below) are identical.
+//
+// Survivor records ("tagged max").  Metrics are held x16; within a block of four trellis steps the candidate of
+// the LOW predecessor carries the tag 1 << k at step k (k = 0..3).  Both candidates being otherwise multiples
+// of 16 plus the tags of earlier steps (< 1 << k), "high + garbage_h > low + garbage_l + tag" holds exactly
+// when the high predecessor is strictly better, so one packed max both selects the survivor and leaves, in the
+// low nibble of every state, the four decisions ALONG THAT STATE'S SURVIVOR PATH.  That nibble is all the
+// chain-back needs to step four trellis steps back, so it is collected once per block (8 words per lane per 4
+// steps, the same volume as one bit per state and step) and the nibbles are cleared with the re-pairing.
 #include <hip/hip_runtime.h>
 
 #include <utility>
@@ -61,39 +69,27 @@ typedef short __attribute__((ext_vector_type(2))) pk16;
 typedef unsigned short __attribute__((ext_vector_type(2))) upk16;
 
 __device__ __forceinline__ pk16 as_pk(uint32_t x) { return __builtin_bit_cast(pk16, x); }
+__device__ __forceinline__ upk16 as_upk(uint32_t x) { return __builtin_bit_cast(upk16, x); }
+constexpr int kMetricShift = 4;                           // metrics x16: four tag bits below every metric
 __device__ __forceinline__ uint32_t as_u32(pk16 x) { return __builtin_bit_cast(uint32_t, x); }
 
 __host__ __device__ constexpr int expand_bit(int r, int tau) { return ((r >> tau) << (tau + 1)) | (r & ((1 << tau) - 1)); }
 __host__ __device__ constexpr int compress_bit(int k, int tau) { return ((k >> (tau + 1)) << tau) | (k & ((1 << tau) - 1)); }
 
-// where the survivor decision of new state s lands in the 64-bit word of a step of type tau
-__host__ __device__ constexpr int decision_bit(int tau, int s)
-{
-  const int b = s & 1, jj = s >> 1, delta = 1 << tau;
-  const int half = (jj >> tau) & 1;
-  const int j = half ? (jj ^ delta) : jj;
-  const int idx = 2 * compress_bit(j, tau) + b;          // D register index 0..31
-  return (idx >> 4) * 32 + (idx & 15) + 16 * half;
-}
-
 template <int kTau, int kR>
-__device__ __forceinline__ void butterfly_pair(const pk16 (&p)[32], pk16 (&n)[32], const pk16 (&bb)[8], uint32_t& d0, uint32_t& d1)
+__device__ __forceinline__ void butterfly_pair(const pk16 (&p)[32], pk16 (&n)[32], const pk16 (&bl)[8], const pk16 (&bh)[8])
 {
   constexpr int j = expand_bit(kR, kTau);                 // butterfly index of the low half; high half is j ^ delta
   constexpr unsigned c = branch_code3(2 * j);
-  const pk16 x = p[kR], y = p[16 + kR];
-  // Metrics are kept non-negative and < 2^15, so the two halves of a register can be advanced by ONE 32-bit
-  // add without a carry crossing over (v_add_u32 issues at twice the rate of the packed 16-bit forms on gfx950).
-  const pk16 t0 = as_pk(as_u32(x) + as_u32(bb[c])), t1 = as_pk(as_u32(y) + as_u32(bb[c ^ 7]));      // into states 2j, 2j'      (viterbi.c:404-414)
-  const pk16 t2 = as_pk(as_u32(x) + as_u32(bb[c ^ 7])), t3 = as_pk(as_u32(y) + as_u32(bb[c]));      // into states 2j+1, 2j'+1  (viterbi.c:415-421)
-  const pk16 e = __builtin_elementwise_max(t0, t1), o = __builtin_elementwise_max(t2, t3);
-  // decision = 1 iff the high predecessor is strictly better: sign bits (15 and 31) of (low - high), moved to
-  // bit i and bit 16 + i of the decision word with 32-bit shift/and/or (full-rate encodings)
-  const uint32_t de = as_u32(t0 - t1), dd = as_u32(t2 - t3);
-  constexpr int ie = 2 * kR, io = 2 * kR + 1;
-  constexpr uint32_t ke = 0x00010001u << (ie & 15), ko = 0x00010001u << (io & 15);
-  if (ie < 16) { d0 |= (de >> (15 - (ie & 15))) & ke; d0 |= (dd >> (15 - (io & 15))) & ko; }
-  else { d1 |= (de >> (15 - (ie & 15))) & ke; d1 |= (dd >> (15 - (io & 15))) & ko; }
+  const uint32_t x = as_u32(p[kR]), y = as_u32(p[16 + kR]);
+  // Metrics are non-negative and < 2^16, so the two halves of a register can be advanced by ONE 32-bit add
+  // without a carry crossing over (v_add_u32 issues at twice the rate of the packed 16-bit forms on gfx950).
+  // bl = branch metric + tag (low predecessor), bh = branch metric (high predecessor).
+  const upk16 t0 = as_upk(x + as_u32(bl[c])), t1 = as_upk(y + as_u32(bh[c ^ 7]));      // into states 2j, 2j'      (viterbi.c:404-414)
+  const upk16 t2 = as_upk(x + as_u32(bl[c ^ 7])), t3 = as_upk(y + as_u32(bh[c]));      // into states 2j+1, 2j'+1  (viterbi.c:415-421)
+  // the high predecessor wins iff it is strictly better (viterbi.c:411: "if (m1 > m0)"): the tag decides ties
+  const pk16 e = as_pk(__builtin_bit_cast(uint32_t, __builtin_elementwise_max(t0, t1)));
+  const pk16 o = as_pk(__builtin_bit_cast(uint32_t, __builtin_elementwise_max(t2, t3)));
   // results already form the pairs of the next layout
   constexpr int k_e = 2 * j, k_o = 2 * j + 1;
   if (kTau < 3) {
@@ -106,10 +102,10 @@ __device__ __forceinline__ void butterfly_pair(const pk16 (&p)[32], pk16 (&n)[32
 }
 
 template <int kTau, int... kRs>
-__device__ __forceinline__ void all_pairs(const pk16 (&p)[32], pk16 (&n)[32], const pk16 (&bb)[8], uint32_t& d0, uint32_t& d1,
+__device__ __forceinline__ void all_pairs(const pk16 (&p)[32], pk16 (&n)[32], const pk16 (&bl)[8], const pk16 (&bh)[8],
                                           std::integer_sequence<int, kRs...>)
 {
-  (butterfly_pair<kTau, kRs>(p, n, bb, d0, d1), ...);
+  (butterfly_pair<kTau, kRs>(p, n, bl, bh), ...);
 }
 
 // branch metrics of the 8 distinct code words (bit3 = bit0) for one trellis step
@@ -141,34 +137,37 @@ __device__ __forceinline__ void branch_metrics_soft(unsigned nib16, int (&bm)[8]
 }
 
 template <int kTau>
-__device__ __forceinline__ void acs_step_bm(const int (&bm)[8], const pk16 (&p)[32], pk16 (&n)[32], uint2& dec)
+__device__ __forceinline__ void acs_step_bm(const int (&bm)[8], const pk16 (&p)[32], pk16 (&n)[32])
 {
   constexpr unsigned gamma = branch_code3(2u << kTau);    // code difference between the two members of a pair
-  pk16 bb[8];
+  constexpr uint32_t tag = 0x00010001u << kTau;
+  pk16 bl[8], bh[8];
 #pragma unroll
-  for (unsigned c = 0; c < 8; ++c) bb[c] = as_pk(static_cast<uint32_t>(bm[c]) | (static_cast<uint32_t>(bm[c ^ gamma]) << 16));
-  uint32_t d0 = 0, d1 = 0;
-  all_pairs<kTau>(p, n, bb, d0, d1, std::make_integer_sequence<int, 16>{});
-  dec = make_uint2(d0, d1);
+  for (unsigned c = 0; c < 8; ++c) {
+    const uint32_t b = (static_cast<uint32_t>(bm[c]) | (static_cast<uint32_t>(bm[c ^ gamma]) << 16)) << kMetricShift;
+    bh[c] = as_pk(b);
+    bl[c] = as_pk(b + tag);
+  }
+  all_pairs<kTau>(p, n, bl, bh, std::make_integer_sequence<int, 16>{});
 }
 
 template <int kTau>
-__device__ __forceinline__ void acs_step(unsigned sb, const pk16 (&p)[32], pk16 (&n)[32], uint2& dec)
+__device__ __forceinline__ void acs_step(unsigned sb, const pk16 (&p)[32], pk16 (&n)[32])
 {
   int bm[8];
   branch_metrics_hard(sb, bm);
-  acs_step_bm<kTau>(bm, p, n, dec);
+  acs_step_bm<kTau>(bm, p, n);
 }
 
 template <int kTau>
-__device__ __forceinline__ void acs_step_soft(unsigned nib16, const pk16 (&p)[32], pk16 (&n)[32], uint2& dec)
+__device__ __forceinline__ void acs_step_soft(unsigned nib16, const pk16 (&p)[32], pk16 (&n)[32])
 {
   int bm[8];
   branch_metrics_soft(nib16, bm);
-  acs_step_bm<kTau>(bm, p, n, dec);
+  acs_step_bm<kTau>(bm, p, n);
 }
 
-// L(4) (pairs (k, k^16)) -> L(0) (pairs (k, k^1)): one byte permute per register
+// L(4) (pairs (k, k^16)) -> L(0) (pairs (k, k^1)): one byte permute per register; the tag nibbles are cleared here
 __device__ __forceinline__ void repair_layout(const pk16 (&n)[32], pk16 (&p)[32])
 {
 #pragma unroll
@@ -177,21 +176,41 @@ __device__ __forceinline__ void repair_layout(const pk16 (&n)[32], pk16 (&p)[32]
     for (int q = 0; q < 16; ++q) {
       const int a = side * 16 + ((2 * q) & 15);           // register holding state 2q (low half if 2q < 16)
       const uint32_t sel = (2 * q < 16) ? 0x05040100u : 0x07060302u;
-      p[side * 16 + q] = as_pk(__builtin_amdgcn_perm(as_u32(n[a + 1]), as_u32(n[a]), sel));
+      p[side * 16 + q] = as_pk(__builtin_amdgcn_perm(as_u32(n[a + 1]), as_u32(n[a]), sel) & 0xfff0fff0u);
     }
 }
 
-struct DecisionTable {
-  uint8_t pos[4][64];
-};
-__host__ __device__ constexpr DecisionTable make_decision_table()
+// Survivor record of a block: the tag nibbles of the 64 states, 8 words per lane.  Register R (in the L(4) numbering:
+// low half = state 32 (R >> 4) + (R & 15), high half = that + 16) lands in word R >> 2, nibble
+// 4 (R & 1) + 2 half + ((R >> 1) & 1).  After a partial block (layouts L(1..3)) only state 0 is read back, and state 0
+// is the low half of register 0 in every layout.
+__device__ __forceinline__ void survivor_record(const pk16 (&n)[32], uint4* rec)
 {
-  DecisionTable t{};
-  for (int tau = 0; tau < 4; ++tau)
-    for (int s = 0; s < 64; ++s) t.pos[tau][s] = static_cast<uint8_t>(decision_bit(tau, s));
-  return t;
+  uint32_t d[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t pa = __builtin_amdgcn_perm(as_u32(n[4 * i + 1]), as_u32(n[4 * i]), 0x06040200u);       // low bytes of 4 halves
+    const uint32_t pb = __builtin_amdgcn_perm(as_u32(n[4 * i + 3]), as_u32(n[4 * i + 2]), 0x06040200u);
+    d[i] = (pa & 0x0f0f0f0fu) | ((pb & 0x0f0f0f0fu) << 4);
+  }
+  rec[0] = make_uint4(d[0], d[1], d[2], d[3]);
+  rec[64] = make_uint4(d[4], d[5], d[6], d[7]);
 }
-__constant__ DecisionTable kDecisionTable = make_decision_table();
+__device__ __forceinline__ uint32_t in_vgpr(uint32_t x)
+{
+  asm volatile("" : "+v"(x));   // keeps the 8-way select below a v_cndmask tree (the optimiser would index a scratch copy instead)
+  return x;
+}
+__device__ __forceinline__ unsigned survivor_nibble(const uint4& lo, const uint4& hi, unsigned state)
+{
+  const unsigned r = ((state >> 5) << 4) | (state & 15u), half = (state >> 4) & 1u;
+  const unsigned i = r >> 2, nib = 4u * (r & 1u) + 2u * half + ((r >> 1) & 1u);
+  const bool i0 = i & 1u, i1 = i & 2u, i2 = i & 4u;
+  const uint32_t a = i0 ? in_vgpr(lo.y) : in_vgpr(lo.x), b = i0 ? in_vgpr(lo.w) : in_vgpr(lo.z);
+  const uint32_t c = i0 ? in_vgpr(hi.y) : in_vgpr(hi.x), d = i0 ? in_vgpr(hi.w) : in_vgpr(hi.z);
+  const uint32_t ab = i1 ? b : a, cd = i1 ? d : c;
+  return ((i2 ? cd : ab) >> (4u * nib)) & 15u;
+}
 
 // ---------------------------------------------------------------------------------------
 // regroup: logical CIF rows (planes interleaved word by word, one row per ETI frame) ->
@@ -249,80 +268,115 @@ __global__ __launch_bounds__(256) void fic_group_kernel(const uint32_t* __restri
 }
 
 // ---------------------------------------------------------------------------------------
-// shared by both Viterbi kernels: 4 trellis steps = one pass through the register layouts
-__device__ __forceinline__ void acs4(uint32_t ww, pk16 (&pm)[32], pk16 (&pn)[32], pk16 (&pl4)[32], uint2* dec_rows)
+// shared by both Viterbi kernels: 4 trellis steps = one pass through the register layouts = one survivor record
+__device__ __forceinline__ void acs4(uint32_t ww, pk16 (&pm)[32], pk16 (&pn)[32], pk16 (&pl4)[32], uint4* rec)
 {
-  uint2 d0, d1, d2, d3;
-  acs_step<0>(ww & 0xff, pm, pn, d0);
-  acs_step<1>((ww >> 8) & 0xff, pn, pm, d1);
-  acs_step<2>((ww >> 16) & 0xff, pm, pn, d2);
-  acs_step<3>(ww >> 24, pn, pl4, d3);
+  acs_step<0>(ww & 0xff, pm, pn);
+  acs_step<1>((ww >> 8) & 0xff, pn, pm);
+  acs_step<2>((ww >> 16) & 0xff, pm, pn);
+  acs_step<3>(ww >> 24, pn, pl4);
+  survivor_record(pl4, rec);
   repair_layout(pl4, pm);
-  dec_rows[0] = d0;
-  dec_rows[64] = d1;
-  dec_rows[128] = d2;
-  dec_rows[192] = d3;
 }
 
-__device__ __forceinline__ void acs4_soft(uint64_t nibs, pk16 (&pm)[32], pk16 (&pn)[32], pk16 (&pl4)[32], uint2* dec_rows)
+__device__ __forceinline__ void acs4_soft(uint64_t nibs, pk16 (&pm)[32], pk16 (&pn)[32], pk16 (&pl4)[32], uint4* rec)
 {
-  uint2 d0, d1, d2, d3;
-  acs_step_soft<0>(static_cast<unsigned>(nibs) & 0xffffu, pm, pn, d0);
-  acs_step_soft<1>(static_cast<unsigned>(nibs >> 16) & 0xffffu, pn, pm, d1);
-  acs_step_soft<2>(static_cast<unsigned>(nibs >> 32) & 0xffffu, pm, pn, d2);
-  acs_step_soft<3>(static_cast<unsigned>(nibs >> 48), pn, pl4, d3);
+  acs_step_soft<0>(static_cast<unsigned>(nibs) & 0xffffu, pm, pn);
+  acs_step_soft<1>(static_cast<unsigned>(nibs >> 16) & 0xffffu, pn, pm);
+  acs_step_soft<2>(static_cast<unsigned>(nibs >> 32) & 0xffffu, pm, pn);
+  acs_step_soft<3>(static_cast<unsigned>(nibs >> 48), pn, pl4);
+  survivor_record(pl4, rec);
   repair_layout(pl4, pm);
-  dec_rows[0] = d0;
-  dec_rows[64] = d1;
-  dec_rows[128] = d2;
-  dec_rows[192] = d3;
 }
 
-// chain back from state 0 (viterbi.c:438-450), descramble (misc.c:41-58), pack MSB first
-__device__ __forceinline__ void chain_back(const uint2* my_dec, int nsteps, const uint8_t* dec_pos, const uint32_t* __restrict__ prbs_words,
-                                           uint32_t* dst)
+// the last r = 1..3 steps of a code word whose length is not a multiple of four: no re-pairing, the record is
+// only read for state 0
+__device__ __forceinline__ void acs_tail(uint32_t ww, int r, pk16 (&pm)[32], pk16 (&pn)[32], uint4* rec)
+{
+  acs_step<0>(ww & 0xff, pm, pn);
+  if (r == 1) { survivor_record(pn, rec); return; }
+  acs_step<1>((ww >> 8) & 0xff, pn, pm);
+  if (r == 2) { survivor_record(pm, rec); return; }
+  acs_step<2>((ww >> 16) & 0xff, pm, pn);
+  survivor_record(pn, rec);
+}
+__device__ __forceinline__ void acs_tail_soft(uint64_t nibs, int r, pk16 (&pm)[32], pk16 (&pn)[32], uint4* rec)
+{
+  acs_step_soft<0>(static_cast<unsigned>(nibs) & 0xffffu, pm, pn);
+  if (r == 1) { survivor_record(pn, rec); return; }
+  acs_step_soft<1>(static_cast<unsigned>(nibs >> 16) & 0xffffu, pn, pm);
+  if (r == 2) { survivor_record(pm, rec); return; }
+  acs_step_soft<2>(static_cast<unsigned>(nibs >> 32) & 0xffffu, pm, pn);
+  survivor_record(pn, rec);
+}
+
+// chain back from state 0 (viterbi.c:438-450), descramble (misc.c:41-58), pack MSB first.  my_rec: this lane's
+// records, block b at my_rec[128 b] and my_rec[128 b + 64].
+__device__ __forceinline__ void chain_back(const uint4* my_rec, int nsteps, const uint32_t* __restrict__ prbs_words, uint32_t* dst)
 {
   unsigned state = 0;
   uint32_t acc = 0;
-  // decision words are fetched 8 steps at a time (their addresses do not depend on the path)
-  for (int t_hi = nsteps - 1; t_hi >= 6; t_hi -= 8) {
-    uint2 d[8];
+  auto consume = [&](unsigned nib, int t0, int k_hi) {     // steps t0 + k_hi .. t0, newest first
 #pragma unroll
-    for (int u = 0; u < 8; ++u) d[u] = my_dec[static_cast<size_t>(max(t_hi - u, 0)) * 64];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int t = t_hi - u;
-      if (t < 6) break;
-      const unsigned pos = dec_pos[(t & 3) * 64 + state];
-      const unsigned bit = ((pos & 32u) ? (d[u].y >> (pos & 31u)) : (d[u].x >> pos)) & 1u;
-      state = (state | (bit << 6)) >> 1;
-      const int i = t - 6;                               // data bit index
-      acc |= bit << (8 * ((i >> 3) & 3) + (7 - (i & 7)));
-      if ((i & 31) == 0) {
-        dst[i >> 5] = acc ^ prbs_words[i >> 5];
-        acc = 0;
+    for (int k = 3; k >= 0; --k) {
+      const int t = t0 + k;
+      if (k <= k_hi && t >= 6) {                           // steps 0..5 only flush the encoder's initial zeros
+        const unsigned bit = ((nib >> k) & 1u) ^ 1u;       // tag set = low predecessor survived = decision 0
+        state = (state | (bit << 6)) >> 1;
+        const int i = t - 6;                               // data bit index
+        acc |= bit << (8 * ((i >> 3) & 3) + (7 - (i & 7)));
+        if ((i & 31) == 0) {
+          dst[i >> 5] = acc ^ prbs_words[i >> 5];
+          acc = 0;
+        }
       }
+    }
+  };
+  const int nfull = nsteps >> 2, r = nsteps & 3;
+  if (r) consume(my_rec[static_cast<size_t>(nfull) * 128].x & 15u, 4 * nfull, r - 1);
+  // records are fetched 4 blocks at a time (their addresses do not depend on the path)
+  for (int b_hi = nfull - 1; b_hi >= 1; b_hi -= 4) {
+    uint4 lo[4], hi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t b = static_cast<size_t>(max(b_hi - u, 0));
+      lo[u] = my_rec[b * 128];
+      hi[u] = my_rec[b * 128 + 64];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = b_hi - u;
+      if (b >= 1) consume(survivor_nibble(lo[u], hi[u], state), 4 * b, 3);
     }
   }
 }
 
+template <int kBits>
+struct MetricScale {
+  // state 0 is kept at kBase at every re-base; the other states stay within 6 steps' worth of branch metric of it
+  // (24 agreements hard, 6 x 56 soft), x16, plus tags: kBase exceeds that, so nothing goes negative.  The same gap
+  // is the start condition (viterbi.c:387-389: 0 vs -999999; it only has to exceed what six steps can collect).
+  static constexpr uint32_t kBase = kBits == 1 ? 1024u : 8192u;
+  // growth per step <= 16 x 4 (hard) / 16 x 56 (soft): re-base long before the unsigned 16-bit range ends
+  static constexpr int kRebaseSteps = kBits == 1 ? 256 : 32;
+};
+
+template <int kBits>
 __device__ __forceinline__ void init_metrics(pk16 (&pm)[32])
 {
-  // L(0): register r = states (2r, 2r+1), register 16 + r = states (32 + 2r, 33 + 2r).  State 0 starts 1024
-  // above every other ("unreachable") state (viterbi.c:387-389: 0 vs -999999, scaled to agreement counts: the
-  // gap only has to exceed the 24 agreements six steps can collect); all values stay non-negative.
+  // L(0): register r = states (2r, 2r+1), register 16 + r = states (32 + 2r, 33 + 2r)
 #pragma unroll
   for (int r = 0; r < 32; ++r) pm[r] = as_pk(0u);
-  pm[0] = as_pk(0x00000400u);                                      // (1024, 0)
+  pm[0] = as_pk(MetricScale<kBits>::kBase);
 }
 
-// agreement counts grow by <= 4 per step: re-base on state 0 long before int16 could overflow
+template <int kBits>
 __device__ __forceinline__ void rebase_metrics(pk16 (&pm)[32])
 {
-  const uint32_t s0 = (as_u32(pm[0]) & 0xffffu) - 1024u;          // keep state 0 at 1024: all states stay within +-24 of it
-  const pk16 base = as_pk(s0 | (s0 << 16));
+  const uint32_t s0 = (as_u32(pm[0]) & 0xffffu) - MetricScale<kBits>::kBase;
+  const uint32_t base = s0 | (s0 << 16);                  // every half is >= s0: no borrow crosses
 #pragma unroll
-  for (int r = 0; r < 32; ++r) pm[r] = pm[r] - base;
+  for (int r = 0; r < 32; ++r) pm[r] = as_pk(as_u32(pm[r]) - base);
 }
 
 // one wave (64 lanes) per group of <= 64 equal-length code words; trellis input = one byte per step (gather_kernel)
@@ -331,20 +385,18 @@ __global__ __launch_bounds__(64) void viterbi_kernel(const WaveGroup* __restrict
                                                      uint2* __restrict__ decisions, const uint32_t* __restrict__ prbs_words,
                                                      uint8_t* __restrict__ out, int record_stride)
 {
-  __shared__ uint8_t dec_pos[4 * 64];
   const int lane = threadIdx.x;
   const WaveGroup grp = groups[blockIdx.x];
   const int nsteps = grp.nsteps;
   const uint4* my_steps = steps + grp.step_base * 64 + lane;
-  uint2* my_dec = decisions + grp.dec_base * 64 + lane;
-  for (int i = lane; i < 256; i += 64) dec_pos[i] = kDecisionTable.pos[i >> 6][i & 63];
+  uint4* my_rec = reinterpret_cast<uint4*>(decisions + grp.dec_base * 64) + lane;
 
   pk16 pm[32], pn[32], pl4[32];
-  init_metrics(pm);
+  init_metrics<1>(pm);
   const int n16 = (nsteps + 15) >> 4;
   uint4 pack = my_steps[0];
   for (int t16 = 0; t16 < n16; ++t16) {
-    // fetch the next 16 steps before this block's decision stores are issued: the wait for it then
+    // fetch the next 16 steps before this block's record stores are issued: the wait for it then
     // does not have to drain those stores (loads and stores retire in order on one counter)
     const uint4 next = my_steps[static_cast<size_t>(min(t16 + 1, n16 - 1)) * 64];
     const uint32_t w[4] = {pack.x, pack.y, pack.z, pack.w};
@@ -353,17 +405,17 @@ __global__ __launch_bounds__(64) void viterbi_kernel(const WaveGroup* __restrict
       const int t = 16 * t16 + 4 * q;
       if (t >= nsteps) break;
       const uint32_t ww = (q == 0) ? w[0] : (q == 1) ? w[1] : (q == 2) ? w[2] : w[3];
-      acs4(ww, pm, pn, pl4, my_dec + static_cast<size_t>(t) * 64);   // steps past nsteps land in slack rows
+      uint4* rec = my_rec + static_cast<size_t>(t >> 2) * 128;
+      if (t + 4 <= nsteps) acs4(ww, pm, pn, pl4, rec);
+      else acs_tail(ww, nsteps - t, pm, pn, rec);
     }
-    if ((t16 & 127) == 127) rebase_metrics(pm);
+    if ((t16 & 15) == 15) rebase_metrics<1>(pm);
     pack = next;
   }
-  __syncthreads();
   if (lane >= grp.count) return;
   const CodewordPlan pl = plans[grp.plan];
   const int record = job_ids ? job_ids[grp.first + lane] : grp.first + lane;
-  chain_back(my_dec, nsteps, dec_pos, prbs_words,
-             reinterpret_cast<uint32_t*>(out + static_cast<size_t>(record) * record_stride + pl.out_offset));
+  chain_back(my_rec, nsteps, prbs_words, reinterpret_cast<uint32_t*>(out + static_cast<size_t>(record) * record_stride + pl.out_offset));
 }
 
 // Decoder with the de-puncturing fused into the load (depuncture.c:45-132): lane = output record (ETI frame or FIC
@@ -378,12 +430,11 @@ __global__ __launch_bounds__(64, 4) void viterbi_fused_kernel(const WaveGroup* _
                                                               uint2* __restrict__ decisions, const uint32_t* __restrict__ prbs_words,
                                                               uint8_t* __restrict__ out, int record_stride)
 {
-  __shared__ uint8_t dec_pos[4 * 64];
   const int lane = threadIdx.x;
   const WaveGroup grp = groups[blockIdx.x];
   const CodewordPlan pl = plans[grp.plan];
-  uint2* my_dec = decisions + grp.dec_base * 64 + lane;
-  for (int i = lane; i < 256; i += 64) dec_pos[i] = kDecisionTable.pos[i >> 6][i & 63];
+  const int nsteps = grp.nsteps;             // 32 x blocks + 6: the tail unit holds 6 steps
+  uint4* my_rec = reinterpret_cast<uint4*>(decisions + grp.dec_base * 64) + lane;
 
   // received words of this lane's record: tile = grp.first / 64 (job lists are padded to tiles of 64)
   const int word0 = (pl.start_bit * kBits) >> 5;
@@ -401,7 +452,7 @@ __global__ __launch_bounds__(64, 4) void viterbi_fused_kernel(const WaveGroup* _
   };
 
   pk16 pm[32], pn[32], pl4[32];
-  init_metrics(pm);
+  init_metrics<kBits>(pm);
   int t = 0;
   for (int seg = 0; seg < 5; ++seg) {
     const uint32_t mask = seg < 4 ? pl.mask[seg] : (puncture_mask(8) & 0x00ffffffu);
@@ -423,12 +474,14 @@ __global__ __launch_bounds__(64, 4) void viterbi_fused_kernel(const WaveGroup* _
           ww[g >> 2] |= sb << (8 * (g & 3));
         }
         have -= need;
-        acs4(ww[0], pm, pn, pl4, my_dec + static_cast<size_t>(t) * 64);
-        acs4(ww[1], pm, pn, pl4, my_dec + static_cast<size_t>(t + 4) * 64);
+        if (t + 4 <= nsteps) acs4(ww[0], pm, pn, pl4, my_rec + static_cast<size_t>(t >> 2) * 128);
+        if (t + 8 <= nsteps) acs4(ww[1], pm, pn, pl4, my_rec + static_cast<size_t>((t >> 2) + 1) * 128);
+        else if (t + 4 < nsteps) acs_tail(ww[1], nsteps - t - 4, pm, pn, my_rec + static_cast<size_t>((t >> 2) + 1) * 128);
       } else {
+        uint64_t nibs[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          uint64_t nibs = 0;
+          nibs[h] = 0;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int nb = 4 * ((counts >> (3 * (4 * h + g))) & 7);      // bits of this step: 4 per received value
@@ -436,21 +489,20 @@ __global__ __launch_bounds__(64, 4) void viterbi_fused_kernel(const WaveGroup* _
             const uint64_t v = fifo & ((1ull << nb) - 1ull);
             fifo >>= nb;
             have -= nb;
-            nibs |= v << (16 * g);
+            nibs[h] |= v << (16 * g);
           }
-          acs4_soft(nibs, pm, pn, pl4, my_dec + static_cast<size_t>(t + 4 * h) * 64);
         }
+        if (t + 4 <= nsteps) acs4_soft(nibs[0], pm, pn, pl4, my_rec + static_cast<size_t>(t >> 2) * 128);
+        if (t + 8 <= nsteps) acs4_soft(nibs[1], pm, pn, pl4, my_rec + static_cast<size_t>((t >> 2) + 1) * 128);
+        else if (t + 4 < nsteps) acs_tail_soft(nibs[1], nsteps - t - 4, pm, pn, my_rec + static_cast<size_t>((t >> 2) + 1) * 128);
       }
       t += 8;
-      // metrics grow by <= 4 (hard) / <= 56 (soft) per step: re-base long before int16 could overflow
-      if ((t & (kBits == 1 ? 2047 : 127)) == 0) rebase_metrics(pm);
+      if ((t & (MetricScale<kBits>::kRebaseSteps - 1)) == 0 && t < nsteps) rebase_metrics<kBits>(pm);
     }
   }
-  __syncthreads();
   if (lane >= grp.count) return;
   const int record = job_ids ? job_ids[grp.first + lane] : grp.first + lane;
-  chain_back(my_dec, grp.nsteps, dec_pos, prbs_words,
-             reinterpret_cast<uint32_t*>(out + static_cast<size_t>(record) * record_stride + pl.out_offset));
+  chain_back(my_rec, nsteps, prbs_words, reinterpret_cast<uint32_t*>(out + static_cast<size_t>(record) * record_stride + pl.out_offset));
 }
 
 // ---------------------------------------------------------------------------------------
