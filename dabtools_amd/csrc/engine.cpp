@@ -59,9 +59,10 @@ Engine::Engine(int device) : device_(device)
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device: libdabhip has no CPU fallback"); return; }
   if (device < 0 || device >= ndev) { set_error("device index out of range"); return; }
   if (!check(hipSetDevice(device), "hipSetDevice")) return;
-  if (!check(hipStreamCreate(&stream_), "hipStreamCreate")) return;
+  if (!check(hipStreamCreate(&stream_), "hipStreamCreate") || !check(hipStreamCreate(&copy_stream_), "hipStreamCreate")) return;
   for (auto& e : ev_)
     if (!check(hipEventCreate(&e), "hipEventCreate")) return;
+  if (!check(hipEventCreate(&ev_upload_), "hipEventCreate")) return;
 
   std::vector<double2> tw2048(2048), tw1536(1536);
   std::vector<float2> twf(2048);
@@ -115,6 +116,9 @@ Engine::~Engine()
 {
   for (auto& e : ev_)
     if (e) (void)hipEventDestroy(e);
+  for (auto& e : chunk_ev_) (void)hipEventDestroy(e);
+  if (ev_upload_) (void)hipEventDestroy(ev_upload_);
+  if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -171,67 +175,62 @@ void Engine::build_batch(const std::vector<std::pair<int, const std::vector<int>
   }
 }
 
-// run gather + Viterbi over a batch, in slices that bound the decision buffer
-bool Engine::run_decode_batch(DecodeBatch& b, bool fic, const std::vector<DecodeJob>& jobs, const uint32_t* bits,
-                              const int* d_stream_cif_base, const uint32_t* prbs, uint8_t* out, int record_stride,
-                              float* gather_ms, float* viterbi_ms)
+// slices of wave-groups whose survivor records fit the cap; record offsets are per slice
+void Engine::plan_decode_batch(DecodeBatch& b)
 {
+  b.slice_start = {0};
+  b.max_dec_rows = 0;
+  int64_t dec_rows = 0;
   const int ng = static_cast<int>(b.groups.size());
-  if (ng == 0) return true;
-  // slices of groups whose survivor decisions fit the cap; offsets are per slice
-  std::vector<int> slice_start = {0};
-  std::vector<int64_t> slice_steps, slice_dec;
-  int64_t step_rows = 0, dec_rows = 0;
   for (int g = 0; g < ng; ++g) {
-    const int64_t dr = (b.groups[g].nsteps + 7) / 8 * 8, sr = 0;
-    if (g > slice_start.back() && dec_rows + dr > kMaxDecisionRows) {
-      slice_start.push_back(g);
-      slice_steps.push_back(step_rows);
-      slice_dec.push_back(dec_rows);
-      step_rows = dec_rows = 0;
+    const int64_t dr = (b.groups[g].nsteps + 7) / 8 * 8;
+    if (g > b.slice_start.back() && dec_rows + dr > kMaxDecisionRows) {
+      b.slice_start.push_back(g);
+      b.max_dec_rows = std::max(b.max_dec_rows, dec_rows);
+      dec_rows = 0;
     }
-    b.groups[g].step_base = step_rows;
+    b.groups[g].step_base = 0;
     b.groups[g].dec_base = dec_rows;
-    step_rows += sr;
     dec_rows += dr;
   }
-  slice_start.push_back(ng);
-  slice_steps.push_back(step_rows);
-  slice_dec.push_back(dec_rows);
-  const int64_t max_steps = *std::max_element(slice_steps.begin(), slice_steps.end());
-  const int64_t max_dec = *std::max_element(slice_dec.begin(), slice_dec.end());
-  if (!d_plans_.upload(plans_, stream_) || !d_groups_.upload(b.groups, stream_) || !d_job_ids_.upload(b.job_ids, stream_) ||
-      !d_jobs_.upload(jobs, stream_) || !d_steps_.reserve(static_cast<size_t>(max_steps) * 64) ||
-      !d_decisions_.reserve(static_cast<size_t>(max_dec) * 64))
-    return false;
-  const int* ids = b.job_ids.empty() ? nullptr : d_job_ids_.get();
+  b.slice_start.push_back(ng);
+  b.max_dec_rows = std::max(b.max_dec_rows, dec_rows);
+  b.job_ids.resize((b.job_ids.size() + 63) / 64 * 64, -1);     // tiles of 64 records
+}
+
+// work lists of a batch to the device (any stream: only the launches below consume them)
+bool Engine::upload_decode_batch(const DecodeBatch& b, const std::vector<DecodeJob>& jobs, hipStream_t s)
+{
+  if (b.groups.empty()) return true;
   const int row_words = kCifWords * (soft_bits_ ? 4 : 1);
-  {
-    b.job_ids.resize((b.job_ids.size() + 63) / 64 * 64, -1);
-    const int ntiles = static_cast<int>(b.job_ids.size() / 64);
-    if (!d_job_ids_.upload(b.job_ids, stream_) || !d_grouped_.reserve(static_cast<size_t>(ntiles) * row_words * 64)) return false;
-    ids = d_job_ids_.get();
-    (void)hipEventRecord(ev_[0], stream_);
-    if (!check(launch_regroup(soft_bits_, ids, ntiles, d_jobs_.get(), d_stream_cif_base, bits, d_grouped_.get(), stream_), "regroup launch")) return false;
-    (void)hipEventRecord(ev_[1], stream_);
-    if (!check(hipEventSynchronize(ev_[1]), "regroup")) return false;
-    float ms = 0;
-    if (gather_ms && hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) *gather_ms += ms;
-  }
-  for (size_t s = 0; s + 1 < slice_start.size(); ++s) {
-    const int g0 = slice_start[s], n = slice_start[s + 1] - g0;
-    (void)hipEventRecord(ev_[0], stream_);
-    (void)hipEventRecord(ev_[1], stream_);
+  const size_t ntiles = b.job_ids.size() / 64;
+  return d_plans_.upload(plans_, s) && d_groups_.upload(b.groups, s) && d_job_ids_.upload(b.job_ids, s) && d_jobs_.upload(jobs, s) &&
+         d_decisions_.reserve(static_cast<size_t>(b.max_dec_rows) * 64) && d_grouped_.reserve(ntiles * row_words * 64);
+}
+
+// regroup + Viterbi over an uploaded batch
+bool Engine::launch_decode_batch(const DecodeBatch& b, const uint32_t* bits, const int* d_stream_cif_base, const uint32_t* prbs, uint8_t* out,
+                                 int record_stride, float* gather_ms, float* viterbi_ms)
+{
+  if (b.groups.empty()) return true;
+  const int* ids = d_job_ids_.get();
+  const int row_words = kCifWords * (soft_bits_ ? 4 : 1);
+  const int ntiles = static_cast<int>(b.job_ids.size() / 64);
+  (void)hipEventRecord(ev_[0], stream_);
+  if (!check(launch_regroup(soft_bits_, ids, ntiles, d_jobs_.get(), d_stream_cif_base, bits, d_grouped_.get(), stream_), "regroup launch")) return false;
+  (void)hipEventRecord(ev_[1], stream_);
+  for (size_t sl = 0; sl + 1 < b.slice_start.size(); ++sl) {
+    const int g0 = b.slice_start[sl], n = b.slice_start[sl + 1] - g0;
     if (!check(launch_viterbi_fused(soft_bits_, d_groups_.get() + g0, n, ids, d_plans_.get(), d_grouped_.get(), row_words, d_decisions_.get(), prbs,
                                     out, record_stride, stream_),
                "viterbi launch"))
       return false;
-    (void)hipEventRecord(ev_[2], stream_);
-    if (!check(hipEventSynchronize(ev_[2]), "decode batch")) return false;
-    float ms = 0;
-    if (gather_ms && hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) *gather_ms += ms;
-    if (viterbi_ms && hipEventElapsedTime(&ms, ev_[1], ev_[2]) == hipSuccess) *viterbi_ms += ms;
   }
+  (void)hipEventRecord(ev_[2], stream_);
+  if (!check(hipEventSynchronize(ev_[2]), "decode batch")) return false;
+  float ms = 0;
+  if (gather_ms && hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) *gather_ms += ms;
+  if (viterbi_ms && hipEventElapsedTime(&ms, ev_[1], ev_[2]) == hipSuccess) *viterbi_ms += ms;
   return true;
 }
 
@@ -420,27 +419,30 @@ bool Engine::msc_prepare(const std::vector<const std::vector<EtiJob>*>& stream_j
   for (size_t l = 0; l < layouts.size(); ++l)
     for (int pid : layouts[l].plan_ids) plan_jobs.emplace_back(pid, &layout_frames[l]);
   build_batch(plan_jobs, out.batch);
+  plan_decode_batch(out.batch);
   return true;
 }
 
-bool Engine::msc_run(MscWork& w)
+// work lists, ETI header bytes and frame records of a prepared batch to the device; `s` may be a side stream
+bool Engine::msc_upload(const MscWork& w, hipStream_t s)
+{
+  if (w.nframes == 0) return true;
+  return d_eti_.reserve(w.nframes * kEtiBytes) && d_meta_.upload(w.meta, s) && d_headers_.upload(w.headers, s) &&
+         d_stream_cif_base_.upload(w.stream_row_base, s) && upload_decode_batch(w.batch, w.jobs, s);
+}
+
+bool Engine::msc_launch(const MscWork& w)
 {
   const size_t nf = w.nframes;
   if (nf == 0) return true;
   std::unique_lock<std::mutex> heavy;
   if (heavy_mu_) heavy = std::unique_lock<std::mutex>(*heavy_mu_);
-  const std::vector<DecodeJob>& jobs = w.jobs;
-  DecodeBatch& batch = w.batch;
-  const int header_stride = w.header_stride;
-  if (!d_eti_.reserve(nf * kEtiBytes) || !d_meta_.upload(w.meta, stream_) || !d_headers_.upload(w.headers, stream_) ||
-      !d_stream_cif_base_.upload(w.stream_row_base, stream_))
-    return false;
   if (!check(hipMemsetAsync(d_eti_.get(), 0x55, nf * kEtiBytes, stream_), "eti memset")) return false;   // padding, misc.c:295
-  if (!run_decode_batch(batch, false, jobs, d_msc_bits_.get(), d_stream_cif_base_.get(), d_prbs_.get(), d_eti_.get(), kEtiBytes,
-                        &times_.gather, &times_.viterbi))
+  if (!launch_decode_batch(w.batch, d_msc_bits_.get(), d_stream_cif_base_.get(), d_prbs_.get(), d_eti_.get(), kEtiBytes, &times_.gather,
+                           &times_.viterbi))
     return false;
   (void)hipEventRecord(ev_[0], stream_);
-  if (!check(launch_eti_finish(d_meta_.get(), static_cast<int>(nf), d_headers_.get(), header_stride, d_fibs_.get(), d_crc_tab_.get(), d_crc_shift_.get(), d_eti_.get(), stream_), "eti finish launch"))
+  if (!check(launch_eti_finish(d_meta_.get(), static_cast<int>(nf), d_headers_.get(), w.header_stride, d_fibs_.get(), d_crc_tab_.get(), d_crc_shift_.get(), d_eti_.get(), stream_), "eti finish launch"))
     return false;
   (void)hipEventRecord(ev_[1], stream_);
   if (!check(hipEventSynchronize(ev_[1]), "eti finish")) return false;
@@ -448,6 +450,8 @@ bool Engine::msc_run(MscWork& w)
   if (hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) times_.eti += ms;
   return true;
 }
+
+bool Engine::msc_run(MscWork& w) { return msc_upload(w, stream_) && msc_launch(w); }
 
 bool Engine::read_eti(int64_t first, int64_t n, uint8_t* dst)
 {
@@ -504,7 +508,7 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
              "sync scan launch"))
     return -1;
   (void)hipEventRecord(ev_[1], stream_);
-  h_descs_.resize(ndesc);
+  if (!h_descs_.resize(ndesc)) return -1;
   if (!check(hipMemcpyAsync(h_descs_.data(), d_descs_.get(), ndesc * sizeof(CallDesc), hipMemcpyDeviceToHost, stream_), "desc download") ||
       !check(hipMemcpyAsync(states.data(), d_states_.get(), states.size() * sizeof(StreamState), hipMemcpyDeviceToHost, stream_), "state download") ||
       !check(hipStreamSynchronize(stream_), "sync scan"))
@@ -548,7 +552,9 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
   if (heavy_mu_) heavy = std::unique_lock<std::mutex>(*heavy_mu_);
   const int chunk = std::min(ntf, kFftChunkTfs);
   if (!d_spectra_.reserve(static_cast<size_t>(chunk) * kSymbolsPerTf * 2048)) return -1;
-  std::vector<uint8_t> fibs(static_cast<size_t>(ntf) * 384), ok(static_cast<size_t>(ntf) * 12);
+  if (!h_fibs_.resize(static_cast<size_t>(ntf) * 384) || !h_fib_ok_.resize(static_cast<size_t>(ntf) * 12)) return -1;
+  uint8_t* const fibs = h_fibs_.data();
+  uint8_t* const ok = h_fib_ok_.data();
   (void)hipEventRecord(ev_[3], stream_);
   for (int first = 0; first < ntf; first += chunk * 19) {       // 4 of 76 symbols: 19 x as many TFs fit the spectra buffer
     const int n = std::min(chunk * 19, ntf - first);
@@ -557,7 +563,7 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
                "fic pre-pass launch"))
       return -1;
   }
-  if (!fic_decode_slots(0, ntf, fibs.data(), ok.data())) return -1;
+  if (!fic_decode_slots(0, ntf, fibs, ok)) return -1;
   {
     hipEvent_t end = ev_[0];
     (void)hipEventRecord(end, stream_);
@@ -572,11 +578,12 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
   bool host_ok = true;
   std::string host_error;
   std::thread host([&]() {
+    (void)hipSetDevice(device_);               // the current device is per thread
     const auto t0 = std::chrono::steady_clock::now();
     pool_->parallel_for(nstreams, [&](int b) {
       stream_jobs[b].reserve(static_cast<size_t>(4) * (tf_base[b + 1] - tf_base[b]));
       for (int s = tf_base[b]; s < tf_base[b + 1]; ++s)
-        planes[b].on_tf(s - tf_base[b], fibs.data() + static_cast<size_t>(s) * 384, ok.data() + static_cast<size_t>(s) * 12, stream_jobs[b]);
+        planes[b].on_tf(s - tf_base[b], fibs + static_cast<size_t>(s) * 384, ok + static_cast<size_t>(s) * 12, stream_jobs[b]);
     });
     std::vector<const ControlPlane*> plane_ptrs(nstreams);
     std::vector<const std::vector<EtiJob>*> job_ptrs(nstreams);
@@ -590,30 +597,39 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
     }
     times_.control = since(t0);
     const auto t1 = std::chrono::steady_clock::now();
-    host_ok = msc_prepare(job_ptrs, plane_ptrs, row_base, fib_base, work);
+    // the work lists go up on the side stream while the OFDM stage still runs on the main one
+    host_ok = msc_prepare(job_ptrs, plane_ptrs, row_base, fib_base, work) && msc_upload(work, copy_stream_) &&
+              check(hipEventRecord(ev_upload_, copy_stream_), "work list upload");
     if (!host_ok) host_error = dabhip_last_error();
     times_.worklist = since(t1);
   });
 
-  // K2 + K2b in chunks
+  // K2 + K2b in chunks (they share one spectra buffer; stream order keeps them apart), timed with per-chunk events
   bool gpu_ok = true;
-  for (int first = 0; first < ntf && gpu_ok; first += chunk) {
-    const int n = std::min(chunk, ntf - first);
-    (void)hipEventRecord(ev_[0], stream_);
+  const int nchunks = (ntf + chunk - 1) / chunk;
+  while (static_cast<int>(chunk_ev_.size()) < 3 * nchunks) {
+    hipEvent_t e = nullptr;
+    if (!check(hipEventCreate(&e), "hipEventCreate")) { gpu_ok = false; break; }
+    chunk_ev_.push_back(e);
+  }
+  for (int c = 0; c < nchunks && gpu_ok; ++c) {
+    const int first = c * chunk, n = std::min(chunk, ntf - first);
+    (void)hipEventRecord(chunk_ev_[3 * c], stream_);
     gpu_ok = check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(), stream_), "fft launch");
-    (void)hipEventRecord(ev_[1], stream_);
+    (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
     gpu_ok = gpu_ok && check(launch_demap(true, soft_bits_, d_spectra_.get(), first, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch");
-    (void)hipEventRecord(ev_[2], stream_);
-    gpu_ok = gpu_ok && check(hipEventSynchronize(ev_[2]), "fft/demap");
-    if (!gpu_ok) break;
-    float a = 0, c = 0;
-    (void)hipEventElapsedTime(&a, ev_[0], ev_[1]);
-    (void)hipEventElapsedTime(&c, ev_[1], ev_[2]);
+    (void)hipEventRecord(chunk_ev_[3 * c + 2], stream_);
+  }
+  gpu_ok = gpu_ok && check(hipStreamSynchronize(stream_), "fft/demap");
+  for (int c = 0; c < nchunks && gpu_ok; ++c) {
+    float a = 0, d = 0;
+    (void)hipEventElapsedTime(&a, chunk_ev_[3 * c], chunk_ev_[3 * c + 1]);
+    (void)hipEventElapsedTime(&d, chunk_ev_[3 * c + 1], chunk_ev_[3 * c + 2]);
     times_.fft += a;
-    times_.demap += c;
+    times_.demap += d;
     fft_ms_ += a;
     fft_launches_ += 1;
-    fft_tfs_ += n;
+    fft_tfs_ += std::min(chunk, ntf - c * chunk);
   }
   if (heavy.owns_lock()) heavy.unlock();
   host.join();
@@ -621,7 +637,7 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
   if (!host_ok) { set_error(host_error); return -1; }
 
   // K4 + K5
-  if (!msc_run(work)) return -1;
+  if (!check(hipStreamWaitEvent(stream_, ev_upload_, 0), "work list wait") || !msc_launch(work)) return -1;
   times_.wall = since(wall0);
   return total_eti_;
 }

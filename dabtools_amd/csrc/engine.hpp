@@ -67,6 +67,39 @@ class DeviceBuffer {
   size_t cap_ = 0;
 };
 
+// grow-only page-locked host allocation (device copies to and from it run at full PCIe rate and truly asynchronously)
+template <class T>
+class PinnedBuffer {
+ public:
+  PinnedBuffer() = default;
+  PinnedBuffer(const PinnedBuffer&) = delete;
+  PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+  ~PinnedBuffer() { if (p_) (void)hipHostFree(p_); }
+  bool resize(size_t n)
+  {
+    size_ = n;
+    if (n <= cap_) return true;
+    if (p_) (void)hipHostFree(p_);
+    p_ = nullptr;
+    cap_ = 0;
+    if (hipHostMalloc(reinterpret_cast<void**>(&p_), n * sizeof(T), hipHostMallocDefault) != hipSuccess) {
+      p_ = nullptr;
+      size_ = 0;
+      set_error("hipHostMalloc of " + std::to_string(n * sizeof(T)) + " bytes failed");
+      return false;
+    }
+    cap_ = n;
+    return true;
+  }
+  T* data() const { return p_; }
+  size_t size() const { return size_; }
+  T& operator[](size_t i) const { return p_[i]; }
+
+ private:
+  T* p_ = nullptr;
+  size_t cap_ = 0, size_ = 0;
+};
+
 struct StageTimes {
   float sync = 0, fft = 0, demap = 0, fic = 0, control = 0, gather = 0, viterbi = 0, eti = 0;
   float setup = 0, frames = 0, worklist = 0, wall = 0;   // host-side phases (wall clock)
@@ -75,7 +108,9 @@ struct StageTimes {
 // Work list for gather + Viterbi launches: wave-groups of <= 64 equal-length code words.
 struct DecodeBatch {
   std::vector<WaveGroup> groups;   // longest code words first
-  std::vector<int> job_ids;        // lanes of group g decode jobs job_ids[g.first .. g.first + g.count)
+  std::vector<int> job_ids;        // lanes of group g decode jobs job_ids[g.first .. g.first + g.count); padded to tiles of 64
+  std::vector<int> slice_start;    // launches: groups [slice_start[i], slice_start[i+1]) share the survivor-record buffer
+  int64_t max_dec_rows = 0;
 };
 
 // Everything the MSC decode of a set of ETI frames needs, prepared on the host (no GPU work)
@@ -142,6 +177,8 @@ class Engine {
   bool msc_prepare(const std::vector<const std::vector<EtiJob>*>& stream_jobs, const std::vector<const ControlPlane*>& planes,
                    const std::vector<int>& stream_row_base, const std::vector<int>& stream_fib_base, MscWork& out);
   bool msc_run(MscWork& w);
+  bool msc_upload(const MscWork& w, hipStream_t s);
+  bool msc_launch(const MscWork& w);
   bool read_eti(int64_t first, int64_t n, uint8_t* dst);
   // front end on an explicit single stream (S2 seam): calls [call, call+1)
   bool scan_one_call(const uint8_t* iq_virtual_base, int64_t fed_bytes, StreamState* d_state, int call, CallDesc* out);
@@ -152,10 +189,11 @@ class Engine {
   bool check(hipError_t e, const char* what);
   // plan_jobs[i] = (plan id, job indices decoded with that plan)
   void build_batch(const std::vector<std::pair<int, const std::vector<int>*>>& plan_jobs, DecodeBatch& out);
-  // fic = true: gather from FIC rows + step-byte Viterbi; fic = false: regroup logical CIF rows + fused Viterbi
-  bool run_decode_batch(DecodeBatch& b, bool fic, const std::vector<DecodeJob>& jobs, const uint32_t* bits,
-                        const int* d_stream_cif_base, const uint32_t* prbs, uint8_t* out, int record_stride, float* gather_ms,
-                        float* viterbi_ms);
+  // MSC decode batch: slices and record offsets (host), work lists to the device, regroup + fused Viterbi launches
+  void plan_decode_batch(DecodeBatch& b);
+  bool upload_decode_batch(const DecodeBatch& b, const std::vector<DecodeJob>& jobs, hipStream_t s);
+  bool launch_decode_batch(const DecodeBatch& b, const uint32_t* bits, const int* d_stream_cif_base, const uint32_t* prbs, uint8_t* out,
+                           int record_stride, float* gather_ms, float* viterbi_ms);
   int plan_id(const CodewordPlan& p);
   bool unpack_tf_slot(int slot, uint8_t* fic_bytes, uint8_t* msc_bytes);
 
@@ -165,8 +203,10 @@ class Engine {
   std::mutex* heavy_mu_ = nullptr;
   std::unique_ptr<ThreadPool> pool_;   // host threads for per-stream control-plane work
   int device_ = 0;
-  hipStream_t stream_ = nullptr;
+  hipStream_t stream_ = nullptr, copy_stream_ = nullptr;   // copy_stream_: work-list uploads from the control-plane thread
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_upload_ = nullptr;
+  std::vector<hipEvent_t> chunk_ev_;
 
   // constant tables
   DeviceBuffer<double2> d_tw2048_, d_tw1536_;
@@ -200,7 +240,8 @@ class Engine {
   std::vector<CodewordPlan> plans_;
   std::map<std::vector<int32_t>, int> plan_index_;
 
-  std::vector<CallDesc> h_descs_;
+  PinnedBuffer<CallDesc> h_descs_;
+  PinnedBuffer<uint8_t> h_fibs_, h_fib_ok_;
   int max_calls_ = 0, nstreams_ = 0;
   std::vector<int64_t> eti_base_, eti_count_;
   int64_t total_eti_ = 0;

@@ -108,16 +108,16 @@ __device__ __forceinline__ void all_pairs(const pk16 (&p)[32], pk16 (&n)[32], co
   (butterfly_pair<kTau, kRs>(p, n, bl, bh), ...);
 }
 
-// branch metrics of the 8 distinct code words (bit3 = bit0) for one trellis step
+// branch metrics of the 8 distinct code words (bit3 = bit0) for one trellis step, already x16 (kMetricShift)
 // hard decisions: agreement count with the received nibble v under the "transmitted" mask m (sb = v | m << 4)
 __device__ __forceinline__ void branch_metrics_hard(unsigned sb, int (&bm)[8])
 {
   const unsigned v = sb & 15u, m = (sb >> 4) & 15u;
-  const int ntx = __popc(m);
+  const int ntx = __popc(m) << kMetricShift;
 #pragma unroll
   for (unsigned c = 0; c < 4; ++c) {
     const unsigned cw = c | ((c & 1u) << 3);
-    bm[c] = __popc(~(v ^ cw) & m);
+    bm[c] = __popc(~(v ^ cw) & m) << kMetricShift;
     bm[c ^ 7] = ntx - bm[c];
   }
 }
@@ -131,8 +131,8 @@ __device__ __forceinline__ void branch_metrics_soft(unsigned nib16, int (&bm)[8]
   const int corr[4] = {a + rest, rest - a, a + diff, diff - a};   // code words 0..3: bit0 flips s0,s3; bit1 flips s1
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    bm[c] = 28 + corr[c];
-    bm[c ^ 7] = 28 - corr[c];
+    bm[c] = (28 << kMetricShift) + (corr[c] << kMetricShift);
+    bm[c ^ 7] = (28 << kMetricShift) - (corr[c] << kMetricShift);
   }
 }
 
@@ -144,7 +144,7 @@ __device__ __forceinline__ void acs_step_bm(const int (&bm)[8], const pk16 (&p)[
   pk16 bl[8], bh[8];
 #pragma unroll
   for (unsigned c = 0; c < 8; ++c) {
-    const uint32_t b = (static_cast<uint32_t>(bm[c]) | (static_cast<uint32_t>(bm[c ^ gamma]) << 16)) << kMetricShift;
+    const uint32_t b = static_cast<uint32_t>(bm[c]) | (static_cast<uint32_t>(bm[c ^ gamma]) << 16);
     bh[c] = as_pk(b);
     bl[c] = as_pk(b + tag);
   }
@@ -191,7 +191,7 @@ __device__ __forceinline__ void survivor_record(const pk16 (&n)[32], uint4* rec)
   for (int i = 0; i < 8; ++i) {
     const uint32_t pa = __builtin_amdgcn_perm(as_u32(n[4 * i + 1]), as_u32(n[4 * i]), 0x06040200u);       // low bytes of 4 halves
     const uint32_t pb = __builtin_amdgcn_perm(as_u32(n[4 * i + 3]), as_u32(n[4 * i + 2]), 0x06040200u);
-    d[i] = (pa & 0x0f0f0f0fu) | ((pb & 0x0f0f0f0fu) << 4);
+    d[i] = (pa & 0x0f0f0f0fu) | ((pb << 4) & 0xf0f0f0f0u);                                               // one v_bfi_b32
   }
   rec[0] = make_uint4(d[0], d[1], d[2], d[3]);
   rec[64] = make_uint4(d[4], d[5], d[6], d[7]);
