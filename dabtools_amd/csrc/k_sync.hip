@@ -48,27 +48,53 @@ __device__ __forceinline__ int rail(int byte) { return static_cast<int>(static_c
 
 __device__ __forceinline__ unsigned brev(unsigned x, int bits) { return __brev(x) >> (32 - bits); }
 
-// nbatch independent DFTs of size N = 1 << LOGN stored back to back in LDS, radix-2
-// decimation in frequency, in place; X[k] ends up at index brev(k).  sign = -1 forward.
-template <int LOGN>
-__device__ void dft_dif(double2* buf, int nbatch, double sign, const double2* tw2048)
+// nbatch independent DFTs of size N = 1 << LOGN stored back to back in LDS, radix-2 decimation in frequency, in
+// place; X[k] ends up at index brev(k).  sign = -1 forward.
+// The scan is a chain of dependent LDS round trips with only 2 waves per SIMD to hide them, so L consecutive
+// radix-2 levels are fused: a thread holds the 2^L points it needs in registers, runs the L levels on them (the same
+// butterflies, in the same order of operations as level-by-level radix 2) and meets the others at ONE barrier.
+template <int LOGN, int L>
+__device__ __forceinline__ void dif_levels(double2* buf, int nbatch, int s, double sign, const double2* tw2048)
 {
-  constexpr int N = 1 << LOGN;
-  for (int s = 0; s < LOGN; ++s) {
-    const int half = N >> (s + 1);
-    for (int idx = threadIdx.x; idx < nbatch * (N / 2); idx += kThreads) {
-      const int batch = idx / (N / 2), j = idx % (N / 2);
-      const int blk = j / half, k = j % half;
-      const int a = batch * N + blk * 2 * half + k, b = a + half;
-      const double2 A = buf[a], B = buf[b];
-      double2 w = tw2048[k * (1024 / half)];
-      w.y *= sign;
-      const double dr = A.x - B.x, di = A.y - B.y;
-      buf[a] = make_double2(A.x + B.x, A.y + B.y);
-      buf[b] = make_double2(dr * w.x - di * w.y, dr * w.y + di * w.x);
+  constexpr int N = 1 << LOGN, R = 1 << L;
+  const int ms = N >> s;                         // size of the sub-transforms at level s
+  const int q = ms >> L;                         // distance between the points one thread holds
+  constexpr int per_batch = N >> L;
+  for (int idx = threadIdx.x; idx < nbatch * per_batch; idx += kThreads) {
+    const int batch = idx / per_batch, w = idx % per_batch;
+    const int blk = w / q, k = w % q;
+    double2* x = buf + batch * N + blk * ms + k;
+    double2 r[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) r[j] = x[j * q];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int span = R >> (l + 1);             // partner distance in units of q
+      const int half = ms >> (l + 1);
+      const int twstep = 1024 / half;
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        if (j & span) continue;
+        const int pos = k + (j & (span - 1)) * q;          // index of the butterfly inside its sub-transform
+        const double2 A = r[j], B = r[j + span];
+        double2 tw = tw2048[pos * twstep];
+        tw.y *= sign;
+        const double dr = A.x - B.x, di = A.y - B.y;
+        r[j] = make_double2(A.x + B.x, A.y + B.y);
+        r[j + span] = make_double2(dr * tw.x - di * tw.y, dr * tw.y + di * tw.x);
+      }
     }
-    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < R; ++j) x[j * q] = r[j];
   }
+  __syncthreads();
+}
+
+template <int LOGN, int... Ls>
+__device__ __forceinline__ void dft_dif(double2* buf, int nbatch, double sign, const double2* tw2048)
+{
+  int s = 0;
+  ((dif_levels<LOGN, Ls>(buf, nbatch, s, sign, tw2048), s += Ls), ...);
 }
 
 constexpr int kWaves = kThreads / 64;
@@ -256,14 +282,14 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
           A[n] = view_sample(stream, view, p, nco);
         }
         __syncthreads();
-        dft_dif<11>(A, 1, -1.0, tw);
+        dft_dif<11, 3, 3, 3, 2>(A, 1, -1.0, tw);
         for (int i = tid; i < kCarriers; i += kThreads) {
           const int bin = i < 768 ? i + 1280 : i - 765;
           const double2 c = mul_conj_prs(A[brev(bin, 11)], prs_q[i]);
           Bf[(i % 3) * 512 + i / 3] = c;       // decimate by 3 for the 3 x 512 inverse DFT
         }
         __syncthreads();
-        dft_dif<9>(Bf, 3, +1.0, tw);
+        dft_dif<9, 3, 3, 3>(Bf, 3, +1.0, tw);
         float fv = -99999.0f;
         int fi = 0x7fffffff;
         for (int kk = tid; kk < kCarriers; kk += kThreads) {
@@ -287,7 +313,7 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
           A[n] = view_sample(stream, view, p, nco);
         }
         __syncthreads();
-        dft_dif<11>(A, 1, -1.0, tw);
+        dft_dif<11, 3, 3, 3, 2>(A, 1, -1.0, tw);
         for (int idx = tid; idx < 29 * 128; idx += kThreads) {
           const int kk = idx / 128 - 14, s = idx % 128;
           const int shifted = 14 + kk + 256 + s;              // index into the fftshifted spectrum
@@ -295,7 +321,7 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
           Bf[idx] = mul_conj_prs(A[brev(bin, 11)], prs_q[14 + s]);
         }
         __syncthreads();
-        dft_dif<7>(Bf, 29, +1.0, tw);
+        dft_dif<7, 3, 2, 2>(Bf, 29, +1.0, tw);
         // per-offset maximum |.|, then first maximum over offsets
         float cv = -99999.0f;
         int ci = 0x7fffffff;
