@@ -33,22 +33,27 @@ FFT_PMC_BYTES_PER_TF = (2 * 165800 + 1259500) * 1024 // 1024   # KiB per 1024 TF
 REALTIME_FPS = 1000.0 / 24.0
 
 
-def make_streams(torch, dev, nstreams, ntf, ndistinct, rank, snr_db=1000.0):
-    """ndistinct different synthetic ensembles generated on the host cores, tiled to nstreams on the device."""
+def make_streams(torch, dev, nstreams, ntf, ndistinct, rank, snr_db=1000.0, host_synth=False):
+    """nstreams synthetic ensembles resident on the device.  Default: every stream its own ensemble (payload, CIF
+    counter, noise), modulated by the device-side modulator (k_synth.hip).  --host-synth: the host generator,
+    ndistinct ensembles tiled to nstreams (the round-1 recipe; slow beyond a few streams)."""
     import dabtools_amd as dab
 
     from dabtools_amd import shard
 
-    def gen(i):   # global stream index of this rank's i-th distinct ensemble -> seed rule of SURVEY.md 8(d)
+    def cfg_of(i):   # global stream index of this rank's i-th ensemble -> seed rule of SURVEY.md 8(d)
         g = rank * nstreams + i
-        cfg = dab.synth_preset(0, seed=shard.stream_seed(2, g), cif_count0=(97 * g) % 5000, snr_db=snr_db)
-        return dab.synth_generate(cfg, ntf)
+        return dab.synth_preset(0, seed=shard.stream_seed(2, g), cif_count0=(97 * g) % 5000, snr_db=snr_db)
 
-    with ThreadPoolExecutor(max_workers=min(8, ndistinct)) as ex:
-        host = list(ex.map(gen, range(ndistinct)))
-    base = [torch.from_numpy(h).to(dev) for h in host]
-    tensors = [base[i] if i < ndistinct else base[i % ndistinct].clone() for i in range(nstreams)]
-    return host, tensors
+    if host_synth:
+        with ThreadPoolExecutor(max_workers=min(8, ndistinct)) as ex:
+            host = list(ex.map(lambda i: dab.synth_generate(cfg_of(i), ntf), range(ndistinct)))
+        base = [torch.from_numpy(h).to(dev) for h in host]
+        return [base[i] if i < ndistinct else base[i % ndistinct].clone() for i in range(nstreams)], ndistinct
+    cfgs = [cfg_of(i) for i in range(nstreams)]
+    tensors = [torch.empty(dab.synth_bytes(c, ntf), dtype=torch.uint8, device=dev) for c in cfgs]
+    dab.synth_generate_device(cfgs, ntf, [t.data_ptr() for t in tensors], dev.index or 0)
+    return tensors, nstreams
 
 
 def payload_stats(dab, eng, first_global_stream, nstreams, ntf):
@@ -146,7 +151,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
     ap.add_argument("--tfs", type=int, default=64, help="transmission frames per stream")
-    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic ensembles generated on the host")
+    ap.add_argument("--host-synth", action="store_true", help="modulate on the host (--distinct ensembles, tiled) instead of on the GPU")
+    ap.add_argument("--distinct", type=int, default=16, help="with --host-synth: distinct ensembles generated on the host")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--snr", type=float, default=1000.0, help="AWGN SNR in dB over the 2.048 MHz band (BASELINE config 5: 5 dB); default: clean")
     ap.add_argument("--soft", action="store_true", help="soft-decision decoding (extension; default: hard = reference semantics)")
@@ -165,7 +171,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    host, tensors = make_streams(torch, dev, args.streams, args.tfs, min(args.distinct, args.streams), rank, args.snr)
+    t_gen = time.perf_counter()
+    tensors, ndistinct = make_streams(torch, dev, args.streams, args.tfs, min(args.distinct, args.streams), rank, args.snr, args.host_synth)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
     ptrs = [t.data_ptr() for t in tensors]
     sizes = [t.numel() for t in tensors]
     eng = dab.Engine(local_rank)
@@ -203,7 +212,8 @@ def main():
             "value": value, "unit": "ETI frames/s", "x_realtime": value / REALTIME_FPS,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic (%d distinct ensembles per GPU tiled to %d streams)" % (min(args.distinct, args.streams), args.streams),
+            "vs_baseline": None, "dtype": "u8", "data": ("synthetic (%d distinct ensembles per GPU tiled to %d streams, host modulator)" % (ndistinct, args.streams)) if args.host_synth
+                    else ("synthetic (%d distinct ensembles per GPU, device-side modulator, %.1f s)" % (args.streams, t_gen)),
             "config": {"workload": "BASELINE configs[2]: batch=%d synthetic Mode-I streams x %d TF per GPU, 12 sub-channels (6 UEP + 6 EEP) 1136 kbit/s full MSC"
                                    % (args.streams, args.tfs),
                        "streams_per_gpu": args.streams, "tf_per_stream": args.tfs, "eti_frames_per_step": total_frames_per_step,
@@ -221,9 +231,9 @@ def main():
         if args.snr < 100.0:
             out["config"]["snr_db"] = args.snr
             out["config"]["decisions"] = "soft (4-bit)" if args.soft else "hard"
-            out["payload"] = payload_stats(dab, eng, rank * args.streams, min(args.distinct, args.streams), args.tfs)
+            out["payload"] = payload_stats(dab, eng, rank * args.streams, min(16, args.streams), args.tfs)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host, args.tfs)
+            out["cpu_baseline"] = cpu_baseline([t.cpu().numpy() for t in tensors[:10]], args.tfs)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -84,6 +84,7 @@ _SIGNATURES = {
     "dabhip_synth_generate": (C.c_int64, [C.POINTER(SynthCfg), C.c_int, u8p, C.c_size_t]),
     "dabhip_synth_payload": (C.c_int, [C.POINTER(SynthCfg), C.c_int, C.c_int, u8p, C.c_int]),
     "dabhip_synth_fibs": (C.c_int, [C.POINTER(SynthCfg), C.c_int, u8p]),
+    "dabhip_synth_generate_device": (C.c_int, [C.POINTER(SynthCfg), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int]),
 }
 
 _lib = None
@@ -149,6 +150,17 @@ def synth_generate(cfg, ntf):
     got = lib().dabhip_synth_generate(C.byref(cfg), ntf, _p(iq), n)
     _need(got == n, "synth_generate")
     return iq
+
+
+def synth_bytes(cfg, ntf):
+    return lib().dabhip_synth_bytes(C.byref(cfg), ntf)
+
+
+def synth_generate_device(cfgs, ntf, ptrs, device=0):
+    """Modulate the ensembles cfgs on the GPU into the device buffers at ptrs (ints; synth_bytes(cfg, ntf) bytes each)."""
+    arr = (SynthCfg * len(cfgs))(*cfgs)
+    p = (C.c_void_p * len(ptrs))(*ptrs)
+    _need(lib().dabhip_synth_generate_device(arr, len(cfgs), ntf, p, device) == 0, "synth_generate_device")
 
 
 def synth_payload(cfg, cif_index, slot):

@@ -444,3 +444,10 @@ int dabhip_host_control_replay(const uint8_t* fibs, const uint8_t* crc_ok, int n
 }
 
 }  // extern "C"
+
+// ---- device-side modulator (k_synth.hip) ------------------------------------------------------
+namespace dabhip { int synth_generate_device(const dabhip_synth_cfg* cfgs, int nstreams, int ntf, uint8_t* const* iq, int device); }
+extern "C" int dabhip_synth_generate_device(const dabhip_synth_cfg* cfgs, int nstreams, int ntf, uint8_t* const* iq, int device)
+{
+  return dabhip::synth_generate_device(cfgs, nstreams, ntf, iq, device);
+}

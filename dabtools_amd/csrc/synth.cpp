@@ -11,6 +11,7 @@
 #include "../../include/dabhip.h"
 #include "dab_bits.hpp"
 #include "dab_tables.hpp"
+#include "synth.hpp"
 
 namespace dabhip {
 void set_error(const std::string& msg);
@@ -225,6 +226,35 @@ struct Gauss {
 };
 
 }  // namespace
+
+uint64_t synth_noise_key(uint64_t seed, uint64_t ctr, uint64_t which) { return key(seed, kDomNoise, ctr, which); }
+
+bool synth_validate(const dabhip_synth_cfg& cfg) { return validate(cfg); }
+
+double synth_noise_rms(const dabhip_synth_cfg& cfg)
+{
+  return cfg.snr_db >= 100.0 ? 0.0 : cfg.amplitude * std::sqrt(static_cast<double>(kCarriers)) / std::pow(10.0, cfg.snr_db / 20.0) / std::sqrt(2.0);
+}
+
+SymbolBits::SymbolBits(const dabhip_synth_cfg& cfg) : cfg_(cfg), window_(16, std::vector<uint8_t>(kCifBits))
+{
+  for (int r = -15; r < 0; ++r) logical_cif(cfg_, r, window_[(r + 16) & 15].data());
+}
+
+void SymbolBits::next_tf(uint8_t* symbits)
+{
+  static const int tmap[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+  for (int q = 0; q < 4; ++q) {
+    const int c = 4 * tf_ + q;
+    fic_bits_of_cif(cfg_, c, symbits + 2304 * q);
+    logical_cif(cfg_, c, window_[c & 15].data());
+    // time interleaving: inverse of misc.c:29-39 (tx CIF c carries logical CIF c - map[i&15])
+    uint8_t* txcif = symbits + 3 * kBitsPerSym + static_cast<size_t>(q) * kCifBits;
+    for (int i = 0; i < kCifBits; ++i) txcif[i] = window_[(c - tmap[i & 15]) & 15][i];
+  }
+  ++tf_;
+}
+
 }  // namespace dabhip
 
 using namespace dabhip;
@@ -285,18 +315,12 @@ extern "C" int64_t dabhip_synth_generate(const dabhip_synth_cfg* cfg, int ntf, u
   const size_t total = dabhip_synth_bytes(cfg, ntf);
   if (cap < total) { set_error("synth_generate: buffer too small"); return -1; }
 
-  static const int tmap[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
   const auto& qpsk_of_carrier = carrier_to_qpsk();
   const auto& prs = prs_quarter_turns();
-  // logical CIFs -15 .. ncif-1, kept in a sliding window of 16
-  std::vector<std::vector<uint8_t>> window(16, std::vector<uint8_t>(kCifBits));
-  for (int r = -15; r < 0; ++r) logical_cif(*cfg, r, window[(r + 16) & 15].data());
-
-  const double noise_rms_rail =
-      cfg->snr_db >= 100.0 ? 0.0 : cfg->amplitude * std::sqrt(static_cast<double>(kCarriers)) / std::pow(10.0, cfg->snr_db / 20.0) / std::sqrt(2.0);
+  SymbolBits bits(*cfg);                                                  // logical CIFs in a sliding window of 16
+  const double noise_rms_rail = synth_noise_rms(*cfg);
   Gauss gauss{cfg->seed};
   std::vector<uint8_t> symbits(static_cast<size_t>(kBitsPerSym) * 75);   // data symbols 1..75 of one TF
-  std::vector<uint8_t> txcif(kCifBits);
   std::vector<double> re(2048), im(2048);
   std::vector<uint8_t> phase(kCarriers);                                  // in eighth turns
   static const double c8[8] = {1, M_SQRT1_2, 0, -M_SQRT1_2, -1, -M_SQRT1_2, 0, M_SQRT1_2};
@@ -321,14 +345,7 @@ extern "C" int64_t dabhip_synth_generate(const dabhip_synth_cfg* cfg, int ntf, u
   };
 
   for (int tf = 0; tf < ntf; ++tf) {
-    for (int q = 0; q < 4; ++q) {
-      const int c = 4 * tf + q;
-      fic_bits_of_cif(*cfg, c, symbits.data() + 2304 * q);
-      logical_cif(*cfg, c, window[c & 15].data());
-      // time interleaving: inverse of misc.c:29-39 (tx CIF c carries logical CIF c - map[i&15])
-      for (int i = 0; i < kCifBits; ++i) txcif[i] = window[(c - tmap[i & 15]) & 15][i];
-      std::memcpy(symbits.data() + 3 * kBitsPerSym + static_cast<size_t>(q) * kCifBits, txcif.data(), kCifBits);
-    }
+    bits.next_tf(symbits.data());
     for (int n = 0; n < kNullSamples; ++n) emit(0, 0);
     for (int l = 0; l < kSymbolsPerTf; ++l) {
       if (l == 0) {

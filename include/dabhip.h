@@ -13,7 +13,7 @@
  *   S3  back-end seam     dab.h:91-92 (+ eti_callback dab.h:88)    -> dabhip_dab_*
  *   batch engine (new: B independent ensembles resident in HBM)    -> dabhip_engine_*
  *   stage entries for parity tests                                 -> dabhip_stage_*
- *   synthetic Mode-I modulator (host only, workload generator)     -> dabhip_synth_*
+ *   synthetic Mode-I modulator (workload generator; host, or on the GPU) -> dabhip_synth_*
  */
 #ifndef DABHIP_H
 #define DABHIP_H
@@ -188,6 +188,11 @@ int64_t dabhip_synth_generate(const dabhip_synth_cfg *cfg, int ntf, uint8_t *iq,
 int dabhip_synth_payload(const dabhip_synth_cfg *cfg, int cif_index, int slot, uint8_t *out, int cap);
 /* The 96 FIB bytes (3 FIBs with CRC) carried by CIF n. */
 int dabhip_synth_fibs(const dabhip_synth_cfg *cfg, int cif_index, uint8_t *out96);
+/* Device-side modulator (needs a GPU): the ensembles cfgs[0..nstreams) modulated on `device`
+ * straight into DEVICE buffers iq[i] of dabhip_synth_bytes(&cfgs[i], ntf) bytes each.  The bit content comes from the
+ * same generator as dabhip_synth_generate; samples may differ from the host generator's by one LSB where fp32 and
+ * fp64 round apart, and the AWGN uses the same keyed generator.  Returns 0, <0 on error. */
+int dabhip_synth_generate_device(const dabhip_synth_cfg *cfgs, int nstreams, int ntf, uint8_t *const *iq, int device);
 
 #ifdef __cplusplus
 }
