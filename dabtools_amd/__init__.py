@@ -84,6 +84,16 @@ _SIGNATURES = {
     "dabhip_synth_generate": (C.c_int64, [C.POINTER(SynthCfg), C.c_int, u8p, C.c_size_t]),
     "dabhip_synth_payload": (C.c_int, [C.POINTER(SynthCfg), C.c_int, C.c_int, u8p, C.c_int]),
     "dabhip_synth_fibs": (C.c_int, [C.POINTER(SynthCfg), C.c_int, u8p]),
+    "dabhip_stream_create": (C.c_void_p, [C.c_int, C.c_int]),
+    "dabhip_stream_destroy": (None, [C.c_void_p]),
+    "dabhip_stream_feed": (C.c_int64, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int]),
+    "dabhip_stream_eti_count": (C.c_int64, [C.c_void_p, C.c_int]),
+    "dabhip_stream_eti_read": (C.c_int64, [C.c_void_p, C.c_int, u8p, C.c_int64]),
+    "dabhip_stream_eti_drain": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dabhip_stream_set_afc": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_stream_set_soft": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "dabhip_host_free": (None, [C.c_void_p]),
     "dabhip_synth_generate_device": (C.c_int, [C.POINTER(SynthCfg), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int]),
 }
 
@@ -394,3 +404,46 @@ class Engine:
 
     def __del__(self):
         self.close()
+
+
+class Stream:
+    """Streaming session (dabhip_stream_*): B unbounded captures decoded segment by segment; the concatenated ETI
+    frames equal one Engine.decode of the whole captures."""
+
+    def __init__(self, nstreams, device=0, afc=False, soft=False):
+        self._h = lib().dabhip_stream_create(device, nstreams)
+        _need(self._h, "stream_create")
+        self.nstreams = nstreams
+        if afc:
+            _need(lib().dabhip_stream_set_afc(self._h, 1) == 0, "stream_set_afc")
+        if soft:
+            _need(lib().dabhip_stream_set_soft(self._h, 1) == 0, "stream_set_soft")
+
+    def feed(self, segments):
+        """segments: one numpy uint8 array (possibly empty) per stream -> ETI frames produced by this segment."""
+        arrs = [np.ascontiguousarray(s, dtype=np.uint8) for s in segments]
+        _need(len(arrs) == self.nstreams, "stream_feed: one segment per stream")
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        sizes = (C.c_size_t * len(arrs))(*[a.size for a in arrs])
+        n = lib().dabhip_stream_feed(self._h, ptrs, sizes, 0)
+        _need(n >= 0, "stream_feed")
+        return n
+
+    def eti(self, stream):
+        n = lib().dabhip_stream_eti_count(self._h, stream)
+        _need(n >= 0, "stream_eti_count")
+        out = np.zeros((n, ETI_BYTES), dtype=np.uint8)
+        if n:
+            _need(lib().dabhip_stream_eti_read(self._h, stream, _p(out), n) == n, "stream_eti_read")
+        return out
+
+    def close(self):
+        if self._h:
+            lib().dabhip_stream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

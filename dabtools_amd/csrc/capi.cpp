@@ -451,3 +451,92 @@ extern "C" int dabhip_synth_generate_device(const dabhip_synth_cfg* cfgs, int ns
 {
   return dabhip::synth_generate_device(cfgs, nstreams, ntf, iq, device);
 }
+
+// ---- streaming sessions -----------------------------------------------
+// B parallel unbounded streams decoded segment by segment.  Per stream the session keeps a device window holding the
+// bytes the front end may still read (FIFO backlog and stale-tail sources, Engine::stream_need_from) followed by the
+// new segment; windows ping-pong between two allocations so that the kept bytes never overlap their destination.
+struct dabhip_stream {
+  Engine eng;
+  int n = 0;
+  bool first = true;
+  std::vector<std::unique_ptr<DeviceBuffer<uint8_t>>> win[2];
+  std::vector<int> cur;
+  std::vector<int64_t> base, avail;
+  dabhip_stream(int device, int nstreams) : eng(device), n(nstreams), cur(nstreams, 0), base(nstreams, 0), avail(nstreams, 0)
+  {
+    for (int s = 0; s < 2; ++s)
+      for (int b = 0; b < nstreams; ++b) win[s].emplace_back(new DeviceBuffer<uint8_t>());
+  }
+};
+
+extern "C" dabhip_stream* dabhip_stream_create(int device, int nstreams)
+{
+  if (nstreams <= 0) { set_error("stream_create: no streams"); return nullptr; }
+  dabhip_stream* s = new dabhip_stream(device, nstreams);
+  if (!s->eng.ok()) { delete s; return nullptr; }
+  return s;
+}
+extern "C" void dabhip_stream_destroy(dabhip_stream* s) { delete s; }
+extern "C" int dabhip_stream_set_afc(dabhip_stream* s, int on) { if (!s) return -1; s->eng.set_afc(on != 0); return 0; }
+extern "C" int dabhip_stream_set_soft(dabhip_stream* s, int on)
+{
+  if (!s) return -1;
+  if (!s->first) { set_error("stream_set_soft: only before the first segment"); return -1; }
+  s->eng.set_soft(on != 0);
+  return 0;
+}
+
+extern "C" int64_t dabhip_stream_feed(dabhip_stream* s, const uint8_t* const* iq, const size_t* nbytes, int on_device)
+{
+  if (!s || !iq || !nbytes) { set_error("stream_feed: null argument"); return -1; }
+  if (hipSetDevice(s->eng.device()) != hipSuccess) { set_error("stream_feed: hipSetDevice failed"); return -1; }
+  std::vector<const uint8_t*> virt(s->n);
+  std::vector<size_t> avail(s->n);
+  for (int b = 0; b < s->n; ++b) {
+    const int64_t need = s->first ? 0 : std::min(s->eng.stream_need_from(b), s->avail[b]);
+    const size_t kept = static_cast<size_t>(s->avail[b] - need), total = kept + nbytes[b];
+    DeviceBuffer<uint8_t>& from = *s->win[s->cur[b]][b];
+    DeviceBuffer<uint8_t>& to = *s->win[s->cur[b] ^ 1][b];
+    if (!to.reserve(std::max<size_t>(total, 16))) return -1;
+    if (kept && hipMemcpyAsync(to.get(), from.get() + (need - s->base[b]), kept, hipMemcpyDeviceToDevice, s->eng.stream()) != hipSuccess) { set_error("stream_feed: window move failed"); return -1; }
+    if (nbytes[b] && hipMemcpyAsync(to.get() + kept, iq[b], nbytes[b], on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->eng.stream()) != hipSuccess) { set_error("stream_feed: segment upload failed"); return -1; }
+    s->cur[b] ^= 1;
+    s->base[b] = need;
+    s->avail[b] += static_cast<int64_t>(nbytes[b]);
+    virt[b] = to.get() - need;           // byte x of the stream lives at virt[b][x]
+    avail[b] = static_cast<size_t>(s->avail[b]);
+  }
+  const int64_t frames = s->eng.feed(virt.data(), avail.data(), s->n, s->first);
+  if (frames >= 0) s->first = false;
+  return frames;
+}
+extern "C" int64_t dabhip_stream_eti_count(const dabhip_stream* s, int stream) { return s ? s->eng.eti_count(stream) : -1; }
+extern "C" int64_t dabhip_stream_eti_read(dabhip_stream* s, int stream, uint8_t* dst, int64_t cap_frames)
+{
+  if (!s || !dst) { set_error("stream_eti_read: null argument"); return -1; }
+  return s->eng.eti_read(stream, dst, cap_frames);
+}
+extern "C" int64_t dabhip_stream_eti_drain(dabhip_stream* s, dabhip_eti_sink sink, void* user)
+{
+  if (!s || !sink) { set_error("stream_eti_drain: null argument"); return -1; }
+  int64_t total = 0;
+  std::vector<uint8_t> buf;
+  for (int b = 0; b < s->n; ++b) {
+    const int64_t n = s->eng.eti_count(b);
+    if (n < 0) return -1;
+    buf.resize(static_cast<size_t>(n) * DABHIP_ETI_BYTES);
+    if (n && s->eng.eti_read(b, buf.data(), n) != n) return -1;
+    for (int64_t f = 0; f < n; ++f) sink(buf.data() + f * DABHIP_ETI_BYTES, b, user);
+    total += n;
+  }
+  return total;
+}
+// page-locked host memory for the segments handed to dabhip_stream_feed (read the next one while this one decodes)
+extern "C" void* dabhip_host_alloc(size_t nbytes)
+{
+  void* p = nullptr;
+  if (hipHostMalloc(&p, nbytes, hipHostMallocDefault) != hipSuccess) { set_error("host_alloc: hipHostMalloc failed"); return nullptr; }
+  return p;
+}
+extern "C" void dabhip_host_free(void* p) { if (p) (void)hipHostFree(p); }

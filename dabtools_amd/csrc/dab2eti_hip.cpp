@@ -3,14 +3,25 @@
 //
 //   dab2eti-hip capture.cu8 [more.cu8 ...] > ensemble.eti
 //
+//   rtl_sdr -f 220352000 -s 2048000 - | dab2eti-hip - > ensemble.eti         (streaming: "-" = stdin)
+//   dab2eti-hip --stream [--segment-calls N] huge.cu8 > ensemble.eti
+//
+// Streaming mode (any input "-", or --stream) decodes unbounded input in segments of N 262,144-byte calls (default
+// 64 = 16 MiB) through a dabhip_stream session: a reader thread fills one page-locked buffer while the GPU decodes the
+// other, frames leave as soon as their segment is done, memory stays bounded, output bytes are those of the one-shot mode.
+//
 // Each file is one 2.048 Msps cu8 IQ capture (I at even bytes, Q at odd bytes), replayed in
 // 262,144-byte calls exactly as librtlsdr would deliver it (dab2eti.c:117-130,238), without tuner
 // feedback (a file has no tuner).  Several files are decoded as one batch of
 // independent ensembles; their frames are emitted file by file.
 #include <unistd.h>
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/dabhip.h"
@@ -25,14 +36,87 @@ void to_stdout(const uint8_t* eti, int /*stream*/, void* /*user*/)
     done += static_cast<size_t>(n);
   }
 }
+
+// streaming mode: double-buffered page-locked segments, one reader thread
+int run_streaming(const std::vector<const char*>& names, size_t seg_bytes)
+{
+  const int n = static_cast<int>(names.size());
+  std::vector<FILE*> in(n);
+  for (int i = 0; i < n; ++i) {
+    in[i] = std::strcmp(names[i], "-") == 0 ? stdin : std::fopen(names[i], "rb");
+    if (!in[i]) { std::perror(names[i]); return 1; }
+  }
+  dabhip_stream* s = dabhip_stream_create(0, n);
+  if (!s) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); return 2; }
+  uint8_t* buf[2];
+  for (auto& b : buf)
+    if (!(b = static_cast<uint8_t*>(dabhip_host_alloc(seg_bytes * n)))) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); return 2; }
+  std::vector<size_t> got[2] = {std::vector<size_t>(n, 0), std::vector<size_t>(n, 0)};
+  std::mutex mu;
+  std::condition_variable cv;
+  int filled[2] = {0, 0};          // 0 = free, 1 = full, 2 = full and last
+  std::thread reader([&]() {
+    std::vector<bool> eof(n, false);
+    for (int k = 0;; k ^= 1) {
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return filled[k] == 0; }); }
+      bool any = false, all_eof = true;
+      for (int i = 0; i < n; ++i) {
+        size_t done = 0;
+        while (!eof[i] && done < seg_bytes) {
+          const size_t r = std::fread(buf[k] + seg_bytes * i + done, 1, seg_bytes - done, in[i]);
+          if (r == 0) eof[i] = true;
+          done += r;
+        }
+        got[k][i] = done;
+        any = any || done;
+        all_eof = all_eof && eof[i];
+      }
+      { std::lock_guard<std::mutex> lk(mu); filled[k] = all_eof ? 2 : 1; }
+      cv.notify_all();
+      if (all_eof) return;
+      (void)any;
+    }
+  });
+  std::vector<long long> total(n, 0);
+  int rc = 0;
+  for (int k = 0;; k ^= 1) {
+    int state;
+    { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return filled[k] != 0; }); state = filled[k]; }
+    std::vector<const uint8_t*> ptrs(n);
+    for (int i = 0; i < n; ++i) ptrs[i] = buf[k] + seg_bytes * i;
+    const int64_t frames = dabhip_stream_feed(s, ptrs.data(), got[k].data(), 0);
+    if (frames < 0 || dabhip_stream_eti_drain(s, to_stdout, nullptr) != frames) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); rc = 2; }
+    for (int i = 0; i < n && rc == 0; ++i) total[i] += dabhip_stream_eti_count(s, i);
+    { std::lock_guard<std::mutex> lk(mu); filled[k] = 0; }
+    cv.notify_all();
+    if (state == 2 || rc) break;
+  }
+  if (rc) std::_Exit(rc);          // the reader may be blocked in fread
+  reader.join();
+  for (int i = 0; i < n; ++i) std::fprintf(stderr, "%s: %lld ETI frames\n", names[i], total[i]);
+  for (auto& b : buf) dabhip_host_free(b);
+  dabhip_stream_destroy(s);
+  return 0;
+}
 }  // namespace
 
 int main(int argc, char** argv)
 {
-  if (argc < 2) {
-    std::fprintf(stderr, "Usage: dab2eti-hip capture.cu8 [more.cu8 ...] > out.eti\n");
+  bool streaming = false;
+  size_t seg_calls = 64;
+  std::vector<const char*> names;
+  for (int i = 1; i < argc; ++i) {
+    if (std::strcmp(argv[i], "--stream") == 0) streaming = true;
+    else if (std::strcmp(argv[i], "--segment-calls") == 0 && i + 1 < argc) seg_calls = static_cast<size_t>(std::max(1, std::atoi(argv[++i])));
+    else { names.push_back(argv[i]); streaming = streaming || std::strcmp(argv[i], "-") == 0; }
+  }
+  if (names.empty()) {
+    std::fprintf(stderr, "Usage: dab2eti-hip [--stream] [--segment-calls N] capture.cu8|- [more.cu8 ...] > out.eti\n");
     return 1;
   }
+  if (streaming) return run_streaming(names, seg_calls * 262144);
+  argc = static_cast<int>(names.size()) + 1;
+  for (int i = 1; i < argc; ++i) argv[i] = const_cast<char*>(names[i - 1]);
   std::vector<std::vector<uint8_t>> files;
   for (int i = 1; i < argc; ++i) {
     FILE* f = std::fopen(argv[i], "rb");

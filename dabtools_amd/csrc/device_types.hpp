@@ -71,6 +71,14 @@ struct WaveGroup {
   int64_t dec_base;      // row offset into the decision buffer (rows of 64 x 8 bytes)
 };
 
+// One piece of a batched device-to-device copy (sizes are multiples of 4 bytes, pointers 4-byte aligned)
+struct CopyDesc {
+  const uint8_t* src;
+  uint8_t* dst;
+  uint32_t nbytes;
+  uint32_t pad;
+};
+
 // Per ETI frame: what eti_finish_kernel needs besides the decoded sub-channel data.
 constexpr int kEtiHeaderMax = 272;   // 8 + 4*64 + 4 bytes of SYNC/FC/STC/EOH, rounded up
 struct EtiFrameMeta {

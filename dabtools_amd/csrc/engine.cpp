@@ -460,7 +460,75 @@ bool Engine::read_eti(int64_t first, int64_t n, uint8_t* dst)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Session carry-over: the FIC blocks, FIBs and CRC flags of each stream's last carry_keep_ TF slots and its logical CIF rows
+// from 15 before the oldest kept CIF move from the previous segment's layout to the front of the stream's part of the new
+// one (through a dense temporary: the buffers may be re-allocated in between).
+bool Engine::carry_and_reserve(const std::vector<int>& tf_base, const std::vector<int>& row_base, int nslots, int nrows)
+{
+  const size_t bits = soft_bits_ ? 4 : 1;
+  const size_t unit[4] = {kFicWords * 4 * bits, 384, 12, kCifWords * 4 * bits};
+  std::vector<CopyDesc> out, in;
+  size_t tmp_bytes = 0;
+  const int n = static_cast<int>(carry_keep_.size());
+  uint8_t* base[4] = {reinterpret_cast<uint8_t*>(d_fic_bits_.get()), d_fibs_.get(), d_fib_ok_.get(), reinterpret_cast<uint8_t*>(d_msc_bits_.get())};
+  struct Piece { int which; size_t src, dst, bytes, tmp; };
+  std::vector<Piece> pieces;
+  for (int b = 0; b < n; ++b) {
+    const int keep = carry_keep_[b];
+    if (keep == 0) continue;
+    const size_t src_slot = static_cast<size_t>(prev_tf_base_[b]) + prev_used_[b] - keep, dst_slot = tf_base[b];
+    for (int w = 0; w < 3; ++w) {
+      pieces.push_back(Piece{w, src_slot * unit[w], dst_slot * unit[w], keep * unit[w], tmp_bytes});
+      tmp_bytes += (keep * unit[w] + 15) & ~size_t(15);
+    }
+    const size_t src_row = static_cast<size_t>(prev_row_base_[b]) - kRowLead + 4 * (prev_used_[b] - keep), dst_row = static_cast<size_t>(row_base[b]) - kRowLead;
+    const size_t rows = 4 * static_cast<size_t>(keep) + kRowLead;
+    pieces.push_back(Piece{3, src_row * unit[3], dst_row * unit[3], rows * unit[3], tmp_bytes});
+    tmp_bytes += rows * unit[3];
+  }
+  if (!pieces.empty()) {
+    if (!d_carry_.reserve(tmp_bytes)) return false;
+    for (const Piece& p : pieces) out.push_back(CopyDesc{base[p.which] + p.src, d_carry_.get() + p.tmp, static_cast<uint32_t>(p.bytes)});
+    if (!d_copy_descs_.upload(out, stream_) || !check(launch_batched_copy(d_copy_descs_.get(), static_cast<int>(out.size()), stream_), "carry out") ||
+        !check(hipStreamSynchronize(stream_), "carry out"))
+      return false;
+  }
+  if (!reserve_tf_slots(nslots, nrows)) return false;
+  if (!pieces.empty()) {
+    uint8_t* nbase[4] = {reinterpret_cast<uint8_t*>(d_fic_bits_.get()), d_fibs_.get(), d_fib_ok_.get(), reinterpret_cast<uint8_t*>(d_msc_bits_.get())};
+    for (const Piece& p : pieces) in.push_back(CopyDesc{d_carry_.get() + p.tmp, nbase[p.which] + p.dst, static_cast<uint32_t>(p.bytes)});
+    if (!d_copy_descs_.upload(in, stream_) || !check(launch_batched_copy(d_copy_descs_.get(), static_cast<int>(in.size()), stream_), "carry in"))
+      return false;
+  }
+  return true;
+}
+
 int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device)
+{
+  return decode_impl(iq, nbytes, nstreams, on_device, false);
+}
+
+// Streaming continuation: iq[b] are DEVICE pointers positioned so that iq[b][x] is byte x of stream b counted from the
+// start of the session (only the bytes stream_need_from(b) .. avail[b] have to be backed by memory); avail[b] = bytes
+// of the stream received so far.  Decodes the calls that became complete since the previous segment; state carried:
+// the front-end state (K1), the lock / CIF-ring state of the control plane, the FIC blocks and FIBs of the last 4 TFs
+// and the partly filled logical CIF rows.  The ETI frames of all segments concatenated equal those of one decode().
+int64_t Engine::feed(const uint8_t* const* iq, const size_t* avail, int nstreams, bool first_segment)
+{
+  return decode_impl(iq, avail, nstreams, true, !first_segment);
+}
+
+int64_t Engine::stream_need_from(int b) const
+{
+  if (b < 0 || b >= static_cast<int>(h_states_.size())) return 0;
+  const StreamState& st = h_states_[b];
+  int64_t need = st.consumed;
+  for (int i = 0; i < st.view.nseg; ++i)
+    if (st.view.seg_src[i] >= 0) need = std::min(need, st.view.seg_src[i] + (i ? st.view.seg_end[i - 1] : 0));
+  return std::max<int64_t>(need, 0) & ~int64_t(1);
+}
+
+int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont)
 {
   if (!ok_) { set_error("engine not initialised (no GPU?)"); return -1; }
   if (nstreams <= 0) { set_error("decode: no streams"); return -1; }
@@ -470,10 +538,20 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
   times_ = StageTimes{};
   fft_launches_ = fft_tfs_ = 0;
   fft_ms_ = 0;
+  if (cont && (nstreams != nstreams_ || static_cast<int>(planes_.size()) != nstreams)) { set_error("feed: the number of streams changed within a session"); return -1; }
   nstreams_ = nstreams;
   eti_base_.assign(nstreams, 0);
   eti_count_.assign(nstreams, 0);
   total_eti_ = 0;
+  if (!cont) {
+    planes_.assign(nstreams, ControlPlane());
+    carry_keep_.assign(nstreams, 0);
+    prev_used_.assign(nstreams, 0);
+    calls_done_.assign(nstreams, 0);
+    ord_done_.assign(nstreams, 0);
+    prev_tf_base_.assign(nstreams + 1, 0);
+    prev_row_base_.assign(nstreams, 0);
+  }
 
   std::vector<const uint8_t*> ptrs(nstreams);
   std::vector<int64_t> nb(nstreams);
@@ -481,7 +559,7 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
   size_t total = 0;
   for (int b = 0; b < nstreams; ++b) {
     nb[b] = static_cast<int64_t>(nbytes[b]);
-    max_calls_ = std::max<int>(max_calls_, static_cast<int>(nbytes[b] / kChunkBytes));
+    max_calls_ = std::max<int>(max_calls_, static_cast<int>(nbytes[b] / kChunkBytes) - calls_done_[b]);
     total += (nbytes[b] + 15) & ~size_t(15);
   }
   if (on_device) {
@@ -495,15 +573,19 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
       off += (nbytes[b] + 15) & ~size_t(15);
     }
   }
-  std::vector<StreamState> states(nstreams, initial_state());
+  std::vector<StreamState>& states = h_states_;
   const size_t ndesc = static_cast<size_t>(nstreams) * max_calls_;
-  if (!d_iq_ptrs_.upload(ptrs, stream_) || !d_nbytes_.upload(nb, stream_) || !d_states_.upload(states, stream_) || !d_descs_.reserve(ndesc)) return -1;
+  if (!cont) {
+    states.assign(nstreams, initial_state());
+    if (!d_states_.upload(states, stream_)) return -1;
+  }
+  if (!d_iq_ptrs_.upload(ptrs, stream_) || !d_nbytes_.upload(nb, stream_) || !d_descs_.reserve(ndesc)) return -1;
   if (!check(hipMemsetAsync(d_descs_.get(), 0, ndesc * sizeof(CallDesc), stream_), "desc memset")) return -1;
 
   times_.setup = since(wall0);
   // K1
   (void)hipEventRecord(ev_[0], stream_);
-  if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), nstreams, max_calls_, 0, -1,
+  if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), nstreams, max_calls_, -1, -1,
                               d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), afc_ ? 1 : 0, stream_),
              "sync scan launch"))
     return -1;
@@ -517,32 +599,37 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
   for (const StreamState& st : states)
     if (st.overflow) { set_error("sync scan: stale-tail bookkeeping overflow (more than kMaxSeg nested short reads)"); return -1; }
 
-  // frame list: demodulated TFs, stream-major
+  // frame list: demodulated TFs, stream-major.  Slots and logical CIF rows of a stream: first the ones carried over from
+  // the previous segment of a session (the last <= 4 TFs), then this segment's.
   const auto tfr = std::chrono::steady_clock::now();
   std::vector<int2> frames;
-  std::vector<int> frame_slot, frame_cif_row, tf_base(nstreams + 1, 0), row_base(nstreams), fib_base(nstreams);
+  std::vector<int> frame_slot, frame_cif_row, tf_base(nstreams + 1, 0), row_base(nstreams), fib_base(nstreams), nnew(nstreams, 0);
   int next_row = 0;
   for (int b = 0; b < nstreams; ++b) {
     int n = 0;
-    const int ncalls = static_cast<int>(nbytes[b] / kChunkBytes);
+    const int keep = carry_keep_[b];
+    const int ncalls = static_cast<int>(nbytes[b] / kChunkBytes) - calls_done_[b];
     for (int k = 0; k < ncalls; ++k) {
       const CallDesc& d = h_descs_[static_cast<size_t>(b) * max_calls_ + k];
       if (d.status == 2) {
+        const int local = keep + (d.ordinal - ord_done_[b]);
         frames.push_back(make_int2(b, k));
-        frame_slot.push_back(tf_base[b] + d.ordinal);
-        frame_cif_row.push_back(next_row + kRowLead + 4 * d.ordinal);
+        frame_slot.push_back(tf_base[b] + local);
+        frame_cif_row.push_back(next_row + kRowLead + 4 * local);
         ++n;
       }
     }
-    tf_base[b + 1] = tf_base[b] + n;
+    nnew[b] = n;
+    tf_base[b + 1] = tf_base[b] + keep + n;
     fib_base[b] = 4 * tf_base[b];
     row_base[b] = next_row + kRowLead;      // each stream gets 15 lead-in rows for the scatter of its first CIFs
-    next_row += kRowLead + 4 * n;
+    next_row += kRowLead + 4 * (keep + n);
   }
-  const int ntf = static_cast<int>(frames.size());
-  if (ntf == 0) return 0;
-  if (!reserve_tf_slots(ntf, next_row + 1) || !d_frames_.upload(frames, stream_) || !d_frame_slot_.upload(frame_slot, stream_) ||
-      !d_frame_cif_row_.upload(frame_cif_row, stream_))
+  for (int b = 0; b < nstreams; ++b) calls_done_[b] = std::max(calls_done_[b], static_cast<int>(nbytes[b] / kChunkBytes));
+  const int ntf = static_cast<int>(frames.size()), nslots = tf_base[nstreams];
+  if (ntf == 0) return 0;                   // nothing demodulated: layout and carried data stay as they are
+  if (!carry_and_reserve(tf_base, row_base, nslots, next_row + 1) || !d_frames_.upload(frames, stream_) ||
+      !d_frame_slot_.upload(frame_slot, stream_) || !d_frame_cif_row_.upload(frame_cif_row, stream_))
     return -1;
 
   times_.frames = since(tfr);
@@ -552,7 +639,7 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
   if (heavy_mu_) heavy = std::unique_lock<std::mutex>(*heavy_mu_);
   const int chunk = std::min(ntf, kFftChunkTfs);
   if (!d_spectra_.reserve(static_cast<size_t>(chunk) * kSymbolsPerTf * 2048)) return -1;
-  if (!h_fibs_.resize(static_cast<size_t>(ntf) * 384) || !h_fib_ok_.resize(static_cast<size_t>(ntf) * 12)) return -1;
+  if (!h_fibs_.resize(static_cast<size_t>(nslots) * 384) || !h_fib_ok_.resize(static_cast<size_t>(nslots) * 12)) return -1;
   uint8_t* const fibs = h_fibs_.data();
   uint8_t* const ok = h_fib_ok_.data();
   (void)hipEventRecord(ev_[3], stream_);
@@ -563,7 +650,7 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
                "fic pre-pass launch"))
       return -1;
   }
-  if (!fic_decode_slots(0, ntf, fibs, ok)) return -1;
+  if (!fic_decode_slots(0, nslots, fibs, ok)) return -1;      // carried slots are decoded again: their FIBs are read by K5
   {
     hipEvent_t end = ev_[0];
     (void)hipEventRecord(end, stream_);
@@ -572,7 +659,7 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
   }
 
   // control plane + work lists on a host thread, hidden behind K2 + K2b
-  std::vector<ControlPlane> planes(nstreams);
+  std::vector<ControlPlane>& planes = planes_;
   std::vector<std::vector<EtiJob>> stream_jobs(nstreams);
   MscWork work;
   bool host_ok = true;
@@ -581,8 +668,9 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
     (void)hipSetDevice(device_);               // the current device is per thread
     const auto t0 = std::chrono::steady_clock::now();
     pool_->parallel_for(nstreams, [&](int b) {
-      stream_jobs[b].reserve(static_cast<size_t>(4) * (tf_base[b + 1] - tf_base[b]));
-      for (int s = tf_base[b]; s < tf_base[b + 1]; ++s)
+      stream_jobs[b].reserve(static_cast<size_t>(4) * nnew[b]);
+      planes[b].rebase(4 * (prev_used_[b] - carry_keep_[b]));   // CIF numbering of this segment's layout
+      for (int s = tf_base[b] + carry_keep_[b]; s < tf_base[b + 1]; ++s)
         planes[b].on_tf(s - tf_base[b], fibs + static_cast<size_t>(s) * 384, ok + static_cast<size_t>(s) * 12, stream_jobs[b]);
     });
     std::vector<const ControlPlane*> plane_ptrs(nstreams);
@@ -638,6 +726,14 @@ int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstre
 
   // K4 + K5
   if (!check(hipStreamWaitEvent(stream_, ev_upload_, 0), "work list wait") || !msc_launch(work)) return -1;
+  // what the next segment of a session starts from
+  for (int b = 0; b < nstreams; ++b) {
+    prev_used_[b] = carry_keep_[b] + nnew[b];
+    carry_keep_[b] = std::min(4, prev_used_[b]);
+    ord_done_[b] += nnew[b];
+  }
+  prev_tf_base_ = tf_base;
+  prev_row_base_ = row_base;
   times_.wall = since(wall0);
   return total_eti_;
 }

@@ -143,6 +143,9 @@ class Engine {
 
   // -- batch path ---------------------------------------------------------------------------
   int64_t decode(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device);
+  // -- streaming sessions: decode() of an unbounded stream, one segment at a time ------------
+  int64_t feed(const uint8_t* const* iq_virtual, const size_t* avail, int nstreams, bool first_segment);
+  int64_t stream_need_from(int stream) const;   // oldest stream byte the next segment may still read
   int64_t eti_count(int stream) const;
   int64_t eti_read(int stream, uint8_t* dst, int64_t cap_frames);
   const uint8_t* eti_device(int64_t* nframes) const;
@@ -184,9 +187,12 @@ class Engine {
   bool scan_one_call(const uint8_t* iq_virtual_base, int64_t fed_bytes, StreamState* d_state, int call, CallDesc* out);
   bool demod_one_frame(const uint8_t* iq_virtual_base, const CallDesc& desc, uint8_t* fic_bytes, uint8_t* msc_bytes);
   hipStream_t stream() const { return stream_; }
+  int device() const { return device_; }
 
  private:
   bool check(hipError_t e, const char* what);
+  int64_t decode_impl(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont);
+  bool carry_and_reserve(const std::vector<int>& tf_base, const std::vector<int>& row_base, int nslots, int nrows);
   // plan_jobs[i] = (plan id, job indices decoded with that plan)
   void build_batch(const std::vector<std::pair<int, const std::vector<int>*>>& plan_jobs, DecodeBatch& out);
   // MSC decode batch: slices and record offsets (host), work lists to the device, regroup + fused Viterbi launches
@@ -236,6 +242,13 @@ class Engine {
   DeviceBuffer<EtiFrameMeta> d_meta_;
   DeviceBuffer<uint8_t> d_headers_, d_eti_, d_bytes_;
   int tf_slots_ = 0, msc_rows_ = 0;
+
+  // session state (decode() resets it, feed() continues it)
+  std::vector<ControlPlane> planes_;
+  std::vector<StreamState> h_states_;
+  std::vector<int> carry_keep_, prev_used_, calls_done_, ord_done_, prev_tf_base_, prev_row_base_;
+  DeviceBuffer<uint8_t> d_carry_;
+  DeviceBuffer<CopyDesc> d_copy_descs_;
 
   std::vector<CodewordPlan> plans_;
   std::map<std::vector<int32_t>, int> plan_index_;

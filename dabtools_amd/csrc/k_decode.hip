@@ -506,6 +506,17 @@ __global__ __launch_bounds__(64, 4) void viterbi_fused_kernel(const WaveGroup* _
 }
 
 // ---------------------------------------------------------------------------------------
+// batched device-to-device copy (session carry-over of slots and rows): grid (piece, slice)
+__global__ __launch_bounds__(256) void batched_copy_kernel(const CopyDesc* __restrict__ descs)
+{
+  const CopyDesc d = descs[blockIdx.x];
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(d.src);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(d.dst);
+  const uint32_t nw = d.nbytes >> 2;
+  for (uint32_t i = blockIdx.y * 256u + threadIdx.x; i < nw; i += gridDim.y * 256u) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------------------
 // CRC of the 12 FIBs of each TF (misc.c:145-150)
 __device__ __forceinline__ uint16_t crc16_step(uint16_t crc, uint8_t byte, const uint16_t* tab)
 {
@@ -575,6 +586,13 @@ __global__ __launch_bounds__(256) void eti_finish_kernel(const EtiFrameMeta* __r
 }
 
 }  // namespace
+
+hipError_t launch_batched_copy(const CopyDesc* descs, int n, hipStream_t stream)
+{
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(batched_copy_kernel, dim3(n, 16), dim3(256), 0, stream, descs);
+  return hipGetLastError();
+}
 
 hipError_t launch_viterbi(const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans, const uint4* steps,
                           uint2* decisions, const uint32_t* prbs_words, uint8_t* out, int record_stride, hipStream_t stream)

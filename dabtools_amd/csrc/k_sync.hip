@@ -193,11 +193,14 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
   const uint8_t* stream = iq[b];
   const int64_t total_calls = nbytes[b] / kChunkBytes;
   const int kend = call_end < 0 ? static_cast<int>(total_calls) : min(call_end, static_cast<int>(total_calls));
+  // call_begin < 0: continue where the stream's state stands (calls already fed), descriptors numbered from there
+  const int kfirst = call_begin >= 0 ? call_begin : static_cast<int>(states[b].fed / kChunkBytes);
+  const int kdesc0 = call_begin >= 0 ? 0 : kfirst;
   if (tid == 0) { sh.st = states[b]; sh.fine_fs = sh.st.fine_freq_shift; }
   for (int i = tid; i < 1024; i += kThreads) tw[i] = tw2048[i];
   __syncthreads();
 
-  for (int k = call_begin; k < kend; ++k) {
+  for (int k = kfirst; k < kend; ++k) {
     // ---- FIFO bookkeeping: input_sdr.c:36-55 over sdr_fifo.c:43-61 --------------------
     if (tid == 0) {
       StreamState& st = sh.st;
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
     }
     __syncthreads();
     if (tid == 0) {
-      CallDesc& d = descs[static_cast<size_t>(b) * max_calls + k];
+      CallDesc& d = descs[static_cast<size_t>(b) * max_calls + (k - kdesc0)];
       d.status = sh.status;
       d.ordinal = sh.status == 2 ? sh.st.next_ordinal++ : -1;
       d.coarse_timeshift = sh.st.coarse_timeshift;

@@ -116,6 +116,28 @@ int dabhip_engine_set_afc(dabhip_engine *e, int enable);
  * without errors and is better (lower BER) at low SNR. */
 int dabhip_engine_set_soft(dabhip_engine *e, int enable);
 
+/* ---- streaming sessions ---------------------------------------------
+ * The batch engine over UNBOUNDED streams: B parallel captures fed segment by segment (stdin, a socket, a file too
+ * large for the device).  The state dab2eti keeps between calls -- FIFO backlog and stale frame tail (sdr_fifo.c),
+ * timing corrections (input_sdr.c:36-112), lock counter and the 16-CIF ring (dab.c:35-98) -- is carried on the device and
+ * in the host control plane, so the ETI frames of all segments, concatenated, are byte-identical to one
+ * dabhip_engine_decode() of the whole capture, whatever the segment sizes (they need not be multiples of 262144).
+ * After each feed the frames of THAT segment are read with the eti_* calls below. */
+typedef struct dabhip_stream dabhip_stream;
+dabhip_stream *dabhip_stream_create(int device, int nstreams);
+void dabhip_stream_destroy(dabhip_stream *s);
+/* Append nbytes[b] bytes to stream b (host pointers, or device pointers when on_device != 0) and decode every
+ * 262144-byte call that became complete.  Returns the ETI frames produced by this segment, <0 on error. */
+int64_t dabhip_stream_feed(dabhip_stream *s, const uint8_t *const *iq, const size_t *nbytes, int on_device);
+int64_t dabhip_stream_eti_count(const dabhip_stream *s, int stream);
+int64_t dabhip_stream_eti_read(dabhip_stream *s, int stream, uint8_t *dst, int64_t cap_frames);
+int64_t dabhip_stream_eti_drain(dabhip_stream *s, dabhip_eti_sink sink, void *user);
+int dabhip_stream_set_afc(dabhip_stream *s, int enable);
+int dabhip_stream_set_soft(dabhip_stream *s, int enable);   /* before the first segment only */
+/* Page-locked host memory for segments: fill the next one while the current one decodes (double buffering). */
+void *dabhip_host_alloc(size_t nbytes);
+void dabhip_host_free(void *p);
+
 /* Per sdr_demod call trace of one stream, for parity with the reference's state after each
  * call: {ok, frame_read, coarse_timeshift, fine_timeshift, coarse_freq_shift, fifo_count}
  * as int32[6] per call plus fine_freq_shift as double per call. */

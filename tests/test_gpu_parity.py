@@ -303,6 +303,12 @@ def test_cli_stdout_contract(tmp_path):
     out = subprocess.run([exe] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
     got = np.frombuffer(out, dtype=np.uint8).reshape(-1, 6144)
     assert np.array_equal(got, np.concatenate(want))
+    # streaming mode: stdin, small segments, bounded memory -- the same bytes
+    with open(files[1], "rb") as f:
+        out = subprocess.run([exe, "--segment-calls", "5", "-"], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    assert np.array_equal(np.frombuffer(out, dtype=np.uint8).reshape(-1, 6144), want[1])
+    out = subprocess.run([exe, "--stream", files[0]], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    assert np.array_equal(np.frombuffer(out, dtype=np.uint8).reshape(-1, 6144), want[0])
 
 
 def test_engine_e2e_low_snr_lock_loss(engine):
@@ -523,3 +529,47 @@ def test_device_modulator_matches_host_generator_and_decodes():
         want, _ = ol.or_replay(g)
         assert np.array_equal(eng.eti(i), want)
     assert len(eng.eti(0)) == 4 * (ntf - 15)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("soft", [False, True])
+def test_streaming_session_equals_one_shot_decode(soft):
+    """captures fed to a session in segments of arbitrary size (not multiples of the 262144-byte
+    call, ragged across streams, some empty) give, concatenated, the ETI frames of one decode of the whole captures --
+    for an aligned stream, a mid-frame start, a noisy one that loses lock, and one with a coarse resync."""
+    ntf = 34
+    cfgs = [dab.synth_preset(1, seed=21), dab.synth_preset(0, seed=22, skip_samples=77777, cif_count0=4995),
+            dab.synth_preset(1, seed=23, snr_db=7.5), dab.synth_preset(1, seed=24, skip_samples=150001)]
+    caps = [dab.synth_generate(c, ntf) for c in cfgs]
+    caps[3] = np.concatenate([caps[3][:9 * 393216 + 1000], caps[3][9 * 393216 + 61000:]])   # 30000 samples vanish: coarse resync
+    eng = dab.Engine(0)
+    eng.set_soft(soft)
+    eng.decode(caps)
+    want = [eng.eti(i) for i in range(len(caps))]
+    assert len(want[0]) == 4 * (ntf - 15) and len(want[3]) > 0
+    if not soft:
+        for c, w in zip(caps, want):
+            assert np.array_equal(w, ol.or_replay(c)[0])
+    rng = np.random.default_rng(5)
+    for trial, sizes in enumerate([[262144 * 12] * 4, [1000003, 3 * 262144, 5000000, 262144 * 7 + 2], None]):
+        st = dab.Stream(len(caps), soft=soft)
+        pos = [0] * len(caps)
+        got = [[] for _ in caps]
+        nseg = 0
+        while any(p < c.size for p, c in zip(pos, caps)):
+            segs = []
+            for b, c in enumerate(caps):
+                n = sizes[b] if sizes else int(rng.choice([0, 2, 300000, 262144 * 3, 393216 * 5 + 6, 4000000]))
+                n -= n & 1
+                segs.append(c[pos[b]:pos[b] + n])
+                pos[b] += segs[-1].size
+            total = st.feed(segs)
+            nseg += 1
+            per = [st.eti(b) for b in range(len(caps))]
+            assert total == sum(len(p) for p in per)
+            for b, p in enumerate(per):
+                got[b].append(p)
+        assert nseg > 3
+        for b in range(len(caps)):
+            assert np.array_equal(np.concatenate(got[b]), want[b]), "trial %d stream %d" % (trial, b)
+        st.close()
