@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdabhip.so")
+LIB_PATH = os.environ.get("DABHIP_LIB") or os.path.join(_HERE, "libdabhip.so")   # override: experiments with another build
 
 TF_BYTES = 393216
 CHUNK_BYTES = 262144
@@ -84,6 +84,7 @@ _SIGNATURES = {
     "dabhip_synth_generate": (C.c_int64, [C.POINTER(SynthCfg), C.c_int, u8p, C.c_size_t]),
     "dabhip_synth_payload": (C.c_int, [C.POINTER(SynthCfg), C.c_int, C.c_int, u8p, C.c_int]),
     "dabhip_synth_fibs": (C.c_int, [C.POINTER(SynthCfg), C.c_int, u8p]),
+    "dabhip_engine_set_fused": (C.c_int, [C.c_void_p, C.c_int]),
     "dabhip_stream_create": (C.c_void_p, [C.c_int, C.c_int]),
     "dabhip_stream_destroy": (None, [C.c_void_p]),
     "dabhip_stream_feed": (C.c_int64, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int]),
@@ -312,6 +313,10 @@ class Engine:
     def set_soft(self, enable):
         """Soft-decision decoding (4-bit soft values into the Viterbi metrics); off = parity mode."""
         _need(lib().dabhip_engine_set_soft(self._h, 1 if enable else 0) == 0, "set_soft")
+
+    def set_fused(self, enable):
+        """One kernel for OFDM transform + demap (spectra never written); identical output; off = default pipeline."""
+        _need(lib().dabhip_engine_set_fused(self._h, 1 if enable else 0) == 0, "set_fused")
 
     def decode(self, streams):
         """streams: list of numpy uint8 arrays (host) -> total ETI frames."""

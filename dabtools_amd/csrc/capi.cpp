@@ -201,6 +201,12 @@ int dabhip_engine_set_soft(dabhip_engine* e, int enable)
   for (auto& l : e->lanes) l->set_soft(enable != 0);
   return 0;
 }
+int dabhip_engine_set_fused(dabhip_engine* e, int enable)
+{
+  if (!e) return -1;
+  for (auto& l : e->lanes) l->set_fused(enable != 0);
+  return 0;
+}
 int dabhip_engine_fft_stats(const dabhip_engine* e, int64_t* launches, int64_t* tfs, double* ms)
 {
   if (!e) return -1;

@@ -703,9 +703,16 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   for (int c = 0; c < nchunks && gpu_ok; ++c) {
     const int first = c * chunk, n = std::min(chunk, ntf - first);
     (void)hipEventRecord(chunk_ev_[3 * c], stream_);
-    gpu_ok = check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(), stream_), "fft launch");
-    (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
-    gpu_ok = gpu_ok && check(launch_demap(true, soft_bits_, d_spectra_.get(), first, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch");
+    if (fused_ && soft_bits_ == 0) {
+      gpu_ok = check(launch_ofdm_demap_fused(afc_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_twf_.get(), d_frame_slot_.get(),
+                                             d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_),
+                     "fused fft/demap launch");
+      (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
+    } else {
+      gpu_ok = check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(), stream_), "fft launch");
+      (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
+      gpu_ok = gpu_ok && check(launch_demap(true, soft_bits_, d_spectra_.get(), first, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch");
+    }
     (void)hipEventRecord(chunk_ev_[3 * c + 2], stream_);
   }
   gpu_ok = gpu_ok && check(hipStreamSynchronize(stream_), "fft/demap");

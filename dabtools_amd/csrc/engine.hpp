@@ -139,6 +139,9 @@ class Engine {
   void set_afc(bool on) { afc_ = on; }
   // soft-decision decoding (not in the reference): 4-bit soft values from the demapper through
   // de-interleaving and de-puncturing into the Viterbi branch metrics.  Batch path only; off = parity mode.
+  // K2 + K2b as one kernel that never writes the spectra (k_fused.hip; hard decisions only).  Off by default: the default
+  // pipeline keeps the HBM-roofline stage K2 separate; the output bits are identical either way.
+  void set_fused(bool on) { fused_ = on; }
   void set_soft(bool on) { soft_bits_ = on ? 4 : 0; tf_slots_ = 0; msc_rows_ = 0; }
 
   // -- batch path ---------------------------------------------------------------------------
@@ -204,7 +207,7 @@ class Engine {
   bool unpack_tf_slot(int slot, uint8_t* fic_bytes, uint8_t* msc_bytes);
 
   bool ok_ = false;
-  bool afc_ = false;
+  bool afc_ = false, fused_ = false;
   int soft_bits_ = 0;
   std::mutex* heavy_mu_ = nullptr;
   std::unique_ptr<ThreadPool> pool_;   // host threads for per-stream control-plane work

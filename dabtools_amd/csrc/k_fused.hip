@@ -1,0 +1,259 @@
+// k_fused.hip — K2 and K2b in one pass (optional variant, hard decisions): the 2048-point transforms of k_fft.hip with the
+// differential demodulation, hard QPSK demap, frequency de-interleave (input_sdr.c:132-162) and the time-de-interleaving
+// scatter of demap_kernel<true, 1> applied to the bins while they are still in registers.  The complex64 spectra are never
+// written: per TF the kernel reads 311,296 B of IQ and writes 28,800 B of bits, so it is NOT the HBM-roofline stage
+// (reported separately from the K2 roofline number, never instead of it).  Output bits are identical to
+// ofdm_fft_kernel + demap_kernel: same butterflies, same products, same comparisons.
+#include <hip/hip_runtime.h>
+
+#include "dab_tables.hpp"
+#include "device_types.hpp"
+#include "fft_core.hpp"
+#include "kernels.hpp"
+
+namespace dabhip {
+namespace {
+
+// the transform of k_fft.hip's fft2048_store with the bins left in registers:
+// x[k3] = bin 2 tid + 512 k3, y[k3] = bin 2 tid + 1 + 512 k3
+__device__ __forceinline__ void fft2048_first(float2 (&v)[8], float2* bufP, const Twiddles& tw)
+{
+  const int tid = threadIdx.x;
+  dft8(v);
+#pragma unroll
+  for (int q = 1; q < 8; ++q) v[q] = cmul(v[q], tw.s1[q - 1]);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) bufP[q * 256 + tid] = v[q];
+  __syncthreads();
+}
+__device__ __forceinline__ void fft2048_rest(float2 (&v)[8], float2* bufP, float2* bufQ, const Twiddles& tw, float2 (&x)[4], float2 (&y)[4])
+{
+  const int tid = threadIdx.x;
+  {
+    const int q = tid >> 5, t1 = tid & 31;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = bufP[q * 256 + t1 + 32 * r];
+    dft8(v);
+#pragma unroll
+    for (int q2 = 1; q2 < 8; ++q2) v[q2] = cmul(v[q2], tw.s2[q2 - 1]);
+#pragma unroll
+    for (int q2 = 0; q2 < 8; ++q2) bufQ[q * kEx2Stride + q2 * 32 + t1] = v[q2];
+  }
+  __syncthreads();
+  {
+    const int q = tid & 7, t2 = (tid >> 3) & 3, q2 = tid >> 5;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = bufQ[q * kEx2Stride + q2 * 32 + t2 + 4 * r];
+    dft8(v);
+#pragma unroll
+    for (int q3 = 1; q3 < 8; ++q3) v[q3] = cmul(v[q3], tw.s3[q3]);
+#pragma unroll
+    for (int q3 = 0; q3 < 8; ++q3) bufP[t2 * kEx3Stride + q + 8 * q2 + 64 * q3] = v[q3];
+  }
+  __syncthreads();
+  const float4* src = reinterpret_cast<const float4*>(bufP);
+  const float4 a0 = src[tid], a1 = src[kEx3Stride / 2 + tid], a2 = src[kEx3Stride + tid], a3 = src[3 * kEx3Stride / 2 + tid];
+  x[0] = make_float2(a0.x, a0.y); x[1] = make_float2(a1.x, a1.y); x[2] = make_float2(a2.x, a2.y); x[3] = make_float2(a3.x, a3.y);
+  y[0] = make_float2(a0.z, a0.w); y[1] = make_float2(a1.z, a1.w); y[2] = make_float2(a2.z, a2.w); y[3] = make_float2(a3.z, a3.w);
+  dft4(x[0], x[1], x[2], x[3]);
+  dft4(y[0], y[1], y[2], y[3]);
+}
+
+// Hard decisions of one symbol against the previous one, for the 8 bins of this thread (input_sdr.c:132-162), written as
+// 0/1 BYTES into `dec` at the place where the output word wants them: byte 32 t + b = bit b of output word t.  Every one
+// of the 3072 places is written by exactly one carrier, so the array needs no clearing.  FIC symbols (1..3) leave in natural
+// order (t = i >> 5); MSC symbols as the 16 planes i & 15 of 6 words each (the layout of demap_kernel<true, 1>).
+__device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4], const float2 (&px)[4], const float2 (&py)[4],
+                                       const int (&qk)[8], bool fic, uint8_t* dec)
+{
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const float2 cur = (m & 1) ? y[m >> 1] : x[m >> 1], prev = (m & 1) ? py[m >> 1] : px[m >> 1];
+    const float re = cur.x * prev.x + cur.y * prev.y;     // Re(cur conj(prev))
+    const float im = cur.x * prev.y - cur.y * prev.x;     // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
+    const int p0 = qk[m], p1 = 1536 + qk[m];
+    const int a0 = fic ? p0 : (((p0 & 15) * 6 + (p0 >> 9)) * 32 + ((p0 >> 4) & 31));
+    const int a1 = fic ? p1 : (((p1 & 15) * 6 + (p1 >> 9)) * 32 + ((p1 >> 4) & 31));
+    if (qk[m] >= 0) {                                     // bins without a carrier (DC, guard bands) decide nothing
+      dec[a0] = (re > 0.0f) ? 0 : 1;                      // input_sdr.c:157
+      dec[a1] = (im > 0.0f) ? 1 : 0;                      // input_sdr.c:158
+    }
+  }
+}
+
+// 32 decision bytes -> one output word, by thread t < 96
+__device__ __forceinline__ uint32_t pack_word(const uint8_t* dec, int t)
+{
+  const uint4* p = reinterpret_cast<const uint4*>(dec + 32 * t);
+  const uint4 lo = p[0], hi = p[1];
+  const uint32_t d[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  uint32_t w = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w |= ((d[k] * 0x01020408u) >> 24 & 15u) << (4 * k);   // bytes b0..b3 (0/1) -> b0 | b1<<1 | b2<<2 | b3<<3
+  return w;
+}
+
+// A symbol whose window reaches into the stale tail of the reference's frame buffer (symbol 75 after a negative timing
+// shift, frames after a coarse resync): its samples come through the view, one at a time, via an LDS staging row, so that
+// this rare path adds no register pressure to the symbol loop.
+__device__ __forceinline__ void load_symbol_view(const uint8_t* stream, const FrameView& view, int sym, uint16_t* stage, unsigned (&raw)[8])
+{
+  const int tid = threadIdx.x;
+  const int start = 2 * (kNullSamples + kSymSamples * sym + kCpSamples);
+#pragma unroll 1
+  for (int r = 0; r < 8; ++r) {
+    const int p = start + 2 * (tid + 256 * r);
+    stage[tid + 256 * r] = static_cast<uint16_t>(view_byte(stream, view, p) | (view_byte(stream, view, p + 1) << 8));
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) raw[r] = stage[tid + 256 * r];     // each thread reads back what it wrote: no barrier
+}
+
+struct FusedOut {
+  uint32_t* fic_row;     // this TF's 288 FIC words
+  uint32_t* msc;         // logical CIF rows
+  int cif_row;
+};
+
+__device__ __forceinline__ void flush_symbol(const uint8_t* dec, int sym, const FusedOut& o)
+{
+  const int tid = threadIdx.x;
+  if (tid >= 96) return;
+  const uint32_t bits = pack_word(dec, tid);
+  if (sym <= 3) {
+    o.fic_row[(sym - 1) * 96 + tid] = bits;
+  } else {
+    const int q = (sym - 4) / 18, sidx = (sym - 4) % 18;
+    const int r = tid / 6, wq = tid % 6;
+    const int delay = static_cast<int>(__brev(static_cast<unsigned>(r)) >> 28);   // map[r], misc.c:32
+    o.msc[static_cast<size_t>(o.cif_row + q - delay) * 1728 + (sidx * 6 + wq) * 16 + r] = bits;
+  }
+}
+
+// symbols [sym_begin, sym_end): transform, and from the second one on demap against the one before
+template <bool kFast, bool kNco>
+__device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t* stream, const FrameView& view, int sym_begin, int sym_end,
+                                              bool have_prev, float2 (&px)[4], float2 (&py)[4], float2* exA, float2* exB, uint8_t* decA,
+                                              uint8_t* decB, uint16_t* stage, const Twiddles& tw, const int (&qk)[8], uint32_t nco_inc, const FusedOut& out)
+{
+  if (sym_begin >= sym_end) return;
+  bool have_out = false;                                // decisions of the previous symbol wait in the other dec array
+  unsigned raw[8];
+  if (kFast) load_symbol<true>(fast_src, stream, view, sym_begin, raw);
+  else load_symbol_view(stream, view, sym_begin, stage, raw);
+  // two symbols per trip: the LDS buffers swap roles every symbol, so the trip body sees them at fixed places
+  for (int sym = sym_begin; sym < sym_end; sym += 2) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int s = sym + h;
+      if (s < sym_end) {
+        float2 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = make_float2(rail(raw[r] & 0xff), rail(raw[r] >> 8));
+        if (kNco && nco_inc) derotate(v, nco_inc, kNullSamples + kSymSamples * s + kCpSamples + static_cast<int>(threadIdx.x));
+        // prefetch under the transform; unconditional (a branch here makes the compiler wait for the loads at once)
+        if (kFast) load_symbol<true>(fast_src, stream, view, min(s + 1, sym_end - 1), raw);
+        else load_symbol_view(stream, view, min(s + 1, sym_end - 1), stage, raw);
+        float2 x[4], y[4];
+        fft2048_first(v, h ? exB : exA, tw);
+        // the barrier just passed also orders the previous symbol's decisions: they leave now, one symbol late, so that
+        // the wait for the NEXT prefetch (issued above) never has to drain a store issued right before it
+        if (have_out) flush_symbol(h ? decA : decB, s - 1, out);
+        if (h) fft2048_rest(v, exB, exA, tw, x, y);
+        else fft2048_rest(v, exA, exB, tw, x, y);
+        if (have_prev) decide(x, y, px, py, qk, s <= 3, h ? decB : decA);
+        have_out = have_prev;
+        have_prev = true;
+#pragma unroll
+        for (int k3 = 0; k3 < 4; ++k3) { px[k3] = x[k3]; py[k3] = y[k3]; }
+      }
+    }
+  }
+  if (have_out) {                                       // the run's last symbol ((sym_end - 1 - sym_begin) & 1 picks its array)
+    __syncthreads();
+    flush_symbol(((sym_end - 1 - sym_begin) & 1) ? decB : decA, sym_end - 1, out);
+  }
+}
+
+// grid = 4 * nframes: workgroup part p of a frame demaps data symbols max(1, 19 p) .. 19 p + 18 (parts 1..3 transform symbol
+// 19 p - 1 once more as their differential reference)
+template <bool kNco>
+__global__ __launch_bounds__(kThreads, 3) void ofdm_demap_kernel(const uint8_t* const* __restrict__ iq, const CallDesc* __restrict__ descs,
+                                                                 int max_calls, const int2* __restrict__ frames, int first,
+                                                                 const float2* __restrict__ tw_global, const int* __restrict__ frame_slot,
+                                                                 const int* __restrict__ frame_cif_row,
+                                                                 const uint16_t* __restrict__ qpsk_of_carrier,
+                                                                 uint32_t* __restrict__ fic_bits, uint32_t* __restrict__ msc_bits)
+{
+  __shared__ __attribute__((aligned(16))) float2 exA[kExSize];
+  __shared__ __attribute__((aligned(16))) float2 exB[kExSize];
+  __shared__ __attribute__((aligned(16))) uint8_t decA[kBitsPerSym], decB[kBitsPerSym];
+  __shared__ uint16_t stage[2048];
+  __shared__ FrameView view;
+  __shared__ float2 tw3[4 * 8];
+  const int tid = threadIdx.x;
+  const int j = blockIdx.x >> 2, part = blockIdx.x & 3;
+  const int2 fr = frames[first + j];
+  const CallDesc* desc = descs + static_cast<size_t>(fr.x) * max_calls + fr.y;
+  const uint8_t* stream = iq[fr.x];
+  if (tid == 0) view = desc->view;
+  if (tid < 32) tw3[tid] = tw_global[64 * (tid >> 3) * (tid & 7)];
+  Twiddles tw;
+  {
+    const int t1 = tid & 31, t2 = (tid >> 3) & 3;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+      tw.s1[q - 1] = tw_global[tid * q];
+      tw.s2[q - 1] = tw_global[8 * t1 * q];
+    }
+    tw.s3 = tw3 + 8 * t2;
+  }
+  // QPSK symbol index of each of this thread's 8 bins (frequency de-interleaver, dab_tables.c:164); -1 = no carrier there.
+  // Raw bin k: carriers 768..1535 sit at k = 1..768, carriers 0..767 at k = 1280..2047 (input_sdr.c:146-162 on the shifted array).
+  int qk[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int k = 2 * tid + 512 * (m >> 1) + (m & 1);
+    const int c = (k >= 1 && k <= 768) ? k + 767 : (k >= 1280 ? k - 1280 : -1);
+    qk[m] = c >= 0 ? qpsk_of_carrier[c] : -1;
+  }
+  const FusedOut out{fic_bits + static_cast<size_t>(frame_slot[first + j]) * 288, msc_bits, frame_cif_row[first + j]};
+  const int seg_end0 = desc->view.seg_end[0];
+  const int64_t seg_src0 = desc->view.seg_src[0];
+  const int nco_hz = desc->nco_hz;
+  __syncthreads();
+
+  int nfast = 0;                                        // symbols whose window lies inside what this call read (see fft_block)
+  if (seg_src0 >= 0) {
+    const int avail = (seg_end0 - 4096) / 2 - kNullSamples - kCpSamples;
+    if (seg_end0 >= 4096 && avail >= 0) nfast = min(kSymbolsPerTf, avail / kSymSamples + 1);
+  }
+  GlobalU16 src = reinterpret_cast<GlobalU16>(reinterpret_cast<uintptr_t>(stream + (seg_src0 >= 0 ? seg_src0 : 0)));
+  const uint32_t nco_inc = nco_hz ? static_cast<uint32_t>(static_cast<int64_t>(llrint(nco_hz * (4294967296.0 / 2048000.0)))) : 0u;
+
+  const int sym_begin = part ? part * kSymPerBlock - 1 : 0, sym_end = (part + 1) * kSymPerBlock;
+  // fast run (an even number of symbols, so that the LDS buffers end where they started), then the rest through the view
+  int fast_end = max(sym_begin, min(sym_end, nfast));
+  fast_end -= (fast_end - sym_begin) & 1;
+  float2 px[4], py[4];                                  // the previous symbol's bins
+  fused_symbols<true, kNco>(src, stream, view, sym_begin, fast_end, false, px, py, exA, exB, decA, decB, stage, tw, qk, nco_inc, out);
+  fused_symbols<false, kNco>(src, stream, view, fast_end, sym_end, fast_end > sym_begin, px, py, exA, exB, decA, decB, stage, tw, qk, nco_inc, out);
+}
+
+}  // namespace
+
+hipError_t launch_ofdm_demap_fused(bool afc, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
+                                   const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
+                                   uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream)
+{
+  if (nframes <= 0) return hipSuccess;
+  if (afc)
+    hipLaunchKernelGGL(ofdm_demap_kernel<true>, dim3(4 * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
+                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits);
+  else
+    hipLaunchKernelGGL(ofdm_demap_kernel<false>, dim3(4 * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
+                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits);
+  return hipGetLastError();
+}
+
+}  // namespace dabhip

@@ -44,6 +44,9 @@ hipError_t launch_viterbi_fused(int soft_bits, const WaveGroup* groups, int ngro
                                 const uint32_t* grouped, int row_words, uint2* decisions, const uint32_t* prbs_words, uint8_t* out,
                                 int record_stride, hipStream_t stream);
 
+hipError_t launch_ofdm_demap_fused(bool afc, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
+                                   const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
+                                   uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream);
 hipError_t launch_batched_copy(const CopyDesc* descs, int n, hipStream_t stream);
 hipError_t launch_fib_crc(const uint8_t* fibs, int nfib, const uint16_t* crc_tab, uint8_t* ok, hipStream_t stream);
 

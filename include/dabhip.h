@@ -116,6 +116,13 @@ int dabhip_engine_set_afc(dabhip_engine *e, int enable);
  * without errors and is better (lower BER) at low SNR. */
 int dabhip_engine_set_soft(dabhip_engine *e, int enable);
 
+/* Fused OFDM stage (optional): the 2048-point transforms and the DQPSK demap / de-interleave scatter in ONE kernel that
+ * never writes the complex64 spectra (311,296 B read + 28,800 B written per TF instead of 1,556,480 + 1.2 MB re-read).
+ * Output bits, hence ETI bytes, are identical to the default two-kernel stage.  Off by default: the default pipeline keeps
+ * K2 as the separately measured HBM-roofline stage; with this on, dabhip_engine_fft_stats describes the
+ * fused kernel and is not a roofline figure.  Hard decisions only (ignored with soft decisions on). */
+int dabhip_engine_set_fused(dabhip_engine *e, int enable);
+
 /* ---- streaming sessions ---------------------------------------------
  * The batch engine over UNBOUNDED streams: B parallel captures fed segment by segment (stdin, a socket, a file too
  * large for the device).  The state dab2eti keeps between calls -- FIFO backlog and stale frame tail (sdr_fifo.c),

@@ -573,3 +573,26 @@ def test_streaming_session_equals_one_shot_decode(soft):
         for b in range(len(caps)):
             assert np.array_equal(np.concatenate(got[b]), want[b]), "trial %d stream %d" % (trial, b)
         st.close()
+
+
+@pytest.mark.gpu
+def test_fused_ofdm_stage_gives_identical_frames():
+    """The one-kernel OFDM stage (k_fused.hip, spectra never written) against the default K2 + K2b: identical ETI on clean,
+    unaligned, noisy (lock loss) and resynchronising captures, with and without the software AFC."""
+    ntf = 24
+    cfgs = [dab.synth_preset(0, seed=31), dab.synth_preset(1, seed=32, skip_samples=123457), dab.synth_preset(1, seed=33, snr_db=6.5),
+            dab.synth_preset(0, seed=34, snr_db=9.0, cif_count0=4990), dab.synth_preset(1, seed=35, cfo_hz=-1700.0)]
+    caps = [dab.synth_generate(c, ntf) for c in cfgs]
+    caps.append(np.concatenate([caps[0][:7 * 393216], caps[0][7 * 393216 + 50000:]]))
+    for afc in (False, True):
+        eng = dab.Engine(0)
+        eng.set_afc(afc)
+        eng.decode(caps)
+        want = [eng.eti(i) for i in range(len(caps))]
+        eng.set_fused(True)
+        eng.decode(caps)
+        for i in range(len(caps)):
+            assert np.array_equal(eng.eti(i), want[i]), "stream %d afc %d" % (i, afc)
+        assert sum(len(w) for w in want) > 100
+        if not afc:
+            assert np.array_equal(want[0], ol.or_replay(caps[0])[0])
