@@ -167,6 +167,53 @@ __device__ __forceinline__ void acs_step_soft(unsigned nib16, const pk16 (&p)[32
   acs_step_bm<kTau>(bm, p, n);
 }
 
+// Hard decisions with the de-puncturing fused in (viterbi_fused_kernel<1>): a step receives the first n = 0..4 bits of its group of
+// four (wave-uniform n), so only 16 + 8 + 4 + 2 + 1 = 31 (mask, value) pairs occur.  Their eight packed branch-metric words
+// per layout tau sit in an LDS table (4 x 2 x 32 x 16 B); a step fetches its row with two 16-byte reads instead of ~26
+// VALU instructions.  Rows of one n are 16 bytes apart = disjoint banks, equal rows broadcast: the reads are conflict-free.
+__device__ __forceinline__ unsigned lut_row_base(int n) { return n == 4 ? 0u : (0x10181c1eu >> (8 * n)) & 0xffu; }   // n = 4, 3, 2, 1, 0 -> row 0, 16, 24, 28, 30
+
+__device__ __forceinline__ void build_metric_lut(uint4 (*lut)[2][32])
+{
+  for (int e = threadIdx.x; e < 256; e += 64) {
+    const int tau = e >> 6, half = (e >> 5) & 1, row = e & 31;
+    const int n = row < 16 ? 4 : row < 24 ? 3 : row < 28 ? 2 : row < 30 ? 1 : 0;
+    const unsigned v = row < 30 ? static_cast<unsigned>(row) - lut_row_base(n) : 0u, m = (1u << n) - 1u;
+    int bm[8];
+    branch_metrics_hard(v | (m << 4), bm);
+    const unsigned gamma = tau == 0 ? branch_code3(2u) : tau == 1 ? branch_code3(4u) : tau == 2 ? branch_code3(8u) : branch_code3(16u);
+    uint32_t w[4];
+#pragma unroll
+    for (unsigned k = 0; k < 4; ++k) {
+      const unsigned c = 4u * half + k;
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (unsigned q = 0; q < 8; ++q) {                // bm[] is indexed with run-time values: select, do not index
+        lo = (q == c) ? static_cast<uint32_t>(bm[q]) : lo;
+        hi = (q == (c ^ gamma)) ? static_cast<uint32_t>(bm[q]) : hi;
+      }
+      w[k] = lo | (hi << 16);
+    }
+    lut[tau][half][row] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  __syncthreads();
+}
+
+template <int kTau>
+__device__ __forceinline__ void acs_step_lut(unsigned row, const uint4 (*lut)[2][32], const pk16 (&p)[32], pk16 (&n)[32])
+{
+  constexpr uint32_t tag = 0x00010001u << kTau;
+  const uint4 lo = lut[kTau][0][row], hi = lut[kTau][1][row];
+  const uint32_t b[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  pk16 bl[8], bh[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    bh[c] = as_pk(b[c]);
+    bl[c] = as_pk(b[c] + tag);
+  }
+  all_pairs<kTau>(p, n, bl, bh, std::make_integer_sequence<int, 16>{});
+}
+
 // L(4) (pairs (k, k^16)) -> L(0) (pairs (k, k^1)): one byte permute per register; the tag nibbles are cleared here
 __device__ __forceinline__ void repair_layout(const pk16 (&n)[32], pk16 (&p)[32])
 {
@@ -307,6 +354,26 @@ __device__ __forceinline__ void acs_tail_soft(uint64_t nibs, int r, pk16 (&pm)[3
   acs_step_soft<1>(static_cast<unsigned>(nibs >> 16) & 0xffffu, pn, pm);
   if (r == 2) { survivor_record(pm, rec); return; }
   acs_step_soft<2>(static_cast<unsigned>(nibs >> 32) & 0xffffu, pm, pn);
+  survivor_record(pn, rec);
+}
+
+// the same with table rows (one byte per step) instead of (value | mask << 4) bytes
+__device__ __forceinline__ void acs4_lut(uint32_t rows, const uint4 (*lut)[2][32], pk16 (&pm)[32], pk16 (&pn)[32], pk16 (&pl4)[32], uint4* rec)
+{
+  acs_step_lut<0>(rows & 0xff, lut, pm, pn);
+  acs_step_lut<1>((rows >> 8) & 0xff, lut, pn, pm);
+  acs_step_lut<2>((rows >> 16) & 0xff, lut, pm, pn);
+  acs_step_lut<3>(rows >> 24, lut, pn, pl4);
+  survivor_record(pl4, rec);
+  repair_layout(pl4, pm);
+}
+__device__ __forceinline__ void acs_tail_lut(uint32_t rows, int r, const uint4 (*lut)[2][32], pk16 (&pm)[32], pk16 (&pn)[32], uint4* rec)
+{
+  acs_step_lut<0>(rows & 0xff, lut, pm, pn);
+  if (r == 1) { survivor_record(pn, rec); return; }
+  acs_step_lut<1>((rows >> 8) & 0xff, lut, pn, pm);
+  if (r == 2) { survivor_record(pm, rec); return; }
+  acs_step_lut<2>((rows >> 16) & 0xff, lut, pm, pn);
   survivor_record(pn, rec);
 }
 
@@ -451,6 +518,9 @@ __global__ __launch_bounds__(64, 4) void viterbi_fused_kernel(const WaveGroup* _
     ++widx;
   };
 
+  __shared__ uint4 lut[kBits == 1 ? 4 : 1][2][32];
+  if (kBits == 1) build_metric_lut(lut);
+
   pk16 pm[32], pn[32], pl4[32];
   init_metrics<kBits>(pm);
   int t = 0;
@@ -469,14 +539,14 @@ __global__ __launch_bounds__(64, 4) void viterbi_fused_kernel(const WaveGroup* _
         for (int g = 0; g < 8; ++g) {
           const int n = (counts >> (3 * g)) & 7;
           const uint32_t m = (1u << n) - 1u;
-          const uint32_t sb = (static_cast<uint32_t>(fifo) & m) | (m << 4);
+          const uint32_t row = (static_cast<uint32_t>(fifo) & m) + lut_row_base(n);     // table row of (value, mask)
           fifo >>= n;
-          ww[g >> 2] |= sb << (8 * (g & 3));
+          ww[g >> 2] |= row << (8 * (g & 3));
         }
         have -= need;
-        if (t + 4 <= nsteps) acs4(ww[0], pm, pn, pl4, my_rec + static_cast<size_t>(t >> 2) * 128);
-        if (t + 8 <= nsteps) acs4(ww[1], pm, pn, pl4, my_rec + static_cast<size_t>((t >> 2) + 1) * 128);
-        else if (t + 4 < nsteps) acs_tail(ww[1], nsteps - t - 4, pm, pn, my_rec + static_cast<size_t>((t >> 2) + 1) * 128);
+        if (t + 4 <= nsteps) acs4_lut(ww[0], lut, pm, pn, pl4, my_rec + static_cast<size_t>(t >> 2) * 128);
+        if (t + 8 <= nsteps) acs4_lut(ww[1], lut, pm, pn, pl4, my_rec + static_cast<size_t>((t >> 2) + 1) * 128);
+        else if (t + 4 < nsteps) acs_tail_lut(ww[1], nsteps - t - 4, lut, pm, pn, my_rec + static_cast<size_t>((t >> 2) + 1) * 128);
       } else {
         uint64_t nibs[2];
 #pragma unroll
