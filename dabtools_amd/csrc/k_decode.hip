@@ -173,7 +173,7 @@ __device__ __forceinline__ void acs_step_soft(unsigned nib16, const pk16 (&p)[32
 // VALU instructions.  Rows of one n are 16 bytes apart = disjoint banks, equal rows broadcast: the reads are conflict-free.
 __device__ __forceinline__ unsigned lut_row_base(int n) { return n == 4 ? 0u : (0x10181c1eu >> (8 * n)) & 0xffu; }   // n = 4, 3, 2, 1, 0 -> row 0, 16, 24, 28, 30
 
-__device__ __forceinline__ void build_metric_lut(uint4 (*lut)[2][32])
+__device__ __forceinline__ void build_metric_lut(uint4 (*lut)[2][32])   // entries x256 (byte tags, see acs8_lut)
 {
   for (int e = threadIdx.x; e < 256; e += 64) {
     const int tau = e >> 6, half = (e >> 5) & 1, row = e & 31;
@@ -192,17 +192,17 @@ __device__ __forceinline__ void build_metric_lut(uint4 (*lut)[2][32])
         lo = (q == c) ? static_cast<uint32_t>(bm[q]) : lo;
         hi = (q == (c ^ gamma)) ? static_cast<uint32_t>(bm[q]) : hi;
       }
-      w[k] = lo | (hi << 16);
+      w[k] = (lo | (hi << 16)) << (8 - kMetricShift);
     }
     lut[tau][half][row] = make_uint4(w[0], w[1], w[2], w[3]);
   }
   __syncthreads();
 }
 
-template <int kTau>
+template <int kTau, int kTagBit>
 __device__ __forceinline__ void acs_step_lut(unsigned row, const uint4 (*lut)[2][32], const pk16 (&p)[32], pk16 (&n)[32])
 {
-  constexpr uint32_t tag = 0x00010001u << kTau;
+  constexpr uint32_t tag = 0x00010001u << kTagBit;
   const uint4 lo = lut[kTau][0][row], hi = lut[kTau][1][row];
   const uint32_t b[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
   pk16 bl[8], bh[8];
@@ -357,24 +357,126 @@ __device__ __forceinline__ void acs_tail_soft(uint64_t nibs, int r, pk16 (&pm)[3
   survivor_record(pn, rec);
 }
 
-// the same with table rows (one byte per step) instead of (value | mask << 4) bytes
-__device__ __forceinline__ void acs4_lut(uint32_t rows, const uint4 (*lut)[2][32], pk16 (&pm)[32], pk16 (&pn)[32], pk16 (&pl4)[32], uint4* rec)
+// ---- hard decisions, byte tags (viterbi_fused_kernel<1>) --------------------------------------
+// Metrics x256: the tag of step k = 0..7 of a block of EIGHT steps is 1 << k, so the low BYTE of every state collects the
+// eight decisions along its survivor path.  Records are then plain byte gathers (16 v_perm per 8 steps, no masking or
+// merging), and the re-pairing permute that follows a record clears the tags for free (selector 0x0c = constant zero).
+template <bool kClear>
+__device__ __forceinline__ void repair_layout8(const pk16 (&n)[32], pk16 (&p)[32])
 {
-  acs_step_lut<0>(rows & 0xff, lut, pm, pn);
-  acs_step_lut<1>((rows >> 8) & 0xff, lut, pn, pm);
-  acs_step_lut<2>((rows >> 16) & 0xff, lut, pm, pn);
-  acs_step_lut<3>(rows >> 24, lut, pn, pl4);
-  survivor_record(pl4, rec);
-  repair_layout(pl4, pm);
+#pragma unroll
+  for (int side = 0; side < 2; ++side)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int a = side * 16 + ((2 * q) & 15);           // register holding state 2q (low half if 2q < 16)
+      const uint32_t sel = (2 * q < 16) ? (kClear ? 0x050c010cu : 0x05040100u) : (kClear ? 0x070c030cu : 0x07060302u);
+      p[side * 16 + q] = as_pk(__builtin_amdgcn_perm(as_u32(n[a + 1]), as_u32(n[a]), sel));
+    }
 }
-__device__ __forceinline__ void acs_tail_lut(uint32_t rows, int r, const uint4 (*lut)[2][32], pk16 (&pm)[32], pk16 (&pn)[32], uint4* rec)
+// register R (L(4) numbering, see survivor_record) lands in word R >> 1, byte 2 (R & 1) + half
+__device__ __forceinline__ void survivor_record8(const pk16 (&n)[32], uint4* rec)
 {
-  acs_step_lut<0>(rows & 0xff, lut, pm, pn);
-  if (r == 1) { survivor_record(pn, rec); return; }
-  acs_step_lut<1>((rows >> 8) & 0xff, lut, pn, pm);
-  if (r == 2) { survivor_record(pm, rec); return; }
-  acs_step_lut<2>((rows >> 16) & 0xff, lut, pm, pn);
-  survivor_record(pn, rec);
+  uint32_t d[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) d[i] = __builtin_amdgcn_perm(as_u32(n[2 * i + 1]), as_u32(n[2 * i]), 0x06040200u);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rec[64 * j] = make_uint4(d[4 * j], d[4 * j + 1], d[4 * j + 2], d[4 * j + 3]);
+}
+__device__ __forceinline__ unsigned survivor_byte(const uint4 (&r)[4], unsigned state)
+{
+  const unsigned reg = ((state >> 5) << 4) | (state & 15u), half = (state >> 4) & 1u;
+  const unsigned i = reg >> 1, byte = 2u * (reg & 1u) + half;
+  uint32_t w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                          // word i & 3 of each of the four 16-byte parts, then part i >> 2
+    const uint32_t a = (i & 1u) ? in_vgpr(r[j].y) : in_vgpr(r[j].x), b = (i & 1u) ? in_vgpr(r[j].w) : in_vgpr(r[j].z);
+    w[j] = (i & 2u) ? b : a;
+  }
+  const uint32_t lo = (i & 4u) ? w[1] : w[0], hi = (i & 4u) ? w[3] : w[2];
+  return (((i & 8u) ? hi : lo) >> (8u * byte)) & 255u;
+}
+
+// 8 trellis steps from 8 table rows (one byte each): two passes through the register layouts, one survivor record
+__device__ __forceinline__ void acs8_lut(uint32_t rows0, uint32_t rows1, const uint4 (*lut)[2][32], pk16 (&pm)[32], pk16 (&pn)[32],
+                                         pk16 (&pl4)[32], uint4* rec)
+{
+  acs_step_lut<0, 0>(rows0 & 0xff, lut, pm, pn);
+  acs_step_lut<1, 1>((rows0 >> 8) & 0xff, lut, pn, pm);
+  acs_step_lut<2, 2>((rows0 >> 16) & 0xff, lut, pm, pn);
+  acs_step_lut<3, 3>(rows0 >> 24, lut, pn, pl4);
+  repair_layout8<false>(pl4, pm);
+  acs_step_lut<0, 4>(rows1 & 0xff, lut, pm, pn);
+  acs_step_lut<1, 5>((rows1 >> 8) & 0xff, lut, pn, pm);
+  acs_step_lut<2, 6>((rows1 >> 16) & 0xff, lut, pm, pn);
+  acs_step_lut<3, 7>(rows1 >> 24, lut, pn, pl4);
+  survivor_record8(pl4, rec);
+  repair_layout8<true>(pl4, pm);
+}
+// the last r = 1..7 steps of a code word: the record is only read for state 0 (low half of register 0 in every layout)
+__device__ __forceinline__ void acs8_tail_lut(uint32_t rows0, uint32_t rows1, int r, const uint4 (*lut)[2][32], pk16 (&pm)[32],
+                                              pk16 (&pn)[32], pk16 (&pl4)[32], uint4* rec)
+{
+  if (r >= 4) {
+    acs_step_lut<0, 0>(rows0 & 0xff, lut, pm, pn);
+    acs_step_lut<1, 1>((rows0 >> 8) & 0xff, lut, pn, pm);
+    acs_step_lut<2, 2>((rows0 >> 16) & 0xff, lut, pm, pn);
+    acs_step_lut<3, 3>(rows0 >> 24, lut, pn, pl4);
+    repair_layout8<false>(pl4, pm);
+    if (r == 4) { survivor_record8(pm, rec); return; }
+    acs_step_lut<0, 4>(rows1 & 0xff, lut, pm, pn);
+    if (r == 5) { survivor_record8(pn, rec); return; }
+    acs_step_lut<1, 5>((rows1 >> 8) & 0xff, lut, pn, pm);
+    if (r == 6) { survivor_record8(pm, rec); return; }
+    acs_step_lut<2, 6>((rows1 >> 16) & 0xff, lut, pm, pn);
+    survivor_record8(pn, rec);
+    return;
+  }
+  acs_step_lut<0, 0>(rows0 & 0xff, lut, pm, pn);
+  if (r == 1) { survivor_record8(pn, rec); return; }
+  acs_step_lut<1, 1>((rows0 >> 8) & 0xff, lut, pn, pm);
+  if (r == 2) { survivor_record8(pm, rec); return; }
+  acs_step_lut<2, 2>((rows0 >> 16) & 0xff, lut, pm, pn);
+  survivor_record8(pn, rec);
+}
+
+// chain back over byte-tag records: block b of 8 steps at my_rec[256 b + 64 j], j = 0..3
+__device__ __forceinline__ void chain_back8(const uint4* my_rec, int nsteps, const uint32_t* __restrict__ prbs_words, uint32_t* dst)
+{
+  unsigned state = 0;
+  uint32_t acc = 0;
+  auto consume = [&](unsigned tags, int t0, int k_hi) {    // steps t0 + k_hi .. t0, newest first
+#pragma unroll
+    for (int k = 7; k >= 0; --k) {
+      const int t = t0 + k;
+      if (k <= k_hi && t >= 6) {                           // steps 0..5 only flush the encoder's initial zeros
+        const unsigned bit = ((tags >> k) & 1u) ^ 1u;      // tag set = low predecessor survived = decision 0
+        state = (state | (bit << 6)) >> 1;
+        const int i = t - 6;                               // data bit index
+        acc |= bit << (8 * ((i >> 3) & 3) + (7 - (i & 7)));
+        if ((i & 31) == 0) {
+          dst[i >> 5] = acc ^ prbs_words[i >> 5];
+          acc = 0;
+        }
+      }
+    }
+  };
+  const int nfull = nsteps >> 3, r = nsteps & 7;
+  if (r) consume(my_rec[static_cast<size_t>(nfull) * 256].x & 255u, 8 * nfull, r - 1);
+  // records are fetched 2 blocks (16 steps) at a time (their addresses do not depend on the path)
+  for (int b_hi = nfull - 1; b_hi >= 0; b_hi -= 2) {
+    uint4 rec[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t b = static_cast<size_t>(max(b_hi - u, 0));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rec[u][j] = my_rec[b * 256 + 64 * j];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int b = b_hi - u;
+      if (b >= 0) consume(survivor_byte(rec[u], state), 8 * b, 7);
+    }
+  }
 }
 
 // chain back from state 0 (viterbi.c:438-450), descramble (misc.c:41-58), pack MSB first.  my_rec: this lane's
@@ -423,8 +525,10 @@ struct MetricScale {
   // state 0 is kept at kBase at every re-base; the other states stay within 6 steps' worth of branch metric of it
   // (24 agreements hard, 6 x 56 soft), x16, plus tags: kBase exceeds that, so nothing goes negative.  The same gap
   // is the start condition (viterbi.c:387-389: 0 vs -999999; it only has to exceed what six steps can collect).
-  static constexpr uint32_t kBase = kBits == 1 ? 1024u : 8192u;
-  // growth per step <= 16 x 4 (hard) / 16 x 56 (soft): re-base long before the unsigned 16-bit range ends
+  // key 8 = hard decisions with byte tags (metrics x256, viterbi_fused_kernel<1>): state 0 at 64 agreements, the others
+  // within 24 of it, growth <= 4 per step: 64 + 24 + 32 x 4 = 216 < 256
+  static constexpr uint32_t kBase = kBits == 1 ? 1024u : kBits == 8 ? 16384u : 8192u;
+  // growth per step <= 16 x 4 (hard) / 16 x 56 (soft) / 256 x 4 (byte tags): re-base long before the unsigned 16-bit range ends
   static constexpr int kRebaseSteps = kBits == 1 ? 256 : 32;
 };
 
@@ -521,8 +625,9 @@ __global__ __launch_bounds__(64, 4) void viterbi_fused_kernel(const WaveGroup* _
   __shared__ uint4 lut[kBits == 1 ? 4 : 1][2][32];
   if (kBits == 1) build_metric_lut(lut);
 
+  constexpr int kScale = kBits == 1 ? 8 : kBits;     // hard decisions run on byte tags here
   pk16 pm[32], pn[32], pl4[32];
-  init_metrics<kBits>(pm);
+  init_metrics<kScale>(pm);
   int t = 0;
   for (int seg = 0; seg < 5; ++seg) {
     const uint32_t mask = seg < 4 ? pl.mask[seg] : (puncture_mask(8) & 0x00ffffffu);
@@ -544,9 +649,8 @@ __global__ __launch_bounds__(64, 4) void viterbi_fused_kernel(const WaveGroup* _
           ww[g >> 2] |= row << (8 * (g & 3));
         }
         have -= need;
-        if (t + 4 <= nsteps) acs4_lut(ww[0], lut, pm, pn, pl4, my_rec + static_cast<size_t>(t >> 2) * 128);
-        if (t + 8 <= nsteps) acs4_lut(ww[1], lut, pm, pn, pl4, my_rec + static_cast<size_t>((t >> 2) + 1) * 128);
-        else if (t + 4 < nsteps) acs_tail_lut(ww[1], nsteps - t - 4, lut, pm, pn, my_rec + static_cast<size_t>((t >> 2) + 1) * 128);
+        if (t + 8 <= nsteps) acs8_lut(ww[0], ww[1], lut, pm, pn, pl4, my_rec + static_cast<size_t>(t >> 3) * 256);
+        else if (t < nsteps) acs8_tail_lut(ww[0], ww[1], nsteps - t, lut, pm, pn, pl4, my_rec + static_cast<size_t>(t >> 3) * 256);
       } else {
         uint64_t nibs[2];
 #pragma unroll
@@ -567,12 +671,14 @@ __global__ __launch_bounds__(64, 4) void viterbi_fused_kernel(const WaveGroup* _
         else if (t + 4 < nsteps) acs_tail_soft(nibs[1], nsteps - t - 4, pm, pn, my_rec + static_cast<size_t>((t >> 2) + 1) * 128);
       }
       t += 8;
-      if ((t & (MetricScale<kBits>::kRebaseSteps - 1)) == 0 && t < nsteps) rebase_metrics<kBits>(pm);
+      if ((t & (MetricScale<kScale>::kRebaseSteps - 1)) == 0 && t < nsteps) rebase_metrics<kScale>(pm);
     }
   }
   if (lane >= grp.count) return;
   const int record = job_ids ? job_ids[grp.first + lane] : grp.first + lane;
-  chain_back(my_rec, nsteps, prbs_words, reinterpret_cast<uint32_t*>(out + static_cast<size_t>(record) * record_stride + pl.out_offset));
+  uint32_t* dst = reinterpret_cast<uint32_t*>(out + static_cast<size_t>(record) * record_stride + pl.out_offset);
+  if (kBits == 1) chain_back8(my_rec, nsteps, prbs_words, dst);
+  else chain_back(my_rec, nsteps, prbs_words, dst);
 }
 
 // ---------------------------------------------------------------------------------------
