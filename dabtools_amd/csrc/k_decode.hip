@@ -169,19 +169,24 @@ __device__ __forceinline__ void acs_step_soft(unsigned nib16, const pk16 (&p)[32
 
 // Hard decisions with the de-puncturing fused in (viterbi_fused_kernel<1>): a step receives the first n = 0..4 bits of its group of
 // four (wave-uniform n), so only 16 + 8 + 4 + 2 + 1 = 31 (mask, value) pairs occur.  Their eight packed branch-metric words
-// per layout tau sit in an LDS table (4 x 2 x 32 x 16 B); a step fetches its row with two 16-byte reads instead of ~26
-// VALU instructions.  Rows of one n are 16 bytes apart = disjoint banks, equal rows broadcast: the reads are conflict-free.
+// per step type sit in an LDS table (8 tag bits x 4 parts x 32 rows x 16 B = 16 KB, shared by the 4 waves of a workgroup); a step
+// fetches its row with four 16-byte reads instead of ~34 VALU instructions.  Rows of one n are 16 bytes apart = disjoint
+// banks, equal rows broadcast: the reads are conflict-free.
 __device__ __forceinline__ unsigned lut_row_base(int n) { return n == 4 ? 0u : (0x10181c1eu >> (8 * n)) & 0xffu; }   // n = 4, 3, 2, 1, 0 -> row 0, 16, 24, 28, 30
 
-__device__ __forceinline__ void build_metric_lut(uint4 (*lut)[2][32])   // entries x256 (byte tags, see acs8_lut)
+// lut[tag bit 0..7][part][row]: parts 0, 1 = the words of the LOW predecessor's candidates (metric + tag, codes 0..3 and 4..7),
+// parts 2, 3 = those of the high predecessor's (metric only); x256 (byte tags, see acs8_lut); layout tau = tag bit & 3
+typedef uint4 MetricLut[4][32];
+__device__ __forceinline__ void build_metric_lut(MetricLut* lut)
 {
-  for (int e = threadIdx.x; e < 256; e += 64) {
-    const int tau = e >> 6, half = (e >> 5) & 1, row = e & 31;
+  for (int e = threadIdx.x; e < 8 * 4 * 32; e += blockDim.x) {
+    const int tagbit = e >> 7, part = (e >> 5) & 3, row = e & 31, tau = tagbit & 3, half = part & 1;
     const int n = row < 16 ? 4 : row < 24 ? 3 : row < 28 ? 2 : row < 30 ? 1 : 0;
     const unsigned v = row < 30 ? static_cast<unsigned>(row) - lut_row_base(n) : 0u, m = (1u << n) - 1u;
     int bm[8];
     branch_metrics_hard(v | (m << 4), bm);
     const unsigned gamma = tau == 0 ? branch_code3(2u) : tau == 1 ? branch_code3(4u) : tau == 2 ? branch_code3(8u) : branch_code3(16u);
+    const uint32_t tag = part < 2 ? (0x00010001u << tagbit) : 0u;
     uint32_t w[4];
 #pragma unroll
     for (unsigned k = 0; k < 4; ++k) {
@@ -192,25 +197,20 @@ __device__ __forceinline__ void build_metric_lut(uint4 (*lut)[2][32])   // entri
         lo = (q == c) ? static_cast<uint32_t>(bm[q]) : lo;
         hi = (q == (c ^ gamma)) ? static_cast<uint32_t>(bm[q]) : hi;
       }
-      w[k] = (lo | (hi << 16)) << (8 - kMetricShift);
+      w[k] = ((lo | (hi << 16)) << (8 - kMetricShift)) + tag;
     }
-    lut[tau][half][row] = make_uint4(w[0], w[1], w[2], w[3]);
+    lut[tagbit][part][row] = make_uint4(w[0], w[1], w[2], w[3]);
   }
   __syncthreads();
 }
 
 template <int kTau, int kTagBit>
-__device__ __forceinline__ void acs_step_lut(unsigned row, const uint4 (*lut)[2][32], const pk16 (&p)[32], pk16 (&n)[32])
+__device__ __forceinline__ void acs_step_lut(unsigned row, const MetricLut* lut, const pk16 (&p)[32], pk16 (&n)[32])
 {
-  constexpr uint32_t tag = 0x00010001u << kTagBit;
-  const uint4 lo = lut[kTau][0][row], hi = lut[kTau][1][row];
-  const uint32_t b[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-  pk16 bl[8], bh[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    bh[c] = as_pk(b[c]);
-    bl[c] = as_pk(b[c] + tag);
-  }
+  static_assert((kTagBit & 3) == kTau, "the tag bit selects the table of its layout");
+  const uint4 l0 = lut[kTagBit][0][row], l1 = lut[kTagBit][1][row], h0 = lut[kTagBit][2][row], h1 = lut[kTagBit][3][row];
+  const pk16 bl[8] = {as_pk(l0.x), as_pk(l0.y), as_pk(l0.z), as_pk(l0.w), as_pk(l1.x), as_pk(l1.y), as_pk(l1.z), as_pk(l1.w)};
+  const pk16 bh[8] = {as_pk(h0.x), as_pk(h0.y), as_pk(h0.z), as_pk(h0.w), as_pk(h1.x), as_pk(h1.y), as_pk(h1.z), as_pk(h1.w)};
   all_pairs<kTau>(p, n, bl, bh, std::make_integer_sequence<int, 16>{});
 }
 
@@ -397,7 +397,7 @@ __device__ __forceinline__ unsigned survivor_byte(const uint4 (&r)[4], unsigned 
 }
 
 // 8 trellis steps from 8 table rows (one byte each): two passes through the register layouts, one survivor record
-__device__ __forceinline__ void acs8_lut(uint32_t rows0, uint32_t rows1, const uint4 (*lut)[2][32], pk16 (&pm)[32], pk16 (&pn)[32],
+__device__ __forceinline__ void acs8_lut(uint32_t rows0, uint32_t rows1, const MetricLut* lut, pk16 (&pm)[32], pk16 (&pn)[32],
                                          pk16 (&pl4)[32], uint4* rec)
 {
   acs_step_lut<0, 0>(rows0 & 0xff, lut, pm, pn);
@@ -413,7 +413,7 @@ __device__ __forceinline__ void acs8_lut(uint32_t rows0, uint32_t rows1, const u
   repair_layout8<true>(pl4, pm);
 }
 // the last r = 1..7 steps of a code word: the record is only read for state 0 (low half of register 0 in every layout)
-__device__ __forceinline__ void acs8_tail_lut(uint32_t rows0, uint32_t rows1, int r, const uint4 (*lut)[2][32], pk16 (&pm)[32],
+__device__ __forceinline__ void acs8_tail_lut(uint32_t rows0, uint32_t rows1, int r, const MetricLut* lut, pk16 (&pm)[32],
                                               pk16 (&pn)[32], pk16 (&pl4)[32], uint4* rec)
 {
   if (r >= 4) {
@@ -595,14 +595,18 @@ __global__ __launch_bounds__(64) void viterbi_kernel(const WaveGroup* __restrict
 // received values of the stream; n is wave-uniform.  kBits = 1: hard bits (the reference's behaviour);
 // kBits = 4: signed 4-bit soft values (extension).
 template <int kBits>
-__global__ __launch_bounds__(64, 4) void viterbi_fused_kernel(const WaveGroup* __restrict__ groups, const int* __restrict__ job_ids,
-                                                              const CodewordPlan* __restrict__ plans,
-                                                              const uint32_t* __restrict__ grouped, int row_words,
-                                                              uint2* __restrict__ decisions, const uint32_t* __restrict__ prbs_words,
-                                                              uint8_t* __restrict__ out, int record_stride)
+__global__ __launch_bounds__(256, 4) void viterbi_fused_kernel(const WaveGroup* __restrict__ groups, int ngroups, const int* __restrict__ job_ids,
+                                                               const CodewordPlan* __restrict__ plans,
+                                                               const uint32_t* __restrict__ grouped, int row_words,
+                                                               uint2* __restrict__ decisions, const uint32_t* __restrict__ prbs_words,
+                                                               uint8_t* __restrict__ out, int record_stride)
 {
-  const int lane = threadIdx.x;
-  const WaveGroup grp = groups[blockIdx.x];
+  // four independent waves per workgroup (one wave-group of code words each); they only share the branch-metric table
+  __shared__ MetricLut lut[kBits == 1 ? 8 : 1];
+  if (kBits == 1) build_metric_lut(lut);
+  const int lane = threadIdx.x & 63, g = 4 * blockIdx.x + (threadIdx.x >> 6);
+  if (g >= ngroups) return;
+  const WaveGroup grp = groups[g];
   const CodewordPlan pl = plans[grp.plan];
   const int nsteps = grp.nsteps;             // 32 x blocks + 6: the tail unit holds 6 steps
   uint4* my_rec = reinterpret_cast<uint4*>(decisions + grp.dec_base * 64) + lane;
@@ -621,9 +625,6 @@ __global__ __launch_bounds__(64, 4) void viterbi_fused_kernel(const WaveGroup* _
     nextw = src[static_cast<size_t>(min(widx, last_word)) * 64];
     ++widx;
   };
-
-  __shared__ uint4 lut[kBits == 1 ? 4 : 1][2][32];
-  if (kBits == 1) build_metric_lut(lut);
 
   constexpr int kScale = kBits == 1 ? 8 : kBits;     // hard decisions run on byte tags here
   pk16 pm[32], pn[32], pl4[32];
@@ -812,11 +813,11 @@ hipError_t launch_viterbi_fused(int soft_bits, const WaveGroup* groups, int ngro
 {
   if (ngroups <= 0) return hipSuccess;
   if (soft_bits)
-    hipLaunchKernelGGL(viterbi_fused_kernel<4>, dim3(ngroups), dim3(64), 0, stream, groups, job_ids, plans, grouped, row_words, decisions,
-                       prbs_words, out, record_stride);
+    hipLaunchKernelGGL(viterbi_fused_kernel<4>, dim3((ngroups + 3) / 4), dim3(256), 0, stream, groups, ngroups, job_ids, plans, grouped, row_words,
+                       decisions, prbs_words, out, record_stride);
   else
-    hipLaunchKernelGGL(viterbi_fused_kernel<1>, dim3(ngroups), dim3(64), 0, stream, groups, job_ids, plans, grouped, row_words, decisions,
-                       prbs_words, out, record_stride);
+    hipLaunchKernelGGL(viterbi_fused_kernel<1>, dim3((ngroups + 3) / 4), dim3(256), 0, stream, groups, ngroups, job_ids, plans, grouped, row_words,
+                       decisions, prbs_words, out, record_stride);
   return hipGetLastError();
 }
 
