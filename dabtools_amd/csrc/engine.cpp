@@ -590,9 +590,17 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
              "sync scan launch"))
     return -1;
   (void)hipEventRecord(ev_[1], stream_);
-  if (!h_descs_.resize(ndesc)) return -1;
-  if (!check(hipMemcpyAsync(h_descs_.data(), d_descs_.get(), ndesc * sizeof(CallDesc), hipMemcpyDeviceToHost, stream_), "desc download") ||
+  // The host only needs {status, ordinal} of every call to lay the frames out: those 8 bytes per descriptor come back
+  // first (strided copy); the full descriptors (trace API) follow on the side stream and are awaited at the end.
+  if (!h_descs_.resize(ndesc) || !h_info_.resize(ndesc)) return -1;
+  struct SideStreamGuard {
+    hipStream_t s;
+    ~SideStreamGuard() { (void)hipStreamSynchronize(s); }
+  } side_guard{copy_stream_};
+  if (!check(hipMemcpy2DAsync(h_info_.data(), sizeof(int2), d_descs_.get(), sizeof(CallDesc), sizeof(int2), ndesc, hipMemcpyDeviceToHost, stream_), "call info download") ||
       !check(hipMemcpyAsync(states.data(), d_states_.get(), states.size() * sizeof(StreamState), hipMemcpyDeviceToHost, stream_), "state download") ||
+      !check(hipStreamWaitEvent(copy_stream_, ev_[1], 0), "desc download") ||
+      !check(hipMemcpyAsync(h_descs_.data(), d_descs_.get(), ndesc * sizeof(CallDesc), hipMemcpyDeviceToHost, copy_stream_), "desc download") ||
       !check(hipStreamSynchronize(stream_), "sync scan"))
     return -1;
   (void)hipEventElapsedTime(&times_.sync, ev_[0], ev_[1]);
@@ -610,9 +618,9 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     const int keep = carry_keep_[b];
     const int ncalls = static_cast<int>(nbytes[b] / kChunkBytes) - calls_done_[b];
     for (int k = 0; k < ncalls; ++k) {
-      const CallDesc& d = h_descs_[static_cast<size_t>(b) * max_calls_ + k];
-      if (d.status == 2) {
-        const int local = keep + (d.ordinal - ord_done_[b]);
+      const int2 d = h_info_[static_cast<size_t>(b) * max_calls_ + k];     // {status, ordinal}
+      if (d.x == 2) {
+        const int local = keep + (d.y - ord_done_[b]);
         frames.push_back(make_int2(b, k));
         frame_slot.push_back(tf_base[b] + local);
         frame_cif_row.push_back(next_row + kRowLead + 4 * local);

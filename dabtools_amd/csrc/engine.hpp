@@ -257,6 +257,7 @@ class Engine {
   std::map<std::vector<int32_t>, int> plan_index_;
 
   PinnedBuffer<CallDesc> h_descs_;
+  PinnedBuffer<int2> h_info_;
   PinnedBuffer<uint8_t> h_fibs_, h_fib_ok_;
   int max_calls_ = 0, nstreams_ = 0;
   std::vector<int64_t> eti_base_, eti_count_;
