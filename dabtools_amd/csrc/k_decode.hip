@@ -736,6 +736,9 @@ __global__ __launch_bounds__(256) void eti_finish_kernel(const EtiFrameMeta* __r
                                                          const uint8_t* __restrict__ fibs, const uint16_t* __restrict__ crc_tab,
                                                          const uint16_t* __restrict__ shift_cols, uint8_t* __restrict__ eti)
 {
+  __shared__ uint16_t tab[256];                          // CRC table in LDS: the byte loop is a chain of dependent look-ups
+  tab[threadIdx.x] = crc_tab[threadIdx.x];
+  __syncthreads();
   const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (f >= nframes) return;
   const EtiFrameMeta m = meta[f];
@@ -749,7 +752,17 @@ __global__ __launch_bounds__(256) void eti_finish_kernel(const EtiFrameMeta* __r
   const int lo = min(n, lane * chunk), hi = min(n, lo + chunk);
   uint16_t crc = lane == 0 ? 0xffff : 0;
   const uint8_t* mst = e + m.header_len;                // MST bytes were written by the Viterbi kernel
-  for (int i = lo; i < hi; ++i) crc = crc16_step(crc, i < 96 ? fb[i] : mst[i], crc_tab);
+  for (int i0 = lo; i0 < hi; i0 += 8) {                  // bytes fetched 8 at a time, ahead of the look-up chain
+    uint8_t byte[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(i0 + u, hi - 1);
+      byte[u] = i < 96 ? fb[i] : mst[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u < hi) crc = crc16_step(crc, byte[u], tab);
+  }
   unsigned acc = crc_shift(crc, n - hi, shift_cols);
 #pragma unroll
   for (int s = 32; s > 0; s >>= 1) acc ^= __shfl_xor(acc, s);
