@@ -18,32 +18,45 @@ constexpr int kExSize = 2080;                    // float2 per exchange buffer
 constexpr int kDemapSyms = 5;                    // data symbols per demap workgroup (75 = 5 x 15)
 constexpr int kDemapGroups = 75 / kDemapSyms;
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// Complex arithmetic on 2-element vectors: the compiler maps these onto the packed fp32 instructions of CDNA3/4
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32), swizzles and sign flips folded into their op_sel / neg modifiers.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f V(float2 a) { return v2f{a.x, a.y}; }
+__device__ __forceinline__ float2 F(v2f a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// b + (-i) d and b - (-i) d: the quarter turn rides in the multiplier (1, -1), no separate negation
+__device__ __forceinline__ v2f add_mi(v2f b, v2f d) { return vfma(d.yx, v2f{1.0f, -1.0f}, b); }
+__device__ __forceinline__ v2f sub_mi(v2f b, v2f d) { return vfma(d.yx, v2f{-1.0f, 1.0f}, b); }
+// complex product a b = a.xx b + ((a.yy (-1, 1)) b.yx)
+__device__ __forceinline__ v2f vmul(v2f a, v2f b) { return vfma(a.yy * v2f{-1.0f, 1.0f}, b.yx, a.xx * b); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return F(vmul(V(a), V(b))); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return F(V(a) + V(b)); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return F(V(a) - V(b)); }
 __device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // * (-i)
 
 // 8-point forward DFT in registers: v[q] <- sum_r v[r] exp(-2 pi i r q / 8)
-__device__ __forceinline__ void dft8(float2 (&v)[8])
+__device__ __forceinline__ void dft8(float2 (&vv)[8])
 {
   constexpr float h = 0.70710678118654752440f;
-  float2 a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
-  float2 a1 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
-  float2 a2 = cadd(v[2], v[6]), a6 = csub(v[2], v[6]);
-  float2 a3 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
-  a5 = make_float2(h * (a5.x + a5.y), h * (a5.y - a5.x));      // * exp(-i pi/4)
-  a6 = mul_mi(a6);                                              // * exp(-i pi/2)
-  a7 = make_float2(h * (a7.y - a7.x), -h * (a7.x + a7.y));     // * exp(-3i pi/4)
-  float2 b0 = cadd(a0, a2), b2 = csub(a0, a2), b1 = cadd(a1, a3), b3 = mul_mi(csub(a1, a3));
-  float2 b4 = cadd(a4, a6), b6 = csub(a4, a6), b5 = cadd(a5, a7), b7 = mul_mi(csub(a5, a7));
-  v[0] = cadd(b0, b1); v[4] = csub(b0, b1); v[2] = cadd(b2, b3); v[6] = csub(b2, b3);
-  v[1] = cadd(b4, b5); v[5] = csub(b4, b5); v[3] = cadd(b6, b7); v[7] = csub(b6, b7);
+  v2f v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = V(vv[i]);
+  const v2f a0 = v[0] + v[4], a4 = v[0] - v[4];
+  const v2f a1 = v[1] + v[5], d5 = v[1] - v[5];
+  const v2f a2 = v[2] + v[6], a6 = v[2] - v[6];
+  const v2f a3 = v[3] + v[7], d7 = v[3] - v[7];
+  const v2f a5 = vfma(d5.yx, v2f{h, -h}, d5 * h);               // * exp(-i pi/4):  h (x + y, y - x)
+  const v2f a7 = vfma(d7.yx, v2f{h, -h}, d7 * -h);              // * exp(-3i pi/4): h (y - x, -x - y)
+  const v2f b0 = a0 + a2, b2 = a0 - a2, b1 = a1 + a3, d13 = a1 - a3;
+  const v2f b4 = add_mi(a4, a6), b6 = sub_mi(a4, a6), b5 = a5 + a7, d57 = a5 - a7;   // a6 enters turned by -i
+  vv[0] = F(b0 + b1); vv[4] = F(b0 - b1); vv[2] = F(add_mi(b2, d13)); vv[6] = F(sub_mi(b2, d13));
+  vv[1] = F(b4 + b5); vv[5] = F(b4 - b5); vv[3] = F(add_mi(b6, d57)); vv[7] = F(sub_mi(b6, d57));
 }
 
 __device__ __forceinline__ void dft4(float2& x0, float2& x1, float2& x2, float2& x3)
 {
-  const float2 d0 = cadd(x0, x2), d2 = csub(x0, x2), d1 = cadd(x1, x3), d3 = mul_mi(csub(x1, x3));
-  x0 = cadd(d0, d1); x2 = csub(d0, d1); x1 = cadd(d2, d3); x3 = csub(d2, d3);
+  const v2f d0 = V(x0) + V(x2), d2 = V(x0) - V(x2), d1 = V(x1) + V(x3), d13 = V(x1) - V(x3);
+  x0 = F(d0 + d1); x2 = F(d0 - d1); x1 = F(add_mi(d2, d13)); x3 = F(sub_mi(d2, d13));
 }
 
 __device__ __forceinline__ int view_byte(const uint8_t* stream, const FrameView& v, int p)
