@@ -267,8 +267,8 @@ bool Engine::store_tf_bytes(int slot, const uint8_t* fic_bytes, const uint8_t* m
       std::fill(plane.begin(), plane.end(), 0u);
       for (int u = 0; u < kCifBits / 16; ++u) plane[u >> 5] |= static_cast<uint32_t>(cif[16 * u + r] & 1u) << (u & 31);
       const size_t row = static_cast<size_t>(kRowLead + 4 * slot + q - tmap[r]);
-      // plane r occupies every 16th word of the logical row (layout of demap_kernel<true>)
-      if (!check(hipMemcpy2D(d_msc_bits_.get() + row * kCifWords + r, 16 * 4, plane.data(), 4, 4, 108, hipMemcpyHostToDevice), "msc upload")) return false;
+      // plane r occupies words [108 r, 108 r + 108) of the logical row (layout of demap_kernel<true>)
+      if (!check(hipMemcpy(d_msc_bits_.get() + row * kCifWords + r * 108, plane.data(), 108 * 4, hipMemcpyHostToDevice), "msc upload")) return false;
     }
   }
   return true;

@@ -260,12 +260,12 @@ __device__ __forceinline__ unsigned survivor_nibble(const uint4& lo, const uint4
 }
 
 // ---------------------------------------------------------------------------------------
-// regroup: logical CIF rows (planes interleaved word by word, one row per ETI frame) ->
+// regroup: logical CIF rows (16 planes of 108 x kBits words each, one row per ETI frame) ->
 // de-interleaved natural bit order, 64 frames interleaved word by word:
 //   grouped[(tile * 1728 + w) * 64 + lane] = bits 32 w .. 32 w + 31 of cif_time_deinterleaved
 // of frame job_ids[64 tile + lane].  The Viterbi kernel (lane = frame) then reads its received
-// bits with fully coalesced 256-byte loads.  Thread = (frame lane, block of 16 output words):
-// one 64-byte line in, 16 words out.
+// bits with fully coalesced 256-byte loads.  Thread = (frame lane, 4 consecutive plane words): 16 loads of
+// 16 bytes (one per plane) in, 64 words out; a workgroup consumes whole 64-byte lines of every plane.
 template <int kBits>
 __global__ __launch_bounds__(256) void regroup_kernel(const int* __restrict__ job_ids, const DecodeJob* __restrict__ jobs,
                                                       const int* __restrict__ stream_cif_base, const uint32_t* __restrict__ rows,
@@ -273,33 +273,37 @@ __global__ __launch_bounds__(256) void regroup_kernel(const int* __restrict__ jo
 {
   constexpr int kRowWords = 1728 * kBits, kBlocks = 108 * kBits;   // blocks of 16 words (one word of each plane)
   const int tile = blockIdx.y, lane = threadIdx.x & 63;
-  const int wb = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wb >= kBlocks) return;
+  const int wb4 = blockIdx.x * 4 + (threadIdx.x >> 6);    // group of 4 consecutive plane words
+  if (wb4 * 4 >= kBlocks) return;
   const int jid = job_ids[tile * 64 + lane];
   if (jid < 0) return;
   const DecodeJob job = jobs[jid];
-  const uint4* src = reinterpret_cast<const uint4*>(rows + (static_cast<size_t>(stream_cif_base[job.stream]) + job.cif) * kRowWords + wb * 16);
-  uint32_t pw[16];
+  // rows are plane-major: plane p (the bits i with i & 15 == p) occupies words [p * kBlocks, (p + 1) * kBlocks)
+  const uint32_t* row = rows + (static_cast<size_t>(stream_cif_base[job.stream]) + job.cif) * kRowWords + wb4 * 4;
+  uint4 v[16];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const uint4 v = src[k];
-    pw[4 * k] = v.x; pw[4 * k + 1] = v.y; pw[4 * k + 2] = v.z; pw[4 * k + 3] = v.w;
-  }
-  uint32_t* dst = grouped + (static_cast<size_t>(tile) * kRowWords + wb * 16) * 64 + lane;
+  for (int p = 0; p < 16; ++p) v[p] = *reinterpret_cast<const uint4*>(row + p * kBlocks);
 #pragma unroll
-  for (int o = 0; o < 16; ++o) {
-    uint32_t w = 0;
-    if (kBits == 1) {        // output word o: bit k <- plane k & 15, bit 2 o + (k >> 4) of that plane's word
+  for (int j = 0; j < 4; ++j) {
+    uint32_t pw[16];
 #pragma unroll
-      for (int p = 0; p < 16; ++p) {
-        const uint32_t two = (pw[p] >> (2 * o)) & 3u;
-        w |= ((two & 1u) << p) | ((two >> 1) << (16 + p));
+    for (int p = 0; p < 16; ++p) pw[p] = j == 0 ? v[p].x : j == 1 ? v[p].y : j == 2 ? v[p].z : v[p].w;
+    uint32_t* dst = grouped + (static_cast<size_t>(tile) * kRowWords + (wb4 * 4 + j) * 16) * 64 + lane;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      uint32_t w = 0;
+      if (kBits == 1) {        // output word o: bit k <- plane k & 15, bit 2 o + (k >> 4) of that plane's word
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+          const uint32_t two = (pw[p] >> (2 * o)) & 3u;
+          w |= ((two & 1u) << p) | ((two >> 1) << (16 + p));
+        }
+      } else {                 // 4-bit soft values: output word o = values of planes 8 (o & 1) .. + 7 at index o >> 1 of their words
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w |= ((pw[8 * (o & 1) + k] >> (4 * (o >> 1))) & 15u) << (4 * k);
       }
-    } else {                 // 4-bit soft values: output word o = values of planes 8 (o & 1) .. + 7 at index o >> 1 of their words
-#pragma unroll
-      for (int k = 0; k < 8; ++k) w |= ((pw[8 * (o & 1) + k] >> (4 * (o >> 1))) & 15u) << (4 * k);
+      dst[static_cast<size_t>(o) * 64] = w;
     }
-    dst[static_cast<size_t>(o) * 64] = w;
   }
 }
 
@@ -800,7 +804,7 @@ hipError_t launch_regroup(int soft_bits, const int* job_ids, int ntiles, const D
   const int bits = soft_bits ? 4 : 1;
   for (int t0 = 0; t0 < ntiles; t0 += 32768) {
     const int nt = min(32768, ntiles - t0);
-    const dim3 grid(27 * bits, nt);
+    const dim3 grid((27 * bits + 3) / 4, nt);           // 108 x bits plane words, 16 per workgroup
     uint32_t* dst = grouped + static_cast<size_t>(t0) * 1728 * bits * 64;
     if (soft_bits) hipLaunchKernelGGL(regroup_kernel<4>, grid, dim3(256), 0, stream, job_ids + static_cast<size_t>(t0) * 64, jobs, stream_cif_base, rows, dst);
     else hipLaunchKernelGGL(regroup_kernel<1>, grid, dim3(256), 0, stream, job_ids + static_cast<size_t>(t0) * 64, jobs, stream_cif_base, rows, dst);

@@ -198,8 +198,8 @@ __global__ __launch_bounds__(kThreads, 4) void fic_fft_kernel(const uint8_t* con
 // MSC output layout (kPlanar): the time de-interleaver (misc.c:29-39) reads bit i of the CIF
 // that lies map[i & 15] CIFs after the oldest one.  Instead of gathering from 16 rows later,
 // every transmitted CIF n is scattered here: its bits with i & 15 == r form "plane r" of
-// LOGICAL row n - map[r] (3456 bits = 108 words per plane, the 16 planes interleaved word by
-// word).  A complete logical row is then exactly the reference's cif_time_deinterleaved:
+// LOGICAL row n - map[r] (3456 bits = 108 words per plane, plane after plane: a symbol then leaves as 16 runs
+// of 6 consecutive words instead of 96 isolated ones).  A complete logical row is then exactly the reference's cif_time_deinterleaved:
 // out[i] = bit ((i >> 4) & 31) of row word ((i >> 9) * 16 + (i & 15)).
 // kBits = 1: hard decisions (the reference); kBits = 4: signed 4-bit soft values (extension):
 // value = round(4.5 x / mean|x|) clamped to +-7 with x = Re(cur conj(prev)) for the first bit and Im(cur conj(prev)) for
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
 #pragma unroll
         for (int b = 0; b < kPer; ++b) w |= static_cast<uint32_t>(bits[16 * (kPer * wq + b) + r]) << (kBits * b);
         const int delay = static_cast<int>(__brev(static_cast<unsigned>(r)) >> 28);   // map[r], misc.c:32
-        msc_bits[static_cast<size_t>(cif_row + q - delay) * (1728 * kBits) + (sidx * 6 * kBits + wq) * 16 + r] = w;
+        msc_bits[static_cast<size_t>(cif_row + q - delay) * (1728 * kBits) + r * (108 * kBits) + sidx * 6 * kBits + wq] = w;
       }
     }
     __syncthreads();

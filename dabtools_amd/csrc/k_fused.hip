@@ -126,7 +126,7 @@ __device__ __forceinline__ void flush_symbol(const uint8_t* dec, int sym, const 
     const int q = (sym - 4) / 18, sidx = (sym - 4) % 18;
     const int r = tid / 6, wq = tid % 6;
     const int delay = static_cast<int>(__brev(static_cast<unsigned>(r)) >> 28);   // map[r], misc.c:32
-    o.msc[static_cast<size_t>(o.cif_row + q - delay) * 1728 + (sidx * 6 + wq) * 16 + r] = bits;
+    o.msc[static_cast<size_t>(o.cif_row + q - delay) * 1728 + r * 108 + sidx * 6 + wq] = bits;
   }
 }
 
