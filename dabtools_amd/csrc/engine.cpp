@@ -62,7 +62,9 @@ Engine::Engine(int device) : device_(device)
   if (!check(hipStreamCreate(&stream_), "hipStreamCreate") || !check(hipStreamCreate(&copy_stream_), "hipStreamCreate")) return;
   for (auto& e : ev_)
     if (!check(hipEventCreate(&e), "hipEventCreate")) return;
-  if (!check(hipEventCreate(&ev_upload_), "hipEventCreate")) return;
+  if (!check(hipEventCreate(&ev_upload_), "hipEventCreate") || !check(hipEventCreate(&ev_fic_), "hipEventCreate") ||
+      !check(hipEventCreate(&ev_fibs_), "hipEventCreate"))
+    return;
 
   std::vector<double2> tw2048(2048), tw1536(1536);
   std::vector<float2> twf(2048);
@@ -118,6 +120,8 @@ Engine::~Engine()
     if (e) (void)hipEventDestroy(e);
   for (auto& e : chunk_ev_) (void)hipEventDestroy(e);
   if (ev_upload_) (void)hipEventDestroy(ev_upload_);
+  if (ev_fic_) (void)hipEventDestroy(ev_fic_);
+  if (ev_fibs_) (void)hipEventDestroy(ev_fibs_);
   if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -303,6 +307,12 @@ bool Engine::unpack_tf_slot(int slot, uint8_t* fic_bytes, uint8_t* msc_bytes)
 
 bool Engine::fic_decode_slots(int first, int n, uint8_t* fibs_host, uint8_t* ok_host)
 {
+  return fic_decode_slots_async(first, n, fibs_host, ok_host, stream_) && check(hipStreamSynchronize(stream_), "fic decode");
+}
+
+// the same without waiting: kernels on the main stream, the FIB / flag download on `copy` (ordered after them by an event)
+bool Engine::fic_decode_slots_async(int first, int n, uint8_t* fibs_host, uint8_t* ok_host, hipStream_t copy)
+{
   if (n <= 0) return true;
   const int bits = soft_bits_ ? 4 : 1;
   const int pid = plan_id(make_plan(fic_plan(), 0, 0));
@@ -322,10 +332,10 @@ bool Engine::fic_decode_slots(int first, int n, uint8_t* fibs_host, uint8_t* ok_
              "fic viterbi launch"))
     return false;
   if (!check(launch_fib_crc(d_fibs_.get() + static_cast<size_t>(first) * 384, n * 12, d_crc_tab_.get(), d_fib_ok_.get() + static_cast<size_t>(first) * 12, stream_), "fib crc launch")) return false;
-  if (!check(hipMemcpyAsync(fibs_host, d_fibs_.get() + static_cast<size_t>(first) * 384, static_cast<size_t>(n) * 384, hipMemcpyDeviceToHost, stream_), "fib download") ||
-      !check(hipMemcpyAsync(ok_host, d_fib_ok_.get() + static_cast<size_t>(first) * 12, static_cast<size_t>(n) * 12, hipMemcpyDeviceToHost, stream_), "fib flag download"))
-    return false;
-  return check(hipStreamSynchronize(stream_), "fic decode");
+  if (copy != stream_ && (!check(hipEventRecord(ev_fic_, stream_), "fic event") || !check(hipStreamWaitEvent(copy, ev_fic_, 0), "fic event"))) return false;
+  return check(hipMemcpyAsync(fibs_host, d_fibs_.get() + static_cast<size_t>(first) * 384, static_cast<size_t>(n) * 384, hipMemcpyDeviceToHost, copy), "fib download") &&
+         check(hipMemcpyAsync(ok_host, d_fib_ok_.get() + static_cast<size_t>(first) * 12, static_cast<size_t>(n) * 12, hipMemcpyDeviceToHost, copy), "fib flag download") &&
+         check(hipEventRecord(ev_fibs_, copy), "fib download event");
 }
 
 bool Engine::msc_prepare(const std::vector<const std::vector<EtiJob>*>& stream_jobs, const std::vector<const ControlPlane*>& planes,
@@ -579,25 +589,27 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     states.assign(nstreams, initial_state());
     if (!d_states_.upload(states, stream_)) return -1;
   }
-  if (!d_iq_ptrs_.upload(ptrs, stream_) || !d_nbytes_.upload(nb, stream_) || !d_descs_.reserve(ndesc)) return -1;
-  if (!check(hipMemsetAsync(d_descs_.get(), 0, ndesc * sizeof(CallDesc), stream_), "desc memset")) return -1;
+  if (!d_iq_ptrs_.upload(ptrs, stream_) || !d_nbytes_.upload(nb, stream_) || !d_descs_.reserve(ndesc) || !d_info_.reserve(ndesc)) return -1;
+  if (!check(hipMemsetAsync(d_descs_.get(), 0, ndesc * sizeof(CallDesc), stream_), "desc memset") ||
+      !check(hipMemsetAsync(d_info_.get(), 0, ndesc * sizeof(int2), stream_), "info memset"))
+    return -1;
 
   times_.setup = since(wall0);
   // K1
   (void)hipEventRecord(ev_[0], stream_);
-  if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), nstreams, max_calls_, -1, -1,
+  if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), nstreams, max_calls_, -1, -1,
                               d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), afc_ ? 1 : 0, stream_),
              "sync scan launch"))
     return -1;
   (void)hipEventRecord(ev_[1], stream_);
-  // The host only needs {status, ordinal} of every call to lay the frames out: those 8 bytes per descriptor come back
-  // first (strided copy); the full descriptors (trace API) follow on the side stream and are awaited at the end.
+  // The host only needs {status, ordinal} of every call to lay the frames out: K1 writes those 8 bytes per call to a
+  // compact array that comes back first; the full descriptors (trace API) follow on the side stream, awaited at the end.
   if (!h_descs_.resize(ndesc) || !h_info_.resize(ndesc)) return -1;
   struct SideStreamGuard {
     hipStream_t s;
     ~SideStreamGuard() { (void)hipStreamSynchronize(s); }
   } side_guard{copy_stream_};
-  if (!check(hipMemcpy2DAsync(h_info_.data(), sizeof(int2), d_descs_.get(), sizeof(CallDesc), sizeof(int2), ndesc, hipMemcpyDeviceToHost, stream_), "call info download") ||
+  if (!check(hipMemcpyAsync(h_info_.data(), d_info_.get(), ndesc * sizeof(int2), hipMemcpyDeviceToHost, stream_), "call info download") ||
       !check(hipMemcpyAsync(states.data(), d_states_.get(), states.size() * sizeof(StreamState), hipMemcpyDeviceToHost, stream_), "state download") ||
       !check(hipStreamWaitEvent(copy_stream_, ev_[1], 0), "desc download") ||
       !check(hipMemcpyAsync(h_descs_.data(), d_descs_.get(), ndesc * sizeof(CallDesc), hipMemcpyDeviceToHost, copy_stream_), "desc download") ||
@@ -658,13 +670,36 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
                "fic pre-pass launch"))
       return -1;
   }
-  if (!fic_decode_slots(0, nslots, fibs, ok)) return -1;      // carried slots are decoded again: their FIBs are read by K5
-  {
-    hipEvent_t end = ev_[0];
-    (void)hipEventRecord(end, stream_);
-    (void)hipEventSynchronize(end);
-    (void)hipEventElapsedTime(&times_.fic, ev_[3], end);
+  // FIC decode kernels on the main stream, the FIB download on the side stream: the OFDM stage is queued right behind
+  // the FIC kernels and starts without waiting for the download or for the host
+  if (!fic_decode_slots_async(0, nslots, fibs, ok, copy_stream_)) return -1;      // carried slots are decoded again: their FIBs are read by K5
+  (void)hipEventRecord(ev_[0], stream_);
+
+  // K2 + K2b in chunks (they share one spectra buffer; stream order keeps them apart), timed with per-chunk events
+  bool gpu_ok = true;
+  const int nchunks = (ntf + chunk - 1) / chunk;
+  while (static_cast<int>(chunk_ev_.size()) < 3 * nchunks) {
+    hipEvent_t e = nullptr;
+    if (!check(hipEventCreate(&e), "hipEventCreate")) { gpu_ok = false; break; }
+    chunk_ev_.push_back(e);
   }
+  for (int c = 0; c < nchunks && gpu_ok; ++c) {
+    const int first = c * chunk, n = std::min(chunk, ntf - first);
+    (void)hipEventRecord(chunk_ev_[3 * c], stream_);
+    if (fused_ && soft_bits_ == 0) {
+      gpu_ok = check(launch_ofdm_demap_fused(afc_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_twf_.get(), d_frame_slot_.get(),
+                                             d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_),
+                     "fused fft/demap launch");
+      (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
+    } else {
+      gpu_ok = check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(), stream_), "fft launch");
+      (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
+      gpu_ok = gpu_ok && check(launch_demap(true, soft_bits_, d_spectra_.get(), first, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch");
+    }
+    (void)hipEventRecord(chunk_ev_[3 * c + 2], stream_);
+  }
+  if (!check(hipEventSynchronize(ev_fibs_), "fic decode")) return -1;
+  (void)hipEventElapsedTime(&times_.fic, ev_[3], ev_[0]);
 
   // control plane + work lists on a host thread, hidden behind K2 + K2b
   std::vector<ControlPlane>& planes = planes_;
@@ -700,29 +735,6 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     times_.worklist = since(t1);
   });
 
-  // K2 + K2b in chunks (they share one spectra buffer; stream order keeps them apart), timed with per-chunk events
-  bool gpu_ok = true;
-  const int nchunks = (ntf + chunk - 1) / chunk;
-  while (static_cast<int>(chunk_ev_.size()) < 3 * nchunks) {
-    hipEvent_t e = nullptr;
-    if (!check(hipEventCreate(&e), "hipEventCreate")) { gpu_ok = false; break; }
-    chunk_ev_.push_back(e);
-  }
-  for (int c = 0; c < nchunks && gpu_ok; ++c) {
-    const int first = c * chunk, n = std::min(chunk, ntf - first);
-    (void)hipEventRecord(chunk_ev_[3 * c], stream_);
-    if (fused_ && soft_bits_ == 0) {
-      gpu_ok = check(launch_ofdm_demap_fused(afc_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_twf_.get(), d_frame_slot_.get(),
-                                             d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_),
-                     "fused fft/demap launch");
-      (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
-    } else {
-      gpu_ok = check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(), stream_), "fft launch");
-      (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
-      gpu_ok = gpu_ok && check(launch_demap(true, soft_bits_, d_spectra_.get(), first, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch");
-    }
-    (void)hipEventRecord(chunk_ev_[3 * c + 2], stream_);
-  }
   gpu_ok = gpu_ok && check(hipStreamSynchronize(stream_), "fft/demap");
   for (int c = 0; c < nchunks && gpu_ok; ++c) {
     float a = 0, d = 0;
@@ -913,7 +925,7 @@ bool Engine::scan_one_call(const uint8_t* iq_virtual_base, int64_t fed_bytes, St
   std::vector<int64_t> nb = {fed_bytes};
   if (!d_iq_ptrs_.upload(ptrs, stream_) || !d_nbytes_.upload(nb, stream_) || !d_descs_.reserve(1)) return false;
   // the kernel indexes descs[stream * max_calls + call]; with max_calls = 0 and the pointer moved back by `call` it hits slot 0
-  if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_state, d_descs_.get() - call, 1, 0, call, call + 1, d_tw2048_.get(),
+  if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_state, d_descs_.get() - call, nullptr, 1, 0, call, call + 1, d_tw2048_.get(),
                               d_tw1536_.get(), d_prs_.get(), 0, stream_),
              "sync scan launch"))
     return false;

@@ -171,6 +171,7 @@ class Engine {
   bool recycle_tf_slots(int used_slots, int keep_slots);
   // FIC-decode TF slots [first, first+n): FIBs and CRC flags to host
   bool fic_decode_slots(int first, int n, uint8_t* fibs_host, uint8_t* ok_host);
+  bool fic_decode_slots_async(int first, int n, uint8_t* fibs_host, uint8_t* ok_host, hipStream_t copy);   // completion: ev_fibs_
   // decode the ETI frames described by the per-stream job lists into the ETI buffer (stream-major order)
   // stream_row_base[b]: logical CIF row of stream b's CIF 0; stream_fib_base[b]: FIB block (4 per TF slot) of its CIF 0
   bool msc_decode(const std::vector<const std::vector<EtiJob>*>& stream_jobs, const std::vector<const ControlPlane*>& planes,
@@ -214,7 +215,7 @@ class Engine {
   int device_ = 0;
   hipStream_t stream_ = nullptr, copy_stream_ = nullptr;   // copy_stream_: work-list uploads from the control-plane thread
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_upload_ = nullptr;
+  hipEvent_t ev_upload_ = nullptr, ev_fic_ = nullptr, ev_fibs_ = nullptr;
   std::vector<hipEvent_t> chunk_ev_;
 
   // constant tables
@@ -230,6 +231,7 @@ class Engine {
   DeviceBuffer<int64_t> d_nbytes_;
   DeviceBuffer<StreamState> d_states_;
   DeviceBuffer<CallDesc> d_descs_;
+  DeviceBuffer<int2> d_info_;
   DeviceBuffer<int2> d_frames_;
   DeviceBuffer<int> d_frame_slot_, d_frame_cif_row_, d_stream_cif_base_;
   DeviceBuffer<float2> d_spectra_;

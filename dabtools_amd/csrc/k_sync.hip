@@ -177,7 +177,7 @@ struct Shared {
 __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* const* __restrict__ iq,
                                                              const int64_t* __restrict__ nbytes,
                                                              StreamState* __restrict__ states,
-                                                             CallDesc* __restrict__ descs, int max_calls, int call_begin,
+                                                             CallDesc* __restrict__ descs, int2* __restrict__ info, int max_calls, int call_begin,
                                                              int call_end, const double2* __restrict__ tw2048,
                                                              const double2* __restrict__ tw1536,
                                                              const uint8_t* __restrict__ prs_q, int afc)
@@ -362,6 +362,7 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
       CallDesc& d = descs[static_cast<size_t>(b) * max_calls + (k - kdesc0)];
       d.status = sh.status;
       d.ordinal = sh.status == 2 ? sh.st.next_ordinal++ : -1;
+      if (info) info[static_cast<size_t>(b) * max_calls + (k - kdesc0)] = make_int2(d.status, d.ordinal);   // what the host lays the frames out with
       d.coarse_timeshift = sh.st.coarse_timeshift;
       d.fine_timeshift = sh.st.fine_timeshift;
       d.coarse_freq_shift = sh.coarse_fs;
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
 
 size_t sync_scan_lds_bytes() { return sizeof(double2) * (2048 + 29 * 128 + 1024) + sizeof(Shared); }
 
-hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, StreamState* states, CallDesc* descs,
+hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, StreamState* states, CallDesc* descs, int2* info,
                             int nstreams, int max_calls, int call_begin, int call_end, const double2* tw2048,
                             const double2* tw1536, const uint8_t* prs_q, int afc, hipStream_t stream)
 {
@@ -403,7 +404,7 @@ hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, Str
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(sync_scan_kernel, dim3(nstreams), dim3(kThreads), lds, stream, iq, nbytes, states, descs, max_calls,
+  hipLaunchKernelGGL(sync_scan_kernel, dim3(nstreams), dim3(kThreads), lds, stream, iq, nbytes, states, descs, info, max_calls,
                      call_begin, call_end, tw2048, tw1536, prs_q, afc);
   return hipGetLastError();
 }

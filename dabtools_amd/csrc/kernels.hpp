@@ -11,7 +11,7 @@
 namespace dabhip {
 
 // K1: synchronisation scan, one workgroup per stream, calls [call_begin, call_end) (call_end < 0: all)
-hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, StreamState* states, CallDesc* descs,
+hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, StreamState* states, CallDesc* descs, int2* info,
                             int nstreams, int max_calls, int call_begin, int call_end, const double2* tw2048,
                             const double2* tw1536, const uint8_t* prs_q, int afc, hipStream_t stream);
 
