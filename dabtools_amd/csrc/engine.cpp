@@ -583,11 +583,12 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
       off += (nbytes[b] + 15) & ~size_t(15);
     }
   }
-  std::vector<StreamState>& states = h_states_;
+  if (!h_states_.resize(nstreams)) return -1;
+  StreamState* const states = h_states_.data();
   const size_t ndesc = static_cast<size_t>(nstreams) * max_calls_;
   if (!cont) {
-    states.assign(nstreams, initial_state());
-    if (!d_states_.upload(states, stream_)) return -1;
+    std::fill(states, states + nstreams, initial_state());
+    if (!d_states_.upload(states, nstreams, stream_)) return -1;
   }
   if (!d_iq_ptrs_.upload(ptrs, stream_) || !d_nbytes_.upload(nb, stream_) || !d_descs_.reserve(ndesc) || !d_info_.reserve(ndesc)) return -1;
   if (!check(hipMemsetAsync(d_descs_.get(), 0, ndesc * sizeof(CallDesc), stream_), "desc memset") ||
@@ -610,46 +611,45 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     ~SideStreamGuard() { (void)hipStreamSynchronize(s); }
   } side_guard{copy_stream_};
   if (!check(hipMemcpyAsync(h_info_.data(), d_info_.get(), ndesc * sizeof(int2), hipMemcpyDeviceToHost, stream_), "call info download") ||
-      !check(hipMemcpyAsync(states.data(), d_states_.get(), states.size() * sizeof(StreamState), hipMemcpyDeviceToHost, stream_), "state download") ||
+      !check(hipMemcpyAsync(states, d_states_.get(), nstreams * sizeof(StreamState), hipMemcpyDeviceToHost, stream_), "state download") ||
       !check(hipStreamWaitEvent(copy_stream_, ev_[1], 0), "desc download") ||
       !check(hipMemcpyAsync(h_descs_.data(), d_descs_.get(), ndesc * sizeof(CallDesc), hipMemcpyDeviceToHost, copy_stream_), "desc download") ||
       !check(hipStreamSynchronize(stream_), "sync scan"))
     return -1;
   (void)hipEventElapsedTime(&times_.sync, ev_[0], ev_[1]);
-  for (const StreamState& st : states)
-    if (st.overflow) { set_error("sync scan: stale-tail bookkeeping overflow (more than kMaxSeg nested short reads)"); return -1; }
+  for (int b = 0; b < nstreams; ++b)
+    if (states[b].overflow) { set_error("sync scan: stale-tail bookkeeping overflow (more than kMaxSeg nested short reads)"); return -1; }
 
   // frame list: demodulated TFs, stream-major.  Slots and logical CIF rows of a stream: first the ones carried over from
   // the previous segment of a session (the last <= 4 TFs), then this segment's.
   const auto tfr = std::chrono::steady_clock::now();
-  std::vector<int2> frames;
-  std::vector<int> frame_slot, frame_cif_row, tf_base(nstreams + 1, 0), row_base(nstreams), fib_base(nstreams), nnew(nstreams, 0);
-  int next_row = 0;
+  std::vector<int> tf_base(nstreams + 1, 0), row_base(nstreams), fib_base(nstreams), nnew(nstreams, 0);
+  if (!h_frames_.resize(ndesc) || !h_frame_slot_.resize(ndesc) || !h_frame_cif_row_.resize(ndesc)) return -1;   // page-locked: uploaded asynchronously
+  int next_row = 0, ntf_new = 0;
   for (int b = 0; b < nstreams; ++b) {
-    int n = 0;
-    const int keep = carry_keep_[b];
+    const int keep = carry_keep_[b], j0 = ntf_new;
     const int ncalls = static_cast<int>(nbytes[b] / kChunkBytes) - calls_done_[b];
+    row_base[b] = next_row + kRowLead;      // each stream gets 15 lead-in rows for the scatter of its first CIFs
     for (int k = 0; k < ncalls; ++k) {
       const int2 d = h_info_[static_cast<size_t>(b) * max_calls_ + k];     // {status, ordinal}
       if (d.x == 2) {
         const int local = keep + (d.y - ord_done_[b]);
-        frames.push_back(make_int2(b, k));
-        frame_slot.push_back(tf_base[b] + local);
-        frame_cif_row.push_back(next_row + kRowLead + 4 * local);
-        ++n;
+        h_frames_[ntf_new] = make_int2(b, k);
+        h_frame_slot_[ntf_new] = tf_base[b] + local;
+        h_frame_cif_row_[ntf_new] = row_base[b] + 4 * local;
+        ++ntf_new;
       }
     }
-    nnew[b] = n;
-    tf_base[b + 1] = tf_base[b] + keep + n;
+    nnew[b] = ntf_new - j0;
+    tf_base[b + 1] = tf_base[b] + keep + nnew[b];
     fib_base[b] = 4 * tf_base[b];
-    row_base[b] = next_row + kRowLead;      // each stream gets 15 lead-in rows for the scatter of its first CIFs
-    next_row += kRowLead + 4 * (keep + n);
+    next_row += kRowLead + 4 * (keep + nnew[b]);
   }
   for (int b = 0; b < nstreams; ++b) calls_done_[b] = std::max(calls_done_[b], static_cast<int>(nbytes[b] / kChunkBytes));
-  const int ntf = static_cast<int>(frames.size()), nslots = tf_base[nstreams];
+  const int ntf = ntf_new, nslots = tf_base[nstreams];
   if (ntf == 0) return 0;                   // nothing demodulated: layout and carried data stay as they are
-  if (!carry_and_reserve(tf_base, row_base, nslots, next_row + 1) || !d_frames_.upload(frames, stream_) ||
-      !d_frame_slot_.upload(frame_slot, stream_) || !d_frame_cif_row_.upload(frame_cif_row, stream_))
+  if (!carry_and_reserve(tf_base, row_base, nslots, next_row + 1) || !d_frames_.upload(h_frames_.data(), ntf, stream_) ||
+      !d_frame_slot_.upload(h_frame_slot_.data(), ntf, stream_) || !d_frame_cif_row_.upload(h_frame_cif_row_.data(), ntf, stream_))
     return -1;
 
   times_.frames = since(tfr);

@@ -250,7 +250,9 @@ class Engine {
 
   // session state (decode() resets it, feed() continues it)
   std::vector<ControlPlane> planes_;
-  std::vector<StreamState> h_states_;
+  PinnedBuffer<StreamState> h_states_;
+  PinnedBuffer<int2> h_frames_;
+  PinnedBuffer<int> h_frame_slot_, h_frame_cif_row_;
   std::vector<int> carry_keep_, prev_used_, calls_done_, ord_done_, prev_tf_base_, prev_row_base_;
   DeviceBuffer<uint8_t> d_carry_;
   DeviceBuffer<CopyDesc> d_copy_descs_;
