@@ -596,3 +596,31 @@ def test_fused_ofdm_stage_gives_identical_frames():
         assert sum(len(w) for w in want) > 100
         if not afc:
             assert np.array_equal(want[0], ol.or_replay(caps[0])[0])
+
+
+@pytest.mark.gpu
+def test_streaming_session_carries_the_afc_state():
+    """The NCO frequency and the tuner rule's generator live in the carried front-end state: an offset capture decodes
+    the same whether it is fed at once or in segments, and the CLI's --afc reaches both modes."""
+    import os
+    import subprocess
+    import tempfile
+    cap = dab.synth_generate(dab.synth_preset(1, seed=41, cfo_hz=2600.0), 44)
+    eng = dab.Engine(0)
+    eng.set_afc(True)
+    eng.decode([cap])
+    want = eng.eti(0)
+    assert len(want) > 60                     # locks after the NCO has pulled in
+    st = dab.Stream(1, afc=True)
+    got, pos = [], 0
+    for n in (262144 * 9, 1234568, 262144 * 30, 5000000, 10 ** 9):
+        st.feed([cap[pos:pos + n]])
+        got.append(st.eti(0))
+        pos += n
+    assert np.array_equal(np.concatenate(got), want)
+    st.close()
+    exe = os.path.join(os.path.dirname(dab.LIB_PATH), "dab2eti-hip")
+    with tempfile.NamedTemporaryFile(suffix=".cu8") as f:
+        cap.tofile(f.name)
+        out = subprocess.run([exe, "--afc", "--segment-calls", "11", "--stream", f.name], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    assert np.array_equal(np.frombuffer(out, dtype=np.uint8).reshape(-1, 6144), want)
