@@ -154,7 +154,10 @@ static CodewordPlan make_plan(const PuncturePlan& pp, int start_bit, int out_off
 // wave-groups of <= 64 jobs per plan, longest code words first
 void Engine::build_batch(const std::vector<std::pair<int, const std::vector<int>*>>& plan_jobs, DecodeBatch& out)
 {
-  out = DecodeBatch{};
+  out.groups.clear();
+  out.job_ids.clear();
+  out.slice_start.clear();
+  out.max_dec_rows = 0;
   std::vector<std::pair<int, size_t>> order;   // (nsteps, index into plan_jobs)
   size_t total = 0;
   for (size_t i = 0; i < plan_jobs.size(); ++i) {
@@ -703,8 +706,11 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
 
   // control plane + work lists on a host thread, hidden behind K2 + K2b
   std::vector<ControlPlane>& planes = planes_;
-  std::vector<std::vector<EtiJob>> stream_jobs(nstreams);
-  MscWork work;
+  // host work lists live in the engine: ~35 MB per step at the benchmark size, reused instead of re-allocated
+  std::vector<std::vector<EtiJob>>& stream_jobs = stream_jobs_;
+  stream_jobs.resize(nstreams);
+  for (auto& v : stream_jobs) v.clear();
+  MscWork& work = work_;
   bool host_ok = true;
   std::string host_error;
   std::thread host([&]() {

@@ -248,6 +248,8 @@ class Engine {
   DeviceBuffer<uint8_t> d_headers_, d_eti_, d_bytes_;
   int tf_slots_ = 0, msc_rows_ = 0;
 
+  std::vector<std::vector<EtiJob>> stream_jobs_;
+  MscWork work_;
   // session state (decode() resets it, feed() continues it)
   std::vector<ControlPlane> planes_;
   PinnedBuffer<StreamState> h_states_;
