@@ -566,8 +566,9 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     prev_row_base_.assign(nstreams, 0);
   }
 
-  std::vector<const uint8_t*> ptrs(nstreams);
-  std::vector<int64_t> nb(nstreams);
+  if (!h_ptrs_.resize(nstreams) || !h_nb_.resize(nstreams)) return -1;      // page-locked staging: asynchronous uploads
+  const uint8_t** const ptrs = h_ptrs_.data();
+  int64_t* const nb = h_nb_.data();
   max_calls_ = 1;
   size_t total = 0;
   for (int b = 0; b < nstreams; ++b) {
@@ -593,7 +594,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     std::fill(states, states + nstreams, initial_state());
     if (!d_states_.upload(states, nstreams, stream_)) return -1;
   }
-  if (!d_iq_ptrs_.upload(ptrs, stream_) || !d_nbytes_.upload(nb, stream_) || !d_descs_.reserve(ndesc) || !d_info_.reserve(ndesc)) return -1;
+  if (!d_iq_ptrs_.upload(ptrs, nstreams, stream_) || !d_nbytes_.upload(nb, nstreams, stream_) || !d_descs_.reserve(ndesc) || !d_info_.reserve(ndesc)) return -1;
   if (!check(hipMemsetAsync(d_descs_.get(), 0, ndesc * sizeof(CallDesc), stream_), "desc memset") ||
       !check(hipMemsetAsync(d_info_.get(), 0, ndesc * sizeof(int2), stream_), "info memset"))
     return -1;

@@ -254,6 +254,8 @@ class Engine {
   std::vector<ControlPlane> planes_;
   PinnedBuffer<StreamState> h_states_;
   PinnedBuffer<int2> h_frames_;
+  PinnedBuffer<const uint8_t*> h_ptrs_;
+  PinnedBuffer<int64_t> h_nb_;
   PinnedBuffer<int> h_frame_slot_, h_frame_cif_row_;
   std::vector<int> carry_keep_, prev_used_, calls_done_, ord_done_, prev_tf_base_, prev_row_base_;
   DeviceBuffer<uint8_t> d_carry_;
