@@ -541,17 +541,10 @@ int64_t Engine::stream_need_from(int b) const
   return std::max<int64_t>(need, 0) & ~int64_t(1);
 }
 
-int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont)
+// session bookkeeping at the start of a decode (fresh) or of a further segment (cont)
+bool Engine::begin_decode(int nstreams, bool cont)
 {
-  if (!ok_) { set_error("engine not initialised (no GPU?)"); return -1; }
-  if (nstreams <= 0) { set_error("decode: no streams"); return -1; }
-  if (!check(hipSetDevice(device_), "hipSetDevice")) return -1;
-  const auto wall0 = std::chrono::steady_clock::now();
-  auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - a).count(); };
-  times_ = StageTimes{};
-  fft_launches_ = fft_tfs_ = 0;
-  fft_ms_ = 0;
-  if (cont && (nstreams != nstreams_ || static_cast<int>(planes_.size()) != nstreams)) { set_error("feed: the number of streams changed within a session"); return -1; }
+  if (cont && (nstreams != nstreams_ || static_cast<int>(planes_.size()) != nstreams)) { set_error("feed: the number of streams changed within a session"); return false; }
   nstreams_ = nstreams;
   eti_base_.assign(nstreams, 0);
   eti_count_.assign(nstreams, 0);
@@ -565,8 +558,15 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     prev_tf_base_.assign(nstreams + 1, 0);
     prev_row_base_.assign(nstreams, 0);
   }
+  return true;
+}
 
-  if (!h_ptrs_.resize(nstreams) || !h_nb_.resize(nstreams)) return -1;      // page-locked staging: asynchronous uploads
+// K1 over the calls that became complete: stages pointers / sizes / states, launches the scan, brings back {status, ordinal}
+// per call and the front-end states (main stream, awaited) and the full descriptors (side stream, awaited by the caller's guard)
+bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont)
+{
+  const auto wall0 = std::chrono::steady_clock::now();
+  if (!h_ptrs_.resize(nstreams) || !h_nb_.resize(nstreams)) return false;   // page-locked staging: asynchronous uploads
   const uint8_t** const ptrs = h_ptrs_.data();
   int64_t* const nb = h_nb_.data();
   max_calls_ = 1;
@@ -579,50 +579,66 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   if (on_device) {
     for (int b = 0; b < nstreams; ++b) ptrs[b] = iq[b];
   } else {
-    if (!d_iq_own_.reserve(total)) return -1;
+    if (!d_iq_own_.reserve(total)) return false;
     size_t off = 0;
     for (int b = 0; b < nstreams; ++b) {
-      if (!check(hipMemcpyAsync(d_iq_own_.get() + off, iq[b], nbytes[b], hipMemcpyHostToDevice, stream_), "IQ upload")) return -1;
+      if (!check(hipMemcpyAsync(d_iq_own_.get() + off, iq[b], nbytes[b], hipMemcpyHostToDevice, stream_), "IQ upload")) return false;
       ptrs[b] = d_iq_own_.get() + off;
       off += (nbytes[b] + 15) & ~size_t(15);
     }
   }
-  if (!h_states_.resize(nstreams)) return -1;
+  if (!h_states_.resize(nstreams)) return false;
   StreamState* const states = h_states_.data();
   const size_t ndesc = static_cast<size_t>(nstreams) * max_calls_;
   if (!cont) {
     std::fill(states, states + nstreams, initial_state());
-    if (!d_states_.upload(states, nstreams, stream_)) return -1;
+    if (!d_states_.upload(states, nstreams, stream_)) return false;
   }
-  if (!d_iq_ptrs_.upload(ptrs, nstreams, stream_) || !d_nbytes_.upload(nb, nstreams, stream_) || !d_descs_.reserve(ndesc) || !d_info_.reserve(ndesc)) return -1;
+  if (!d_iq_ptrs_.upload(ptrs, nstreams, stream_) || !d_nbytes_.upload(nb, nstreams, stream_) || !d_descs_.reserve(ndesc) || !d_info_.reserve(ndesc)) return false;
   if (!check(hipMemsetAsync(d_descs_.get(), 0, ndesc * sizeof(CallDesc), stream_), "desc memset") ||
       !check(hipMemsetAsync(d_info_.get(), 0, ndesc * sizeof(int2), stream_), "info memset"))
-    return -1;
+    return false;
+  scan_setup_ms_ = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
 
-  times_.setup = since(wall0);
-  // K1
   (void)hipEventRecord(ev_[0], stream_);
   if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), nstreams, max_calls_, -1, -1,
                               d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), afc_ ? 1 : 0, stream_),
              "sync scan launch"))
-    return -1;
+    return false;
   (void)hipEventRecord(ev_[1], stream_);
   // The host only needs {status, ordinal} of every call to lay the frames out: K1 writes those 8 bytes per call to a
-  // compact array that comes back first; the full descriptors (trace API) follow on the side stream, awaited at the end.
-  if (!h_descs_.resize(ndesc) || !h_info_.resize(ndesc)) return -1;
-  struct SideStreamGuard {
-    hipStream_t s;
-    ~SideStreamGuard() { (void)hipStreamSynchronize(s); }
-  } side_guard{copy_stream_};
+  // compact array that comes back first; the full descriptors (trace API) follow on the side stream.
+  if (!h_descs_.resize(ndesc) || !h_info_.resize(ndesc)) return false;
   if (!check(hipMemcpyAsync(h_info_.data(), d_info_.get(), ndesc * sizeof(int2), hipMemcpyDeviceToHost, stream_), "call info download") ||
       !check(hipMemcpyAsync(states, d_states_.get(), nstreams * sizeof(StreamState), hipMemcpyDeviceToHost, stream_), "state download") ||
       !check(hipStreamWaitEvent(copy_stream_, ev_[1], 0), "desc download") ||
       !check(hipMemcpyAsync(h_descs_.data(), d_descs_.get(), ndesc * sizeof(CallDesc), hipMemcpyDeviceToHost, copy_stream_), "desc download") ||
       !check(hipStreamSynchronize(stream_), "sync scan"))
-    return -1;
+    return false;
   (void)hipEventElapsedTime(&times_.sync, ev_[0], ev_[1]);
   for (int b = 0; b < nstreams; ++b)
-    if (states[b].overflow) { set_error("sync scan: stale-tail bookkeeping overflow (more than kMaxSeg nested short reads)"); return -1; }
+    if (states[b].overflow) { set_error("sync scan: stale-tail bookkeeping overflow (more than kMaxSeg nested short reads)"); return false; }
+  return true;
+}
+
+int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont)
+{
+  if (!ok_) { set_error("engine not initialised (no GPU?)"); return -1; }
+  if (nstreams <= 0) { set_error("decode: no streams"); return -1; }
+  if (!check(hipSetDevice(device_), "hipSetDevice")) return -1;
+  const auto wall0 = std::chrono::steady_clock::now();
+  auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+  times_ = StageTimes{};
+  fft_launches_ = fft_tfs_ = 0;
+  fft_ms_ = 0;
+  if (!begin_decode(nstreams, cont)) return -1;
+  struct SideStreamGuard {                   // whatever was queued on the side stream is awaited before returning
+    hipStream_t s;
+    ~SideStreamGuard() { (void)hipStreamSynchronize(s); }
+  } side_guard{copy_stream_};
+  if (!scan_streams(iq, nbytes, nstreams, on_device, cont)) return -1;
+  times_.setup = scan_setup_ms_;
+  const size_t ndesc = static_cast<size_t>(nstreams) * max_calls_;
 
   // frame list: demodulated TFs, stream-major.  Slots and logical CIF rows of a stream: first the ones carried over from
   // the previous segment of a session (the last <= 4 TFs), then this segment's.

@@ -196,6 +196,8 @@ class Engine {
  private:
   bool check(hipError_t e, const char* what);
   int64_t decode_impl(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont);
+  bool begin_decode(int nstreams, bool cont);
+  bool scan_streams(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont);
   bool carry_and_reserve(const std::vector<int>& tf_base, const std::vector<int>& row_base, int nslots, int nrows);
   // plan_jobs[i] = (plan id, job indices decoded with that plan)
   void build_batch(const std::vector<std::pair<int, const std::vector<int>*>>& plan_jobs, DecodeBatch& out);
@@ -268,6 +270,7 @@ class Engine {
   PinnedBuffer<int2> h_info_;
   PinnedBuffer<uint8_t> h_fibs_, h_fib_ok_;
   int max_calls_ = 0, nstreams_ = 0;
+  float scan_setup_ms_ = 0;
   std::vector<int64_t> eti_base_, eti_count_;
   int64_t total_eti_ = 0;
   StageTimes times_;
