@@ -624,3 +624,36 @@ def test_streaming_session_carries_the_afc_state():
         cap.tofile(f.name)
         out = subprocess.run([exe, "--afc", "--segment-calls", "11", "--stream", f.name], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
     assert np.array_equal(np.frombuffer(out, dtype=np.uint8).reshape(-1, 6144), want)
+
+
+@pytest.mark.gpu
+def test_engine_reuse_across_batch_shapes_and_modes():
+    """One engine, decodes of different shapes and modes back to back (grow-only buffers, reused work lists, persistent
+    session state must not leak from one call into the next): every result equals that of a fresh engine."""
+    a = [dab.synth_generate(dab.synth_preset(0, seed=51 + i, skip_samples=1000 * i), 22) for i in range(5)]
+    b = [dab.synth_generate(dab.synth_preset(1, seed=61, snr_db=8.0), 30)]
+    c = [dab.synth_generate(dab.synth_preset(1, seed=62), 17), np.zeros(0, np.uint8), dab.synth_generate(dab.synth_preset(1, seed=63), 3)]
+
+    def fresh(caps, **kw):
+        e = dab.Engine(0)
+        for k, v in kw.items():
+            getattr(e, "set_" + k)(v)
+        e.decode(caps)
+        return [e.eti(i) for i in range(len(caps))]
+
+    want_a, want_b, want_c = fresh(a), fresh(b), fresh(c)
+    want_b_soft, want_a_fused = fresh(b, soft=True), fresh(a, fused=True)
+    eng = dab.Engine(0)
+    for caps, want, mode in ((a, want_a, {}), (b, want_b, {}), (c, want_c, {}), (b, want_b_soft, {"soft": True}), (a, want_a, {"soft": False}),
+                             (a, want_a_fused, {"fused": True}), (c, want_c, {"fused": False}), (a, want_a, {})):
+        for k, v in mode.items():
+            getattr(eng, "set_" + k)(v)
+        eng.decode(caps)
+        for i, w in enumerate(want):
+            assert np.array_equal(eng.eti(i), w)
+    st = dab.Stream(1)                                    # a session after one-shot decodes on the same device
+    st.feed([b[0][:5000000]])
+    first = st.eti(0)
+    st.feed([b[0][5000000:]])
+    assert np.array_equal(np.concatenate([first, st.eti(0)]), want_b[0])
+    assert all(np.array_equal(x, y) for x, y in zip(want_a, want_a_fused))
