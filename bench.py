@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--snr", type=float, default=1000.0, help="AWGN SNR in dB over the 2.048 MHz band (BASELINE config 5: 5 dB); default: clean")
     ap.add_argument("--no-fused-variant", action="store_true", help="skip the extra timed pass with the fused OFDM stage")
+    ap.add_argument("--subchannels", type=str, default="", help="extension: decode only these SubChIds, e.g. 5 or 1,9 (default: all = reference frames)")
     ap.add_argument("--soft", action="store_true", help="soft-decision decoding (extension; default: hard = reference semantics)")
     args = ap.parse_args()
 
@@ -181,6 +182,8 @@ def main():
     eng = dab.Engine(local_rank)
     if args.soft:
         eng.set_soft(True)
+    if args.subchannels:
+        eng.set_subchannels([int(x) for x in args.subchannels.split(",")])
     eng.decode_device(ptrs[:2], [min(s, 20 * 393216) for s in sizes[:2]])   # loads the code objects (tiny, untimed, part of set-up)
 
     def barrier():
@@ -250,6 +253,8 @@ def main():
         }
         if fused:
             out["fused_variant"] = fused
+        if args.subchannels:
+            out["config"]["subchannel_filter"] = args.subchannels
         if args.snr < 100.0:
             out["config"]["snr_db"] = args.snr
             out["config"]["decisions"] = "soft (4-bit)" if args.soft else "hard"

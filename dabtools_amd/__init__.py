@@ -85,6 +85,8 @@ _SIGNATURES = {
     "dabhip_synth_payload": (C.c_int, [C.POINTER(SynthCfg), C.c_int, C.c_int, u8p, C.c_int]),
     "dabhip_synth_fibs": (C.c_int, [C.POINTER(SynthCfg), C.c_int, u8p]),
     "dabhip_engine_set_fused": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_engine_set_subchannels": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
+    "dabhip_stream_set_subchannels": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
     "dabhip_stream_create": (C.c_void_p, [C.c_int, C.c_int]),
     "dabhip_stream_destroy": (None, [C.c_void_p]),
     "dabhip_stream_feed": (C.c_int64, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int]),
@@ -314,6 +316,12 @@ class Engine:
         """Soft-decision decoding (4-bit soft values into the Viterbi metrics); off = parity mode."""
         _need(lib().dabhip_engine_set_soft(self._h, 1 if enable else 0) == 0, "set_soft")
 
+    def set_subchannels(self, ids):
+        """Decode and carry only these SubChIds (None / empty = all, the reference's frames)."""
+        ids = list(ids or [])
+        arr = (C.c_int32 * max(len(ids), 1))(*ids)
+        _need(lib().dabhip_engine_set_subchannels(self._h, arr, len(ids)) == 0, "set_subchannels")
+
     def set_fused(self, enable):
         """One kernel for OFDM transform + demap (spectra never written); identical output; off = default pipeline."""
         _need(lib().dabhip_engine_set_fused(self._h, 1 if enable else 0) == 0, "set_fused")
@@ -415,10 +423,13 @@ class Stream:
     """Streaming session (dabhip_stream_*): B unbounded captures decoded segment by segment; the concatenated ETI
     frames equal one Engine.decode of the whole captures."""
 
-    def __init__(self, nstreams, device=0, afc=False, soft=False):
+    def __init__(self, nstreams, device=0, afc=False, soft=False, subchannels=None):
         self._h = lib().dabhip_stream_create(device, nstreams)
         _need(self._h, "stream_create")
         self.nstreams = nstreams
+        if subchannels:
+            ids = list(subchannels)
+            _need(lib().dabhip_stream_set_subchannels(self._h, (C.c_int32 * len(ids))(*ids), len(ids)) == 0, "stream_set_subchannels")
         if afc:
             _need(lib().dabhip_stream_set_afc(self._h, 1) == 0, "stream_set_afc")
         if soft:

@@ -201,6 +201,20 @@ int dabhip_engine_set_soft(dabhip_engine* e, int enable)
   for (auto& l : e->lanes) l->set_soft(enable != 0);
   return 0;
 }
+static uint64_t subchannel_mask(const int32_t* ids, int n)
+{
+  if (!ids || n <= 0) return ~0ull;
+  uint64_t m = 0;
+  for (int i = 0; i < n; ++i)
+    if (ids[i] >= 0 && ids[i] < 64) m |= 1ull << ids[i];
+  return m;
+}
+int dabhip_engine_set_subchannels(dabhip_engine* e, const int32_t* ids, int n)
+{
+  if (!e) return -1;
+  for (auto& l : e->lanes) l->set_subchannel_filter(subchannel_mask(ids, n));
+  return 0;
+}
 int dabhip_engine_set_fused(dabhip_engine* e, int enable)
 {
   if (!e) return -1;
@@ -484,6 +498,13 @@ extern "C" dabhip_stream* dabhip_stream_create(int device, int nstreams)
   return s;
 }
 extern "C" void dabhip_stream_destroy(dabhip_stream* s) { delete s; }
+extern "C" int dabhip_stream_set_subchannels(dabhip_stream* s, const int32_t* ids, int n)
+{
+  if (!s) return -1;
+  if (!s->first) { set_error("stream_set_subchannels: only before the first segment"); return -1; }
+  s->eng.set_subchannel_filter(subchannel_mask(ids, n));
+  return 0;
+}
 extern "C" int dabhip_stream_set_afc(dabhip_stream* s, int on) { if (!s) return -1; s->eng.set_afc(on != 0); return 0; }
 extern "C" int dabhip_stream_set_soft(dabhip_stream* s, int on)
 {

@@ -93,7 +93,8 @@ inline void decode_fibs(EnsembleInfo& info, const uint8_t* fibs /*12 x 32*/, con
 }
 
 // SYNC, FC, STC, EOH of one ETI(NI) frame; returns the byte count (8 + 4 NST + 4).
-inline int build_eti_header(uint8_t* eti, const EnsembleInfo& info)
+// keep: bit i set = sub-channel id i is carried (sub-channel filter, TODO.md:28-31; all ones = the reference's frame)
+inline int build_eti_header(uint8_t* eti, const EnsembleInfo& info, uint64_t keep = ~0ull)
 {
   int n = 0, nst = 0, fl = 0;
   eti[n++] = 0xff;                                              // ERR
@@ -103,14 +104,14 @@ inline int build_eti_header(uint8_t* eti, const EnsembleInfo& info)
   eti[n++] = odd ? 0x49 : 0xb6;
   eti[n++] = info.cif_lo;                                       // FCT
   for (const SubChannel& sc : info.sub)
-    if (sc.id >= 0) { ++nst; fl += sc.bitrate * 3 / 4; }
+    if (sc.id >= 0 && ((keep >> sc.id) & 1)) { ++nst; fl += sc.bitrate * 3 / 4; }
   fl += nst + 1 + 24;                                           // STC + EOH + FIC (Mode I) in words
   eti[n++] = static_cast<uint8_t>(0x80 | nst);                  // FICF | NST
   const int fp = (info.cif_hi * 250 + info.cif_lo) % 8;
   eti[n++] = static_cast<uint8_t>((fp << 5) | (1 << 3) | ((fl & 0x700) >> 8));   // FP, MID = 1, FL
   eti[n++] = static_cast<uint8_t>(fl & 0xff);
   for (const SubChannel& sc : info.sub) {
-    if (sc.id < 0) continue;
+    if (sc.id < 0 || !((keep >> sc.id) & 1)) continue;
     const int tpl = sc.slform ? (0x20 | sc.protlev) : (0x10 | (sc.protlev - 1));
     const int stl = sc.bitrate * 3 / 8;
     eti[n++] = static_cast<uint8_t>((sc.id << 2) | ((sc.start_cu & 0x300) >> 8));
@@ -179,7 +180,7 @@ class ControlPlane {
     if (layout_changed) {
       std::vector<SubChannel> active;
       for (const SubChannel& sc : ens_.sub)
-        if (sc.id >= 0) active.push_back(sc);
+        if (sc.id >= 0 && ((keep_ >> sc.id) & 1)) active.push_back(sc);
       layouts_.push_back(std::move(active));
     }
 
@@ -192,7 +193,7 @@ class ControlPlane {
       EtiJob job;
       job.first_cif = ring_first_++;
       job.layout = static_cast<int32_t>(layouts_.size()) - 1;
-      job.header_len = build_eti_header(job.header, ens_);
+      job.header_len = build_eti_header(job.header, ens_, keep_);
       jobs.push_back(job);
       if (++ens_.cif_lo == 250) {
         ens_.cif_lo = 0;
@@ -206,10 +207,13 @@ class ControlPlane {
   const std::vector<std::vector<SubChannel>>& layouts() const { return layouts_; }
   // streaming use: CIF indices are rebased when old TF slots are dropped
   void rebase(int cif_shift) { ring_first_ -= cif_shift; }
+  // sub-channel filter: only these SubChIds are listed in the STC, decoded and carried (set before the first frame)
+  void set_filter(uint64_t keep) { keep_ = keep; }
 
  private:
   EnsembleInfo tf_info_, ens_;
   bool locked_ = false;
+  uint64_t keep_ = ~0ull;
   int okcount_ = 0, ncifs_ = 0, ring_first_ = 0;
   std::vector<std::vector<SubChannel>> layouts_;
 };

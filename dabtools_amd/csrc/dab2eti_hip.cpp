@@ -38,7 +38,7 @@ void to_stdout(const uint8_t* eti, int /*stream*/, void* /*user*/)
 }
 
 // streaming mode: double-buffered page-locked segments, one reader thread
-int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool afc, bool soft)
+int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool afc, bool soft, const std::vector<int32_t>& subch)
 {
   const int n = static_cast<int>(names.size());
   std::vector<FILE*> in(n);
@@ -50,6 +50,7 @@ int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool 
   if (!s) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); return 2; }
   if (afc) dabhip_stream_set_afc(s, 1);
   if (soft) dabhip_stream_set_soft(s, 1);
+  if (!subch.empty()) dabhip_stream_set_subchannels(s, subch.data(), static_cast<int>(subch.size()));
   uint8_t* buf[2];
   for (auto& b : buf)
     if (!(b = static_cast<uint8_t*>(dabhip_host_alloc(seg_bytes * n)))) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); return 2; }
@@ -106,19 +107,27 @@ int main(int argc, char** argv)
 {
   bool streaming = false, afc = false, soft = false;
   size_t seg_calls = 64;
+  std::vector<int32_t> subch;                  // --subch 3,7: decode and carry only these SubChIds (TODO.md:28-31)
   std::vector<const char*> names;
   for (int i = 1; i < argc; ++i) {
     if (std::strcmp(argv[i], "--stream") == 0) streaming = true;
     else if (std::strcmp(argv[i], "--afc") == 0) afc = true;          // software AFC: captures with a carrier offset (no tuner to steer)
     else if (std::strcmp(argv[i], "--soft") == 0) soft = true;        // 4-bit soft decisions (not the reference's hard ones)
+    else if (std::strcmp(argv[i], "--subch") == 0 && i + 1 < argc) {
+      for (const char* p = argv[++i]; *p;) {
+        subch.push_back(static_cast<int32_t>(std::strtol(p, const_cast<char**>(&p), 10)));
+        if (*p == ',') ++p;
+        else if (*p) { std::fprintf(stderr, "dab2eti-hip: bad --subch list\n"); return 1; }
+      }
+    }
     else if (std::strcmp(argv[i], "--segment-calls") == 0 && i + 1 < argc) seg_calls = static_cast<size_t>(std::max(1, std::atoi(argv[++i])));
     else { names.push_back(argv[i]); streaming = streaming || std::strcmp(argv[i], "-") == 0; }
   }
   if (names.empty()) {
-    std::fprintf(stderr, "Usage: dab2eti-hip [--stream] [--segment-calls N] [--afc] [--soft] capture.cu8|- [more.cu8 ...] > out.eti\n");
+    std::fprintf(stderr, "Usage: dab2eti-hip [--stream] [--segment-calls N] [--afc] [--soft] [--subch ID[,ID...]] capture.cu8|- [more.cu8 ...] > out.eti\n");
     return 1;
   }
-  if (streaming) return run_streaming(names, seg_calls * 262144, afc, soft);
+  if (streaming) return run_streaming(names, seg_calls * 262144, afc, soft, subch);
   argc = static_cast<int>(names.size()) + 1;
   for (int i = 1; i < argc; ++i) argv[i] = const_cast<char*>(names[i - 1]);
   std::vector<std::vector<uint8_t>> files;
@@ -137,6 +146,7 @@ int main(int argc, char** argv)
   if (!e) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); return 2; }
   if (afc) dabhip_engine_set_afc(e, 1);
   if (soft) dabhip_engine_set_soft(e, 1);
+  if (!subch.empty()) dabhip_engine_set_subchannels(e, subch.data(), static_cast<int>(subch.size()));
   std::vector<const uint8_t*> ptrs;
   std::vector<size_t> sizes;
   for (const auto& b : files) { ptrs.push_back(b.data()); sizes.push_back(b.size()); }

@@ -551,6 +551,7 @@ bool Engine::begin_decode(int nstreams, bool cont)
   total_eti_ = 0;
   if (!cont) {
     planes_.assign(nstreams, ControlPlane());
+    for (ControlPlane& p : planes_) p.set_filter(subch_keep_);
     carry_keep_.assign(nstreams, 0);
     prev_used_.assign(nstreams, 0);
     calls_done_.assign(nstreams, 0);

@@ -142,6 +142,9 @@ class Engine {
   // K2 + K2b as one kernel that never writes the spectra (k_fused.hip; hard decisions only).  Off by default: the default
   // pipeline keeps the HBM-roofline stage K2 separate; the output bits are identical either way.
   void set_fused(bool on) { fused_ = on; }
+  // sub-channel filter (TODO.md:28-31): bit i = SubChId i is decoded and carried in the ETI frames; takes effect with the next
+  // decode() / first segment of a session.  All ones (default) = the reference's frames.
+  void set_subchannel_filter(uint64_t keep) { subch_keep_ = keep; }
   void set_soft(bool on) { soft_bits_ = on ? 4 : 0; tf_slots_ = 0; msc_rows_ = 0; }
 
   // -- batch path ---------------------------------------------------------------------------
@@ -211,6 +214,7 @@ class Engine {
 
   bool ok_ = false;
   bool afc_ = false, fused_ = false;
+  uint64_t subch_keep_ = ~0ull;
   int soft_bits_ = 0;
   std::mutex* heavy_mu_ = nullptr;
   std::unique_ptr<ThreadPool> pool_;   // host threads for per-stream control-plane work

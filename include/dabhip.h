@@ -116,6 +116,12 @@ int dabhip_engine_set_afc(dabhip_engine *e, int enable);
  * without errors and is better (lower BER) at low SNR. */
 int dabhip_engine_set_soft(dabhip_engine *e, int enable);
 
+/* Sub-channel filter (the reference's TODO.md:28-31, "save CPU time by not decoding data which will later be discarded"):
+ * only the listed SubChIds (0..63) are decoded and carried; the ETI frames then list exactly those in their STC (NST, FL,
+ * HCRC and EOF CRC follow; the FIC is passed on unchanged), each one's payload identical to the unfiltered frame's.
+ * n <= 0 = all (default, the reference's frames).  Takes effect with the next decode. */
+int dabhip_engine_set_subchannels(dabhip_engine *e, const int32_t *ids, int n);
+
 /* Fused OFDM stage (optional): the 2048-point transforms and the DQPSK demap / de-interleave scatter in ONE kernel that
  * never writes the complex64 spectra (311,296 B read + 28,800 B written per TF instead of 1,556,480 + 1.2 MB re-read).
  * Output bits, hence ETI bytes, are identical to the default two-kernel stage.  Off by default: the default pipeline keeps
@@ -140,6 +146,7 @@ int64_t dabhip_stream_eti_count(const dabhip_stream *s, int stream);
 int64_t dabhip_stream_eti_read(dabhip_stream *s, int stream, uint8_t *dst, int64_t cap_frames);
 int64_t dabhip_stream_eti_drain(dabhip_stream *s, dabhip_eti_sink sink, void *user);
 int dabhip_stream_set_afc(dabhip_stream *s, int enable);
+int dabhip_stream_set_subchannels(dabhip_stream *s, const int32_t *ids, int n);   /* before the first segment only */
 int dabhip_stream_set_soft(dabhip_stream *s, int enable);   /* before the first segment only */
 /* Page-locked host memory for segments: fill the next one while the current one decodes (double buffering). */
 void *dabhip_host_alloc(size_t nbytes);

@@ -657,3 +657,33 @@ def test_engine_reuse_across_batch_shapes_and_modes():
     st.feed([b[0][5000000:]])
     assert np.array_equal(np.concatenate([first, st.eti(0)]), want_b[0])
     assert all(np.array_equal(x, y) for x, y in zip(want_a, want_a_fused))
+
+
+@pytest.mark.gpu
+def test_subchannel_filter_carries_exactly_the_selected_payload():
+    """TODO.md:28-31: with a sub-channel filter the frames list only the chosen SubChIds (valid header, FL, CRCs), each
+    payload byte-identical to the unfiltered frame's, the FIC untouched; an empty list restores the reference's frames."""
+    import eti_check
+    cap = dab.synth_generate(dab.synth_preset(0, seed=71, cif_count0=123), 20)
+    eng = dab.Engine(0)
+    eng.decode([cap])
+    full = eng.eti(0)
+    assert len(full) == 20 and np.array_equal(full, ol.or_replay(cap)[0])
+    eng.set_subchannels([5, 9, 40])                      # 40 is not in the ensemble
+    eng.decode([cap])
+    part = eng.eti(0)
+    assert len(part) == len(full)
+    for f, p in zip(full, part):
+        a, b = eti_check.parse(f), eti_check.parse(p)
+        assert [s[0] for s in b["stc"]] == [5, 9] and b["fct"] == a["fct"] and np.array_equal(a["fic"], b["fic"])
+        for entry, payload in zip(b["stc"], b["subch"]):
+            i = [s[0] for s in a["stc"]].index(entry[0])
+            assert a["stc"][i] == entry and np.array_equal(a["subch"][i], payload)
+    st = dab.Stream(1, subchannels=[5, 9])
+    st.feed([cap[:3000000]])
+    first = st.eti(0)
+    st.feed([cap[3000000:]])
+    assert np.array_equal(np.concatenate([first, st.eti(0)]), part)
+    eng.set_subchannels([])
+    eng.decode([cap])
+    assert np.array_equal(eng.eti(0), full)
