@@ -212,8 +212,13 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
                                                          const uint16_t* __restrict__ qpsk_of_carrier,
                                                          uint32_t* __restrict__ fic_bits, uint32_t* __restrict__ msc_bits)
 {
-  __shared__ uint8_t bits[kBitsPerSym];
-  __shared__ float wave_sum[kThreads / 64];
+  // The decisions of a symbol are written as bytes where the output word wants them: byte kPer t + b = value b of output
+  // word t (kPer = values per word), so the packing threads read their word's bytes contiguously (the straightforward
+  // "bits[i]" array made 96 lanes hit 4 LDS banks: 75 % of this kernel's LDS cycles were bank conflicts).  Two arrays
+  // alternate from symbol to symbol: one barrier per symbol.
+  constexpr int kPer = 32 / kBits;                        // received values per 32-bit word
+  __shared__ __attribute__((aligned(16))) uint8_t dec[2][kBitsPerSym];
+  __shared__ float wave_sum[2][kThreads / 64];
   const int tid = threadIdx.x;
   const int j = blockIdx.x / groups_per_tf, grp = blockIdx.x % groups_per_tf;
   const int slot = frame_slot[first + j];                 // TF slot (FIC rows, FIB records)
@@ -229,6 +234,8 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
     prev[m] = tf[(group_syms * grp) * 2048 + bin[m]];
   }
   for (int l = group_syms * grp + 1; l <= group_syms * grp + group_syms; ++l) {
+    uint8_t* d = dec[l & 1];
+    const bool natural = l <= 3 || !kPlanar;
     float re[6], im[6];
 #pragma unroll
     for (int m = 0; m < 6; ++m) {
@@ -237,52 +244,62 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
       im[m] = cur.x * prev[m].y - cur.y * prev[m].x;     // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
       prev[m] = cur;
     }
-    if (kBits == 1) {
-#pragma unroll
-      for (int m = 0; m < 6; ++m) {
-        bits[qk[m]] = (re[m] > 0.0f) ? 0 : 1;            // input_sdr.c:157
-        bits[1536 + qk[m]] = (im[m] > 0.0f) ? 1 : 0;     // input_sdr.c:158
-      }
-    } else {
+    float scale = 0.0f;
+    if (kBits != 1) {
       float acc = 0;
 #pragma unroll
       for (int m = 0; m < 6; ++m) acc += fabsf(re[m]) + fabsf(im[m]);
 #pragma unroll
       for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
-      if ((tid & 63) == 0) wave_sum[tid >> 6] = acc;
+      if ((tid & 63) == 0) wave_sum[l & 1][tid >> 6] = acc;
       __syncthreads();
       float total = 0;
 #pragma unroll
-      for (int w = 0; w < kThreads / 64; ++w) total += wave_sum[w];
-      const float scale = total > 0.0f ? 4.5f * 3072.0f / total : 0.0f;
+      for (int w = 0; w < kThreads / 64; ++w) total += wave_sum[l & 1][w];
+      scale = total > 0.0f ? 4.5f * 3072.0f / total : 0.0f;
+    }
 #pragma unroll
-      for (int m = 0; m < 6; ++m) {
+    for (int m = 0; m < 6; ++m) {
+      // position i of a value inside the symbol -> its byte: natural order i, or plane i & 15, value i >> 4 of that plane
+      const int i0 = qk[m], i1 = 1536 + qk[m];
+      const int a0 = natural ? i0 : ((i0 & 15) * (6 * kBits) + (i0 >> 4) / kPer) * kPer + (i0 >> 4) % kPer;
+      const int a1 = natural ? i1 : ((i1 & 15) * (6 * kBits) + (i1 >> 4) / kPer) * kPer + (i1 >> 4) % kPer;
+      if (kBits == 1) {
+        d[a0] = (re[m] > 0.0f) ? 0 : 1;                  // input_sdr.c:157
+        d[a1] = (im[m] > 0.0f) ? 1 : 0;                  // input_sdr.c:158
+      } else {
         const int q0 = max(-7, min(7, __float2int_rn(re[m] * scale)));     // > 0: first bit is 0
         const int q1 = max(-7, min(7, __float2int_rn(-im[m] * scale)));    // stored im > 0 means bit 1
-        bits[qk[m]] = static_cast<uint8_t>(q0 & 15);
-        bits[1536 + qk[m]] = static_cast<uint8_t>(q1 & 15);
+        d[a0] = static_cast<uint8_t>(q0 & 15);
+        d[a1] = static_cast<uint8_t>(q1 & 15);
       }
     }
     __syncthreads();
-    constexpr int kPer = 32 / kBits;                      // received values per 32-bit word
     for (int t = tid; t < 96 * kBits; t += kThreads) {
-      if (l <= 3 || !kPlanar) {
-        uint32_t w = 0;
+      uint32_t w;
+      if (kBits == 1) {
+        const uint4* p = reinterpret_cast<const uint4*>(d + 32 * t);
+        const uint4 lo = p[0], hi = p[1];
+        const uint32_t x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        w = 0;
 #pragma unroll
-        for (int b = 0; b < kPer; ++b) w |= static_cast<uint32_t>(bits[kPer * t + b]) << (kBits * b);
+        for (int k = 0; k < 8; ++k) w |= ((x[k] * 0x01020408u) >> 24 & 15u) << (4 * k);   // bytes (0/1) b0..b3 -> b0 | b1<<1 | b2<<2 | b3<<3
+      } else {
+        const uint2 x = *reinterpret_cast<const uint2*>(d + 8 * t);
+        const uint32_t y0 = (x.x | (x.x >> 4)) & 0x00ff00ffu, y1 = (x.y | (x.y >> 4)) & 0x00ff00ffu;   // nibbles of bytes 0,1 and 2,3 joined
+        w = ((y0 | (y0 >> 8)) & 0xffffu) | (((y1 | (y1 >> 8)) & 0xffffu) << 16);
+      }
+      if (natural) {
         if (l <= 3) fic_bits[static_cast<size_t>(slot) * (288 * kBits) + (l - 1) * (96 * kBits) + t] = w;
         else msc_bits[static_cast<size_t>(cif_row) * (1728 * kBits) + (l - 4) * (96 * kBits) + t] = w;
       } else {
         const int q = (l - 4) / 18, sidx = (l - 4) % 18;          // CIF within the TF, symbol within the CIF
         const int r = t / (6 * kBits), wq = t % (6 * kBits);      // plane (i & 15) and word within this symbol's 192 values
-        uint32_t w = 0;
-#pragma unroll
-        for (int b = 0; b < kPer; ++b) w |= static_cast<uint32_t>(bits[16 * (kPer * wq + b) + r]) << (kBits * b);
         const int delay = static_cast<int>(__brev(static_cast<unsigned>(r)) >> 28);   // map[r], misc.c:32
         msc_bits[static_cast<size_t>(cif_row + q - delay) * (1728 * kBits) + r * (108 * kBits) + sidx * 6 * kBits + wq] = w;
       }
     }
-    __syncthreads();
+    // no second barrier: the next symbol writes the other array, and two barriers lie between two uses of one array
   }
 }
 
