@@ -141,6 +141,16 @@ def cpu_baseline(host_streams, ntf, nsample=10):
         out[key] = {"value": n / dt, "unit": "ETI frames/s", "cores": 1,
                     "sample": "real reference dab_process_frame (%s) on %d demapped TF: %d ETI frames in %.2f s; back end only"
                               % ("viterbi_spiral SSE2" if sse else "scalar viterbi.c", ntfs, n, dt)}
+        # per-stage micro-timing: the reference's decoder alone, data Mbit/s on 4608-bit code words (192 kbit/s)
+        nbits, reps = 4608, (40 if sse else 8)
+        rng = np.random.default_rng(1)
+        sym = np.where(rng.integers(0, 2, 4 * (nbits + 6)) > 0, 255 if sse else 129, 0 if sse else 127).astype(np.uint8)
+        data = np.zeros(nbits // 8 + 8, np.uint8)
+        H = R.refh_new()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            R.refh_viterbi(H, oracle_lib._ptr(sym), oracle_lib._ptr(data), nbits)
+        out[key]["viterbi_mbit_s"] = reps * nbits / (time.perf_counter() - t0) / 1e6
     return out
 
 
