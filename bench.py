@@ -257,6 +257,9 @@ def main():
                          "traffic_note": "bytes per launch; per-TF HBM bytes from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                          "(profiles/r01_k2_pmc_traffic.csv, FETCH_SIZE x2 gfx950 correction) x TFs per launch",
                          "achieved_vs_measured_copy_ceiling": achieved / 6290.0,
+                         # a kernel with K2's loads and stores and no transform (tools/k2_traffic_probe.cpp, profiles/r01_k2_traffic_probe.txt):
+                         # 5317 GB/s with K2's workgroup shape and prefetch, 5696 GB/s at the finest granularity
+                         "achieved_vs_traffic_only_probe": achieved / 5317.0,
                          "launches": fft_launches, "tf_per_launch": fft_tfs / max(fft_launches, 1),
                          "avg_launch_ms": fft_ms / max(fft_launches, 1), "algorithmic_bytes_per_tf": FFT_BYTES_PER_TF},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
