@@ -206,7 +206,7 @@ void Engine::plan_decode_batch(DecodeBatch& b)
 }
 
 // work lists of a batch to the device (any stream: only the launches below consume them)
-bool Engine::upload_decode_batch(const DecodeBatch& b, const std::vector<DecodeJob>& jobs, hipStream_t s)
+bool Engine::upload_decode_batch(const DecodeBatch& b, const HostList<DecodeJob>& jobs, hipStream_t s)
 {
   if (b.groups.empty()) return true;
   const int row_words = kCifWords * (soft_bits_ ? 4 : 1);
@@ -358,8 +358,8 @@ bool Engine::msc_prepare(const std::vector<const std::vector<EtiJob>*>& stream_j
   std::map<std::vector<int32_t>, int> layout_index;
   std::vector<Layout> layouts;
   std::vector<std::vector<int>> layout_frames;
-  std::vector<DecodeJob>& jobs = out.jobs;
-  std::vector<EtiFrameMeta>& meta = out.meta;
+  HostList<DecodeJob>& jobs = out.jobs;
+  HostList<EtiFrameMeta>& meta = out.meta;
   jobs.assign(nf, DecodeJob{0, 0});
   meta.assign(nf, EtiFrameMeta{0, 0, 0, 0});
   int max_header = 0;
@@ -367,7 +367,7 @@ bool Engine::msc_prepare(const std::vector<const std::vector<EtiJob>*>& stream_j
     for (const EtiJob& j : *v) max_header = std::max(max_header, j.header_len);
   const int header_stride = (max_header + 15) & ~15;
   out.header_stride = header_stride;
-  std::vector<uint8_t>& headers = out.headers;
+  HostList<uint8_t>& headers = out.headers;
   headers.assign(nf * static_cast<size_t>(header_stride), 0);
   // pass 1 (serial, cheap): global layout id of every (stream, local layout)
   const size_t nstreams = stream_jobs.size();

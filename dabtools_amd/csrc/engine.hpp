@@ -16,6 +16,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -58,7 +59,8 @@ class DeviceBuffer {
     if (!reserve(n ? n : 1)) return false;
     return n == 0 || hipMemcpyAsync(p_, src, n * sizeof(T), hipMemcpyHostToDevice, s) == hipSuccess;
   }
-  bool upload(const std::vector<T>& v, hipStream_t s) { return upload(v.data(), v.size(), s); }
+  template <class A>
+  bool upload(const std::vector<T, A>& v, hipStream_t s) { return upload(v.data(), v.size(), s); }
   T* get() const { return p_; }
   size_t capacity() const { return cap_; }
 
@@ -66,6 +68,29 @@ class DeviceBuffer {
   T* p_ = nullptr;
   size_t cap_ = 0;
 };
+
+// std::allocator over page-locked host memory: vectors that are uploaded every decode (the work lists) go to the device
+// as plain asynchronous DMA instead of staged copies that block the issuing thread
+template <class T>
+struct PinnedAllocator {
+  using value_type = T;
+  PinnedAllocator() = default;
+  template <class U>
+  PinnedAllocator(const PinnedAllocator<U>&) {}
+  T* allocate(size_t n)
+  {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault) != hipSuccess) throw std::bad_alloc();
+    return static_cast<T*>(p);
+  }
+  void deallocate(T* p, size_t) { (void)hipHostFree(p); }
+  template <class U>
+  bool operator==(const PinnedAllocator<U>&) const { return true; }
+  template <class U>
+  bool operator!=(const PinnedAllocator<U>&) const { return false; }
+};
+template <class T>
+using HostList = std::vector<T, PinnedAllocator<T>>;
 
 // grow-only page-locked host allocation (device copies to and from it run at full PCIe rate and truly asynchronously)
 template <class T>
@@ -107,17 +132,17 @@ struct StageTimes {
 
 // Work list for gather + Viterbi launches: wave-groups of <= 64 equal-length code words.
 struct DecodeBatch {
-  std::vector<WaveGroup> groups;   // longest code words first
-  std::vector<int> job_ids;        // lanes of group g decode jobs job_ids[g.first .. g.first + g.count); padded to tiles of 64
+  HostList<WaveGroup> groups;      // longest code words first
+  HostList<int> job_ids;           // lanes of group g decode jobs job_ids[g.first .. g.first + g.count); padded to tiles of 64
   std::vector<int> slice_start;    // launches: groups [slice_start[i], slice_start[i+1]) share the survivor-record buffer
   int64_t max_dec_rows = 0;
 };
 
 // Everything the MSC decode of a set of ETI frames needs, prepared on the host (no GPU work)
 struct MscWork {
-  std::vector<DecodeJob> jobs;
-  std::vector<EtiFrameMeta> meta;
-  std::vector<uint8_t> headers;
+  HostList<DecodeJob> jobs;
+  HostList<EtiFrameMeta> meta;
+  HostList<uint8_t> headers;
   int header_stride = 0;
   DecodeBatch batch;
   std::vector<int> stream_row_base;
@@ -180,8 +205,7 @@ class Engine {
   bool msc_decode(const std::vector<const std::vector<EtiJob>*>& stream_jobs, const std::vector<const ControlPlane*>& planes,
                   const std::vector<int>& stream_row_base, const std::vector<int>& stream_fib_base)
   {
-    MscWork w;
-    return msc_prepare(stream_jobs, planes, stream_row_base, stream_fib_base, w) && msc_run(w);
+    return msc_prepare(stream_jobs, planes, stream_row_base, stream_fib_base, work_s3_) && msc_run(work_s3_);   // reused: its lists are page-locked
   }
   // host half (work lists, headers, plans) and GPU half (regroup, Viterbi, ETI finish) of msc_decode
   bool msc_prepare(const std::vector<const std::vector<EtiJob>*>& stream_jobs, const std::vector<const ControlPlane*>& planes,
@@ -206,7 +230,7 @@ class Engine {
   void build_batch(const std::vector<std::pair<int, const std::vector<int>*>>& plan_jobs, DecodeBatch& out);
   // MSC decode batch: slices and record offsets (host), work lists to the device, regroup + fused Viterbi launches
   void plan_decode_batch(DecodeBatch& b);
-  bool upload_decode_batch(const DecodeBatch& b, const std::vector<DecodeJob>& jobs, hipStream_t s);
+  bool upload_decode_batch(const DecodeBatch& b, const HostList<DecodeJob>& jobs, hipStream_t s);
   bool launch_decode_batch(const DecodeBatch& b, const uint32_t* bits, const int* d_stream_cif_base, const uint32_t* prbs, uint8_t* out,
                            int record_stride, float* gather_ms, float* viterbi_ms);
   int plan_id(const CodewordPlan& p);
@@ -255,7 +279,7 @@ class Engine {
   int tf_slots_ = 0, msc_rows_ = 0;
 
   std::vector<std::vector<EtiJob>> stream_jobs_;
-  MscWork work_;
+  MscWork work_, work_s3_;
   // session state (decode() resets it, feed() continues it)
   std::vector<ControlPlane> planes_;
   PinnedBuffer<StreamState> h_states_;
