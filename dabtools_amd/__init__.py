@@ -262,7 +262,10 @@ class Sdr:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- S3 -----------------------------------------------------------------------------------------
@@ -298,7 +301,10 @@ class Dab:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- batch engine -------------------------------------------------------------------------------
@@ -416,7 +422,10 @@ class Engine:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:                       # at interpreter shutdown the module globals may already be gone
+            self.close()
+        except Exception:
+            pass
 
 
 class Stream:
