@@ -155,6 +155,29 @@ def main():
                         synth=np.array([1, 606, 4960, ntf]), snr_db=np.array(9.0))
     print("golden written: %d TF, %d ETI frames" % (len(tf_bits), n))
 
+    # ---- whole path, small: synthetic cu8 (seed + config + SHA-256 stored, not the 7 MB of samples)
+    # -> front-end restatement (the reference's own needs libfftw3) -> the REAL reference back end -> its ETI bytes
+    cases, out = [(1, 707, 0, 0, 1000.0, 20), (0, 708, 4990, 31337, 10.0, 26)], {}
+    for ci, (preset, seed, cif0, skip, snr, ntf) in enumerate(cases):
+        cfg = dab.synth_preset(preset, seed=seed, cif_count0=cif0, skip_samples=skip, snr_db=snr)
+        iq = dab.synth_generate(cfg, ntf)
+        S, Hd = O.or_sdr_new(), R.refh_new()
+        for off in range(0, iq.size - dab.CHUNK_BYTES + 1, dab.CHUNK_BYTES):
+            ch = iq[off:off + dab.CHUNK_BYTES]
+            if O.or_sdr_demod(S, _ptr(ch), dab.CHUNK_BYTES, _ptr(fic), _ptr(msc)):
+                C.memmove(R.refh_tf_fic(Hd), _ptr(fic), fic.size)
+                C.memmove(R.refh_tf_msc(Hd), _ptr(msc), msc.size)
+                R.refh_process(Hd)
+        n = R.refh_neti(Hd)
+        assert n >= 8
+        out["case%d_cfg" % ci] = np.array([preset, seed, cif0, skip, ntf], np.int64)
+        out["case%d_snr" % ci] = np.array(snr)
+        out["case%d_sha256" % ci] = np.frombuffer(hashlib.sha256(iq.tobytes()).digest(), np.uint8)
+        out["case%d_eti" % ci] = np.ctypeslib.as_array(R.refh_eti(Hd), (n, 6144)).copy()
+        print("e2e_small case %d: %d ETI frames" % (ci, n))
+    out["ncases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(HERE, "e2e_small.npz"), **out)
+
 
 if __name__ == "__main__":
     main()

@@ -687,3 +687,20 @@ def test_subchannel_filter_carries_exactly_the_selected_payload():
     eng.set_subchannels([])
     eng.decode([cap])
     assert np.array_equal(eng.eti(0), full)
+
+
+@pytest.mark.gpu
+def test_whole_path_small_golden_on_gpu():
+    """The committed whole-path fixture (tests/golden/e2e_small.npz: ETI bytes out of the real reference back end) against
+    the batch engine, clean and at 10 dB with a mid-frame start."""
+    import test_oracle_golden as tg
+    caps, wants = [], []
+    for ci, iq, same, want in tg._e2e_small_cases():
+        if same:
+            caps.append(iq)
+            wants.append(want)
+    assert caps, "no capture matched its recorded SHA-256"
+    eng = dab.Engine(0)
+    eng.decode(caps)
+    for i, w in enumerate(wants):
+        assert np.array_equal(eng.eti(i), w)
