@@ -79,6 +79,9 @@ _SIGNATURES = {
     "dabhip_host_parse_fibs": (C.c_int, [u8p, u8p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "dabhip_host_eti_header": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), u8p, C.c_int]),
     "dabhip_host_control_replay": (C.c_int, [u8p, u8p, C.c_int, C.POINTER(C.c_int32), u8p, C.POINTER(C.c_int32), C.c_int]),
+    "dabhip_host_fifo_new": (C.c_void_p, []),
+    "dabhip_host_fifo_free": (None, [C.c_void_p]),
+    "dabhip_host_fifo_call": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "dabhip_synth_preset": (C.c_int, [C.c_int, C.POINTER(SynthCfg)]),
     "dabhip_synth_bytes": (C.c_size_t, [C.POINTER(SynthCfg), C.c_int]),
     "dabhip_synth_generate": (C.c_int64, [C.POINTER(SynthCfg), C.c_int, u8p, C.c_size_t]),
@@ -221,6 +224,46 @@ def host_control_replay(fibs, crc_ok):
                                          hlen.ctypes.data_as(C.POINTER(C.c_int32)), cap)
     _need(n >= 0, "host_control_replay")
     return first[:n], [hdrs[i, :hlen[i]].copy() for i in range(n)]
+
+
+class HostFifo:
+    """The FIFO / frame-buffer bookkeeping of the sync-scan kernel, on the host (dabhip_host_fifo_*)."""
+
+    def __init__(self):
+        self._h = lib().dabhip_host_fifo_new()
+        _need(self._h, "host_fifo_new")
+
+    def call(self, coarse_timeshift, fine_timeshift):
+        """One sdr_demod call -> (status 0/1/2, [(seg_end, seg_src), ...], fifo_count)."""
+        nseg, cnt = C.c_int32(0), C.c_int32(0)
+        ends = np.zeros(12, dtype=np.int32)
+        srcs = np.zeros(12, dtype=np.int64)
+        r = lib().dabhip_host_fifo_call(self._h, coarse_timeshift, fine_timeshift, C.byref(nseg), ends.ctypes.data_as(C.POINTER(C.c_int32)),
+                                        srcs.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(cnt))
+        _need(r >= 0, "host_fifo_call")
+        return r, [(int(ends[i]), int(srcs[i])) for i in range(nseg.value)], cnt.value
+
+    @staticmethod
+    def materialise(stream, view):
+        """The 393216 bytes of sdr->buffer a view describes."""
+        buf = np.zeros(TF_BYTES, dtype=np.uint8)
+        lo = 0
+        for end, src in view:
+            if src >= 0:
+                buf[lo:end] = stream[src + lo:src + end]
+            lo = end
+        return buf
+
+    def close(self):
+        if self._h:
+            lib().dabhip_host_fifo_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- S1 -----------------------------------------------------------------------------------------

@@ -13,6 +13,7 @@
 
 #include "../../include/dabhip.h"
 #include "engine.hpp"
+#include "fifo_view.hpp"
 
 using namespace dabhip;
 
@@ -300,8 +301,7 @@ dabhip_sdr* dabhip_sdr_init(int device)
   if (!s->eng.ok() || !s->window.reserve(kWindowBytes) || !s->state.reserve(1)) { delete s; return nullptr; }
   StreamState st;
   std::memset(&st, 0, sizeof st);
-  st.view.nseg = 1;
-  for (int i = 0; i < kMaxSeg; ++i) { st.view.seg_end[i] = kTfBytes; st.view.seg_src[i] = -1; }
+  fifo_reset(st);
   if (hipMemcpy(s->state.get(), &st, sizeof st, hipMemcpyHostToDevice) != hipSuccess) { set_error("sdr_init: state upload failed"); delete s; return nullptr; }
   std::memset(&s->last, 0, sizeof s->last);
   return s;
@@ -464,6 +464,33 @@ int dabhip_host_control_replay(const uint8_t* fibs, const uint8_t* crc_ok, int n
 }
 
 }  // extern "C"
+
+// ---- FIFO / frame-buffer bookkeeping of K1 on the host (fifo_view.hpp), callable without a GPU ---------
+struct dabhip_fifo {
+  StreamState st;
+};
+extern "C" dabhip_fifo* dabhip_host_fifo_new(void)
+{
+  dabhip_fifo* f = new (std::nothrow) dabhip_fifo;
+  if (!f) return nullptr;
+  std::memset(&f->st, 0, sizeof f->st);
+  fifo_reset(f->st);
+  return f;
+}
+extern "C" void dabhip_host_fifo_free(dabhip_fifo* f) { delete f; }
+extern "C" int dabhip_host_fifo_call(dabhip_fifo* f, int32_t coarse_timeshift, int32_t fine_timeshift, int32_t* nseg, int32_t* seg_end,
+                                     int64_t* seg_src, int32_t* fifo_count)
+{
+  if (!f || !nseg || !seg_end || !seg_src) { set_error("host_fifo_call: null argument"); return -1; }
+  f->st.coarse_timeshift = coarse_timeshift;
+  f->st.fine_timeshift = fine_timeshift;
+  const FifoCall c = fifo_call(f->st);
+  if (f->st.overflow) { set_error("host_fifo_call: more than kMaxSeg nested short reads"); return -1; }
+  *nseg = f->st.view.nseg;
+  for (int i = 0; i < kMaxSeg; ++i) { seg_end[i] = f->st.view.seg_end[i]; seg_src[i] = f->st.view.seg_src[i]; }
+  if (fifo_count) *fifo_count = c.fifo_count;
+  return c.status ? (c.do_sync ? 2 : 1) : 0;
+}
 
 // ---- device-side modulator (k_synth.hip) ------------------------------------------------------
 namespace dabhip { int synth_generate_device(const dabhip_synth_cfg* cfgs, int nstreams, int ntf, uint8_t* const* iq, int device); }

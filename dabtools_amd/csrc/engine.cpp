@@ -6,12 +6,14 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <thread>
 
 #include "dab_bits.hpp"
 #include "dab_tables.hpp"
+#include "fifo_view.hpp"
 #include "../../include/dabhip.h"
 #include "kernels.hpp"
 
@@ -29,9 +31,7 @@ StreamState initial_state()
 {
   StreamState st;
   std::memset(&st, 0, sizeof st);
-  st.rng = 1;
-  st.view.nseg = 1;                                       // the calloc'ed frame buffer: all zero bytes
-  for (int i = 0; i < kMaxSeg; ++i) { st.view.seg_end[i] = kTfBytes; st.view.seg_src[i] = -1; }
+  fifo_reset(st);                                         // empty FIFO, calloc'ed frame buffer (fifo_view.hpp)
   return st;
 }
 
@@ -45,6 +45,15 @@ void pack_bits(const uint8_t* bytes, int nbits, uint32_t* words)
   for (int i = 0; i < nbits; ++i) words[i >> 5] |= static_cast<uint32_t>(bytes[i] & 1u) << (i & 31);
 }
 }  // namespace
+
+// The single-TF seams and stage entries carry the reference's hard 0/1 bytes (dab.h:27-33): their row strides are those of
+// one bit per value.  With soft decisions on, the rows hold four bits per value, so these entry points refuse to run.
+bool Engine::hard_only(const char* what)
+{
+  if (soft_bits_ == 0) return true;
+  set_error(std::string(what) + ": not available with soft decisions on (dabhip_engine_set_soft): this entry point carries hard bits");
+  return false;
+}
 
 bool Engine::check(hipError_t e, const char* what)
 {
@@ -109,8 +118,12 @@ Engine::Engine(int device) : device_(device)
       !d_prbs_.upload(prbs, stream_) || !d_zero_words_.upload(zeros, stream_))
     return;
   if (!check(hipStreamSynchronize(stream_), "table upload")) return;
+  // host threads for the per-stream control plane: half the cores, at most 24; DABHIP_HOST_THREADS overrides it (bench.py
+  // gives each of N ranks on a node cores / N, so that 8 ranks do not start 8 x 24 busy threads)
   const int hw = static_cast<int>(std::thread::hardware_concurrency());
-  pool_.reset(new ThreadPool(std::max(0, std::min(hw / 2, 24) - 1)));
+  int nthreads = std::min(hw / 2, 24);
+  if (const char* env = std::getenv("DABHIP_HOST_THREADS")) nthreads = std::max(1, std::min(64, std::atoi(env)));
+  pool_.reset(new ThreadPool(std::max(0, nthreads - 1)));
   ok_ = true;
 }
 
@@ -264,6 +277,7 @@ bool Engine::reserve_tf_slots(int nslots, int msc_rows)
 // CIF 0 at row kRowLead), the same layout demap_kernel<true> produces
 bool Engine::store_tf_bytes(int slot, const uint8_t* fic_bytes, const uint8_t* msc_bytes)
 {
+  if (!hard_only("store_tf_bytes")) return false;
   static const int tmap[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
   std::vector<uint32_t> f(kFicWords), plane(108);
   pack_bits(fic_bytes, kFicBits, f.data());
@@ -283,6 +297,7 @@ bool Engine::store_tf_bytes(int slot, const uint8_t* fic_bytes, const uint8_t* m
 
 bool Engine::recycle_tf_slots(int used_slots, int keep_slots)
 {
+  if (!hard_only("recycle_tf_slots")) return false;
   // FIC rows / FIB records: the newest keep_slots; logical CIF rows: everything from 15 rows before the oldest kept CIF
   const int src_slot = used_slots - keep_slots;
   const size_t row_src = static_cast<size_t>(4 * src_slot), nrows = static_cast<size_t>(4 * keep_slots + kRowLead);
@@ -299,6 +314,7 @@ bool Engine::recycle_tf_slots(int used_slots, int keep_slots)
 // S2 / stage_demap: the TF was demapped in NATURAL order (demap_kernel<false>) into FIC slot `slot`, CIF rows 4*slot..
 bool Engine::unpack_tf_slot(int slot, uint8_t* fic_bytes, uint8_t* msc_bytes)
 {
+  if (!hard_only("unpack_tf_slot")) return false;
   std::vector<uint32_t> f(kFicWords), m(kMscWords);
   if (!check(hipMemcpy(f.data(), d_fic_bits_.get() + static_cast<size_t>(slot) * kFicWords, f.size() * 4, hipMemcpyDeviceToHost), "fic download") ||
       !check(hipMemcpy(m.data(), d_msc_bits_.get() + static_cast<size_t>(slot) * kMscWords, m.size() * 4, hipMemcpyDeviceToHost), "msc download"))
@@ -866,6 +882,7 @@ int Engine::stage_ofdm_fft(const uint8_t* frames, int nframes, float* spectra, b
 
 int Engine::stage_demap(const float* spectra, int nframes, uint8_t* fic, uint8_t* msc)
 {
+  if (!hard_only("stage_demap")) return -1;
   if (!ok_) { set_error("engine not initialised (no GPU?)"); return -1; }
   if (nframes <= 0) return 0;
   const size_t nspec = static_cast<size_t>(nframes) * kSymbolsPerTf * 2048;
@@ -883,6 +900,7 @@ int Engine::stage_demap(const float* spectra, int nframes, uint8_t* fic, uint8_t
 
 int Engine::stage_fic_decode(const uint8_t* fic, int nframes, uint8_t* fibs, uint8_t* crc_ok)
 {
+  if (!hard_only("stage_fic_decode")) return -1;
   if (!ok_) { set_error("engine not initialised (no GPU?)"); return -1; }
   if (nframes <= 0) return 0;
   if (!reserve_tf_slots(nframes)) return -1;

@@ -222,6 +222,7 @@ class Engine {
 
  private:
   bool check(hipError_t e, const char* what);
+  bool hard_only(const char* what);
   int64_t decode_impl(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont);
   bool begin_decode(int nstreams, bool cont);
   bool scan_streams(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont);

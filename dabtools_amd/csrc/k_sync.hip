@@ -14,6 +14,7 @@
 
 #include "dab_tables.hpp"
 #include "device_types.hpp"
+#include "fifo_view.hpp"
 #include "kernels.hpp"
 
 namespace dabhip {
@@ -201,44 +202,13 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
   __syncthreads();
 
   for (int k = kfirst; k < kend; ++k) {
-    // ---- FIFO bookkeeping: input_sdr.c:36-55 over sdr_fifo.c:43-61 --------------------
+    // ---- FIFO bookkeeping: input_sdr.c:36-55 over sdr_fifo.c:43-61 (fifo_view.hpp) -------
     if (tid == 0) {
-      StreamState& st = sh.st;
-      st.fed += kChunkBytes;
-      int64_t count = st.fed - st.consumed;
-      sh.status = 0;
-      sh.do_sync = 0;
+      const FifoCall fc = fifo_call(sh.st);
+      sh.status = fc.status;
+      sh.do_sync = fc.do_sync;
+      sh.fifo_count = fc.fifo_count;
       sh.coarse_fs = 0;
-      if (count >= 3 * kTfSamples) {
-        const int shift = st.coarse_timeshift + st.fine_timeshift;
-        int len;
-        if (shift > 0) {
-          st.consumed += shift;
-          count -= shift;
-          len = count < kTfBytes ? static_cast<int>(count) : kTfBytes;
-        } else {
-          len = kTfBytes + shift;
-        }
-        FrameView nv;
-        int n = 1;
-        nv.seg_end[0] = len;
-        nv.seg_src[0] = st.consumed;
-        for (int i = 0; i < st.view.nseg; ++i) {
-          if (st.view.seg_end[i] > len) {
-            if (n < kMaxSeg) { nv.seg_end[n] = st.view.seg_end[i]; nv.seg_src[n] = st.view.seg_src[i]; ++n; }
-            else st.overflow = 1;
-          }
-        }
-        nv.nseg = n;
-        for (int i = n; i < kMaxSeg; ++i) { nv.seg_end[i] = kTfBytes; nv.seg_src[i] = -1; }
-        st.view = nv;
-        st.consumed += len;
-        count -= len;
-        sh.status = 1;
-        if (st.startup_delay <= 0) st.startup_delay++;   // input_sdr.c:51-55, GAIN_SETTLE_TIME 0
-        else sh.do_sync = 1;
-      }
-      sh.fifo_count = static_cast<int>(count);
     }
     __syncthreads();
 
@@ -381,7 +351,9 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
           const int step = static_cast<int>((st.rng >> 16) % 1000u);
           st.tuner_hz += c < 0 ? -step : step;
         }
-        if (c == 0 && fabs(sh.fine_fs) > 50) st.tuner_hz += static_cast<int>(sh.fine_fs / 3);
+        // dab2eti.c:97-98 in its integer semantics: abs() is the int one (the double is truncated first: |ffs| >= 51), and
+        // "frequency = frequency + ffs/3" stores a double into the unsigned tuner frequency, i.e. floors the sum
+        if (c == 0 && abs(static_cast<int>(sh.fine_fs)) > 50) st.tuner_hz += static_cast<int>(floor(sh.fine_fs / 3));
       }
     }
     __syncthreads();

@@ -3,6 +3,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <cstdint>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -32,53 +33,70 @@ class ThreadPool {
   void parallel_for(int n, const std::function<void(int)>& fn)
   {
     if (n <= 0) return;
+    Job job;
     {
       std::lock_guard<std::mutex> lk(mu_);
-      fn_ = &fn;
-      n_ = n;
-      next_.store(0);
+      job = Job{&fn, n, ++epoch_};
+      job_ = job;
       pending_ = n;
-      ++epoch_;
+      ticket_.store(static_cast<uint64_t>(job.epoch) << 32);
     }
     cv_.notify_all();
-    run();
+    run(job);
     std::unique_lock<std::mutex> lk(mu_);
     done_.wait(lk, [this] { return pending_ == 0; });
-    fn_ = nullptr;
   }
 
  private:
-  void run()
+  struct Job {
+    const std::function<void(int)>* fn = nullptr;
+    int n = 0;
+    uint32_t epoch = 0;
+  };
+  // Tickets carry the epoch they belong to: a worker that woke late for an earlier parallel_for finds the epoch of its
+  // snapshot gone and takes nothing, so an item can neither run twice nor after its parallel_for has returned.
+  void run(const Job& job)
   {
     int did = 0;
-    for (int i = next_.fetch_add(1); i < n_; i = next_.fetch_add(1)) { (*fn_)(i); ++did; }
+    uint64_t cur = ticket_.load();
+    for (;;) {
+      if (static_cast<uint32_t>(cur >> 32) != job.epoch) break;
+      const int i = static_cast<int>(cur & 0xffffffffu);
+      if (i >= job.n) break;
+      if (!ticket_.compare_exchange_weak(cur, cur + 1)) continue;   // cur reloaded
+      (*job.fn)(i);
+      ++did;
+      cur = ticket_.load();
+    }
     if (did) {
       std::lock_guard<std::mutex> lk(mu_);
-      pending_ -= did;
+      pending_ -= did;            // same epoch: a ticket of epoch e is only handed out while parallel_for e waits
       if (pending_ == 0) done_.notify_all();
     }
   }
   void loop()
   {
-    unsigned seen = 0;
+    uint32_t seen = 0;
     for (;;) {
+      Job job;
       {
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
         if (stop_) return;
         seen = epoch_;
+        job = job_;               // function, count and epoch taken together under the lock
       }
-      run();
+      run(job);
     }
   }
 
   std::vector<std::thread> workers_;
   std::mutex mu_;
   std::condition_variable cv_, done_;
-  const std::function<void(int)>* fn_ = nullptr;
-  std::atomic<int> next_{0};
-  int n_ = 0, pending_ = 0;
-  unsigned epoch_ = 0;
+  Job job_;
+  std::atomic<uint64_t> ticket_{0};   // epoch << 32 | next index
+  int pending_ = 0;
+  uint32_t epoch_ = 0;
   bool stop_ = false;
 };
 

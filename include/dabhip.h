@@ -192,6 +192,18 @@ int dabhip_host_eti_header(const int32_t *hdr3, const int32_t *sub, uint8_t *out
 int dabhip_host_control_replay(const uint8_t *fibs, const uint8_t *crc_ok, int ntf, int32_t *first_cif,
                                uint8_t *headers, int32_t *header_len, int cap_frames);
 
+/* The FIFO of sdr_demod (cbWrite / sdr_read_fifo, sdr_fifo.c:26-61; input_sdr.c:36-55) as the sync-scan kernel keeps it:
+ * in closed form over the resident stream.  One call = one 262144-byte sdr_demod call entered with the timing
+ * corrections the previous processed frame left in sdr->coarse_timeshift / fine_timeshift.  Returns 0 = nothing read
+ * (fewer than 1.5 TF queued), 1 = the first frame, read and discarded (input_sdr.c:51-55), 2 = a frame read for
+ * processing; <0 = error.  The view says what sdr->buffer holds afterwards: buffer positions [seg_end[i-1], seg_end[i])
+ * hold stream bytes seg_src[i] + position (seg_src < 0: the calloc'ed zero bytes); 12 entries each. */
+typedef struct dabhip_fifo dabhip_fifo;
+dabhip_fifo *dabhip_host_fifo_new(void);
+void dabhip_host_fifo_free(dabhip_fifo *f);
+int dabhip_host_fifo_call(dabhip_fifo *f, int32_t coarse_timeshift, int32_t fine_timeshift, int32_t *nseg,
+                          int32_t *seg_end, int64_t *seg_src, int32_t *fifo_count);
+
 /* ---- synthetic Mode-I modulator (host only) --------------------------------------------- */
 typedef struct dabhip_subch_cfg {
   int32_t id;          /* SubChId 0..63 */

@@ -168,3 +168,77 @@ def test_eti2mpa_extracts_subchannel_from_reference_eti(tmp_path):
         assert out == want
     r = subprocess.run([exe, "33"], input=eti.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 4 and r.stdout == b""
+
+
+def _fifo_view_matches_oracle(iq):
+    """Replays the K1 FIFO / frame-buffer bookkeeping (fifo_view.hpp via dabhip_host_fifo_*) next to the oracle front end,
+    whose buffer is filled byte by byte like sdr_fifo.c:43-61: after every call the view must describe exactly the
+    oracle's 393216-byte frame buffer."""
+    O = ol.oracle()
+    S = O.or_sdr_new()
+    fifo = dab.HostFifo()
+    fic = np.zeros(dab.FIC_BITS, np.uint8)
+    msc = np.zeros(dab.MSC_BITS, np.uint8)
+    tr = ol.SdrTrace()
+    coarse = fine = 0
+    reads = short_after_skip = 0
+    for off in range(0, iq.size - dab.CHUNK_BYTES + 1, dab.CHUNK_BYTES):
+        O.or_sdr_demod(S, ol._ptr(iq[off:off + dab.CHUNK_BYTES]), dab.CHUNK_BYTES, ol._ptr(fic), ol._ptr(msc))
+        O.or_sdr_get_trace(S, C.byref(tr))
+        status, view, count = fifo.call(coarse, fine)
+        assert (status > 0) == bool(tr.read_frame) and count == tr.fifo_count, off
+        if status:
+            reads += 1
+            want = np.ctypeslib.as_array(O.or_sdr_buffer(S), (dab.TF_BYTES,))
+            got = dab.HostFifo.materialise(iq, view)
+            assert np.array_equal(got, want), "call at byte %d: view %r" % (off, view)
+            short_after_skip += int(len(view) > 1 and coarse + fine > view[0][0])
+        coarse, fine = tr.coarse_timeshift, tr.fine_timeshift
+    O.or_sdr_free(S)
+    fifo.close()
+    return reads, short_after_skip
+
+
+def test_fifo_view_bookkeeping_matches_oracle_buffer():
+    # aligned, mid-frame start (coarse resync at the start), negative and positive fine corrections
+    for seed, skip in ((3, 0), (4, 123457)):
+        reads, _ = _fifo_view_matches_oracle(dab.synth_generate(dab.synth_preset(1, seed=seed, skip_samples=skip), 12))
+        assert reads >= 10
+
+
+def test_fifo_view_resync_while_locked_short_read_after_large_skip():
+    """Samples vanish mid-stream after lock: the coarse correction (373,220 bytes) exceeds the bytes the FIFO can still
+    deliver after skipping them, so sdr_read_fifo leaves SKIPPED bytes in buffer[len .. shift) (sdr_fifo.c:49-55)."""
+    iq = dab.synth_generate(dab.synth_preset(1, seed=1), 40)
+    cut = 2 * (21 * 196608 + 30000)
+    iq = np.concatenate([iq[:cut], iq[cut + 20000:]])
+    reads, short_after_skip = _fifo_view_matches_oracle(iq)
+    assert reads >= 30 and short_after_skip >= 1
+
+
+def test_fifo_shifted_read_against_reference_fifo():
+    """The same bookkeeping against the REAL sdr_fifo.c (oracle/_ref): shift sequences including positive shifts
+    larger than what remains queued afterwards."""
+    R = ol.ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(11)
+    stream = rng.integers(1, 255, 70 * dab.CHUNK_BYTES, dtype=np.uint8)
+    F = R.refh_fifo_new(C.c_uint32(196608 * 2 * 4))                 # input_sdr.c:184
+    fifo = dab.HostFifo()
+    buf = np.zeros(dab.TF_BYTES, np.uint8)
+    shifts = [0, 0, -300, 40, 380000, -1500, 250000, 16, 389000, 389000, -2, 0, 120000, 300000, -766, 389430]
+    k = nshort = 0
+    for c in range(stream.size // dab.CHUNK_BYTES):
+        R.refh_fifo_write(F, ol._ptr(stream[c * dab.CHUNK_BYTES:(c + 1) * dab.CHUNK_BYTES]), dab.CHUNK_BYTES)
+        shift = shifts[k % len(shifts)]
+        if R.refh_fifo_count(F) >= 196608 * 3:                      # input_sdr.c:41-47
+            R.refh_fifo_read(F, dab.TF_BYTES, shift, ol._ptr(buf))
+            status, view, count = fifo.call(shift, 0)
+            assert status > 0 and count == R.refh_fifo_count(F)
+            assert np.array_equal(dab.HostFifo.materialise(stream, view), buf), (c, shift, view)
+            nshort += int(shift > view[0][0])
+            k += 1
+        else:
+            assert fifo.call(shift, 0)[0] == 0
+    assert k > 20 and nshort >= 2
