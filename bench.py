@@ -1,44 +1,159 @@
 #!/usr/bin/env python3
 """bench.py — ETI frames/s of the MI355X dab2eti hot path on synthetic Mode-I IQ.
 
-One "step" = one pass of the whole hot path (sync scan -> OFDM FFT -> demap -> FIC decode ->
-control plane -> MSC Viterbi -> ETI assembly) over one batch of B independent cu8 streams
-that are already resident in HBM (BASELINE.json configs[2]: batch=256, canonical 12
-sub-channel 1136 kbit/s ensemble, full MSC).  ETI frames stay in HBM.
+One "step" = one pass of the whole hot path (sync scan -> OFDM transform + demap -> FIC decode -> control plane -> MSC
+Viterbi -> ETI assembly) over one batch of B independent cu8 streams that are already resident in HBM
+(BASELINE.json configs[2]: batch=256, canonical 12 sub-channel 1136 kbit/s ensemble, full MSC).  ETI frames stay in HBM.
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 is launched by the driver through torch.distributed.run; every rank decodes its own
-256 streams (weak scaling, no data-path collective: ensembles are independent).
-Rank 0 prints ONE JSON line.
+N > 1: one process per GPU, every rank decodes its own 256 streams (weak scaling; ensembles are independent, so there is
+no data-path collective and no RCCL traffic at all).  Two ways to get the N ranks:
+  * `python bench.py --gpus N` by itself: this process starts N rank processes (before anything here touches the GPU)
+    and plays barrier / reducer for them over their pipes;
+  * `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (RANK / WORLD_SIZE in the environment): the
+    ranks keep their books over a gloo group.
+Either way: W warm-up steps, barrier + device sync, exactly K timed steps, device sync + barrier, MAX of the elapsed time
+over ranks, SUM of the frames; rank 0 prints ONE JSON line.  `--dry-run` exercises launch, sharding and book-keeping
+without a GPU (CPU test-suite).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FFT_BYTES_PER_TF = 311296 + 1245184        # cu8 read + complex64 spectra written
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8.0 TB/s spec
-# HBM bytes per TF of ofdm_fft_kernel from rocprofv3 PMC passes (profiles/r01_k2_pmc_traffic.csv):
-# (2 x FETCH_SIZE + WRITE_SIZE) KiB per 1024-TF launch = 2 x 165.8k + 1259.5k, FETCH_SIZE doubled as the
-# gfx950 note in MI355X_MICROARCH.md (HBM) prescribes.  PMC counters cannot be read from inside this script.
+# HBM bytes per TF of ofdm_fft_kernel from rocprofv3 PMC passes (profiles/r01_k2_pmc_traffic.csv; the kernel is unchanged since):
+# (2 x FETCH_SIZE + WRITE_SIZE) KiB per 1024-TF launch = 2 x 165.8k + 1259.5k, FETCH_SIZE doubled as the gfx950 note in
+# MI355X_MICROARCH.md (HBM) prescribes.  PMC counters cannot be read from inside this script.
 FFT_PMC_BYTES_PER_TF = (2 * 165800 + 1259500) * 1024 // 1024   # KiB per 1024 TF == bytes per TF: 1,591,100
 REALTIME_FPS = 1000.0 / 24.0
+# VALU issue peak: 256 CUs x 4 SIMDs, one wave-instruction per 4 cycles (a quad-cycle) at 2.4 GHz
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4
 
 
+# ---- rank coordination ---------------------------------------------------------------------------------------------
+class Single:
+    rank, world = 0, 1
+
+    def barrier(self):
+        pass
+
+    def gather(self, obj):
+        return [obj]
+
+    def close(self):
+        pass
+
+
+class Pipes:
+    """Child of launch_ranks(): lines '@@<verb> <json>' on stdout, one reply line on stdin."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def _ask(self, verb, obj=None):
+        sys.stdout.write("@@%s %s\n" % (verb, json.dumps(obj)))
+        sys.stdout.flush()
+        line = sys.stdin.readline()
+        if not line:
+            raise RuntimeError("bench launcher went away")
+        return json.loads(line)
+
+    def barrier(self):
+        self._ask("barrier")
+
+    def gather(self, obj):
+        return self._ask("gather", obj)      # every rank gets the list (rank order)
+
+    def close(self):
+        pass
+
+
+class Gloo:
+    """Ranks started by torch.distributed.run: book-keeping over gloo (CPU); the data path has no collective."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        dist.init_process_group("gloo")
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def gather(self, obj):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
+def launch_ranks(args, argv):
+    """`bench.py --gpus N` without a launcher: N rank processes, this process their barrier and reducer.  Nothing in this
+    process has touched torch or HIP."""
+    n = args.gpus
+    cores = os.cpu_count() or 8
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), DABHIP_BENCH_PIPES="1",
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.setdefault("DABHIP_HOST_THREADS", str(max(2, min(24, cores // (2 * n)))))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdin=subprocess.PIPE,
+                                      stdout=subprocess.PIPE, text=True, bufsize=1))
+    lock = threading.Condition()
+    pending = {}          # verb -> {rank: payload}
+    failed = []
+
+    def reader(r, p):
+        for line in p.stdout:
+            if not line.startswith("@@"):
+                sys.stdout.write(line)           # rank 0's JSON line (and anything else a rank prints)
+                sys.stdout.flush()
+                continue
+            verb, _, payload = line[2:].partition(" ")
+            with lock:
+                pending.setdefault(verb, {})[r] = json.loads(payload)
+                if len(pending[verb]) == n:
+                    got = pending.pop(verb)
+                    reply = json.dumps([got[i] for i in range(n)] if verb == "gather" else True)
+                    for q in procs:
+                        try:
+                            q.stdin.write(reply + "\n")
+                            q.stdin.flush()
+                        except BrokenPipeError:
+                            pass
+        if p.wait() != 0:
+            failed.append(r)
+            for q in procs:                      # a dead rank must not leave the others waiting at a barrier
+                if q.poll() is None:
+                    q.terminate()
+
+    threads = [threading.Thread(target=reader, args=(r, p), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    return 1 if failed or any(p.returncode for p in procs) else 0
+
+
+# ---- workload -----------------------------------------------------------------------------------------------------
 def make_streams(torch, dev, nstreams, ntf, ndistinct, rank, snr_db=1000.0, host_synth=False):
     """nstreams synthetic ensembles resident on the device.  Default: every stream its own ensemble (payload, CIF
     counter, noise), modulated by the device-side modulator (k_synth.hip).  --host-synth: the host generator,
     ndistinct ensembles tiled to nstreams (the round-1 recipe; slow beyond a few streams)."""
     import dabtools_amd as dab
-
     from dabtools_amd import shard
 
     def cfg_of(i):   # global stream index of this rank's i-th ensemble -> seed rule of SURVEY.md 8(d)
@@ -57,7 +172,8 @@ def make_streams(torch, dev, nstreams, ntf, ndistinct, rank, snr_db=1000.0, host
 
 
 def payload_stats(dab, eng, first_global_stream, nstreams, ntf):
-    """Decoded payload vs what the modulator sent, over the distinct streams of this rank (noisy configs)."""
+    """Decoded payload vs what the modulator sent, over the first streams of this rank (noisy configs)."""
+    import numpy as np
     from dabtools_amd import shard
     frames = good = bit_err = bits = 0
     expected = nstreams * 4 * (ntf - 15)
@@ -85,73 +201,171 @@ def payload_stats(dab, eng, first_global_stream, nstreams, ntf):
             "payload_ber": (bit_err / bits) if bits else None}
 
 
-def cpu_baseline(host_streams, ntf, nsample=10):
-    """The CPU restatement (oracle/, kind 'port') timed on one host core on a bounded sample of the same
-    workload, plus -- when oracle/_ref was built -- the REAL reference back end (dab_process_frame with the
-    scalar viterbi.c and with ENABLE_SPIRAL_VITERBI) on the same demapped frames.  Checker code, used here
-    only as the reported baseline."""
-    import ctypes as C
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib
-    sample = [h[: ntf * 393216] for h in host_streams[:nsample]]     # ~10 s of scalar work at the default sizes
-    neti, t0 = 0, time.perf_counter()
-    for iq in sample:
-        neti += len(oracle_lib.or_replay(iq)[0])
-    dt = time.perf_counter() - t0
-    out = {
-        "value": neti / dt, "unit": "ETI frames/s", "cores": 1, "kind": "port",
-        "sample": "oracle/or_replay (scalar viterbi.c semantics, own fp64 DFT: libfftw3 absent) on %d streams x %d TF of the same "
-                  "workload: %d ETI frames in %.2f s on 1 of %d host cores" % (len(sample), ntf, neti, dt, os.cpu_count()),
-    }
-    # the reference's own back end (the front end needs libfftw3 and cannot be built): demapped TFs are produced
-    # untimed by the oracle front end, then dab_process_frame of the real objects is timed
-    O = oracle_lib.oracle()
-    fic = np.zeros(9216, np.uint8)
-    msc = np.zeros(221184, np.uint8)
-    streams_tfs = []
-    for iq in sample:
-        S, tfs = O.or_sdr_new(), []
-        for off in range(0, iq.size - 262144 + 1, 262144):
-            if O.or_sdr_demod(S, oracle_lib._ptr(iq[off:off + 262144]), 262144, oracle_lib._ptr(fic), oracle_lib._ptr(msc)):
-                tfs.append((fic.copy(), msc.copy()))
-        O.or_sdr_free(S)
-        streams_tfs.append(tfs)
-    ntfs = sum(len(t) for t in streams_tfs)
-    for key, sse in (("reference_backend_scalar", False), ("reference_backend_sse", True)):
-        R = oracle_lib.ref(sse=sse)
-        if R is None:
-            continue
-        devnull, saved = os.open(os.devnull, os.O_WRONLY), os.dup(2)
-        os.dup2(devnull, 2)                 # the reference prints its ensemble table to stderr
-        try:
-            n, dt = 0, 0.0
-            for tfs in streams_tfs:
-                H = R.refh_new()
-                t0 = time.perf_counter()
-                for f, m in tfs:
-                    C.memmove(R.refh_tf_fic(H), oracle_lib._ptr(f), f.size)
-                    C.memmove(R.refh_tf_msc(H), oracle_lib._ptr(m), m.size)
-                    R.refh_process(H)
-                dt += time.perf_counter() - t0
-                n += R.refh_neti(H)
-        finally:
-            os.dup2(saved, 2)
-            os.close(devnull)
-            os.close(saved)
-        out[key] = {"value": n / dt, "unit": "ETI frames/s", "cores": 1,
-                    "sample": "real reference dab_process_frame (%s) on %d demapped TF: %d ETI frames in %.2f s; back end only"
-                              % ("viterbi_spiral SSE2" if sse else "scalar viterbi.c", ntfs, n, dt)}
-        # per-stage micro-timing (SURVEY.md 8(d)): the reference's decoder alone, data Mbit/s on 4608-bit code words (192 kbit/s)
-        nbits, reps = 4608, (40 if sse else 8)
-        rng = np.random.default_rng(1)
-        sym = np.where(rng.integers(0, 2, 4 * (nbits + 6)) > 0, 255 if sse else 129, 0 if sse else 127).astype(np.uint8)
-        data = np.zeros(nbits // 8 + 8, np.uint8)
-        H = R.refh_new()
+def cpu_baseline(tensors, ntf, nsample):
+    """tools/cpu_baseline.py on the first streams of this very workload, as a CHILD process (one process per core needs
+    fork, which a process that has initialised the GPU must not do)."""
+    with tempfile.TemporaryDirectory(prefix="dabhip_bench_") as tmp:
+        files = []
+        for i, t in enumerate(tensors[:nsample]):
+            path = os.path.join(tmp, "s%d.cu8" % i)
+            t.cpu().numpy().tofile(path)
+            files.append(path)
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--tfs", str(ntf), "--iq"] + files
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    if res.returncode != 0:
+        return {"error": res.stderr[-400:]}
+    return json.loads(res.stdout.strip().splitlines()[-1])
+
+
+def workload_text(args):
+    if args.snr < 100.0:
+        return ("BASELINE configs[4]: batch=%d synthetic Mode-I streams x %d TF per GPU, AWGN %.1f dB, %s-decision Viterbi, 12 sub-channels "
+                "(6 UEP + 6 EEP) 1136 kbit/s full MSC" % (args.streams, args.tfs, args.snr, "soft" if args.soft else "hard"))
+    return ("BASELINE configs[2]: batch=%d synthetic Mode-I streams x %d TF per GPU, 12 sub-channels (6 UEP + 6 EEP) 1136 kbit/s full MSC"
+            % (args.streams, args.tfs))
+
+
+# ---- one rank -----------------------------------------------------------------------------------------------------
+def run_rank(args, coord):
+    rank, world = coord.rank, coord.world
+    from dabtools_amd import shard
+    mine = shard.shard_streams(world * args.streams, world, rank)          # global stream indices of this rank
+    rank_info = {"rank": rank, "first_stream": mine[0], "last_stream": mine[-1], "streams": len(mine),
+                 "first_seed": shard.stream_seed(2, mine[0]), "host_threads": os.environ.get("DABHIP_HOST_THREADS", "auto")}
+
+    if args.dry_run:
+        coord.barrier()
         t0 = time.perf_counter()
-        for _ in range(reps):
-            R.refh_viterbi(H, oracle_lib._ptr(sym), oracle_lib._ptr(data), nbits)
-        out[key]["viterbi_mbit_s"] = reps * nbits / (time.perf_counter() - t0) / 1e6
-    return out
+        time.sleep(0.01 * args.steps * (1 + rank))                         # ranks finish at different times: MAX is what counts
+        elapsed = time.perf_counter() - t0
+        coord.barrier()
+        frames = 4 * (args.tfs - 15) * len(mine)
+        stage, fft, fused_off, extra = {}, None, None, {}
+    else:
+        import torch
+        import dabtools_amd as dab
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        t_gen = time.perf_counter()
+        tensors, ndistinct = make_streams(torch, dev, args.streams, args.tfs, min(args.distinct, args.streams), rank, args.snr, args.host_synth)
+        torch.cuda.synchronize()
+        t_gen = time.perf_counter() - t_gen
+        ptrs = [t.data_ptr() for t in tensors]
+        sizes = [t.numel() for t in tensors]
+        eng = dab.Engine(local_rank)
+        if args.soft:
+            eng.set_soft(True)
+        if args.two_kernel_ofdm:
+            eng.set_fused(False)
+        if args.subchannels:
+            eng.set_subchannels([int(x) for x in args.subchannels.split(",")])
+        eng.decode_device(ptrs[:2], [min(s, 20 * 393216) for s in sizes[:2]])   # loads the code objects (tiny, untimed, part of set-up)
+
+        def barrier():
+            torch.cuda.synchronize(dev)
+            coord.barrier()
+            torch.cuda.synchronize(dev)
+
+        frames = 0
+        for _ in range(args.warmup):
+            frames = eng.decode_device(ptrs, sizes)
+        barrier()
+        t0 = time.perf_counter()
+        stage = {}
+        for _ in range(args.steps):
+            frames = eng.decode_device(ptrs, sizes)
+            for k, v in eng.stage_ms().items():
+                stage[k] = stage.get(k, 0.0) + v
+        barrier()
+        elapsed = time.perf_counter() - t0
+        stage = {k: v / args.steps for k, v in stage.items()}
+
+        # Roofline (SURVEY.md 8(d)): K2 = ofdm_fft_kernel by itself, on the same resident IQ and the frame list of the step just
+        # timed, HIP events on the engine's stream around every launch.  The pipeline's default OFDM stage fuses K2 with the
+        # demapper and never writes the spectra; that kernel is not HBM-bound and carries no roofline figure.
+        fft = None
+        fused_off = None
+        extra = {}
+        if rank == 0:
+            fft = eng.fft_roofline(max(3, min(args.steps, 10)))
+            if not args.soft and not args.two_kernel_ofdm and not args.no_variants:
+                # the same job with the two-kernel OFDM stage (K2 writes the spectra, K2b reads them back), for comparison
+                eng.set_fused(False)
+                eng.decode_device(ptrs, sizes)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    f2 = eng.decode_device(ptrs, sizes)
+                torch.cuda.synchronize(dev)
+                e2 = time.perf_counter() - t1
+                a, b, c = eng.fft_stats()
+                fused_off = {"value": f2 * args.steps / e2, "unit": "ETI frames/s", "ms_per_step": 1e3 * e2 / args.steps,
+                             "stage_ms_per_step": {k: v for k, v in eng.stage_ms().items() if k in ("fft", "demap")},
+                             "k2_in_pipeline_avg_launch_ms": c / max(a, 1),
+                             "note": "dabhip_engine_set_fused(0): K2 (cu8 -> complex64 spectra) + K2b (spectra -> bits) as two kernels, "
+                                     "identical ETI bytes; this rank only, untimed against the other ranks"}
+                eng.set_fused(True)
+            extra["data"] = (("synthetic (%d distinct ensembles per GPU tiled to %d streams, host modulator)" % (ndistinct, args.streams)) if args.host_synth
+                             else ("synthetic (%d distinct ensembles per GPU, device-side modulator, %.1f s)" % (args.streams, t_gen)))
+            if args.snr < 100.0:
+                eng.decode_device(ptrs, sizes)
+                extra["payload"] = payload_stats(dab, eng, rank * args.streams, min(16, args.streams), args.tfs)
+            if not args.no_cpu_baseline and world == 1:
+                extra["cpu_baseline"] = cpu_baseline(tensors, args.tfs, args.cpu_sample)
+
+    rows = coord.gather({"info": rank_info, "elapsed": elapsed, "frames": frames})
+    if rank == 0:
+        elapsed_max = max(r["elapsed"] for r in rows)
+        frames_step = sum(r["frames"] for r in rows)
+        value = frames_step * args.steps / elapsed_max
+        out = {
+            "metric": "ETI frames/s (24 ms each), Mode-I batch, synthetic IQ resident in HBM",
+            "value": value, "unit": "ETI frames/s", "x_realtime": value / REALTIME_FPS,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None,
+            # arithmetic of the path: fp64 sync estimators (K1), fp32 OFDM transform + differential demodulation,
+            # packed-u16 integer add-compare-select, u8 ETI bytes
+            "dtype": "f64 sync / f32 OFDM / u16 ACS / u8 ETI",
+            "data": extra.get("data", "none (dry run)"),
+            "config": {"workload": workload_text(args), "streams_per_gpu": args.streams, "tf_per_stream": args.tfs,
+                       "eti_frames_per_step": frames_step,
+                       "ofdm_stage": "K2 + K2b (two kernels)" if (args.two_kernel_ofdm or args.soft) else "fused transform + demap (default)",
+                       "sharding": "independent ensembles, %d per GPU, stream s on rank s // %d, no collective" % (args.streams, args.streams)},
+            "ranks": [dict(r["info"], elapsed_s=r["elapsed"], eti_frames_per_step=r["frames"]) for r in rows],
+        }
+        if args.dry_run:
+            out["dry_run"] = True
+        if fft:
+            launches, tfs, ms = fft
+            achieved = FFT_BYTES_PER_TF * tfs / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "ofdm_fft_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": FFT_PMC_BYTES_PER_TF * tfs / max(launches, 1),
+                "traffic_note": "bytes per launch; per-TF HBM bytes from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                "(profiles/r01_k2_pmc_traffic.csv, FETCH_SIZE x2 gfx950 correction) x TFs per launch",
+                "how": "dabhip_engine_fft_roofline: K2 alone over the frame list of the timed step (same resident IQ, %d TF per launch), "
+                       "HIP events on the engine's stream; the step itself runs the fused transform + demap kernel" % (tfs // max(launches, 1)),
+                "achieved_vs_measured_copy_ceiling": achieved / 6290.0,
+                "launches": launches, "tf_per_launch": tfs / max(launches, 1), "avg_launch_ms": ms / max(launches, 1),
+                "algorithmic_bytes_per_tf": FFT_BYTES_PER_TF}
+        if stage:
+            out["stage_ms_per_step"] = stage
+        if fused_off:
+            out["two_kernel_ofdm_variant"] = fused_off
+        if args.subchannels:
+            out["config"]["subchannel_filter"] = args.subchannels
+        if args.snr < 100.0:
+            out["config"]["snr_db"] = args.snr
+            out["config"]["decisions"] = "soft (4-bit)" if args.soft else "hard"
+        for k in ("payload", "cpu_baseline"):
+            if k in extra:
+                out[k] = extra[k]
+        print(json.dumps(out))
+        sys.stdout.flush()
+    coord.close()
 
 
 def main():
@@ -161,122 +375,30 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
     ap.add_argument("--tfs", type=int, default=64, help="transmission frames per stream")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: launch, sharding and rank book-keeping only")
     ap.add_argument("--host-synth", action="store_true", help="modulate on the host (--distinct ensembles, tiled) instead of on the GPU")
     ap.add_argument("--distinct", type=int, default=16, help="with --host-synth: distinct ensembles generated on the host")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=6, help="streams of the workload the one-core CPU baseline replays")
     ap.add_argument("--snr", type=float, default=1000.0, help="AWGN SNR in dB over the 2.048 MHz band (BASELINE config 5: 5 dB); default: clean")
-    ap.add_argument("--no-fused-variant", action="store_true", help="skip the extra timed pass with the fused OFDM stage")
+    ap.add_argument("--two-kernel-ofdm", action="store_true", help="time the K2 + K2b OFDM stage instead of the fused default")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra timed pass with the two-kernel OFDM stage")
     ap.add_argument("--subchannels", type=str, default="", help="extension: decode only these SubChIds, e.g. 5 or 1,9 (default: all = reference frames)")
     ap.add_argument("--soft", action="store_true", help="soft-decision decoding (extension; default: hard = reference semantics)")
     args = ap.parse_args()
 
-    import torch
-    import dabtools_amd as dab
-    from dabtools_amd import shard
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    t_gen = time.perf_counter()
-    tensors, ndistinct = make_streams(torch, dev, args.streams, args.tfs, min(args.distinct, args.streams), rank, args.snr, args.host_synth)
-    torch.cuda.synchronize()
-    t_gen = time.perf_counter() - t_gen
-    ptrs = [t.data_ptr() for t in tensors]
-    sizes = [t.numel() for t in tensors]
-    eng = dab.Engine(local_rank)
-    if args.soft:
-        eng.set_soft(True)
-    if args.subchannels:
-        eng.set_subchannels([int(x) for x in args.subchannels.split(",")])
-    eng.decode_device(ptrs[:2], [min(s, 20 * 393216) for s in sizes[:2]])   # loads the code objects (tiny, untimed, part of set-up)
-
-    def barrier():
-        shard.barrier(dev)
-
-    frames = 0
-    for _ in range(args.warmup):
-        frames = eng.decode_device(ptrs, sizes)
-    barrier()
-    t0 = time.perf_counter()
-    fft_launches = fft_tfs = 0
-    fft_ms = 0.0
-    stage = {}
-    for _ in range(args.steps):
-        frames = eng.decode_device(ptrs, sizes)
-        a, b, c = eng.fft_stats()
-        fft_launches += a
-        fft_tfs += b
-        fft_ms += c
-        for k, v in eng.stage_ms().items():
-            stage[k] = stage.get(k, 0.0) + v
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed, total_frames_per_step = shard.aggregate(elapsed, frames, dev)
-
-    # Reported separately: the same job with K2 + K2b fused into one kernel that never writes the spectra.
-    # Not HBM-bound, so it carries no roofline; `value` above is the default pipeline with the separate K2.
-    fused = None
-    if not args.no_fused_variant and not args.soft:
-        eng.set_fused(True)
-        eng.decode_device(ptrs, sizes)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            f2 = eng.decode_device(ptrs, sizes)
-        barrier()
-        e2, f2 = shard.aggregate(time.perf_counter() - t1, f2, dev)
-        fused = {"value": f2 * args.steps / e2, "unit": "ETI frames/s", "ms_per_step": 1e3 * e2 / args.steps,
-                 "stage_ms_per_step": {k: v for k, v in eng.stage_ms().items() if k in ("fft", "demap")},
-                 "note": "dabhip_engine_set_fused(1): OFDM transform + demap in one kernel, 311,296 B read + 28,800 B written per TF, "
-                         "identical ETI bytes; stage 'fft' is the fused kernel"}
-        eng.set_fused(False)
-
-    if rank == 0:
-        value = total_frames_per_step * args.steps / elapsed
-        achieved = FFT_BYTES_PER_TF * fft_tfs / (fft_ms * 1e-3) / 1e9 if fft_ms > 0 else 0.0
-        out = {
-            "metric": "ETI frames/s (24 ms each), Mode-I batch, synthetic IQ resident in HBM",
-            "value": value, "unit": "ETI frames/s", "x_realtime": value / REALTIME_FPS,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": ("synthetic (%d distinct ensembles per GPU tiled to %d streams, host modulator)" % (ndistinct, args.streams)) if args.host_synth
-                    else ("synthetic (%d distinct ensembles per GPU, device-side modulator, %.1f s)" % (args.streams, t_gen)),
-            "config": {"workload": "BASELINE configs[2]: batch=%d synthetic Mode-I streams x %d TF per GPU, 12 sub-channels (6 UEP + 6 EEP) 1136 kbit/s full MSC"
-                                   % (args.streams, args.tfs),
-                       "streams_per_gpu": args.streams, "tf_per_stream": args.tfs, "eti_frames_per_step": total_frames_per_step,
-                       "sharding": "independent ensembles, %d per GPU, no collective" % args.streams},
-            "roofline": {"bound": "hbm", "kernel": "ofdm_fft_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": FFT_PMC_BYTES_PER_TF * fft_tfs / max(fft_launches, 1),
-                         "traffic_note": "bytes per launch; per-TF HBM bytes from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                         "(profiles/r01_k2_pmc_traffic.csv, FETCH_SIZE x2 gfx950 correction) x TFs per launch",
-                         "achieved_vs_measured_copy_ceiling": achieved / 6290.0,
-                         # a kernel with K2's loads and stores and no transform (tools/k2_traffic_probe.cpp, profiles/r01_k2_traffic_probe.txt):
-                         # 5317 GB/s with K2's workgroup shape and prefetch, 5696 GB/s at the finest granularity
-                         "achieved_vs_traffic_only_probe": achieved / 5317.0,
-                         "launches": fft_launches, "tf_per_launch": fft_tfs / max(fft_launches, 1),
-                         "avg_launch_ms": fft_ms / max(fft_launches, 1), "algorithmic_bytes_per_tf": FFT_BYTES_PER_TF},
-            "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
-        }
-        if fused:
-            out["fused_variant"] = fused
-        if args.subchannels:
-            out["config"]["subchannel_filter"] = args.subchannels
-        if args.snr < 100.0:
-            out["config"]["snr_db"] = args.snr
-            out["config"]["decisions"] = "soft (4-bit)" if args.soft else "hard"
-            out["payload"] = payload_stats(dab, eng, rank * args.streams, min(16, args.streams), args.tfs)
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline([t.cpu().numpy() for t in tensors[:10]], args.tfs)
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world_env == 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))          # before any torch / HIP call in this process
+    if os.environ.get("DABHIP_BENCH_PIPES") == "1" and world_env > 1:
+        coord = Pipes(int(os.environ["RANK"]), world_env)
+    elif world_env > 1:
+        cores = os.cpu_count() or 8
+        os.environ.setdefault("DABHIP_HOST_THREADS", str(max(2, min(24, cores // (2 * world_env)))))
+        coord = Gloo()
+    else:
+        coord = Single()
+    run_rank(args, coord)
 
 
 if __name__ == "__main__":

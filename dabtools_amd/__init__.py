@@ -73,6 +73,7 @@ _SIGNATURES = {
     "dabhip_engine_trace": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int]),
     "dabhip_engine_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
     "dabhip_engine_fft_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "dabhip_engine_fft_roofline": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "dabhip_stage_ofdm_fft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "dabhip_stage_demap": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, u8p, u8p]),
     "dabhip_stage_fic_decode": (C.c_int, [C.c_void_p, u8p, C.c_int, u8p, u8p]),
@@ -372,7 +373,7 @@ class Engine:
         _need(lib().dabhip_engine_set_subchannels(self._h, arr, len(ids)) == 0, "set_subchannels")
 
     def set_fused(self, enable):
-        """One kernel for OFDM transform + demap (spectra never written); identical output; off = default pipeline."""
+        """True (default): one kernel for OFDM transform + demap (spectra never written); False: K2 + K2b.  Identical output."""
         _need(lib().dabhip_engine_set_fused(self._h, 1 if enable else 0) == 0, "set_fused")
 
     def decode(self, streams):
@@ -427,6 +428,12 @@ class Engine:
     def fft_stats(self):
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_double(0)
         lib().dabhip_engine_fft_stats(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def fft_roofline(self, reps=3):
+        """K2 alone over the frames of the last decode -> (launches, TFs, total kernel ms)."""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_double(0)
+        _need(lib().dabhip_engine_fft_roofline(self._h, reps, C.byref(a), C.byref(b), C.byref(c)) == 0, "fft_roofline")
         return a.value, b.value, c.value
 
     def stage_ofdm_fft(self, frames, reps=1, device_ptr=None, nframes=None, want_output=True):

@@ -240,6 +240,24 @@ int dabhip_engine_fft_stats(const dabhip_engine* e, int64_t* launches, int64_t* 
   return 0;
 }
 
+int dabhip_engine_fft_roofline(dabhip_engine* e, int reps, int64_t* launches, int64_t* tfs, double* ms)
+{
+  if (!e) { set_error("fft_roofline: null handle"); return -1; }
+  int64_t a = 0, b = 0;
+  double c = 0;
+  const int nl = e->lane_of.size() >= 64 ? static_cast<int>(e->lanes.size()) : 1;
+  for (int l = 0; l < nl; ++l) {
+    int64_t x = 0, y = 0;
+    double z = 0;
+    if (e->lanes[l]->fft_roofline(reps, &x, &y, &z) != 0) return -1;
+    a += x; b += y; c += z;
+  }
+  if (launches) *launches = a;
+  if (tfs) *tfs = b;
+  if (ms) *ms = c;
+  return 0;
+}
+
 // ---- stage entries ----------------------------------------------------------------------------
 int dabhip_stage_ofdm_fft(dabhip_engine* e, const uint8_t* frames, int nframes, float* spectra, int on_device, int reps, float* kernel_ms)
 {

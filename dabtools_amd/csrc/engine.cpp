@@ -684,6 +684,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   }
   for (int b = 0; b < nstreams; ++b) calls_done_[b] = std::max(calls_done_[b], static_cast<int>(nbytes[b] / kChunkBytes));
   const int ntf = ntf_new, nslots = tf_base[nstreams];
+  last_ntf_ = ntf;
   if (ntf == 0) return 0;                   // nothing demodulated: layout and carried data stay as they are
   if (!carry_and_reserve(tf_base, row_base, nslots, next_row + 1) || !d_frames_.upload(h_frames_.data(), ntf, stream_) ||
       !d_frame_slot_.upload(h_frame_slot_.data(), ntf, stream_) || !d_frame_cif_row_.upload(h_frame_cif_row_.data(), ntf, stream_))
@@ -832,6 +833,37 @@ int Engine::trace(int stream, int32_t* ints6, double* ffs, int cap_calls) const
     if (ffs) ffs[k] = d.fine_freq_shift;
   }
   return n;
+}
+
+// K2 (ofdm_fft_kernel) alone over the frames of the last decode: the same IQ, the same frame list and the same launch
+// shape (chunks of kFftChunkTfs) as the two-kernel OFDM stage, whatever stage the decode itself used.  This is the
+// HBM-roofline measurement of SURVEY.md 8(d): 311,296 B read + 1,245,184 B written per TF.
+int Engine::fft_roofline(int reps, int64_t* launches, int64_t* tfs, double* ms)
+{
+  if (!ok_) { set_error("engine not initialised (no GPU?)"); return -1; }
+  if (last_ntf_ <= 0) { set_error("fft_roofline: no decode to measure on"); return -1; }
+  if (!check(hipSetDevice(device_), "hipSetDevice")) return -1;
+  const int ntf = last_ntf_, chunk = std::min(ntf, kFftChunkTfs);
+  if (!d_spectra_.reserve(static_cast<size_t>(chunk) * kSymbolsPerTf * 2048)) return -1;
+  reps = std::max(reps, 1);
+  int64_t nl = 0, nt = 0;
+  double total = 0;
+  for (int r = -1; r < reps; ++r) {                      // r = -1: untimed
+    for (int first = 0; first < ntf; first += chunk) {
+      const int n = std::min(chunk, ntf - first);
+      (void)hipEventRecord(ev_[0], stream_);
+      if (!check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(), stream_), "fft launch")) return -1;
+      (void)hipEventRecord(ev_[1], stream_);
+      if (!check(hipEventSynchronize(ev_[1]), "fft")) return -1;
+      float t = 0;
+      (void)hipEventElapsedTime(&t, ev_[0], ev_[1]);
+      if (r >= 0) { total += t; ++nl; nt += n; }
+    }
+  }
+  if (launches) *launches = nl;
+  if (tfs) *tfs = nt;
+  if (ms) *ms = total;
+  return 0;
 }
 
 void Engine::fft_stats(int64_t* launches, int64_t* tfs, double* ms) const

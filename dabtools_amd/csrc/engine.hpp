@@ -164,8 +164,9 @@ class Engine {
   void set_afc(bool on) { afc_ = on; }
   // soft-decision decoding (not in the reference): 4-bit soft values from the demapper through
   // de-interleaving and de-puncturing into the Viterbi branch metrics.  Batch path only; off = parity mode.
-  // K2 + K2b as one kernel that never writes the spectra (k_fused.hip; hard decisions only).  Off by default: the default
-  // pipeline keeps the HBM-roofline stage K2 separate; the output bits are identical either way.
+  // K2 + K2b as one kernel that never writes the spectra (k_fused.hip; hard decisions only; the default) or as the two
+  // kernels K2 (the HBM-roofline stage of SURVEY.md 8(d), always measurable on its own: fft_roofline) and K2b.  The output
+  // bits are identical either way.
   void set_fused(bool on) { fused_ = on; }
   // sub-channel filter (TODO.md:28-31): bit i = SubChId i is decoded and carried in the ETI frames; takes effect with the next
   // decode() / first segment of a session.  All ones (default) = the reference's frames.
@@ -183,6 +184,7 @@ class Engine {
   int trace(int stream, int32_t* ints6, double* ffs, int cap_calls) const;
   const StageTimes& stage_times() const { return times_; }
   void fft_stats(int64_t* launches, int64_t* tfs, double* ms) const;
+  int fft_roofline(int reps, int64_t* launches, int64_t* tfs, double* ms);   // K2 alone over the last decode's frames
 
   // -- stage entries --------------------------------------------------------------------------
   int stage_ofdm_fft(const uint8_t* frames, int nframes, float* spectra, bool on_device, int reps, float* kernel_ms);
@@ -238,7 +240,7 @@ class Engine {
   bool unpack_tf_slot(int slot, uint8_t* fic_bytes, uint8_t* msc_bytes);
 
   bool ok_ = false;
-  bool afc_ = false, fused_ = false;
+  bool afc_ = false, fused_ = true;
   uint64_t subch_keep_ = ~0ull;
   int soft_bits_ = 0;
   std::mutex* heavy_mu_ = nullptr;
@@ -298,7 +300,7 @@ class Engine {
   PinnedBuffer<CallDesc> h_descs_;
   PinnedBuffer<int2> h_info_;
   PinnedBuffer<uint8_t> h_fibs_, h_fib_ok_;
-  int max_calls_ = 0, nstreams_ = 0;
+  int max_calls_ = 0, nstreams_ = 0, last_ntf_ = 0;
   float scan_setup_ms_ = 0;
   std::vector<int64_t> eti_base_, eti_count_;
   int64_t total_eti_ = 0;

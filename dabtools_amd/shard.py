@@ -2,11 +2,11 @@
 
 Every DAB ensemble is decoded independently end to end, so the batch shards by stream with
 no data-path collective: global stream s runs on rank s // streams_per_gpu.  The only
-cross-rank traffic is the bench bookkeeping below (a barrier, MAX of the elapsed time, SUM of
-the ETI frame counts), carried by torch.distributed (RCCL on GPUs, gloo in the CPU tests).
+cross-rank traffic is the bench bookkeeping (a barrier, MAX of the elapsed time, SUM of the
+ETI frame counts): bench.py carries it over its own pipes or a gloo group; the helpers below
+do the same over whatever torch.distributed group is initialised (gloo in the CPU tests).
+torch is imported only by those helpers: the sharding rules themselves need nothing.
 """
-import torch
-import torch.distributed as dist
 
 
 def shard_streams(total_streams, world, rank):
@@ -22,6 +22,8 @@ def stream_seed(config_id, global_stream):
 
 
 def barrier(device=None):
+    import torch
+    import torch.distributed as dist
     if device is not None and device.type == "cuda":
         torch.cuda.synchronize(device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
@@ -32,6 +34,8 @@ def barrier(device=None):
 
 def aggregate(elapsed_s, frames, device=None):
     """(max elapsed over ranks, total frames over ranks)."""
+    import torch
+    import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(elapsed_s), int(frames)
     dev = device if device is not None else torch.device("cpu")

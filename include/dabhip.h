@@ -122,11 +122,11 @@ int dabhip_engine_set_soft(dabhip_engine *e, int enable);
  * n <= 0 = all (default, the reference's frames).  Takes effect with the next decode. */
 int dabhip_engine_set_subchannels(dabhip_engine *e, const int32_t *ids, int n);
 
-/* Fused OFDM stage (optional): the 2048-point transforms and the DQPSK demap / de-interleave scatter in ONE kernel that
- * never writes the complex64 spectra (311,296 B read + 28,800 B written per TF instead of 1,556,480 + 1.2 MB re-read).
- * Output bits, hence ETI bytes, are identical to the default two-kernel stage.  Off by default: the default pipeline keeps
- * K2 as the separately measured HBM-roofline stage; with this on, dabhip_engine_fft_stats describes the
- * fused kernel and is not a roofline figure.  Hard decisions only (ignored with soft decisions on). */
+/* OFDM stage variant.  enable != 0 (default): the 2048-point transforms and the DQPSK demap / de-interleave scatter run as
+ * ONE kernel that never writes the complex64 spectra (311,296 B read + 28,800 B written per TF).  enable == 0: the two
+ * kernels K2 (cu8 -> complex64 spectra, 1,556,480 B per TF: the HBM-roofline stage of SURVEY.md 8(d)) and K2b (spectra ->
+ * bits, re-reading the 1.2 MB).  Output bits, hence ETI bytes, are identical.  Soft decisions always use K2 + K2b.
+ * dabhip_engine_fft_stats describes whichever kernel ran; dabhip_engine_fft_roofline measures K2 by itself. */
 int dabhip_engine_set_fused(dabhip_engine *e, int enable);
 
 /* ---- streaming sessions ---------------------------------------------
@@ -164,6 +164,11 @@ int dabhip_engine_stage_ms(const dabhip_engine *e, const char **names, float *ms
 /* Per-launch statistics of the OFDM FFT kernel in the last decode: number of launches,
  * transmission frames transformed, total kernel milliseconds (HIP events). */
 int dabhip_engine_fft_stats(const dabhip_engine *e, int64_t *launches, int64_t *tfs, double *ms);
+/* K2 (ofdm_fft_kernel) alone, `reps` times over the transmission frames of the LAST decode: same resident IQ, same frame
+ * list, same launch shape as the two-kernel stage (one untimed pass first).  HIP events on the engine's stream around
+ * every launch: number of timed launches, TFs transformed, total kernel milliseconds.  This is the roofline
+ * measurement for input_sdr.c:115-130 whichever OFDM variant the decode itself used. */
+int dabhip_engine_fft_roofline(dabhip_engine *e, int reps, int64_t *launches, int64_t *tfs, double *ms);
 
 /* ---- stage entries (parity tests) ------------------------------------------------------ */
 /* OFDM FFT stage alone (replaces input_sdr.c:115-130): nframes contiguous cu8 frames of

@@ -1,0 +1,80 @@
+"""bench.py's multi-rank launch, sharding and book-keeping without a GPU (`--dry-run`): `--gpus N` by itself must start N
+ranks (the driver's N = 1 command is plain `python bench.py --gpus 1 ...`; SCALE runs may or may not come through
+torch.distributed.run), each with its own 256 streams, and rank 0 prints ONE JSON line with n_gpus = N."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _one_json_line(out):
+    lines = [l for l in out.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def _check(res, n, steps):
+    assert res["n_gpus"] == n and res["steps"] == steps and res["scaling"] == "weak" and res["dry_run"] is True
+    ranks = res["ranks"]
+    assert [r["rank"] for r in ranks] == list(range(n))
+    for r in ranks:                                              # stream s on rank s // 256, seeds 2000 + s
+        assert (r["first_stream"], r["last_stream"], r["streams"]) == (256 * r["rank"], 256 * r["rank"] + 255, 256)
+        assert r["first_seed"] == 2000 + r["first_stream"]
+        assert r["eti_frames_per_step"] == 256 * 4 * (64 - 15)
+    assert res["config"]["eti_frames_per_step"] == n * 256 * 196
+    slowest = max(r["elapsed_s"] for r in ranks)                 # MAX over ranks, whole-job frames
+    assert abs(res["value"] - n * 256 * 196 * steps / slowest) < 1e-6 * res["value"]
+    assert abs(res["ms_per_step"] - 1e3 * slowest / steps) < 1e-6
+    if n > 1:
+        assert ranks[-1]["elapsed_s"] > ranks[0]["elapsed_s"]   # the dry run makes higher ranks slower on purpose
+        assert all(r["host_threads"] != "auto" for r in ranks)  # per-rank host pool capped (cores / ranks)
+
+
+def test_self_launch_two_and_four_ranks():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    for n in (2, 4):
+        out = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--dry-run", "--steps", "3"], env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True, timeout=120, check=True).stdout
+        _check(_one_json_line(out), n, 3)
+
+
+def test_single_rank_unchanged():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--dry-run", "--steps", "2", "--warmup", "0"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=120, check=True).stdout
+    _check(_one_json_line(out), 1, 2)
+
+
+def test_torchrun_launch_two_ranks_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), BENCH, "--gpus", "2", "--dry-run", "--steps", "2"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=300, check=True).stdout
+    _check(_one_json_line(out), 2, 2)
+
+
+def test_cpu_baseline_tool_small_sample(tmp_path):
+    """tools/cpu_baseline.py (the child bench.py starts for its cpu_baseline object) on a small capture."""
+    sys.path.insert(0, ROOT)
+    import dabtools_amd as dab
+    iq = dab.synth_generate(dab.synth_preset(1, seed=5), 18)
+    path = tmp_path / "s0.cu8"
+    iq.tofile(path)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--tfs", "18", "--cores", "2", "--iq", str(path)],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, check=True).stdout
+    res = json.loads(out.strip().splitlines()[-1])
+    assert res["kind"] == "port" and res["cores"] == 1 and res["value"] > 0 and res["oracle_dft2048_us"] > 0
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdabref.so")):
+        for key in ("reference_backend_scalar", "reference_backend_sse"):
+            assert res[key]["kind"] == "reference" and res[key]["value"] > 0 and res[key]["all_cores"]["cores"] == 2
+        assert res["reference_backend_sse"]["value"] > res["reference_backend_scalar"]["value"]
