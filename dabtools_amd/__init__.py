@@ -80,6 +80,7 @@ _SIGNATURES = {
     "dabhip_host_parse_fibs": (C.c_int, [u8p, u8p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "dabhip_host_eti_header": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), u8p, C.c_int]),
     "dabhip_host_control_replay": (C.c_int, [u8p, u8p, C.c_int, C.POINTER(C.c_int32), u8p, C.POINTER(C.c_int32), C.c_int]),
+    "dabhip_host_table": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.c_int]),
     "dabhip_host_fifo_new": (C.c_void_p, []),
     "dabhip_host_fifo_free": (None, [C.c_void_p]),
     "dabhip_host_fifo_call": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
@@ -225,6 +226,16 @@ def host_control_replay(fibs, crc_ok):
                                          hlen.ctypes.data_as(C.POINTER(C.c_int32)), cap)
     _need(n >= 0, "host_control_replay")
     return first[:n], [hdrs[i, :hlen[i]].copy() for i in range(n)]
+
+
+def host_table(which):
+    """The product's constant tables (dabhip_host_table): 0 UEP profiles (64 x 11), 1 puncturing vectors (24 x 32),
+    2 frequency de-interleaver (1536), 3 phase reference symbol quarter turns (1536)."""
+    out = np.zeros(4096, dtype=np.int32)
+    n = lib().dabhip_host_table(which, out.ctypes.data_as(C.POINTER(C.c_int32)), out.size)
+    _need(n > 0, "host_table")
+    shape = {0: (64, 11), 1: (24, 32)}.get(which, (n,))
+    return out[:n].reshape(shape)
 
 
 class HostFifo:

@@ -483,6 +483,39 @@ int dabhip_host_control_replay(const uint8_t* fibs, const uint8_t* crc_ok, int n
 
 }  // extern "C"
 
+// ---- the product's constant tables (dab_tables.hpp), for the CPU test-suite to compare with the reference's arrays ----
+extern "C" int dabhip_host_table(int which, int32_t* out, int cap)
+{
+  if (!out) { set_error("host_table: null argument"); return -1; }
+  int n = 0;
+  auto put = [&](int v) { if (n < cap) out[n] = v; ++n; };
+  switch (which) {
+    case 0:                                  // 64 rows {bitrate, size_cu, protlevel, L1..L4, PI1..PI4} (PI as in ETSI: 1..24, 0 = unused)
+      for (int i = 0; i < 64; ++i) {
+        const UepProfile& u = uep_table()[i];
+        put(u.bitrate); put(u.size_cu); put(u.protlevel);
+        for (int k = 0; k < 4; ++k) put(u.l[k]);
+        for (int k = 0; k < 4; ++k) put(u.pi[k]);
+      }
+      break;
+    case 1:                                  // puncturing vectors PI = 1..24 as 32 flags each
+      for (int pi = 1; pi <= 24; ++pi)
+        for (int b = 0; b < 32; ++b) put(static_cast<int>((puncture_mask(pi) >> b) & 1u));
+      break;
+    case 2:                                  // frequency de-interleaver: carrier -> QPSK symbol index
+      for (uint16_t v : carrier_to_qpsk()) put(v);
+      break;
+    case 3:                                  // phase reference symbol, quarter turns per carrier
+      for (uint8_t v : prs_quarter_turns()) put(v);
+      break;
+    default:
+      set_error("host_table: unknown table");
+      return -1;
+  }
+  if (n > cap) { set_error("host_table: buffer too small"); return -1; }
+  return n;
+}
+
 // ---- FIFO / frame-buffer bookkeeping of K1 on the host (fifo_view.hpp), callable without a GPU ---------
 struct dabhip_fifo {
   StreamState st;

@@ -3,7 +3,8 @@
 // Replaces the literal arrays of the reference (dab_tables.c:16-127,164-357 and
 // sdr_prstab.c:1) with the standard's generating rules where one exists; the UEP profile
 // rows are ETSI Table 7 / Table 36 data.  Shared by host code and uploaded to the device
-// by Engine (engine.hip).  Checked against the reference's arrays by tests/test_tables.py.
+// by Engine (engine.cpp).  Checked against the reference's arrays (tests/golden/tables.npz) through
+// dabhip_host_table by tests/test_host.py::test_product_tables_match_reference_arrays.
 #pragma once
 
 #include <array>

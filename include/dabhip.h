@@ -197,6 +197,13 @@ int dabhip_host_eti_header(const int32_t *hdr3, const int32_t *sub, uint8_t *out
 int dabhip_host_control_replay(const uint8_t *fibs, const uint8_t *crc_ok, int ntf, int32_t *first_cif,
                                uint8_t *headers, int32_t *header_len, int cap_frames);
 
+/* The constant tables the kernels are built from (dab_tables.hpp generates them from the ETSI rules), so that tests can
+ * hold them against the reference's literal arrays: which = 0: the 64 UEP profiles of ueptable (dab_tables.c:16-81) as rows
+ * {bitrate, size, protection level, L1..L4, PI1..PI4} (PI as in ETSI, 1..24; the reference stores PI - 1); 1: pvec
+ * (dab_tables.c:102-127), 24 x 32 flags; 2: rev_freq_deint_tab (dab_tables.c:164), 1536 entries; 3: the phase reference
+ * symbol (sdr_prstab.c) as quarter turns, 1536 entries.  Returns the number of values written, <0 on error. */
+int dabhip_host_table(int which, int32_t *out, int cap);
+
 /* The FIFO of sdr_demod (cbWrite / sdr_read_fifo, sdr_fifo.c:26-61; input_sdr.c:36-55) as the sync-scan kernel keeps it:
  * in closed form over the resident stream.  One call = one 262144-byte sdr_demod call entered with the timing
  * corrections the previous processed frame left in sdr->coarse_timeshift / fine_timeshift.  Returns 0 = nothing read

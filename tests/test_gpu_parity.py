@@ -576,9 +576,10 @@ def test_streaming_session_equals_one_shot_decode(soft):
 
 
 @pytest.mark.gpu
-def test_fused_ofdm_stage_gives_identical_frames():
-    """The one-kernel OFDM stage (k_fused.hip, spectra never written) against the default K2 + K2b: identical ETI on clean,
-    unaligned, noisy (lock loss) and resynchronising captures, with and without the software AFC."""
+def test_fused_and_two_kernel_ofdm_stages_give_identical_frames():
+    """The one-kernel OFDM stage (k_fused.hip, spectra never written; the default) against K2 + K2b: identical ETI on clean,
+    unaligned, noisy (lock loss) and resynchronising captures, with and without the software AFC -- and, AFC off, both
+    equal to the CPU oracle on every stream."""
     ntf = 24
     cfgs = [dab.synth_preset(0, seed=31), dab.synth_preset(1, seed=32, skip_samples=123457), dab.synth_preset(1, seed=33, snr_db=6.5),
             dab.synth_preset(0, seed=34, snr_db=9.0, cif_count0=4990), dab.synth_preset(1, seed=35, cfo_hz=-1700.0)]
@@ -587,15 +588,20 @@ def test_fused_ofdm_stage_gives_identical_frames():
     for afc in (False, True):
         eng = dab.Engine(0)
         eng.set_afc(afc)
+        eng.set_fused(False)
         eng.decode(caps)
         want = [eng.eti(i) for i in range(len(caps))]
+        assert eng.stage_ms()["demap"] > 0                      # K2b ran
         eng.set_fused(True)
         eng.decode(caps)
+        assert eng.stage_ms()["demap"] == 0                     # ... and now it did not
         for i in range(len(caps)):
             assert np.array_equal(eng.eti(i), want[i]), "stream %d afc %d" % (i, afc)
         assert sum(len(w) for w in want) > 100
         if not afc:
-            assert np.array_equal(want[0], ol.or_replay(caps[0])[0])
+            for i, c in enumerate(caps):
+                assert np.array_equal(want[i], ol.or_replay(c)[0]), i
+        eng.close()
 
 
 @pytest.mark.gpu

@@ -242,3 +242,17 @@ def test_fifo_shifted_read_against_reference_fifo():
         else:
             assert fifo.call(shift, 0)[0] == 0
     assert k > 20 and nshort >= 2
+
+
+def test_product_tables_match_reference_arrays():
+    """dab_tables.hpp (generated from the ETSI rules; what the kernels and the control plane use) against the reference's
+    literal arrays held in tests/golden/tables.npz (ueptable dab_tables.c:16-81, pvec :102-127, rev_freq_deint_tab :164,
+    sdr_prstab.c)."""
+    t = np.load(os.path.join(G, "tables.npz"))
+    uep = dab.host_table(0)
+    want = t["ueptable"].astype(np.int64)
+    assert np.array_equal(uep[:, :7], want[:, :7])                       # bitrate, size, protection level, L1..L4
+    assert np.array_equal(uep[:, 7:] - 1, want[:, 7:])                   # the reference stores PI - 1 (-1 = unused segment)
+    assert np.array_equal(dab.host_table(1), t["pvec"])
+    assert np.array_equal(dab.host_table(2), t["rev_freq_deint_tab"])
+    assert np.array_equal(dab.host_table(3), t["prs_quarter_turns"])
