@@ -12,7 +12,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* REFH_S3_ONLY: only the replay entry points (the back end itself is integration/dab_hip.c over libdabhip);
+ * REFH_NO_ENCODE: the reference's viterbi.c (which also holds encode()) is replaced by integration/viterbi_hip.c */
 #include "dab.h"
+#ifndef REFH_S3_ONLY
 #include "dab_tables.h"
 #include "depuncture.h"
 #include "fic.h"
@@ -27,6 +30,7 @@ int encode(unsigned char *symbols, unsigned char *data, unsigned int nbytes, uns
 #endif
 int init_eti(uint8_t *eti, struct ens_info_t *info);
 void time_deinterleave(uint8_t *dst, uint8_t *cifs[]);
+#endif
 
 struct refh {
   struct dab_state_t *dab;
@@ -64,16 +68,17 @@ void refh_process(void *p)
 int refh_neti(void *p) { return ((struct refh *)p)->neti; }
 const uint8_t *refh_eti(void *p) { return ((struct refh *)p)->eti; }
 int refh_locked(void *p) { return ((struct refh *)p)->dab->locked; }
+int refh_tfidx(void *p) { return ((struct refh *)p)->dab->tfidx; }
+#ifndef REFH_S3_ONLY
 /* FIBs + CRC flags of TF buffer `idx` (0..4) */
 const uint8_t *refh_fibs(void *p, int idx) { return ((struct refh *)p)->dab->tfs[idx].fibs.FIB[0]; }
 const uint8_t *refh_fib_ok(void *p, int idx) { return ((struct refh *)p)->dab->tfs[idx].fibs.FIB_CRC_OK; }
-int refh_tfidx(void *p) { return ((struct refh *)p)->dab->tfidx; }
 
 void refh_viterbi(void *p, uint8_t *symbols, uint8_t *data, int nbits)
 {
   viterbi(p ? ((struct refh *)p)->dab->v : NULL, symbols, data, nbits);
 }
-#ifndef ENABLE_SPIRAL_VITERBI
+#if !defined(ENABLE_SPIRAL_VITERBI) && !defined(REFH_NO_ENCODE)
 void refh_encode(uint8_t *symbols, uint8_t *data, unsigned nbytes) { encode(symbols, data, nbytes, 0, 0); }
 #endif
 void refh_fic_depuncture(uint8_t *out, uint8_t *in) { fic_depuncture(out, in); }
@@ -154,3 +159,4 @@ void *refh_fifo_new(uint32_t size) { CircularBuffer *cb = calloc(1, sizeof *cb);
 void refh_fifo_write(void *cb, uint8_t *p, int n) { int i; for (i = 0; i < n; i++) cbWrite(cb, p + i); }
 void refh_fifo_read(void *cb, uint32_t bytes, int32_t shift, uint8_t *buffer) { sdr_read_fifo(cb, bytes, shift, buffer); }
 uint32_t refh_fifo_count(void *cb) { return ((CircularBuffer *)cb)->count; }
+#endif /* REFH_S3_ONLY */

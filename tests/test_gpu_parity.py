@@ -591,10 +591,10 @@ def test_fused_and_two_kernel_ofdm_stages_give_identical_frames():
         eng.set_fused(False)
         eng.decode(caps)
         want = [eng.eti(i) for i in range(len(caps))]
-        assert eng.stage_ms()["demap"] > 0                      # K2b ran
+        assert eng.stage_ms()["demap"] > 0.05                   # K2b ran
         eng.set_fused(True)
         eng.decode(caps)
-        assert eng.stage_ms()["demap"] == 0                     # ... and now it did not
+        assert eng.stage_ms()["demap"] < 0.05                   # ... and now it did not (two events back to back)
         for i in range(len(caps)):
             assert np.array_equal(eng.eti(i), want[i]), "stream %d afc %d" % (i, afc)
         assert sum(len(w) for w in want) > 100

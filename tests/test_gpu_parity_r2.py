@@ -74,7 +74,7 @@ def test_resync_while_locked_matches_oracle(engine):
             _cut(_cut(base, 17, 5000, 12000), 29, 60000, 130000)]
     wants = [ol.or_replay(c) for c in caps]
     assert all(any(t.coarse_timeshift != 0 for t in tr[12:]) for _, tr in wants)    # a resync after lock in every capture
-    assert all(len(w) > 20 for w, _ in wants)
+    assert all(len(w) >= 20 for w, _ in wants)
     _check_streams(engine, caps, wants)
     # streaming session, segments unrelated to the call size
     st = dab.Stream(len(caps))
@@ -243,3 +243,35 @@ def test_config4_full_size_5db_soft_and_hard():
         got = eng.eti(b)
         assert got.shape == want.shape and np.array_equal(got, want), "stream %d: hard-decision ETI differs from the oracle" % b
     eng.close()
+
+
+@pytest.mark.parametrize("seam", ["S1", "S3"])
+def test_reference_callers_over_the_hip_seams(seam):
+    """The drop-in proven literally.  S1: the reference's own, unmodified fic.c / misc.c / dab.c / depuncture.c (compiled where
+    they lie by oracle/Makefile) call viterbi() / init_viterbi() of integration/viterbi_hip.c, i.e. libdabhip, at fic.c:186
+    and misc.c:262 -- the link-time swap of the reference's Makefile:8-16.  S3: integration/dab_hip.c compiled against the
+    reference's dab.h stands in for init_dab_state / dab_process_frame.  Both replay the golden demapped frames
+    (tests/golden/backend_e2e.npz: 32 TF at 9 dB with a lock loss) and must emit the ETI bytes the all-CPU reference emitted."""
+    so = os.path.join(ol.ORACLE_DIR, "_ref", "libdabref_hip%s.so" % seam)
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libdabref_hip%s.so not built (needs /root/reference at build time)" % seam)
+    L = C.CDLL(so)
+    L.refh_new.restype = C.c_void_p
+    for f in ("refh_tf_fic", "refh_tf_msc", "refh_eti"):
+        getattr(L, f).restype = C.POINTER(C.c_uint8)
+    for f in ("refh_tf_fic", "refh_tf_msc", "refh_eti", "refh_process", "refh_neti", "refh_locked"):
+        getattr(L, f).argtypes = [C.c_void_p]
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "backend_e2e.npz"))
+    H = L.refh_new()
+    assert H
+    locked = []
+    for row in g["tf_bits"]:
+        bits = np.ascontiguousarray(np.unpackbits(row))
+        C.memmove(L.refh_tf_fic(H), ol._ptr(bits[:9216]), 9216)
+        C.memmove(L.refh_tf_msc(H), ol._ptr(bits[9216:]), 221184)
+        L.refh_process(H)
+        locked.append(L.refh_locked(H))
+    n = L.refh_neti(H)
+    got = np.ctypeslib.as_array(L.refh_eti(H), (n, 6144)).copy() if n else np.zeros((0, 6144), np.uint8)
+    assert got.shape == g["eti"].shape and np.array_equal(got, g["eti"])
+    assert 0 in locked[12:] and locked[-1] == 1                # the run loses lock and regains it
