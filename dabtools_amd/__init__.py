@@ -90,6 +90,10 @@ _SIGNATURES = {
     "dabhip_synth_payload": (C.c_int, [C.POINTER(SynthCfg), C.c_int, C.c_int, u8p, C.c_int]),
     "dabhip_synth_fibs": (C.c_int, [C.POINTER(SynthCfg), C.c_int, u8p]),
     "dabhip_engine_set_fused": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_engine_set_parity_guard": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_engine_guard_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "dabhip_stream_set_parity_guard": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_stage_decision_audit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "dabhip_engine_set_subchannels": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
     "dabhip_stream_set_subchannels": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
     "dabhip_stream_create": (C.c_void_p, [C.c_int, C.c_int]),
@@ -386,6 +390,29 @@ class Engine:
     def set_fused(self, enable):
         """True (default): one kernel for OFDM transform + demap (spectra never written); False: K2 + K2b.  Identical output."""
         _need(lib().dabhip_engine_set_fused(self._h, 1 if enable else 0) == 0, "set_fused")
+
+    def set_parity_guard(self, enable):
+        """True (default): decisions inside the fp32 error band are re-decided in fp64 -> bits of exact arithmetic."""
+        _need(lib().dabhip_engine_set_parity_guard(self._h, 1 if enable else 0) == 0, "set_parity_guard")
+
+    def guard_stats(self):
+        """(decisions re-decided by the parity guard, hard decisions taken) of the last decode."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        _need(lib().dabhip_engine_guard_stats(self._h, C.byref(a), C.byref(b)) == 0, "guard_stats")
+        return a.value, b.value
+
+    def decision_audit(self, frames=None, device_ptr=None, nframes=None, guard=False):
+        """fp32 OFDM stage vs fp64 on contiguous cu8 frames -> dict (see dabhip_stage_decision_audit)."""
+        if device_ptr is None:
+            frames = np.ascontiguousarray(frames, dtype=np.uint8)
+            nframes = frames.size // TF_BYTES
+            src, on_dev = frames.ctypes.data, 0
+        else:
+            src, on_dev = device_ptr, 1
+        out = (C.c_double * 8)()
+        _need(lib().dabhip_stage_decision_audit(self._h, src, nframes, on_dev, 1 if guard else 0, out) == nframes, "stage_decision_audit")
+        keys = ("decisions", "disagree", "disagree_outside_guard", "flagged_by_rule", "max_bin_err", "max_dec_err", "max_prod_err", "listed")
+        return dict(zip(keys, list(out)))
 
     def decode(self, streams):
         """streams: list of numpy uint8 arrays (host) -> total ETI frames."""

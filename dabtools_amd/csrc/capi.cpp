@@ -216,6 +216,26 @@ int dabhip_engine_set_subchannels(dabhip_engine* e, const int32_t* ids, int n)
   for (auto& l : e->lanes) l->set_subchannel_filter(subchannel_mask(ids, n));
   return 0;
 }
+int dabhip_engine_set_parity_guard(dabhip_engine* e, int enable)
+{
+  if (!e) return -1;
+  for (auto& l : e->lanes) l->set_parity_guard(enable != 0);
+  return 0;
+}
+int dabhip_engine_guard_stats(const dabhip_engine* e, int64_t* flagged, int64_t* decisions)
+{
+  if (!e) return -1;
+  int64_t a = 0, b = 0;
+  const int nl = e->lane_of.size() >= 64 ? static_cast<int>(e->lanes.size()) : 1;
+  for (int l = 0; l < nl; ++l) {
+    int64_t x = 0, y = 0;
+    e->lanes[l]->guard_stats(&x, &y);
+    a += x; b += y;
+  }
+  if (flagged) *flagged = a;
+  if (decisions) *decisions = b;
+  return 0;
+}
 int dabhip_engine_set_fused(dabhip_engine* e, int enable)
 {
   if (!e) return -1;
@@ -268,6 +288,11 @@ int dabhip_stage_demap(dabhip_engine* e, const float* spectra, int nframes, uint
 {
   if (!e || !spectra || !fic || !msc) { set_error("stage_demap: null argument"); return -1; }
   return e->first().stage_demap(spectra, nframes, fic, msc);
+}
+int dabhip_stage_decision_audit(dabhip_engine* e, const uint8_t* frames, int nframes, int on_device, int guard_on, double* out8)
+{
+  if (!e || !frames || !out8) { set_error("stage_decision_audit: null argument"); return -1; }
+  return e->first().stage_decision_audit(frames, nframes, on_device != 0, guard_on != 0, out8);
 }
 int dabhip_stage_fic_decode(dabhip_engine* e, const uint8_t* fic, int nframes, uint8_t* fibs, uint8_t* crc_ok)
 {
@@ -584,6 +609,7 @@ extern "C" int dabhip_stream_set_subchannels(dabhip_stream* s, const int32_t* id
   return 0;
 }
 extern "C" int dabhip_stream_set_afc(dabhip_stream* s, int on) { if (!s) return -1; s->eng.set_afc(on != 0); return 0; }
+extern "C" int dabhip_stream_set_parity_guard(dabhip_stream* s, int on) { if (!s) return -1; s->eng.set_parity_guard(on != 0); return 0; }
 extern "C" int dabhip_stream_set_soft(dabhip_stream* s, int on)
 {
   if (!s) return -1;

@@ -1,6 +1,8 @@
 // device_types.hpp — plain structs shared by host code and HIP kernels.
 #pragma once
 
+#include <hip/hip_runtime.h>
+
 #include <cstdint>
 
 namespace dabhip {
@@ -77,6 +79,19 @@ struct CopyDesc {
   uint8_t* dst;
   uint32_t nbytes;
   uint32_t pad;
+};
+
+// Parity guard of the OFDM stage (k_parity.hip): decisions whose fp32 margin is inside the error band are listed for an fp64
+// re-decision.  delta[frame * delta_stride + symbol] = kGuardC * sqrt(energy of the symbol's 2048 samples).
+// Constants: >= 5 x the worst dabhip_stage_decision_audit measured over > 10^10 decisions (profiles/r02_decision_audit.json).
+constexpr float kGuardC = 5.0e-6f;       // bound on |X32 - X| of any bin, relative to sqrt(sum_n |x_n|^2)   (measured worst: 6.3e-7)
+constexpr float kGuardProd = 5.0e-7f;    // rounding of the fp32 product Re/Im(cur conj(prev)), relative to |cur|_1 |prev|_1   (measured worst: 1.0e-7)
+struct GuardArgs {
+  const float* delta;    // nullptr: guard off
+  int32_t delta_stride;
+  uint32_t cap;          // capacity of list
+  uint2* list;           // {frame index, symbol << 16 | raw bin}
+  uint32_t* counter;     // entries appended (may exceed cap: overflow, detected by the host)
 };
 
 // Per ETI frame: what eti_finish_kernel needs besides the decoded sub-channel data.

@@ -532,6 +532,42 @@ bool Engine::carry_and_reserve(const std::vector<int>& tf_base, const std::vecto
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Parity guard around one demapping launch: guard_begin() clears the counter and hands the kernel its list; guard_finish()
+// queues the fp64 re-decision of what was listed and the copy of the entry count to the host; guard_check() (after the
+// stream has been awaited) adds the counts up and refuses a result whose list overflowed.
+constexpr int kGuardMaxLaunches = 64;
+bool Engine::guard_begin(int ntf_in_launch, GuardArgs* out)
+{
+  const uint32_t cap = static_cast<uint32_t>(std::max<int64_t>(int64_t(1) << 20, static_cast<int64_t>(ntf_in_launch) * 4096));   // 1.8 % of a TF's decisions
+  if (!d_guard_list_.reserve(cap) || !d_guard_counter_.reserve(4) || !h_guard_counts_.resize(kGuardMaxLaunches)) return false;
+  guard_cap_ = static_cast<uint32_t>(std::min<size_t>(d_guard_list_.capacity(), 0xffffffffu));
+  if (!check(hipMemsetAsync(d_guard_counter_.get(), 0, 4 * sizeof(uint32_t), stream_), "guard counter")) return false;
+  *out = GuardArgs{d_delta_.get(), kSymbolsPerTf, guard_cap_, d_guard_list_.get(), d_guard_counter_.get()};
+  return true;
+}
+bool Engine::guard_finish(bool planar)
+{
+  if (guard_launches_ >= kGuardMaxLaunches) { set_error("parity guard: too many launches in one decode"); return false; }
+  return check(launch_exact_decide(d_guard_list_.get(), d_guard_counter_.get(), guard_cap_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(),
+                                   d_tw2048_.get(), d_qpsk_.get(), d_frame_slot_.get(), d_frame_cif_row_.get(), planar, d_fic_bits_.get(), d_msc_bits_.get(), stream_),
+               "exact decide launch") &&
+         check(hipMemcpyAsync(h_guard_counts_.data() + guard_launches_++, d_guard_counter_.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, stream_), "guard count download");
+}
+bool Engine::guard_check()
+{
+  for (int i = 0; i < guard_launches_; ++i) {
+    if (h_guard_counts_[i] > guard_cap_) {
+      set_error("parity guard: more than " + std::to_string(guard_cap_) + " decisions inside the fp32 error band in one launch (list overflow); "
+                "decode again with dabhip_engine_set_parity_guard(e, 0) to accept fp32 decisions");
+      return false;
+    }
+    guard_flagged_ += h_guard_counts_[i];
+  }
+  guard_launches_ = 0;
+  return true;
+}
+
 int64_t Engine::decode(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device)
 {
   return decode_impl(iq, nbytes, nstreams, on_device, false);
@@ -648,6 +684,8 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   times_ = StageTimes{};
   fft_launches_ = fft_tfs_ = 0;
   fft_ms_ = 0;
+  guard_flagged_ = guard_decisions_ = 0;
+  guard_launches_ = 0;
   if (!begin_decode(nstreams, cont)) return -1;
   struct SideStreamGuard {                   // whatever was queued on the side stream is awaited before returning
     hipStream_t s;
@@ -701,13 +739,21 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   uint8_t* const fibs = h_fibs_.data();
   uint8_t* const ok = h_fib_ok_.data();
   (void)hipEventRecord(ev_[3], stream_);
+  const bool guard = guard_active();
+  if (guard && !d_delta_.reserve(static_cast<size_t>(ntf) * kSymbolsPerTf)) return -1;
   for (int first = 0; first < ntf; first += chunk * 19) {       // 4 of 76 symbols: 19 x as many TFs fit the spectra buffer
     const int n = std::min(chunk * 19, ntf - first);
+    GuardArgs ga{};
+    if (guard && (!guard_begin(n, &ga) ||
+                  !check(launch_symbol_delta(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, 4, d_delta_.get(), kSymbolsPerTf, stream_), "symbol delta launch")))
+      return -1;
     if (!check(launch_fic_prepass(soft_bits_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(),
-                                  d_frame_slot_.get(), d_qpsk_.get(), d_fic_bits_.get(), stream_),
+                                  d_frame_slot_.get(), d_qpsk_.get(), d_fic_bits_.get(), ga, stream_),
                "fic pre-pass launch"))
       return -1;
+    if (guard && !guard_finish(true)) return -1;
   }
+  if (guard) guard_decisions_ += static_cast<int64_t>(ntf) * (kFicBits + kMscBits);
   // FIC decode kernels on the main stream, the FIB download on the side stream: the OFDM stage is queued right behind
   // the FIC kernels and starts without waiting for the download or for the host
   if (!fic_decode_slots_async(0, nslots, fibs, ok, copy_stream_)) return -1;      // carried slots are decoded again: their FIBs are read by K5
@@ -723,17 +769,22 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   }
   for (int c = 0; c < nchunks && gpu_ok; ++c) {
     const int first = c * chunk, n = std::min(chunk, ntf - first);
+    GuardArgs ga{};
+    if (guard && !guard_begin(n, &ga)) { gpu_ok = false; break; }
     (void)hipEventRecord(chunk_ev_[3 * c], stream_);
     if (fused_ && soft_bits_ == 0) {
       gpu_ok = check(launch_ofdm_demap_fused(afc_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_twf_.get(), d_frame_slot_.get(),
-                                             d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_),
+                                             d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_),
                      "fused fft/demap launch");
       (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
     } else {
       gpu_ok = check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(), stream_), "fft launch");
       (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
-      gpu_ok = gpu_ok && check(launch_demap(true, soft_bits_, d_spectra_.get(), first, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch");
+      // the two-kernel stage has no samples in hand when it decides: the per-symbol error bounds come from their own pass
+      if (guard) gpu_ok = gpu_ok && check(launch_symbol_delta(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, kSymbolsPerTf, d_delta_.get(), kSymbolsPerTf, stream_), "symbol delta launch");
+      gpu_ok = gpu_ok && check(launch_demap(true, soft_bits_, d_spectra_.get(), first, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_), "demap launch");
     }
+    if (guard) gpu_ok = gpu_ok && guard_finish(true);       // timed with the demapper: "demap" of the fused stage is the guard's cost
     (void)hipEventRecord(chunk_ev_[3 * c + 2], stream_);
   }
   if (!check(hipEventSynchronize(ev_fibs_), "fic decode")) return -1;
@@ -789,6 +840,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   }
   if (heavy.owns_lock()) heavy.unlock();
   host.join();
+  if (gpu_ok && guard && !guard_check()) return -1;
   if (!gpu_ok) return -1;
   if (!host_ok) { set_error(host_error); return -1; }
 
@@ -922,7 +974,8 @@ int Engine::stage_demap(const float* spectra, int nframes, uint8_t* fic, uint8_t
   for (int j = 0; j < nframes; ++j) { slots[j] = j; rows[j] = 4 * j; }
   if (!reserve_tf_slots(nframes) || !d_spectra_.reserve(nspec) || !d_frame_slot_.upload(slots, stream_) || !d_frame_cif_row_.upload(rows, stream_)) return -1;
   if (!check(hipMemcpyAsync(d_spectra_.get(), spectra, nspec * sizeof(float2), hipMemcpyHostToDevice, stream_), "spectra upload")) return -1;
-  if (!check(launch_demap(false, 0, d_spectra_.get(), 0, nframes, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch") ||
+  // spectra only: no samples to re-decide from, so this stage entry returns the raw fp32 decisions (no parity guard)
+  if (!check(launch_demap(false, 0, d_spectra_.get(), 0, nframes, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), GuardArgs{}, stream_), "demap launch") ||
       !check(hipStreamSynchronize(stream_), "demap"))
     return -1;
   for (int j = 0; j < nframes; ++j)
@@ -940,6 +993,70 @@ int Engine::stage_fic_decode(const uint8_t* fic, int nframes, uint8_t* fibs, uin
   for (int j = 0; j < nframes; ++j) pack_bits(fic + static_cast<size_t>(j) * kFicBits, kFicBits, words.data() + static_cast<size_t>(j) * kFicWords);
   if (!check(hipMemcpy(d_fic_bits_.get(), words.data(), words.size() * 4, hipMemcpyHostToDevice), "fic upload")) return -1;
   return fic_decode_slots(0, nframes, fibs, crc_ok) ? nframes : -1;
+}
+
+// Decision audit (calibration / test tool of the parity guard): nframes contiguous cu8 frames through K2 + K2b (natural
+// layout), optionally with the guard, then decision_audit_kernel's fp64 transforms against the result.
+// out8 = {decisions, disagreements with fp64, disagreements on carriers the guard rule does NOT flag, decisions the rule flags,
+//         max |X32 - X64| / sqrt(symbol energy), max product error / (|cur|_1 s(l-1) + |prev|_1 s(l)), max residual product
+//         error / (|cur|_1 |prev|_1), entries the demapper listed (guard on)}
+int Engine::stage_decision_audit(const uint8_t* frames, int nframes, bool on_device, bool guard_on, double* out8)
+{
+  if (!ok_) { set_error("engine not initialised (no GPU?)"); return -1; }
+  if (!hard_only("stage_decision_audit")) return -1;
+  if (nframes <= 0 || !out8) return 0;
+  struct AuditOut { unsigned long long decisions, disagree, outside, flagged; unsigned bin_bits, dec_bits, prod_bits, pad; };
+  DeviceBuffer<uint8_t> d_out;
+  if (!d_out.reserve(sizeof(AuditOut)) || !check(hipMemsetAsync(d_out.get(), 0, sizeof(AuditOut), stream_), "audit memset")) return -1;
+  const int chunk = 256;
+  uint64_t listed = 0;
+  const uint8_t* d_in = frames;
+  if (!on_device) {
+    if (!d_iq_own_.reserve(static_cast<size_t>(nframes) * kTfBytes) ||
+        !check(hipMemcpy(d_iq_own_.get(), frames, static_cast<size_t>(nframes) * kTfBytes, hipMemcpyHostToDevice), "frame upload"))
+      return -1;
+    d_in = d_iq_own_.get();
+  }
+  for (int first = 0; first < nframes; first += chunk) {
+    const int n = std::min(chunk, nframes - first);
+    std::vector<CallDesc> descs(n);
+    std::vector<int2> list(n);
+    std::vector<int> slots(n), rows(n);
+    for (int j = 0; j < n; ++j) {
+      std::memset(&descs[j], 0, sizeof(CallDesc));
+      descs[j].status = 2;
+      descs[j].ordinal = j;
+      descs[j].view = initial_state().view;
+      descs[j].view.seg_src[0] = static_cast<int64_t>(first + j) * kTfBytes;
+      list[j] = make_int2(0, j);
+      slots[j] = j;
+      rows[j] = 4 * j;
+    }
+    std::vector<const uint8_t*> ptrs = {d_in};
+    max_calls_ = n;
+    if (!reserve_tf_slots(n) || !d_iq_ptrs_.upload(ptrs, stream_) || !d_descs_.upload(descs, stream_) || !d_frames_.upload(list, stream_) ||
+        !d_frame_slot_.upload(slots, stream_) || !d_frame_cif_row_.upload(rows, stream_) || !d_spectra_.reserve(static_cast<size_t>(n) * kSymbolsPerTf * 2048))
+      return -1;
+    GuardArgs ga{};
+    guard_launches_ = 0;
+    guard_flagged_ = 0;
+    if (guard_on && (!d_delta_.reserve(static_cast<size_t>(n) * kSymbolsPerTf) || !guard_begin(n, &ga) ||
+                     !check(launch_symbol_delta(d_iq_ptrs_.get(), d_descs_.get(), n, d_frames_.get(), 0, n, kSymbolsPerTf, d_delta_.get(), kSymbolsPerTf, stream_), "symbol delta launch")))
+      return -1;
+    if (!check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), n, d_frames_.get(), 0, n, d_spectra_.get(), d_twf_.get(), stream_), "fft launch") ||
+        !check(launch_demap(false, 0, d_spectra_.get(), 0, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_), "demap launch") ||
+        (guard_on && !guard_finish(false)) ||
+        !check(launch_decision_audit(d_in + static_cast<size_t>(first) * kTfBytes, n, d_spectra_.get(), d_fic_bits_.get(), d_msc_bits_.get(), d_tw2048_.get(), d_qpsk_.get(), d_out.get(), stream_), "audit launch") ||
+        !check(hipStreamSynchronize(stream_), "audit") || (guard_on && !guard_check()))
+      return -1;
+    listed += static_cast<uint64_t>(guard_flagged_);
+  }
+  AuditOut h;
+  if (!check(hipMemcpy(&h, d_out.get(), sizeof h, hipMemcpyDeviceToHost), "audit download")) return -1;
+  auto f = [](unsigned bits) { float v; std::memcpy(&v, &bits, 4); return static_cast<double>(v); };
+  out8[0] = static_cast<double>(h.decisions); out8[1] = static_cast<double>(h.disagree); out8[2] = static_cast<double>(h.outside);
+  out8[3] = static_cast<double>(h.flagged); out8[4] = f(h.bin_bits); out8[5] = f(h.dec_bits); out8[6] = f(h.prod_bits); out8[7] = static_cast<double>(listed);
+  return nframes;
 }
 
 // S1: n code words of `framebits` data bits, symbols 127/129 hard, 128 erased (depuncture.c:36-43)
@@ -1017,9 +1134,17 @@ bool Engine::demod_one_frame(const uint8_t* iq_virtual_base, const CallDesc& des
       !d_frame_slot_.upload(slots, stream_) || !d_frame_cif_row_.upload(slots, stream_) ||
       !d_spectra_.reserve(static_cast<size_t>(kSymbolsPerTf) * 2048))
     return false;
+  max_calls_ = 1;                                         // the one descriptor uploaded above is frame {0, 0}
+  const bool guard = guard_active();
+  GuardArgs ga{};
+  guard_launches_ = 0;
+  if (guard && (!d_delta_.reserve(kSymbolsPerTf) || !guard_begin(1, &ga) ||
+                !check(launch_symbol_delta(d_iq_ptrs_.get(), d_descs_.get(), 1, d_frames_.get(), 0, 1, kSymbolsPerTf, d_delta_.get(), kSymbolsPerTf, stream_), "symbol delta launch")))
+    return false;
   if (!check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), 1, d_frames_.get(), 0, 1, d_spectra_.get(), d_twf_.get(), stream_), "fft launch") ||
-      !check(launch_demap(false, 0, d_spectra_.get(), 0, 1, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_), "demap launch") ||
-      !check(hipStreamSynchronize(stream_), "demod"))
+      !check(launch_demap(false, 0, d_spectra_.get(), 0, 1, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_), "demap launch") ||
+      (guard && !guard_finish(false)) ||
+      !check(hipStreamSynchronize(stream_), "demod") || (guard && !guard_check()))
     return false;
   return unpack_tf_slot(0, fic_bytes, msc_bytes);
 }

@@ -172,6 +172,12 @@ class Engine {
   // decode() / first segment of a session.  All ones (default) = the reference's frames.
   void set_subchannel_filter(uint64_t keep) { subch_keep_ = keep; }
   void set_soft(bool on) { soft_bits_ = on ? 4 : 0; tf_slots_ = 0; msc_rows_ = 0; }
+  // parity guard (k_parity.hip; default on): hard decisions whose fp32 margin lies inside the error band of the fp32 OFDM
+  // transform are re-decided in fp64 from the int8 samples, so the demapped bits are those of exact arithmetic (what the
+  // reference's fp64 FFTW path yields).  Inactive with soft decisions and with the software AFC (no reference semantics there).
+  void set_parity_guard(bool on) { parity_guard_ = on; }
+  // decisions flagged and re-decided by the guard in the last decode (FIC pre-pass + OFDM stage), and decisions taken
+  void guard_stats(int64_t* flagged, int64_t* decisions) const { if (flagged) *flagged = guard_flagged_; if (decisions) *decisions = guard_decisions_; }
 
   // -- batch path ---------------------------------------------------------------------------
   int64_t decode(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device);
@@ -190,6 +196,7 @@ class Engine {
   int stage_ofdm_fft(const uint8_t* frames, int nframes, float* spectra, bool on_device, int reps, float* kernel_ms);
   int stage_demap(const float* spectra, int nframes, uint8_t* fic, uint8_t* msc);
   int stage_fic_decode(const uint8_t* fic, int nframes, uint8_t* fibs, uint8_t* crc_ok);
+  int stage_decision_audit(const uint8_t* frames, int nframes, bool on_device, bool guard_on, double* out8);
   int viterbi_batch(const uint8_t* symbols, uint8_t* data, int framebits, int n);
 
   // -- building blocks shared with the streaming seams (capi.cpp) ------------------------------
@@ -239,8 +246,14 @@ class Engine {
   int plan_id(const CodewordPlan& p);
   bool unpack_tf_slot(int slot, uint8_t* fic_bytes, uint8_t* msc_bytes);
 
+  // parity guard plumbing: list + counter for one launch, fix-up after it, entry count to the host (checked at the end)
+  bool guard_active() const { return parity_guard_ && soft_bits_ == 0 && !afc_; }
+  bool guard_begin(int ntf_in_launch, GuardArgs* out);
+  bool guard_finish(bool planar);
+  bool guard_check();
+
   bool ok_ = false;
-  bool afc_ = false, fused_ = true;
+  bool afc_ = false, fused_ = true, parity_guard_ = true;
   uint64_t subch_keep_ = ~0ull;
   int soft_bits_ = 0;
   std::mutex* heavy_mu_ = nullptr;
@@ -291,6 +304,13 @@ class Engine {
   PinnedBuffer<int64_t> h_nb_;
   PinnedBuffer<int> h_frame_slot_, h_frame_cif_row_;
   std::vector<int> carry_keep_, prev_used_, calls_done_, ord_done_, prev_tf_base_, prev_row_base_;
+  DeviceBuffer<float> d_delta_;
+  DeviceBuffer<uint2> d_guard_list_;
+  DeviceBuffer<uint32_t> d_guard_counter_;
+  PinnedBuffer<uint32_t> h_guard_counts_;
+  int guard_launches_ = 0;
+  uint32_t guard_cap_ = 0;
+  int64_t guard_flagged_ = 0, guard_decisions_ = 0;
   DeviceBuffer<uint8_t> d_carry_;
   DeviceBuffer<CopyDesc> d_copy_descs_;
 

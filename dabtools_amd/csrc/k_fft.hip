@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
                                                          const int* __restrict__ frame_slot,
                                                          const int* __restrict__ frame_cif_row,
                                                          const uint16_t* __restrict__ qpsk_of_carrier,
-                                                         uint32_t* __restrict__ fic_bits, uint32_t* __restrict__ msc_bits)
+                                                         uint32_t* __restrict__ fic_bits, uint32_t* __restrict__ msc_bits, const GuardArgs guard)
 {
   // The decisions of a symbol are written as bytes where the output word wants them: byte kPer t + b = value b of output
   // word t (kPer = values per word), so the packing threads read their word's bytes contiguously (the straightforward
@@ -237,11 +237,22 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
     uint8_t* d = dec[l & 1];
     const bool natural = l <= 3 || !kPlanar;
     float re[6], im[6];
+    // parity guard (k_parity.hip; hard decisions only): error bounds of this symbol's and the previous symbol's bins
+    const bool guarded = kBits == 1 && guard.delta != nullptr;
+    const float dc = guarded ? guard.delta[static_cast<size_t>(first + j) * guard.delta_stride + l] : 0.0f;
+    const float dp = guarded ? guard.delta[static_cast<size_t>(first + j) * guard.delta_stride + l - 1] : 0.0f;
 #pragma unroll
     for (int m = 0; m < 6; ++m) {
       const float2 cur = tf[l * 2048 + bin[m]];
       re[m] = cur.x * prev[m].x + cur.y * prev[m].y;     // Re(cur conj(prev))
       im[m] = cur.x * prev[m].y - cur.y * prev[m].x;     // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
+      if (guarded) {
+        const float n1c = fabsf(cur.x) + fabsf(cur.y), n1p = fabsf(prev[m].x) + fabsf(prev[m].y);
+        if (fminf(fabsf(re[m]), fabsf(im[m])) < n1c * dp + n1p * dc + kGuardProd * n1c * n1p) {
+          const unsigned at = atomicAdd(guard.counter, 1u);
+          if (at < guard.cap) guard.list[at] = make_uint2(static_cast<unsigned>(first + j), (static_cast<unsigned>(l) << 16) | static_cast<unsigned>((bin[m] + 1024) & 2047));
+        }
+      }
       prev[m] = cur;
     }
     float scale = 0.0f;
@@ -316,35 +327,35 @@ hipError_t launch_ofdm_fft(const uint8_t* const* iq, const CallDesc* descs, int 
 
 hipError_t launch_demap(bool planar, int soft_bits, const float2* spectra, int first, int nframes, const int* frame_slot,
                         const int* frame_cif_row, const uint16_t* qpsk_of_carrier, uint32_t* fic_bits, uint32_t* msc_bits,
-                        hipStream_t stream)
+                        const GuardArgs& guard, hipStream_t stream)
 {
   if (nframes <= 0) return hipSuccess;
   const dim3 grid(kDemapGroups * nframes), block(kThreads);
   if (planar && soft_bits)
     hipLaunchKernelGGL((demap_kernel<true, 4>), grid, block, 0, stream, spectra, kSymbolsPerTf, kDemapSyms, kDemapGroups, first, frame_slot,
-                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits);
+                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard);
   else if (planar)
     hipLaunchKernelGGL((demap_kernel<true, 1>), grid, block, 0, stream, spectra, kSymbolsPerTf, kDemapSyms, kDemapGroups, first, frame_slot,
-                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits);
+                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard);
   else
     hipLaunchKernelGGL((demap_kernel<false, 1>), grid, block, 0, stream, spectra, kSymbolsPerTf, kDemapSyms, kDemapGroups, first, frame_slot,
-                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits);
+                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard);
   return hipGetLastError();
 }
 
 // FIC pre-pass: 4-symbol spectra -> FIC rows only
 hipError_t launch_fic_prepass(int soft_bits, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first,
                               int nframes, float2* spectra4, const float2* tw, const int* frame_slot, const uint16_t* qpsk_of_carrier,
-                              uint32_t* fic_bits, hipStream_t stream)
+                              uint32_t* fic_bits, const GuardArgs& guard, hipStream_t stream)
 {
   if (nframes <= 0) return hipSuccess;
   hipLaunchKernelGGL(fic_fft_kernel, dim3(nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, spectra4, tw);
   if (soft_bits)
     hipLaunchKernelGGL((demap_kernel<false, 4>), dim3(nframes), dim3(kThreads), 0, stream, spectra4, 4, 3, 1, first, frame_slot, frame_slot,
-                       qpsk_of_carrier, fic_bits, static_cast<uint32_t*>(nullptr));
+                       qpsk_of_carrier, fic_bits, static_cast<uint32_t*>(nullptr), guard);
   else
     hipLaunchKernelGGL((demap_kernel<false, 1>), dim3(nframes), dim3(kThreads), 0, stream, spectra4, 4, 3, 1, first, frame_slot, frame_slot,
-                       qpsk_of_carrier, fic_bits, static_cast<uint32_t*>(nullptr));
+                       qpsk_of_carrier, fic_bits, static_cast<uint32_t*>(nullptr), guard);
   return hipGetLastError();
 }
 

@@ -63,8 +63,14 @@ __device__ __forceinline__ void fft2048_rest(float2 (&v)[8], float2* bufP, float
 // 0/1 BYTES into `dec` at the place where the output word wants them: byte 32 t + b = bit b of output word t.  Every one
 // of the 3072 places is written by exactly one carrier, so the array needs no clearing.  FIC symbols (1..3) leave in natural
 // order (t = i >> 5); MSC symbols as the 16 planes i & 15 of 6 words each (the layout of demap_kernel<true, 1>).
+// Parity guard (k_parity.hip): a decision whose margin is inside the fp32 error band (dc, dp = error bounds of this and of the
+// previous symbol's bins) is listed for the fp64 re-decision that follows this kernel.
+struct FusedGuard {
+  GuardArgs g;
+  unsigned frame;        // index of this TF in the frame list
+};
 __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4], const float2 (&px)[4], const float2 (&py)[4],
-                                       const int (&qk)[8], bool fic, uint8_t* dec)
+                                       const int (&qk)[8], bool fic, uint8_t* dec, const FusedGuard& guard, int sym, float dc, float dp)
 {
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
@@ -77,9 +83,30 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
     if (qk[m] >= 0) {                                     // bins without a carrier (DC, guard bands) decide nothing
       dec[a0] = (re > 0.0f) ? 0 : 1;                      // input_sdr.c:157
       dec[a1] = (im > 0.0f) ? 1 : 0;                      // input_sdr.c:158
+      if (guard.g.delta != nullptr) {
+        const float n1c = fabsf(cur.x) + fabsf(cur.y), n1p = fabsf(prev.x) + fabsf(prev.y);
+        if (fminf(fabsf(re), fabsf(im)) < n1c * dp + n1p * dc + kGuardProd * n1c * n1p) {
+          const unsigned at = atomicAdd(guard.g.counter, 1u);
+          const unsigned k = 2u * threadIdx.x + 512u * (m >> 1) + (m & 1);      // raw bin
+          if (at < guard.g.cap) guard.g.list[at] = make_uint2(guard.frame, (static_cast<unsigned>(sym) << 16) | k);
+        }
+      }
     }
   }
 }
+
+// sum of |x_n|^2 over the symbol this workgroup is about to transform: every wave leaves its part in esum[0..3] BEFORE the
+// first barrier of the transform; symbol_bound() reads them after it
+__device__ __forceinline__ void symbol_energy_part(const float2 (&v)[8], float* esum)
+{
+  float e = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) e += v[r].x * v[r].x + v[r].y * v[r].y;
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) e += __shfl_xor(e, sft);
+  if ((threadIdx.x & 63) == 0) esum[threadIdx.x >> 6] = e;
+}
+__device__ __forceinline__ float symbol_bound(const float* esum) { return kGuardC * sqrtf(esum[0] + esum[1] + esum[2] + esum[3]); }
 
 // 32 decision bytes -> one output word, by thread t < 96
 __device__ __forceinline__ uint32_t pack_word(const uint8_t* dec, int t)
@@ -134,9 +161,11 @@ __device__ __forceinline__ void flush_symbol(const uint8_t* dec, int sym, const 
 template <bool kFast, bool kNco>
 __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t* stream, const FrameView& view, int sym_begin, int sym_end,
                                               bool have_prev, float2 (&px)[4], float2 (&py)[4], float2* exA, float2* exB, uint8_t* decA,
-                                              uint8_t* decB, uint16_t* stage, const Twiddles& tw, const int (&qk)[8], uint32_t nco_inc, const FusedOut& out)
+                                              uint8_t* decB, uint16_t* stage, const Twiddles& tw, const int (&qk)[8], uint32_t nco_inc, const FusedOut& out,
+                                              const FusedGuard& guard, float* esum, float& dprev)
 {
   if (sym_begin >= sym_end) return;
+  const bool guarded = guard.g.delta != nullptr;
   bool have_out = false;                                // decisions of the previous symbol wait in the other dec array
   unsigned raw[8];
   if (kFast) load_symbol<true>(fast_src, stream, view, sym_begin, raw);
@@ -155,13 +184,16 @@ __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t*
         if (kFast) load_symbol<true>(fast_src, stream, view, min(s + 1, sym_end - 1), raw);
         else load_symbol_view(stream, view, min(s + 1, sym_end - 1), stage, raw);
         float2 x[4], y[4];
+        if (guarded) symbol_energy_part(v, esum + 4 * h);
         fft2048_first(v, h ? exB : exA, tw);
+        const float dcur = guarded ? symbol_bound(esum + 4 * h) : 0.0f;
         // the barrier just passed also orders the previous symbol's decisions: they leave now, one symbol late, so that
         // the wait for the NEXT prefetch (issued above) never has to drain a store issued right before it
         if (have_out) flush_symbol(h ? decA : decB, s - 1, out);
         if (h) fft2048_rest(v, exB, exA, tw, x, y);
         else fft2048_rest(v, exA, exB, tw, x, y);
-        if (have_prev) decide(x, y, px, py, qk, s <= 3, h ? decB : decA);
+        if (have_prev) decide(x, y, px, py, qk, s <= 3, h ? decB : decA, guard, s, dcur, dprev);
+        dprev = dcur;
         have_out = have_prev;
         have_prev = true;
 #pragma unroll
@@ -183,7 +215,7 @@ __global__ __launch_bounds__(kThreads, 3) void ofdm_demap_kernel(const uint8_t* 
                                                                  const float2* __restrict__ tw_global, const int* __restrict__ frame_slot,
                                                                  const int* __restrict__ frame_cif_row,
                                                                  const uint16_t* __restrict__ qpsk_of_carrier,
-                                                                 uint32_t* __restrict__ fic_bits, uint32_t* __restrict__ msc_bits)
+                                                                 uint32_t* __restrict__ fic_bits, uint32_t* __restrict__ msc_bits, const GuardArgs gargs)
 {
   __shared__ __attribute__((aligned(16))) float2 exA[kExSize];
   __shared__ __attribute__((aligned(16))) float2 exB[kExSize];
@@ -191,6 +223,7 @@ __global__ __launch_bounds__(kThreads, 3) void ofdm_demap_kernel(const uint8_t* 
   __shared__ uint16_t stage[2048];
   __shared__ FrameView view;
   __shared__ float2 tw3[4 * 8];
+  __shared__ float esum[8];                             // per-wave parts of the symbol energy, two symbols in flight
   const int tid = threadIdx.x;
   const int j = blockIdx.x >> 2, part = blockIdx.x & 3;
   const int2 fr = frames[first + j];
@@ -236,23 +269,27 @@ __global__ __launch_bounds__(kThreads, 3) void ofdm_demap_kernel(const uint8_t* 
   int fast_end = max(sym_begin, min(sym_end, nfast));
   fast_end -= (fast_end - sym_begin) & 1;
   float2 px[4], py[4];                                  // the previous symbol's bins
-  fused_symbols<true, kNco>(src, stream, view, sym_begin, fast_end, false, px, py, exA, exB, decA, decB, stage, tw, qk, nco_inc, out);
-  fused_symbols<false, kNco>(src, stream, view, fast_end, sym_end, fast_end > sym_begin, px, py, exA, exB, decA, decB, stage, tw, qk, nco_inc, out);
+  // the guard re-decides from the raw samples: with the software AFC's NCO in the path there is no such exact reference
+  FusedGuard guard{gargs, static_cast<unsigned>(first + j)};
+  if (nco_inc) guard.g.delta = nullptr;
+  float dprev = 0.0f;                                   // error bound of the previous symbol's bins
+  fused_symbols<true, kNco>(src, stream, view, sym_begin, fast_end, false, px, py, exA, exB, decA, decB, stage, tw, qk, nco_inc, out, guard, esum, dprev);
+  fused_symbols<false, kNco>(src, stream, view, fast_end, sym_end, fast_end > sym_begin, px, py, exA, exB, decA, decB, stage, tw, qk, nco_inc, out, guard, esum, dprev);
 }
 
 }  // namespace
 
 hipError_t launch_ofdm_demap_fused(bool afc, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
                                    const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
-                                   uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream)
+                                   uint32_t* fic_bits, uint32_t* msc_bits, const GuardArgs& guard, hipStream_t stream)
 {
   if (nframes <= 0) return hipSuccess;
   if (afc)
     hipLaunchKernelGGL(ofdm_demap_kernel<true>, dim3(4 * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
-                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits);
+                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard);
   else
     hipLaunchKernelGGL(ofdm_demap_kernel<false>, dim3(4 * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
-                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits);
+                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard);
   return hipGetLastError();
 }
 

@@ -1,0 +1,251 @@
+// k_parity.hip — the parity guard of the OFDM stage, and the audit that calibrates it.
+//
+// The reference demaps with sign tests on fp64 FFTW spectra (input_sdr.c:132-162: bit = Re(cur conj(prev)) <= 0 etc.).  K2 /
+// the fused OFDM kernel transform in fp32, so a decision whose |Re| or |Im| lies inside the fp32 error of the product can come
+// out differently.  The demapping kernels therefore flag every decision with
+//     min(|Re|, |Im|)  <  |cur|_1 d(l-1) + |prev|_1 d(l) + kGuardProd |cur|_1 |prev|_1 ,     d(l) = kGuardC sqrt(sum_n |x_n|^2)
+// (d(l) bounds the error of any bin of symbol l's fp32 transform: symbol_delta_kernel; the constants come from the audit
+// below with a 4x margin) and exact_decide_kernel re-decides the flagged carriers from the int8
+// samples in fp64 by direct summation (relative error 1e-13) and patches the two bits.  A few carriers per million at high
+// SNR, ~1e-4 of them at 5 dB: the cost is negligible and the output is the one exact arithmetic gives.
+//
+// decision_audit_kernel is test / calibration infrastructure behind dabhip_stage_decision_audit: fp64 transforms of every
+// symbol on the GPU (fft64.hpp), compared bin by bin and decision by decision with what the fp32 stage produced.
+#include <hip/hip_runtime.h>
+
+#include "dab_tables.hpp"
+#include "device_types.hpp"
+#include "fft64.hpp"
+#include "kernels.hpp"
+
+namespace dabhip {
+namespace {
+
+__device__ __forceinline__ int pview_byte(const uint8_t* stream, const FrameView& v, int p)
+{
+  int i = 0;
+  while (i < v.nseg - 1 && p >= v.seg_end[i]) ++i;
+  const int64_t s = v.seg_src[i];
+  return s < 0 ? 0 : stream[s + p];
+}
+__device__ __forceinline__ int prail(int byte) { return static_cast<int>(static_cast<int8_t>(static_cast<uint8_t>(byte - 127))); }
+
+// ---- d(l) for symbols [sym0, sym0 + nsym) of every frame: one wave per symbol -------------------------------------
+__global__ __launch_bounds__(256) void symbol_delta_kernel(const uint8_t* const* __restrict__ iq, const CallDesc* __restrict__ descs,
+                                                           int max_calls, const int2* __restrict__ frames, int first, int nframes,
+                                                           int nsym, float* __restrict__ delta, int delta_stride)
+{
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= nframes * nsym) return;
+  const int j = w / nsym, l = w % nsym;
+  const int2 fr = frames[first + j];
+  const CallDesc* desc = descs + static_cast<size_t>(fr.x) * max_calls + fr.y;
+  const uint8_t* stream = iq[fr.x];
+  const int start = 2 * (kNullSamples + kSymSamples * l + kCpSamples);
+  int acc = 0;
+  for (int n = lane; n < 2048; n += 64) {
+    const int p = start + 2 * n;
+    const int a = prail(pview_byte(stream, desc->view, p)), b = prail(pview_byte(stream, desc->view, p + 1));
+    acc += a * a + b * b;
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
+  if (lane == 0) delta[static_cast<size_t>(first + j) * delta_stride + l] = kGuardC * sqrtf(static_cast<float>(acc));
+}
+
+// ---- re-decide the flagged carriers in fp64: one wave per entry -----------------------------------------------------
+// entry = {frame index into `frames`, symbol << 16 | raw bin}.  X_l[k] = sum_n x_n exp(-2 pi i n k / 2048) by direct summation.
+__device__ __forceinline__ void exact_bin(const uint8_t* stream, const FrameView& view, int l, int k, const double2* __restrict__ tw2048,
+                                          double* xr, double* xi)
+{
+  const int lane = threadIdx.x & 63;
+  const int start = 2 * (kNullSamples + kSymSamples * l + kCpSamples);
+  double sr = 0, si = 0;
+  for (int n = lane; n < 2048; n += 64) {
+    const int p = start + 2 * n;
+    const double a = prail(pview_byte(stream, view, p)), b = prail(pview_byte(stream, view, p + 1));
+    const double2 w = tw2048[(n * k) & 2047];             // exp(+2 pi i nk / 2048); the forward transform uses the conjugate
+    sr += a * w.x + b * w.y;
+    si += b * w.x - a * w.y;
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) { sr += __shfl_xor(sr, s); si += __shfl_xor(si, s); }
+  *xr = sr;
+  *xi = si;
+}
+
+__global__ __launch_bounds__(256) void exact_decide_kernel(const uint2* __restrict__ list, const unsigned* __restrict__ counter, unsigned cap,
+                                                           const uint8_t* const* __restrict__ iq, const CallDesc* __restrict__ descs, int max_calls,
+                                                           const int2* __restrict__ frames, const double2* __restrict__ tw2048,
+                                                           const uint16_t* __restrict__ qpsk_of_carrier, const int* __restrict__ frame_slot,
+                                                           const int* __restrict__ frame_cif_row, int planar, uint32_t* __restrict__ fic_bits,
+                                                           uint32_t* __restrict__ msc_bits)
+{
+  const unsigned n = min(counter[0], cap);
+  const int lane = threadIdx.x & 63;
+  for (unsigned e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += gridDim.x * 4) {
+    const uint2 ent = list[e];
+    const int f = static_cast<int>(ent.x), l = static_cast<int>(ent.y >> 16), k = static_cast<int>(ent.y & 0xffffu);
+    const int2 fr = frames[f];
+    const CallDesc* desc = descs + static_cast<size_t>(fr.x) * max_calls + fr.y;
+    const uint8_t* stream = iq[fr.x];
+    double cr, ci, pr, pi;
+    exact_bin(stream, desc->view, l, k, tw2048, &cr, &ci);
+    exact_bin(stream, desc->view, l - 1, k, tw2048, &pr, &pi);
+    if (lane != 0) continue;
+    const double re = cr * pr + ci * pi;                  // Re(cur conj(prev)); the reference divides by |prev|^2 > 0 (input_sdr.c:135-143)
+    const double im = cr * pi - ci * pr;                  // the imaginary part as stored there
+    const unsigned b0 = (re > 0.0) ? 0u : 1u, b1 = (im > 0.0) ? 1u : 0u;      // input_sdr.c:157-158
+    const int c = (k >= 1 && k <= 768) ? k + 767 : k - 1280;
+    const int q = qpsk_of_carrier[c];
+    const int pos[2] = {q, 1536 + q};
+    const unsigned bit[2] = {b0, b1};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = pos[h];
+      uint32_t* word;
+      unsigned sh;
+      if (l <= 3) {
+        word = fic_bits + static_cast<size_t>(frame_slot[f]) * 288 + (l - 1) * 96 + (i >> 5);
+        sh = i & 31;
+      } else if (planar) {                               // layout of demap_kernel<true, 1> / the fused kernel
+        const int qc = (l - 4) / 18, sidx = (l - 4) % 18, r = i & 15, u = i >> 4;
+        const int delay = static_cast<int>(__brev(static_cast<unsigned>(r)) >> 28);
+        word = msc_bits + static_cast<size_t>(frame_cif_row[f] + qc - delay) * 1728 + r * 108 + sidx * 6 + (u >> 5);
+        sh = u & 31;
+      } else {
+        word = msc_bits + static_cast<size_t>(frame_cif_row[f]) * 1728 + (l - 4) * 96 + (i >> 5);
+        sh = i & 31;
+      }
+      if (bit[h]) atomicOr(word, 1u << sh);
+      else atomicAnd(word, ~(1u << sh));
+    }
+  }
+}
+
+// ---- audit: fp64 transforms of every symbol vs the fp32 stage ---------------------------------------------------------
+// One 512-thread workgroup per frame (contiguous 393216-byte frames).  out[]: see dabhip_stage_decision_audit.
+struct AuditOut {
+  unsigned long long decisions, disagree, disagree_outside_guard, flagged;
+  unsigned max_bin_err_bits;        // float bits of max |X32 - X64| / sqrt(sum |x|^2)
+  unsigned max_dec_err_bits;        // float bits of max |v32 - v64| / (|cur|_1 s(l-1) + |prev|_1 s(l)), v = Re or Im of the product
+  unsigned max_prod_err_bits;       // float bits of max over decisions of the part of that error the bin errors do not explain / (|cur|_1 |prev|_1)
+  unsigned pad;
+};
+
+__global__ __launch_bounds__(kFft64Threads) void decision_audit_kernel(const uint8_t* __restrict__ frames_iq, const float2* __restrict__ spectra,
+                                                                      const uint32_t* __restrict__ fic_bits, const uint32_t* __restrict__ msc_bits,
+                                                                      const double2* __restrict__ tw2048, const uint16_t* __restrict__ qpsk_of_carrier,
+                                                                      AuditOut* __restrict__ out)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double2* A = reinterpret_cast<double2*>(smem);           // current symbol, bit-reversed after the transform
+  double2* P = A + 2048;                                   // previous symbol
+  double2* tw = P + 2048;                                  // 1024 twiddles
+  __shared__ float s_energy[2];
+  __shared__ int s_acc;
+  const int j = blockIdx.x, tid = threadIdx.x;
+  const uint8_t* frame = frames_iq + static_cast<size_t>(j) * kTfBytes;
+  const float2* spec = spectra + static_cast<size_t>(j) * (kSymbolsPerTf * 2048);
+  for (int i = tid; i < 1024; i += kFft64Threads) tw[i] = tw2048[i];
+  unsigned long long n_dec = 0, n_dis = 0, n_out = 0, n_flag = 0;
+  float m_bin = 0, m_dec = 0, m_prod = 0;
+  for (int l = 0; l < kSymbolsPerTf; ++l) {
+    double2* cur = (l & 1) ? P : A;
+    double2* prev = (l & 1) ? A : P;
+    if (tid == 0) s_acc = 0;
+    __syncthreads();
+    const int start = 2 * (kNullSamples + kSymSamples * l + kCpSamples);
+    int e = 0;
+    for (int n = tid; n < 2048; n += kFft64Threads) {
+      const int a = prail(frame[start + 2 * n]), b = prail(frame[start + 2 * n + 1]);
+      cur[n] = make_double2(a, b);
+      e += a * a + b * b;
+    }
+    atomicAdd(&s_acc, e);
+    __syncthreads();
+    if (tid == 0) s_energy[l & 1] = sqrtf(static_cast<float>(s_acc));
+    dft_dif<11, 3, 3, 3, 2>(cur, 1, -1.0, tw);            // ends with a barrier
+    const float s_cur = s_energy[l & 1], s_prev = s_energy[(l & 1) ^ 1];
+    for (int c = tid; c < kCarriers; c += kFft64Threads) {
+      const int k = c < 768 ? c + 1280 : c - 767;         // raw bin of carrier c
+      const int ks = (k + 1024) & 2047;                   // fftshifted index
+      const double2 x64 = cur[brev(k, 11)];
+      const float2 x32 = spec[l * 2048 + ks];
+      if (s_cur > 0) m_bin = fmaxf(m_bin, static_cast<float>(hypot(x32.x - x64.x, x32.y - x64.y)) / s_cur);
+      if (l == 0) continue;
+      const double2 p64 = prev[brev(k, 11)];
+      const float2 p32 = spec[(l - 1) * 2048 + ks];
+      const double re64 = x64.x * p64.x + x64.y * p64.y, im64 = x64.x * p64.y - x64.y * p64.x;
+      const float re32 = x32.x * p32.x + x32.y * p32.y, im32 = x32.x * p32.y - x32.y * p32.x;
+      const float n1c = fabsf(x32.x) + fabsf(x32.y), n1p = fabsf(p32.x) + fabsf(p32.y);
+      const float unit = n1c * s_prev + n1p * s_cur;
+      const float t = kGuardC * unit + kGuardProd * n1c * n1p;
+      const bool flagged = fminf(fabsf(re32), fabsf(im32)) < t;
+      n_flag += flagged ? 1 : 0;
+      const int q = qpsk_of_carrier[c];
+      const uint32_t* row = l <= 3 ? fic_bits + static_cast<size_t>(j) * 288 + (l - 1) * 96 : msc_bits + static_cast<size_t>(4 * j) * 1728 + (l - 4) * 96;
+      const unsigned got0 = (row[q >> 5] >> (q & 31)) & 1u, got1 = (row[(1536 + q) >> 5] >> ((1536 + q) & 31)) & 1u;
+      const unsigned want0 = (re64 > 0.0) ? 0u : 1u, want1 = (im64 > 0.0) ? 1u : 0u;
+      const int bad = static_cast<int>(got0 != want0) + static_cast<int>(got1 != want1);
+      n_dec += 2;
+      n_dis += bad;
+      // would the guard have caught it?  (audited with the guard OFF: a disagreement on a carrier the rule does not flag is a miss)
+      if (bad && !flagged) n_out += bad;
+      if (unit > 0) {
+        const float err = fmaxf(fabsf(static_cast<float>(re32 - re64)), fabsf(static_cast<float>(im32 - im64)));
+        m_dec = fmaxf(m_dec, err / unit);
+        // what the bin errors cannot explain, relative to |cur|_1 |prev|_1: rounding of the fp32 product itself
+        const float dx = static_cast<float>(hypot(x32.x - x64.x, x32.y - x64.y)), dp = static_cast<float>(hypot(p32.x - p64.x, p32.y - p64.y));
+        const float rest = err - (n1p * dx + n1c * dp);
+        if (n1c * n1p > 0) m_prod = fmaxf(m_prod, rest / (n1c * n1p));
+      }
+    }
+    __syncthreads();
+  }
+  atomicAdd(&out->decisions, n_dec);
+  atomicAdd(&out->disagree, n_dis);
+  atomicAdd(&out->disagree_outside_guard, n_out);
+  atomicAdd(&out->flagged, n_flag);
+  atomicMax(&out->max_bin_err_bits, __float_as_uint(m_bin));      // non-negative floats order like their bit patterns
+  atomicMax(&out->max_dec_err_bits, __float_as_uint(m_dec));
+  atomicMax(&out->max_prod_err_bits, __float_as_uint(fmaxf(m_prod, 0.0f)));
+}
+
+}  // namespace
+
+hipError_t launch_symbol_delta(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
+                               int nsym, float* delta, int delta_stride, hipStream_t stream)
+{
+  if (nframes <= 0) return hipSuccess;
+  hipLaunchKernelGGL(symbol_delta_kernel, dim3((nframes * nsym + 3) / 4), dim3(256), 0, stream, iq, descs, max_calls, frames, first, nframes,
+                     nsym, delta, delta_stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_exact_decide(const uint2* list, const unsigned* counter, unsigned cap, const uint8_t* const* iq, const CallDesc* descs,
+                               int max_calls, const int2* frames, const double2* tw2048, const uint16_t* qpsk_of_carrier, const int* frame_slot,
+                               const int* frame_cif_row, bool planar, uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream)
+{
+  hipLaunchKernelGGL(exact_decide_kernel, dim3(2048), dim3(256), 0, stream, list, counter, cap, iq, descs, max_calls, frames, tw2048,
+                     qpsk_of_carrier, frame_slot, frame_cif_row, planar ? 1 : 0, fic_bits, msc_bits);
+  return hipGetLastError();
+}
+
+hipError_t launch_decision_audit(const uint8_t* frames_iq, int nframes, const float2* spectra, const uint32_t* fic_bits, const uint32_t* msc_bits,
+                                 const double2* tw2048, const uint16_t* qpsk_of_carrier, void* out, hipStream_t stream)
+{
+  if (nframes <= 0) return hipSuccess;
+  static bool attr_set = false;
+  const size_t lds = sizeof(double2) * (2048 + 2048 + 1024);
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decision_audit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(decision_audit_kernel, dim3(nframes), dim3(kFft64Threads), lds, stream, frames_iq, spectra, fic_bits, msc_bits, tw2048,
+                     qpsk_of_carrier, static_cast<AuditOut*>(out));
+  return hipGetLastError();
+}
+
+}  // namespace dabhip

@@ -14,13 +14,14 @@
 
 #include "dab_tables.hpp"
 #include "device_types.hpp"
+#include "fft64.hpp"
 #include "fifo_view.hpp"
 #include "kernels.hpp"
 
 namespace dabhip {
 namespace {
 
-constexpr int kThreads = 512;   // one workgroup per stream: more threads = shorter butterfly stages
+constexpr int kThreads = kFft64Threads;   // 512; one workgroup per stream: more threads = shorter butterfly stages
 
 __device__ __forceinline__ int view_byte(const uint8_t* stream, const FrameView& v, int p)
 {
@@ -46,57 +47,6 @@ __device__ __forceinline__ double2 view_sample(const uint8_t* stream, const Fram
 }
 // u8 -> s8 with DC offset 127 and int8 wrap (input_sdr.c:60-63)
 __device__ __forceinline__ int rail(int byte) { return static_cast<int>(static_cast<int8_t>(static_cast<uint8_t>(byte - 127))); }
-
-__device__ __forceinline__ unsigned brev(unsigned x, int bits) { return __brev(x) >> (32 - bits); }
-
-// nbatch independent DFTs of size N = 1 << LOGN stored back to back in LDS, radix-2 decimation in frequency, in
-// place; X[k] ends up at index brev(k).  sign = -1 forward.
-// The scan is a chain of dependent LDS round trips with only 2 waves per SIMD to hide them, so L consecutive
-// radix-2 levels are fused: a thread holds the 2^L points it needs in registers, runs the L levels on them (the same
-// butterflies, in the same order of operations as level-by-level radix 2) and meets the others at ONE barrier.
-template <int LOGN, int L>
-__device__ __forceinline__ void dif_levels(double2* buf, int nbatch, int s, double sign, const double2* tw2048)
-{
-  constexpr int N = 1 << LOGN, R = 1 << L;
-  const int ms = N >> s;                         // size of the sub-transforms at level s
-  const int q = ms >> L;                         // distance between the points one thread holds
-  constexpr int per_batch = N >> L;
-  for (int idx = threadIdx.x; idx < nbatch * per_batch; idx += kThreads) {
-    const int batch = idx / per_batch, w = idx % per_batch;
-    const int blk = w / q, k = w % q;
-    double2* x = buf + batch * N + blk * ms + k;
-    double2 r[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j) r[j] = x[j * q];
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-      const int span = R >> (l + 1);             // partner distance in units of q
-      const int half = ms >> (l + 1);
-      const int twstep = 1024 / half;
-#pragma unroll
-      for (int j = 0; j < R; ++j) {
-        if (j & span) continue;
-        const int pos = k + (j & (span - 1)) * q;          // index of the butterfly inside its sub-transform
-        const double2 A = r[j], B = r[j + span];
-        double2 tw = tw2048[pos * twstep];
-        tw.y *= sign;
-        const double dr = A.x - B.x, di = A.y - B.y;
-        r[j] = make_double2(A.x + B.x, A.y + B.y);
-        r[j + span] = make_double2(dr * tw.x - di * tw.y, dr * tw.y + di * tw.x);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < R; ++j) x[j * q] = r[j];
-  }
-  __syncthreads();
-}
-
-template <int LOGN, int... Ls>
-__device__ __forceinline__ void dft_dif(double2* buf, int nbatch, double sign, const double2* tw2048)
-{
-  int s = 0;
-  ((dif_levels<LOGN, Ls>(buf, nbatch, s, sign, tw2048), s += Ls), ...);
-}
 
 constexpr int kWaves = kThreads / 64;
 struct Red {

