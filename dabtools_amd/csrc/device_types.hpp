@@ -87,7 +87,7 @@ struct CopyDesc {
 constexpr float kGuardC = 5.0e-6f;       // bound on |X32 - X| of any bin, relative to sqrt(sum_n |x_n|^2)   (measured worst: 6.3e-7)
 constexpr float kGuardProd = 5.0e-7f;    // rounding of the fp32 product Re/Im(cur conj(prev)), relative to |cur|_1 |prev|_1   (measured worst: 1.0e-7)
 struct GuardArgs {
-  const float* delta;    // nullptr: guard off
+  const float* delta;    // nullptr: guard off (the fused OFDM kernel computes its bounds itself and only tests this for null)
   int32_t delta_stride;
   uint32_t cap;          // capacity of list
   uint2* list;           // {frame index, symbol << 16 | raw bin}

@@ -84,7 +84,8 @@ Engine::Engine(int device) : device_(device)
   }
   for (int k = 0; k < 1536; ++k) tw1536[k] = make_double2(std::cos(2 * M_PI * k / 1536), std::sin(2 * M_PI * k / 1536));
   std::vector<uint8_t> prs(prs_quarter_turns().begin(), prs_quarter_turns().end());
-  std::vector<uint16_t> qpsk(carrier_to_qpsk().begin(), carrier_to_qpsk().end());
+  std::vector<uint16_t> qpsk(carrier_to_qpsk().begin(), carrier_to_qpsk().end()), qpsk_inv(kCarriers);
+  for (int c = 0; c < kCarriers; ++c) qpsk_inv[qpsk[c]] = static_cast<uint16_t>(c);
   std::vector<uint16_t> crc(256);
   for (int v = 0; v < 256; ++v) {
     const uint8_t b = static_cast<uint8_t>(v);
@@ -114,7 +115,7 @@ Engine::Engine(int device) : device_(device)
     }
   }
   if (!d_tw2048_.upload(tw2048, stream_) || !d_tw1536_.upload(tw1536, stream_) || !d_twf_.upload(twf, stream_) ||
-      !d_prs_.upload(prs, stream_) || !d_qpsk_.upload(qpsk, stream_) || !d_crc_tab_.upload(crc, stream_) || !d_crc_shift_.upload(crc_shift, stream_) ||
+      !d_prs_.upload(prs, stream_) || !d_qpsk_.upload(qpsk, stream_) || !d_qpsk_inv_.upload(qpsk_inv, stream_) || !d_crc_tab_.upload(crc, stream_) || !d_crc_shift_.upload(crc_shift, stream_) ||
       !d_prbs_.upload(prbs, stream_) || !d_zero_words_.upload(zeros, stream_))
     return;
   if (!check(hipStreamSynchronize(stream_), "table upload")) return;
@@ -550,7 +551,7 @@ bool Engine::guard_finish(bool planar)
 {
   if (guard_launches_ >= kGuardMaxLaunches) { set_error("parity guard: too many launches in one decode"); return false; }
   return check(launch_exact_decide(d_guard_list_.get(), d_guard_counter_.get(), guard_cap_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(),
-                                   d_tw2048_.get(), d_qpsk_.get(), d_frame_slot_.get(), d_frame_cif_row_.get(), planar, d_fic_bits_.get(), d_msc_bits_.get(), stream_),
+                                   d_tw2048_.get(), d_qpsk_.get(), d_qpsk_inv_.get(), d_frame_slot_.get(), d_frame_cif_row_.get(), planar, d_fic_bits_.get(), d_msc_bits_.get(), stream_),
                "exact decide launch") &&
          check(hipMemcpyAsync(h_guard_counts_.data() + guard_launches_++, d_guard_counter_.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, stream_), "guard count download");
 }
@@ -773,18 +774,22 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     if (guard && !guard_begin(n, &ga)) { gpu_ok = false; break; }
     (void)hipEventRecord(chunk_ev_[3 * c], stream_);
     if (fused_ && soft_bits_ == 0) {
-      gpu_ok = check(launch_ofdm_demap_fused(afc_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_twf_.get(), d_frame_slot_.get(),
-                                             d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_),
-                     "fused fft/demap launch");
+      gpu_ok = guard ? check(launch_ofdm_demap_fused_guarded(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_twf_.get(), d_frame_slot_.get(),
+                                                             d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_),
+                             "fused fft/demap launch")
+                     : check(launch_ofdm_demap_fused_plain(afc_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_twf_.get(), d_frame_slot_.get(),
+                                                           d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_),
+                             "fused fft/demap launch");
       (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
     } else {
-      gpu_ok = check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(), stream_), "fft launch");
+      // with the guard on, K2 also leaves the per-symbol error bounds K2b decides with
+      gpu_ok = check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(), stream_,
+                                     guard ? d_delta_.get() : nullptr),
+                     "fft launch");
       (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
-      // the two-kernel stage has no samples in hand when it decides: the per-symbol error bounds come from their own pass
-      if (guard) gpu_ok = gpu_ok && check(launch_symbol_delta(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, kSymbolsPerTf, d_delta_.get(), kSymbolsPerTf, stream_), "symbol delta launch");
       gpu_ok = gpu_ok && check(launch_demap(true, soft_bits_, d_spectra_.get(), first, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_), "demap launch");
     }
-    if (guard) gpu_ok = gpu_ok && guard_finish(true);       // timed with the demapper: "demap" of the fused stage is the guard's cost
+    if (guard) gpu_ok = gpu_ok && guard_finish(true);       // timed with the demapper
     (void)hipEventRecord(chunk_ev_[3 * c + 2], stream_);
   }
   if (!check(hipEventSynchronize(ev_fibs_), "fic decode")) return -1;

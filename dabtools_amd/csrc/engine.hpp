@@ -268,7 +268,7 @@ class Engine {
   DeviceBuffer<double2> d_tw2048_, d_tw1536_;
   DeviceBuffer<uint8_t> d_prs_;
   DeviceBuffer<float2> d_twf_;
-  DeviceBuffer<uint16_t> d_qpsk_, d_crc_tab_, d_crc_shift_;
+  DeviceBuffer<uint16_t> d_qpsk_, d_qpsk_inv_, d_crc_tab_, d_crc_shift_;
   DeviceBuffer<uint32_t> d_prbs_, d_zero_words_;
 
   // batch state

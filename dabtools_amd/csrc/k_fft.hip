@@ -77,10 +77,30 @@ __device__ __forceinline__ void fft2048_store(float2 (&v)[8], float2* bufP, floa
 
 // Transform symbols [sym_begin, sym_end).  `parity` tells which LDS buffer plays which role first and is
 // returned advanced, so that a fast run can be followed by a slow run without an extra barrier.
-template <bool kFast>
+// Parity guard (k_parity.hip): the energy of the symbol about to be transformed.  Every wave leaves its part in LDS before
+// the transform's barriers; thread 0 adds them up after the transform and stores the symbol's error bound.
+struct EnergyOut {
+  float* esum;           // LDS, 2 symbols x 4 waves
+  float* delta_tf;       // this frame's 76 bounds
+};
+__device__ __forceinline__ void energy_part(const float2 (&v)[8], float* esum4)
+{
+  float e = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) e += v[r].x * v[r].x + v[r].y * v[r].y;
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) e += __shfl_xor(e, sft);
+  if ((threadIdx.x & 63) == 0) esum4[threadIdx.x >> 6] = e;
+}
+__device__ __forceinline__ void energy_store(const float* esum4, float* delta_tf, int sym)
+{
+  if (threadIdx.x == 0) delta_tf[sym] = kGuardC * sqrtf(esum4[0] + esum4[1] + esum4[2] + esum4[3]);
+}
+
+template <bool kFast, bool kEnergy>
 __device__ __forceinline__ int transform_symbols(GlobalU16 fast_src, const uint8_t* stream, const FrameView& view, int sym_begin,
                                                  int sym_end, int parity, float2* exA, float2* exB, const Twiddles& tw,
-                                                 float2* __restrict__ out_tf, uint32_t nco_inc)
+                                                 float2* __restrict__ out_tf, uint32_t nco_inc, const EnergyOut& eo)
 {
   if (sym_begin >= sym_end) return parity;
   unsigned raw[8];
@@ -91,18 +111,20 @@ __device__ __forceinline__ int transform_symbols(GlobalU16 fast_src, const uint8
     for (int r = 0; r < 8; ++r) v[r] = make_float2(rail(raw[r] & 0xff), rail(raw[r] >> 8));
     if (nco_inc) derotate(v, nco_inc, kNullSamples + kSymSamples * sym + kCpSamples + static_cast<int>(threadIdx.x));
     if (sym + 1 < sym_end) load_symbol<kFast>(fast_src, stream, view, sym + 1, raw);   // prefetch under the transform
+    if (kEnergy) energy_part(v, eo.esum + 4 * (sym & 1));
     if (parity) fft2048_store(v, exB, exA, tw, out_tf + static_cast<size_t>(sym) * 2048);
     else fft2048_store(v, exA, exB, tw, out_tf + static_cast<size_t>(sym) * 2048);
+    if (kEnergy) energy_store(eo.esum + 4 * (sym & 1), eo.delta_tf, sym);
     parity ^= 1;
   }
   return parity;
 }
 
 // One workgroup: kSyms consecutive OFDM symbols (sym0 ..) of one transmission frame -> out_tf[sym * 2048 ..].
-template <int kSyms>
+template <int kSyms, bool kEnergy>
 __device__ __forceinline__ void fft_block(const uint8_t* stream, const FrameView& view, const int seg_end0, const int64_t seg_src0,
                                           const int sym0, float2* __restrict__ out_tf, const float2* __restrict__ tw_global,
-                                          float2* exA, float2* exB, const int nco_hz)
+                                          float2* exA, float2* exB, const int nco_hz, const EnergyOut& eo)
 {
   const int tid = threadIdx.x;
   __shared__ float2 tw3[4 * 8];
@@ -143,31 +165,38 @@ __device__ __forceinline__ void fft_block(const uint8_t* stream, const FrameView
 #pragma unroll
       for (int r = 0; r < 8; ++r) v[r] = make_float2(rail(raw[r] & 0xff), rail(raw[r] >> 8));
       if (i + 1 < kFixed) load_symbol<true>(src, stream, view, sym0 + i + 1, raw);
+      if (kEnergy) energy_part(v, eo.esum + 4 * ((sym0 + i) & 1));
       if (i & 1) fft2048_store(v, exB, exA, tw, out_tf + static_cast<size_t>(sym0 + i) * 2048);
       else fft2048_store(v, exA, exB, tw, out_tf + static_cast<size_t>(sym0 + i) * 2048);
+      if (kEnergy) energy_store(eo.esum + 4 * ((sym0 + i) & 1), eo.delta_tf, sym0 + i);
     }
     done = sym0 + kFixed;
   }
-  const int parity = transform_symbols<true>(src, stream, view, done, max(done, fast_end), 0, exA, exB, tw, out_tf, nco_inc);
-  transform_symbols<false>(nullptr, stream, view, max(done, fast_end), sym_end, parity, exA, exB, tw, out_tf, nco_inc);
+  const int parity = transform_symbols<true, kEnergy>(src, stream, view, done, max(done, fast_end), 0, exA, exB, tw, out_tf, nco_inc, eo);
+  transform_symbols<false, kEnergy>(nullptr, stream, view, max(done, fast_end), sym_end, parity, exA, exB, tw, out_tf, nco_inc, eo);
 }
 
 // grid = (4 * nframes); frame j of the launch is frames[first + j] = {stream, call}
+// kEnergy: also leave the parity guard's per-symbol error bounds (delta[(first + j) * 76 + symbol]); the plain variant is the
+// one the roofline figure is measured on.
+template <bool kEnergy>
 __global__ __launch_bounds__(kThreads, 4) void ofdm_fft_kernel(const uint8_t* const* __restrict__ iq,
                                                                const CallDesc* __restrict__ descs, int max_calls,
                                                                const int2* __restrict__ frames, int first,
                                                                float2* __restrict__ spectra,
-                                                               const float2* __restrict__ tw_global)
+                                                               const float2* __restrict__ tw_global, float* __restrict__ delta)
 {
   __shared__ __attribute__((aligned(16))) float2 exA[kExSize];
   __shared__ __attribute__((aligned(16))) float2 exB[kExSize];
   __shared__ FrameView view;
+  __shared__ float esum[kEnergy ? 8 : 1];
   const int j = blockIdx.x >> 2, part = blockIdx.x & 3;
   const int2 fr = frames[first + j];
   const CallDesc* desc = descs + static_cast<size_t>(fr.x) * max_calls + fr.y;
   if (threadIdx.x == 0) view = desc->view;
-  fft_block<kSymPerBlock>(iq[fr.x], view, desc->view.seg_end[0], desc->view.seg_src[0], part * kSymPerBlock,
-                          spectra + static_cast<size_t>(j) * (kSymbolsPerTf * 2048), tw_global, exA, exB, desc->nco_hz);
+  const EnergyOut eo{esum, kEnergy ? delta + static_cast<size_t>(first + j) * kSymbolsPerTf : nullptr};
+  fft_block<kSymPerBlock, kEnergy>(iq[fr.x], view, desc->view.seg_end[0], desc->view.seg_src[0], part * kSymPerBlock,
+                                   spectra + static_cast<size_t>(j) * (kSymbolsPerTf * 2048), tw_global, exA, exB, desc->nco_hz, eo);
 }
 
 // FIC pre-pass: only the phase reference symbol and the three FIC symbols (0..3) of every frame, so that the FIC
@@ -186,8 +215,8 @@ __global__ __launch_bounds__(kThreads, 4) void fic_fft_kernel(const uint8_t* con
   const int2 fr = frames[first + j];
   const CallDesc* desc = descs + static_cast<size_t>(fr.x) * max_calls + fr.y;
   if (threadIdx.x == 0) view = desc->view;
-  fft_block<4>(iq[fr.x], view, desc->view.seg_end[0], desc->view.seg_src[0], 0, spectra4 + static_cast<size_t>(j) * (4 * 2048), tw_global,
-               exA, exB, desc->nco_hz);
+  fft_block<4, false>(iq[fr.x], view, desc->view.seg_end[0], desc->view.seg_src[0], 0, spectra4 + static_cast<size_t>(j) * (4 * 2048), tw_global,
+                      exA, exB, desc->nco_hz, EnergyOut{nullptr, nullptr});
 }
 
 // ---- K2b ----------------------------------------------------------------------------------
@@ -317,11 +346,13 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
 }  // namespace
 
 hipError_t launch_ofdm_fft(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first,
-                           int nframes, float2* spectra, const float2* tw, hipStream_t stream)
+                           int nframes, float2* spectra, const float2* tw, hipStream_t stream, float* delta)
 {
   if (nframes <= 0) return hipSuccess;
-  hipLaunchKernelGGL(ofdm_fft_kernel, dim3(4 * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first,
-                     spectra, tw);
+  if (delta)
+    hipLaunchKernelGGL(ofdm_fft_kernel<true>, dim3(4 * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, spectra, tw, delta);
+  else
+    hipLaunchKernelGGL(ofdm_fft_kernel<false>, dim3(4 * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, spectra, tw, delta);
   return hipGetLastError();
 }
 

@@ -4,7 +4,13 @@
 // written: per TF the kernel reads 311,296 B of IQ and writes 28,800 B of bits, so it is NOT the HBM-roofline stage
 // (reported separately from the K2 roofline number, never instead of it).  Output bits are identical to
 // ofdm_fft_kernel + demap_kernel: same butterflies, same products, same comparisons.
+// This file is compiled twice (Makefile): DABHIP_FUSED_GUARD = 1 (default) -> launch_ofdm_demap_fused_guarded, with the parity
+// guard's test in the symbol loop; = 0 -> launch_ofdm_demap_fused_plain, the kernel without any of it (also the AFC variant).
 #include <hip/hip_runtime.h>
+
+#ifndef DABHIP_FUSED_GUARD
+#define DABHIP_FUSED_GUARD 1
+#endif
 
 #include "dab_tables.hpp"
 #include "device_types.hpp"
@@ -64,7 +70,13 @@ __device__ __forceinline__ void fft2048_rest(float2 (&v)[8], float2* bufP, float
 // of the 3072 places is written by exactly one carrier, so the array needs no clearing.  FIC symbols (1..3) leave in natural
 // order (t = i >> 5); MSC symbols as the 16 planes i & 15 of 6 words each (the layout of demap_kernel<true, 1>).
 // Parity guard (k_parity.hip): a decision whose margin is inside the fp32 error band (dc, dp = error bounds of this and of the
-// previous symbol's bins) is listed for the fp64 re-decision that follows this kernel.
+// previous symbol's bins) is listed for the fp64 re-decision that follows this kernel.  The kernel sits at its register limit
+// at three waves per SIMD (two waves cost 40 % of its speed), which makes it touchy: the test below -- inline, per bin, under a
+// run-time flag -- costs 1.6 ms per 16 k TF (5.4 -> 7.0 ms).  Eight arrangements that looked cheaper on paper were built and
+// measured slower (7.6 .. 13 ms; spills or scalar branch ladders in the symbol loop): a symbol-wide threshold in the loop with
+// the exact test in a cold block (inlined, looped over a select chain, as a real call, or on an LDS parking area), a wave-level
+// ballot, v_min3 chains, candidate records filtered by a second kernel, exponent bytes examined at flush time -- and this very
+// code with the flag turned into a template parameter (8.2 ms).  The energy reduction itself is free.
 struct FusedGuard {
   GuardArgs g;
   unsigned frame;        // index of this TF in the frame list
@@ -83,6 +95,7 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
     if (qk[m] >= 0) {                                     // bins without a carrier (DC, guard bands) decide nothing
       dec[a0] = (re > 0.0f) ? 0 : 1;                      // input_sdr.c:157
       dec[a1] = (im > 0.0f) ? 1 : 0;                      // input_sdr.c:158
+#if DABHIP_FUSED_GUARD
       if (guard.g.delta != nullptr) {
         const float n1c = fabsf(cur.x) + fabsf(cur.y), n1p = fabsf(prev.x) + fabsf(prev.y);
         if (fminf(fabsf(re), fabsf(im)) < n1c * dp + n1p * dc + kGuardProd * n1c * n1p) {
@@ -91,6 +104,7 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
           if (at < guard.g.cap) guard.g.list[at] = make_uint2(guard.frame, (static_cast<unsigned>(sym) << 16) | k);
         }
       }
+#endif
     }
   }
 }
@@ -165,7 +179,11 @@ __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t*
                                               const FusedGuard& guard, float* esum, float& dprev)
 {
   if (sym_begin >= sym_end) return;
+#if DABHIP_FUSED_GUARD
   const bool guarded = guard.g.delta != nullptr;
+#else
+  constexpr bool guarded = false;
+#endif
   bool have_out = false;                                // decisions of the previous symbol wait in the other dec array
   unsigned raw[8];
   if (kFast) load_symbol<true>(fast_src, stream, view, sym_begin, raw);
@@ -279,11 +297,23 @@ __global__ __launch_bounds__(kThreads, 3) void ofdm_demap_kernel(const uint8_t* 
 
 }  // namespace
 
-hipError_t launch_ofdm_demap_fused(bool afc, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
-                                   const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
-                                   uint32_t* fic_bits, uint32_t* msc_bits, const GuardArgs& guard, hipStream_t stream)
+#if DABHIP_FUSED_GUARD
+hipError_t launch_ofdm_demap_fused_guarded(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
+                                           const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
+                                           uint32_t* fic_bits, uint32_t* msc_bits, const GuardArgs& guard, hipStream_t stream)
 {
   if (nframes <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ofdm_demap_kernel<false>, dim3(4 * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
+                     frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard);
+  return hipGetLastError();
+}
+#else
+hipError_t launch_ofdm_demap_fused_plain(bool afc, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
+                                         const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
+                                         uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream)
+{
+  if (nframes <= 0) return hipSuccess;
+  const GuardArgs guard{};
   if (afc)
     hipLaunchKernelGGL(ofdm_demap_kernel<true>, dim3(4 * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
                        frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard);
@@ -292,5 +322,6 @@ hipError_t launch_ofdm_demap_fused(bool afc, const uint8_t* const* iq, const Cal
                        frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard);
   return hipGetLastError();
 }
+#endif
 
 }  // namespace dabhip

@@ -43,10 +43,22 @@ __global__ __launch_bounds__(256) void symbol_delta_kernel(const uint8_t* const*
   const uint8_t* stream = iq[fr.x];
   const int start = 2 * (kNullSamples + kSymSamples * l + kCpSamples);
   int acc = 0;
-  for (int n = lane; n < 2048; n += 64) {
-    const int p = start + 2 * n;
-    const int a = prail(pview_byte(stream, desc->view, p)), b = prail(pview_byte(stream, desc->view, p + 1));
-    acc += a * a + b * b;
+  const int seg_end0 = desc->view.seg_end[0];
+  const int64_t seg_src0 = desc->view.seg_src[0];
+  if (seg_src0 >= 0 && start + 4096 <= seg_end0) {        // the window lies inside what this call read: contiguous 2-byte loads
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(stream + seg_src0 + start);
+#pragma unroll 8
+    for (int n = lane; n < 2048; n += 64) {
+      const unsigned w = src[n];
+      const int a = prail(w & 0xff), b = prail(w >> 8);
+      acc += a * a + b * b;
+    }
+  } else {
+    for (int n = lane; n < 2048; n += 64) {
+      const int p = start + 2 * n;
+      const int a = prail(pview_byte(stream, desc->view, p)), b = prail(pview_byte(stream, desc->view, p + 1));
+      acc += a * a + b * b;
+    }
   }
 #pragma unroll
   for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
@@ -77,7 +89,8 @@ __device__ __forceinline__ void exact_bin(const uint8_t* stream, const FrameView
 __global__ __launch_bounds__(256) void exact_decide_kernel(const uint2* __restrict__ list, const unsigned* __restrict__ counter, unsigned cap,
                                                            const uint8_t* const* __restrict__ iq, const CallDesc* __restrict__ descs, int max_calls,
                                                            const int2* __restrict__ frames, const double2* __restrict__ tw2048,
-                                                           const uint16_t* __restrict__ qpsk_of_carrier, const int* __restrict__ frame_slot,
+                                                           const uint16_t* __restrict__ qpsk_of_carrier, const uint16_t* __restrict__ carrier_of_qpsk,
+                                                           const int* __restrict__ frame_slot,
                                                            const int* __restrict__ frame_cif_row, int planar, uint32_t* __restrict__ fic_bits,
                                                            uint32_t* __restrict__ msc_bits)
 {
@@ -85,7 +98,12 @@ __global__ __launch_bounds__(256) void exact_decide_kernel(const uint2* __restri
   const int lane = threadIdx.x & 63;
   for (unsigned e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += gridDim.x * 4) {
     const uint2 ent = list[e];
-    const int f = static_cast<int>(ent.x), l = static_cast<int>(ent.y >> 16), k = static_cast<int>(ent.y & 0xffffu);
+    const int f = static_cast<int>(ent.x), l = static_cast<int>(ent.y >> 16);
+    int k = static_cast<int>(ent.y & 0x7fffu);            // raw bin -- or, with bit 15 set, the position of the decision in the symbol
+    if (ent.y & 0x8000u) {
+      const int c = carrier_of_qpsk[k >= 1536 ? k - 1536 : k];
+      k = c < 768 ? c + 1280 : c - 767;
+    }
     const int2 fr = frames[f];
     const CallDesc* desc = descs + static_cast<size_t>(fr.x) * max_calls + fr.y;
     const uint8_t* stream = iq[fr.x];
@@ -224,11 +242,11 @@ hipError_t launch_symbol_delta(const uint8_t* const* iq, const CallDesc* descs, 
 }
 
 hipError_t launch_exact_decide(const uint2* list, const unsigned* counter, unsigned cap, const uint8_t* const* iq, const CallDesc* descs,
-                               int max_calls, const int2* frames, const double2* tw2048, const uint16_t* qpsk_of_carrier, const int* frame_slot,
-                               const int* frame_cif_row, bool planar, uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream)
+                               int max_calls, const int2* frames, const double2* tw2048, const uint16_t* qpsk_of_carrier, const uint16_t* carrier_of_qpsk,
+                               const int* frame_slot, const int* frame_cif_row, bool planar, uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream)
 {
   hipLaunchKernelGGL(exact_decide_kernel, dim3(2048), dim3(256), 0, stream, list, counter, cap, iq, descs, max_calls, frames, tw2048,
-                     qpsk_of_carrier, frame_slot, frame_cif_row, planar ? 1 : 0, fic_bits, msc_bits);
+                     qpsk_of_carrier, carrier_of_qpsk, frame_slot, frame_cif_row, planar ? 1 : 0, fic_bits, msc_bits);
   return hipGetLastError();
 }
 

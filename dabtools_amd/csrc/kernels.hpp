@@ -16,8 +16,9 @@ hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, Str
                             const double2* tw1536, const uint8_t* prs_q, int afc, hipStream_t stream);
 
 // K2: 76 x 2048-point DFT of frames[first .. first+nframes) -> spectra[nframes][76][2048]
+// delta != nullptr: the kernel also leaves the guard's per-symbol error bound kGuardC sqrt(sum |x|^2) at delta[(first + j) * 76 + symbol]
 hipError_t launch_ofdm_fft(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first,
-                           int nframes, float2* spectra, const float2* tw, hipStream_t stream);
+                           int nframes, float2* spectra, const float2* tw, hipStream_t stream, float* delta = nullptr);
 
 // K2b: DQPSK + demap + frequency de-interleave -> bit-packed rows.  FIC rows at TF slot frame_slot[first + j];
 // MSC rows start at CIF row frame_cif_row[first + j]: planar = scattered into time-de-interleaved logical rows
@@ -44,15 +45,19 @@ hipError_t launch_viterbi_fused(int soft_bits, const WaveGroup* groups, int ngro
                                 const uint32_t* grouped, int row_words, uint2* decisions, const uint32_t* prbs_words, uint8_t* out,
                                 int record_stride, hipStream_t stream);
 
-hipError_t launch_ofdm_demap_fused(bool afc, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
-                                   const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
-                                   uint32_t* fic_bits, uint32_t* msc_bits, const GuardArgs& guard, hipStream_t stream);
+// the one-kernel OFDM stage (k_fused.hip, compiled twice): with the parity guard's test in its symbol loop, and without
+hipError_t launch_ofdm_demap_fused_guarded(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
+                                           const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
+                                           uint32_t* fic_bits, uint32_t* msc_bits, const GuardArgs& guard, hipStream_t stream);
+hipError_t launch_ofdm_demap_fused_plain(bool afc, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
+                                         const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
+                                         uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream);
 // parity guard (k_parity.hip): per-symbol error bounds, fp64 re-decision of the flagged carriers, and the audit
 hipError_t launch_symbol_delta(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
                                int nsym, float* delta, int delta_stride, hipStream_t stream);
 hipError_t launch_exact_decide(const uint2* list, const unsigned* counter, unsigned cap, const uint8_t* const* iq, const CallDesc* descs,
-                               int max_calls, const int2* frames, const double2* tw2048, const uint16_t* qpsk_of_carrier, const int* frame_slot,
-                               const int* frame_cif_row, bool planar, uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream);
+                               int max_calls, const int2* frames, const double2* tw2048, const uint16_t* qpsk_of_carrier, const uint16_t* carrier_of_qpsk,
+                               const int* frame_slot, const int* frame_cif_row, bool planar, uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream);
 hipError_t launch_decision_audit(const uint8_t* frames_iq, int nframes, const float2* spectra, const uint32_t* fic_bits, const uint32_t* msc_bits,
                                  const double2* tw2048, const uint16_t* qpsk_of_carrier, void* out, hipStream_t stream);
 hipError_t launch_batched_copy(const CopyDesc* descs, int n, hipStream_t stream);

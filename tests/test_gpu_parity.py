@@ -591,10 +591,10 @@ def test_fused_and_two_kernel_ofdm_stages_give_identical_frames():
         eng.set_fused(False)
         eng.decode(caps)
         want = [eng.eti(i) for i in range(len(caps))]
-        assert eng.stage_ms()["demap"] > 0.05                   # K2b ran
+        assert eng.stage_ms()["demap"] > 0.5 * eng.stage_ms()["fft"] * 0.5      # K2b ran (it moves about as many bytes as K2)
         eng.set_fused(True)
         eng.decode(caps)
-        assert eng.stage_ms()["demap"] < 0.05                   # ... and now it did not (two events back to back)
+        assert eng.stage_ms()["demap"] < 0.25 * eng.stage_ms()["fft"]           # ... and now only the guard's re-decisions are timed there
         for i in range(len(caps)):
             assert np.array_equal(eng.eti(i), want[i]), "stream %d afc %d" % (i, afc)
         assert sum(len(w) for w in want) > 100
