@@ -591,10 +591,14 @@ def test_fused_and_two_kernel_ofdm_stages_give_identical_frames():
         eng.set_fused(False)
         eng.decode(caps)
         want = [eng.eti(i) for i in range(len(caps))]
-        assert eng.stage_ms()["demap"] > 0.5 * eng.stage_ms()["fft"] * 0.5      # K2b ran (it moves about as many bytes as K2)
+        flagged_two = eng.guard_stats()[0]
         eng.set_fused(True)
         eng.decode(caps)
-        assert eng.stage_ms()["demap"] < 0.25 * eng.stage_ms()["fft"]           # ... and now only the guard's re-decisions are timed there
+        flagged_fused = eng.guard_stats()[0]
+        if afc:
+            assert flagged_two == flagged_fused == 0            # no parity guard with the NCO in the path
+        else:                                                   # both stages list (almost) the same decisions for the fp64 re-decision
+            assert flagged_two > 0 and abs(flagged_fused - flagged_two) <= 2 + flagged_two // 100
         for i in range(len(caps)):
             assert np.array_equal(eng.eti(i), want[i]), "stream %d afc %d" % (i, afc)
         assert sum(len(w) for w in want) > 100
