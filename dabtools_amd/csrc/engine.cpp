@@ -617,7 +617,7 @@ bool Engine::begin_decode(int nstreams, bool cont)
 
 // K1 over the calls that became complete: stages pointers / sizes / states, launches the scan, brings back {status, ordinal}
 // per call and the front-end states (main stream, awaited) and the full descriptors (side stream, awaited by the caller's guard)
-bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont)
+bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont, bool full_scan)
 {
   const auto wall0 = std::chrono::steady_clock::now();
   if (!h_ptrs_.resize(nstreams) || !h_nb_.resize(nstreams)) return false;   // page-locked staging: asynchronous uploads
@@ -654,19 +654,64 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
     return false;
   scan_setup_ms_ = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
 
-  (void)hipEventRecord(ev_[0], stream_);
-  if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), nstreams, max_calls_, -1, -1,
-                              d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), afc_ ? 1 : 0, stream_),
-             "sync scan launch"))
-    return false;
-  (void)hipEventRecord(ev_[1], stream_);
-  // The host only needs {status, ordinal} of every call to lay the frames out: K1 writes those 8 bytes per call to a
-  // compact array that comes back first; the full descriptors (trace API) follow on the side stream.
   if (!h_descs_.resize(ndesc) || !h_info_.resize(ndesc)) return false;
+  sync_rescanned_ = 0;
+  (void)hipEventRecord(ev_[0], stream_);
+  if (afc_ || full_scan) {
+    // the reference's order, call after call: with the software AFC every call's NCO depends on the estimates of the call
+    // before; and the fallback when the split scan's assumption failed
+    if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), nstreams, max_calls_, -1, -1,
+                                d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), afc_ ? 1 : 0, stream_),
+               "sync scan launch"))
+      return false;
+    (void)hipEventRecord(ev_[1], stream_);
+    if (!check(hipStreamWaitEvent(copy_stream_, ev_[1], 0), "desc download") ||
+        !check(hipMemcpyAsync(h_descs_.data(), d_descs_.get(), ndesc * sizeof(CallDesc), hipMemcpyDeviceToHost, copy_stream_), "desc download"))
+      return false;
+  } else {
+    // Split scan: the per-stream chain carries only what the next call depends on (FIFO, coarse and fine time) and assumes the
+    // coarse frequency offset of every frame within +-1 carrier (input_sdr.c:105-109: otherwise the frame is dropped and a
+    // resync forced); both frequency estimates are then computed for all frames in parallel (sync_verify_kernel).  A stream that
+    // breaks the assumption (a capture more than a carrier off tune, noise) is scanned again from its incoming state in the
+    // reference's order, so the result is the same in every case.  (Running the verification on a second stream beside the
+    // OFDM stage was tried: both want the CUs' LDS, nothing is gained.)
+    if (!h_viol_.resize(nstreams) || !d_viol_.reserve(nstreams) || !d_states_prev_.reserve(nstreams) ||
+        !d_calls_before_.upload(calls_done_.data(), nstreams, stream_) ||
+        !check(hipMemcpyAsync(d_states_prev_.get(), d_states_.get(), nstreams * sizeof(StreamState), hipMemcpyDeviceToDevice, stream_), "state backup") ||
+        !check(hipMemsetAsync(d_viol_.get(), 0x7f, nstreams * sizeof(int), stream_), "violation memset") ||
+        !check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), nstreams, max_calls_, -1, -1,
+                                d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), 0, stream_, true),
+               "sync chain launch") ||
+        !check(launch_sync_verify(d_iq_ptrs_.get(), d_nbytes_.get(), d_calls_before_.get(), d_states_.get(), d_descs_.get(), nstreams, max_calls_,
+                                  d_tw2048_.get(), d_prs_.get(), d_viol_.get(), false, stream_),
+               "sync verify launch") ||
+        !check(hipMemcpyAsync(h_viol_.data(), d_viol_.get(), nstreams * sizeof(int), hipMemcpyDeviceToHost, stream_), "violation download") ||
+        !check(hipStreamSynchronize(stream_), "sync verify"))
+      return false;
+    std::vector<int> redo;
+    for (int b = 0; b < nstreams; ++b)
+      if (h_viol_[b] != 0x7f7f7f7f) redo.push_back(b);
+    sync_rescanned_ = static_cast<int>(redo.size());
+    if (!redo.empty() &&
+        (!d_redo_.upload(redo, stream_) ||
+         !check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), static_cast<int>(redo.size()), max_calls_,
+                                 -1, -1, d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), 0, stream_, false, d_states_prev_.get(), d_redo_.get()),
+                "sync rescan launch")))
+      return false;
+    // fine_freq_shift carried through the calls that did not demodulate (streams without a violation), then the descriptors
+    if (!check(launch_sync_verify(d_iq_ptrs_.get(), d_nbytes_.get(), d_calls_before_.get(), d_states_.get(), d_descs_.get(), nstreams, max_calls_,
+                                  d_tw2048_.get(), d_prs_.get(), d_viol_.get(), true, stream_),
+               "sync carry launch"))
+      return false;
+    (void)hipEventRecord(ev_[1], stream_);
+    if (!check(hipStreamWaitEvent(copy_stream_, ev_[1], 0), "desc download") ||
+        !check(hipMemcpyAsync(h_descs_.data(), d_descs_.get(), ndesc * sizeof(CallDesc), hipMemcpyDeviceToHost, copy_stream_), "desc download"))
+      return false;
+  }
+  // The host only needs {status, ordinal} of every call to lay the frames out: K1 writes those 8 bytes per call to a
+  // compact array that comes back first; the full descriptors (trace API) follow on a side stream.
   if (!check(hipMemcpyAsync(h_info_.data(), d_info_.get(), ndesc * sizeof(int2), hipMemcpyDeviceToHost, stream_), "call info download") ||
       !check(hipMemcpyAsync(states, d_states_.get(), nstreams * sizeof(StreamState), hipMemcpyDeviceToHost, stream_), "state download") ||
-      !check(hipStreamWaitEvent(copy_stream_, ev_[1], 0), "desc download") ||
-      !check(hipMemcpyAsync(h_descs_.data(), d_descs_.get(), ndesc * sizeof(CallDesc), hipMemcpyDeviceToHost, copy_stream_), "desc download") ||
       !check(hipStreamSynchronize(stream_), "sync scan"))
     return false;
   (void)hipEventElapsedTime(&times_.sync, ev_[0], ev_[1]);
@@ -675,7 +720,7 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
   return true;
 }
 
-int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont)
+int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont, bool full_scan)
 {
   if (!ok_) { set_error("engine not initialised (no GPU?)"); return -1; }
   if (nstreams <= 0) { set_error("decode: no streams"); return -1; }
@@ -692,7 +737,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     hipStream_t s;
     ~SideStreamGuard() { (void)hipStreamSynchronize(s); }
   } side_guard{copy_stream_};
-  if (!scan_streams(iq, nbytes, nstreams, on_device, cont)) return -1;
+  if (!scan_streams(iq, nbytes, nstreams, on_device, cont, full_scan)) return -1;
   times_.setup = scan_setup_ms_;
   const size_t ndesc = static_cast<size_t>(nstreams) * max_calls_;
 

@@ -232,9 +232,9 @@ class Engine {
  private:
   bool check(hipError_t e, const char* what);
   bool hard_only(const char* what);
-  int64_t decode_impl(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont);
+  int64_t decode_impl(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont, bool full_scan = false);
   bool begin_decode(int nstreams, bool cont);
-  bool scan_streams(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont);
+  bool scan_streams(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont, bool full_scan);
   bool carry_and_reserve(const std::vector<int>& tf_base, const std::vector<int>& row_base, int nslots, int nrows);
   // plan_jobs[i] = (plan id, job indices decoded with that plan)
   void build_batch(const std::vector<std::pair<int, const std::vector<int>*>>& plan_jobs, DecodeBatch& out);
@@ -275,7 +275,10 @@ class Engine {
   DeviceBuffer<uint8_t> d_iq_own_;
   DeviceBuffer<const uint8_t*> d_iq_ptrs_;
   DeviceBuffer<int64_t> d_nbytes_;
-  DeviceBuffer<StreamState> d_states_;
+  DeviceBuffer<StreamState> d_states_, d_states_prev_;
+  DeviceBuffer<int> d_viol_, d_redo_, d_calls_before_;
+  PinnedBuffer<int> h_viol_;
+  int sync_rescanned_ = 0;            // streams the split scan had to scan again in full (last decode)
   DeviceBuffer<CallDesc> d_descs_;
   DeviceBuffer<int2> d_info_;
   DeviceBuffer<int2> d_frames_;

@@ -12,6 +12,8 @@
 // inverse DFTs per TF); arg-max decisions use the reference's float compare, first hit wins.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "dab_tables.hpp"
 #include "device_types.hpp"
 #include "fft64.hpp"
@@ -47,6 +49,55 @@ __device__ __forceinline__ double2 view_sample(const uint8_t* stream, const Fram
 }
 // u8 -> s8 with DC offset 127 and int8 wrap (input_sdr.c:60-63)
 __device__ __forceinline__ int rail(int byte) { return static_cast<int>(static_cast<int8_t>(static_cast<uint8_t>(byte - 127))); }
+
+// Buffer bytes [p0, p1) of the frame almost always lie inside what this call read from the stream (segment 0 of the view);
+// the loads below then go straight to the stream, unrolled, instead of through the per-sample segment search (whose loop
+// keeps the compiler from overlapping the loads: one memory latency per sample).
+__device__ __forceinline__ const uint8_t* contiguous_window(const uint8_t* stream, const FrameView& v, int p0, int p1)
+{
+  return (v.seg_src[0] >= 0 && p1 <= v.seg_end[0]) ? stream + v.seg_src[0] + p0 : nullptr;
+}
+__device__ __forceinline__ double2 sample_of(unsigned w)
+{
+  return make_double2(static_cast<int8_t>(static_cast<uint8_t>((w & 0xff) - 127)), static_cast<int8_t>(static_cast<uint8_t>((w >> 8) - 127)));
+}
+// the same loads issued early (registers), for use after some other work: the chain kernel fetches the samples of the fine time
+// search while the null-symbol test runs
+template <int kCount>
+struct Prefetched {
+  bool ok;
+  unsigned w[kCount / kThreads];
+};
+template <int kCount>
+__device__ __forceinline__ Prefetched<kCount> prefetch_samples(const uint8_t* stream, const FrameView& view, int p0, int nco)
+{
+  Prefetched<kCount> pf;
+  const uint8_t* win = nco == 0 ? contiguous_window(stream, view, p0, p0 + 2 * kCount) : nullptr;
+  pf.ok = win != nullptr;
+  if (pf.ok) {
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(win);
+#pragma unroll
+    for (int i = 0; i < kCount / kThreads; ++i) pf.w[i] = src[threadIdx.x + i * kThreads];
+  }
+  return pf;
+}
+// count (a multiple of kThreads) samples starting at buffer byte p0 -> dst[0 .. count)
+template <int kCount>
+__device__ __forceinline__ void load_samples(const uint8_t* stream, const FrameView& view, int p0, int nco, double2* dst)
+{
+  const int tid = threadIdx.x;
+  const uint8_t* win = nco == 0 ? contiguous_window(stream, view, p0, p0 + 2 * kCount) : nullptr;
+  if (win) {
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(win);
+    unsigned w[kCount / kThreads];
+#pragma unroll
+    for (int i = 0; i < kCount / kThreads; ++i) w[i] = src[tid + i * kThreads];
+#pragma unroll
+    for (int i = 0; i < kCount / kThreads; ++i) dst[tid + i * kThreads] = sample_of(w[i]);
+  } else {
+    for (int n = tid; n < kCount; n += kThreads) dst[n] = view_sample(stream, view, p0 + 2 * n, nco);
+  }
+}
 
 constexpr int kWaves = kThreads / 64;
 struct Red {
@@ -125,30 +176,196 @@ struct Shared {
   double fine_fs;
 };
 
+// LDS: A (2048 points) and the batch buffer Bf lie back to back; the coarse frequency search correlates all 29 offsets in ONE
+// batch of 29 x 128 = 3712 points laid over both (the 156 spectrum bins it needs are set aside first), the fine time search
+// uses 3 x 512 points of Bf.  78 KB in all: two workgroups per CU.
+constexpr int kBatchPoints = 29 * 128 - 2048;              // 1664 >= 3 x 512
+constexpr int kSpecBins = 128 + 28;                        // spectrum bins touched by the 29 offsets
+
+// ---- the estimators of sdr_sync.c, each run by the whole workgroup on LDS buffers ---------------------------------------
+// A: 2048 points; Bf: kBatchPoints; tw: exp(2 pi i k / 2048), k < 1024.  All return the same value in every thread.
+
+// dab_coarse_time_sync (sdr_sync.c:34-68) -> byte shift, 0 = the null symbol is where it should be
+__device__ int coarse_time_sync(const uint8_t* stream, const FrameView& view, int force, Red& red, uint8_t* env)
+{
+  const int tid = threadIdx.x;
+  int e = 0;
+  if (const uint8_t* win = contiguous_window(stream, view, 0, 20 * 266)) {
+    if (tid < 266) e = abs(rail(win[20 * tid]));
+  } else {
+    for (int n = tid; n < 266; n += kThreads) e += abs(rail(view_byte(stream, view, 20 * n)));
+  }
+  e = block_sum_int(red, e);
+  if (e < 5000 && force == 0) return 0;
+  // envelope a[n] = |real[10 n]|, window sums of 266 taps, first minimum
+  constexpr int kEnv = (kTfSamples - kNullSamples) / 10 + 266;   // 19661
+  constexpr int kWin = (kTfSamples - kNullSamples) / 10;        // 19395 windows examined
+  for (int n = tid; n < kEnv; n += kThreads) env[n] = static_cast<uint8_t>(abs(rail(view_byte(stream, view, 20 * n))));
+  __syncthreads();
+  const int per = (kWin + kThreads - 1) / kThreads;
+  const int m0 = tid * per, m1 = min(m0 + per, kWin);
+  float best = 9999999.0f;
+  int bestm = 0x7fffffff;
+  if (m0 < m1) {
+    int s = 0;
+    for (int q = 0; q < 266; ++q) s += env[m0 + q];
+    for (int m = m0; m < m1; ++m) {
+      if (static_cast<float>(s) < best) { best = static_cast<float>(s); bestm = m; }
+      s += env[m + 266] - env[m];
+    }
+  }
+  // arg-min, lowest index wins ties: arg-max of the negated value
+  float bv;
+  int bi;
+  block_argmax(red, -best, bestm, &bv, &bi);
+  const int coarse = (-bv < 9999999.0f) ? bi * 20 : 0;
+  __syncthreads();                                         // env (aliases the batch buffer) is free again
+  return coarse;
+}
+
+// dab_fine_time_sync (sdr_sync.c:71-202) -> signed byte shift
+__device__ int fine_time_sync(const uint8_t* stream, const FrameView& view, int nco, double2* A, double2* Bf, const double2* tw,
+                              const double2* __restrict__ tw1536, const uint8_t* __restrict__ prs_q, Red& red, const Prefetched<2048>& pf)
+{
+  const int tid = threadIdx.x;
+  if (pf.ok) {
+#pragma unroll
+    for (int i = 0; i < 2048 / kThreads; ++i) A[tid + i * kThreads] = sample_of(pf.w[i]);
+  } else {
+    load_samples<2048>(stream, view, 2 * (kNullSamples + kCpSamples), nco, A);
+  }
+  __syncthreads();
+  dft_dif<11, 3, 3, 3, 2>(A, 1, -1.0, tw);
+  for (int i = tid; i < kCarriers; i += kThreads) {
+    const int bin = i < 768 ? i + 1280 : i - 765;
+    const double2 c = mul_conj_prs(A[brev(bin, 11)], prs_q[i]);
+    Bf[(i % 3) * 512 + i / 3] = c;       // decimate by 3 for the 3 x 512 inverse DFT
+  }
+  __syncthreads();
+  dft_dif<9, 3, 3, 3>(Bf, 3, +1.0, tw);
+  float fv = -99999.0f;
+  int fi = 0x7fffffff;
+  for (int kk = tid; kk < kCarriers; kk += kThreads) {
+    const int r = brev(kk & 511, 9);
+    const double2 f0 = Bf[r], f1 = Bf[512 + r], f2 = Bf[1024 + r];
+    const double2 w1 = tw1536[kk], w2 = tw1536[(2 * kk) % 1536];
+    const double xr = f0.x + (f1.x * w1.x - f1.y * w1.y) + (f2.x * w2.x - f2.y * w2.y);
+    const double xi = f0.y + (f1.x * w1.y + f1.y * w1.x) + (f2.x * w2.y + f2.y * w2.x);
+    const float mag = static_cast<float>(sqrt(xr * xr + xi * xi));
+    if (mag > fv) { fv = mag; fi = kk; }     // kk ascending per thread: first maximum kept
+  }
+  float gv;
+  int gi;
+  block_argmax(red, fv, fi, &gv, &gi);
+  return gi < 768 ? gi * 2 + 16 : (gi - 1536) * 2;
+}
+
+// input_sdr.c:90-104 + dab_coarse_freq_sync_2 (sdr_sync.c:205-258) -> carrier offset -14 .. 14
+__device__ int coarse_freq_sync(const uint8_t* stream, const FrameView& view, int nco, int fine, double2* A, double2* spec, const double2* tw,
+                                const uint8_t* __restrict__ prs_q, Red& red)
+{
+  const int tid = threadIdx.x;
+  load_samples<2048>(stream, view, 2 * (kNullSamples + kCpSamples + 1 + fine), nco, A);
+  __syncthreads();
+  dft_dif<11, 3, 3, 3, 2>(A, 1, -1.0, tw);
+  // offset kk = -14 .. 14 correlates bins 14 + kk + 256 + s (s < 128) of the fftshifted spectrum: 256 .. 411
+  for (int j = tid; j < kSpecBins; j += kThreads) spec[j] = A[brev((256 + j + 1024) & 2047, 11)];
+  __syncthreads();
+  double2* W = A;                                          // 29 x 128 points over A and the batch buffer behind it
+  for (int idx = tid; idx < 29 * 128; idx += kThreads) {
+    const int o = idx / 128, s = idx % 128;                // o = kk + 14
+    W[idx] = mul_conj_prs(spec[o + s], prs_q[14 + s]);
+  }
+  __syncthreads();
+  dft_dif<7, 3, 2, 2>(W, 29, +1.0, tw);
+  // per-offset maximum |.|, then first maximum over offsets
+  float cv = -99999.0f;
+  int ci = 0x7fffffff;
+  for (int idx = tid; idx < 29 * 128; idx += kThreads) {
+    const double2 x = W[idx];
+    const float mag = static_cast<float>(sqrt(x.x * x.x + x.y * x.y));
+    if (mag > cv) { cv = mag; ci = idx / 128; }            // idx ascending per thread
+  }
+  float hv;
+  int hi;
+  block_argmax(red, cv, ci, &hv, &hi);
+  return hi - 14;
+}
+
+// dab_fine_freq_corr (sdr_sync.c:259-302): estimate only, in Hz
+__device__ double fine_freq_corr(const uint8_t* stream, const FrameView& view, int nco, Red& red)
+{
+  double acc = 0;
+  const uint8_t* win = nco == 0 ? contiguous_window(stream, view, 2 * kNullSamples, 2 * (kNullSamples + 2048 + kCpSamples)) : nullptr;
+  for (int n = threadIdx.x; n < kCpSamples; n += kThreads) {
+    const int pl = 2 * (kNullSamples + 2048 + n), pr = 2 * (kNullSamples + n);
+    double2 l, r;
+    if (win) {
+      const uint16_t* src = reinterpret_cast<const uint16_t*>(win);
+      l = sample_of(src[2048 + n]);
+      r = sample_of(src[n]);
+    } else {
+      l = view_sample(stream, view, pl, nco);
+      r = view_sample(stream, view, pr, nco);
+    }
+    const double lr = l.x, li = l.y, rr = r.x, ri = r.y;
+    acc += atan2(-lr * ri + li * rr, lr * rr + li * ri);
+  }
+  acc = block_sum_double(red, acc);
+  return acc / 504 / (2 * M_PI) * 1000;
+}
+
+struct SyncLds {
+  double2* A;
+  double2* Bf;
+  double2* tw;
+  double2* spec;
+  Shared* sh;
+};
+__device__ __forceinline__ SyncLds sync_lds(unsigned char* smem, const double2* __restrict__ tw2048)
+{
+  SyncLds l;
+  l.A = reinterpret_cast<double2*>(smem);                  // 2048: main DFT buffer
+  l.Bf = l.A + 2048;                                        // batch buffer (also the envelope bytes of the coarse time search)
+  l.tw = l.Bf + kBatchPoints;                               // 1024: LDS copy of the twiddle table
+  l.spec = l.tw + 1024;                                     // kSpecBins
+  l.sh = reinterpret_cast<Shared*>(l.spec + kSpecBins);
+  for (int i = threadIdx.x; i < 1024; i += kThreads) l.tw[i] = tw2048[i];
+  return l;
+}
+
+// kChainOnly = false: sdr_demod's synchronisation as the reference runs it, call after call.
+// kChainOnly = true : only what the NEXT call depends on -- FIFO bookkeeping, coarse time, fine time.  The coarse frequency
+//   offset is assumed to come out within +-1 carrier (so the frame is demodulated and no resync is forced) and left, with the
+//   fine frequency estimate, to sync_verify_kernel, which runs over all transmission frames in parallel; a stream whose
+//   assumption fails is scanned again in full (Engine::scan_streams).  Not with the software AFC, where the NCO of the next
+//   frame depends on both estimates.
+template <bool kChainOnly>
 __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* const* __restrict__ iq,
                                                              const int64_t* __restrict__ nbytes,
-                                                             StreamState* __restrict__ states,
+                                                             const StreamState* __restrict__ states_in, StreamState* __restrict__ states,
+                                                             const int* __restrict__ stream_list,
                                                              CallDesc* __restrict__ descs, int2* __restrict__ info, int max_calls, int call_begin,
                                                              int call_end, const double2* __restrict__ tw2048,
                                                              const double2* __restrict__ tw1536,
                                                              const uint8_t* __restrict__ prs_q, int afc)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double2* A = reinterpret_cast<double2*>(smem);   // 2048: main DFT buffer
-  double2* Bf = A + 2048;                            // 3712: 3 x 512 or 29 x 128 batch buffer
-  double2* tw = Bf + 29 * 128;                       // 1024: exp(2 pi i k / 2048), LDS copy of the twiddle table
-  Shared& sh = *reinterpret_cast<Shared*>(tw + 1024);
-  uint8_t* env = reinterpret_cast<uint8_t*>(Bf);     // 19660 bytes, coarse search only
+  const SyncLds lds = sync_lds(smem, tw2048);
+  double2* A = lds.A;
+  double2* Bf = lds.Bf;
+  double2* tw = lds.tw;
+  Shared& sh = *lds.sh;
+  uint8_t* env = reinterpret_cast<uint8_t*>(Bf);     // 19661 bytes, coarse search only
 
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = stream_list ? stream_list[blockIdx.x] : blockIdx.x, tid = threadIdx.x;
   const uint8_t* stream = iq[b];
   const int64_t total_calls = nbytes[b] / kChunkBytes;
   const int kend = call_end < 0 ? static_cast<int>(total_calls) : min(call_end, static_cast<int>(total_calls));
   // call_begin < 0: continue where the stream's state stands (calls already fed), descriptors numbered from there
-  const int kfirst = call_begin >= 0 ? call_begin : static_cast<int>(states[b].fed / kChunkBytes);
+  const int kfirst = call_begin >= 0 ? call_begin : static_cast<int>(states_in[b].fed / kChunkBytes);
   const int kdesc0 = call_begin >= 0 ? 0 : kfirst;
-  if (tid == 0) { sh.st = states[b]; sh.fine_fs = sh.st.fine_freq_shift; }
-  for (int i = tid; i < 1024; i += kThreads) tw[i] = tw2048[i];
+  if (tid == 0) { sh.st = states_in[b]; sh.fine_fs = sh.st.fine_freq_shift; }
   __syncthreads();
 
   for (int k = kfirst; k < kend; ++k) {
@@ -165,114 +382,26 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
     const int nco = afc ? sh.st.tuner_hz : 0;
     if (sh.do_sync) {
       const FrameView& view = sh.st.view;
-      // ---- coarse time: sdr_sync.c:34-68 ------------------------------------------------
-      int e = 0;
-      for (int n = tid; n < 266; n += kThreads) e += abs(rail(view_byte(stream, view, 20 * n)));
-      e = block_sum_int(sh.red, e);
-      int coarse = 0;
-      if (!(e < 5000 && sh.st.force_timesync == 0)) {
-        // envelope a[n] = |real[10 n]|, window sums of 266 taps, first minimum
-        constexpr int kEnv = (kTfSamples - kNullSamples) / 10 + 266;   // 19661
-        constexpr int kWin = (kTfSamples - kNullSamples) / 10;        // 19395 windows examined
-        for (int n = tid; n < kEnv; n += kThreads) env[n] = static_cast<uint8_t>(abs(rail(view_byte(stream, view, 20 * n))));
-        __syncthreads();
-        const int per = (kWin + kThreads - 1) / kThreads;
-        const int m0 = tid * per, m1 = min(m0 + per, kWin);
-        float best = 9999999.0f;
-        int bestm = 0x7fffffff;
-        if (m0 < m1) {
-          int s = 0;
-          for (int q = 0; q < 266; ++q) s += env[m0 + q];
-          for (int m = m0; m < m1; ++m) {
-            if (static_cast<float>(s) < best) { best = static_cast<float>(s); bestm = m; }
-            s += env[m + 266] - env[m];
-          }
-        }
-        // arg-min, lowest index wins ties: arg-max of the negated value
-        float bv;
-        int bi;
-        block_argmax(sh.red, -best, bestm, &bv, &bi);
-        coarse = (-bv < 9999999.0f) ? bi * 20 : 0;
-      }
-      __syncthreads();
+      const Prefetched<2048> pf = prefetch_samples<2048>(stream, view, 2 * (kNullSamples + kCpSamples), nco);   // for the fine time search
+      const int coarse = coarse_time_sync(stream, view, sh.st.force_timesync, sh.red, env);      // input_sdr.c:64-74
       if (tid == 0) { sh.st.coarse_timeshift = coarse; sh.st.force_timesync = 0; }
       __syncthreads();
-
       if (coarse == 0) {
-        // ---- fine time: sdr_sync.c:71-202 -------------------------------------------------
-        for (int n = tid; n < 2048; n += kThreads) {
-          const int p = 2 * (kNullSamples + kCpSamples + n);
-          A[n] = view_sample(stream, view, p, nco);
-        }
-        __syncthreads();
-        dft_dif<11, 3, 3, 3, 2>(A, 1, -1.0, tw);
-        for (int i = tid; i < kCarriers; i += kThreads) {
-          const int bin = i < 768 ? i + 1280 : i - 765;
-          const double2 c = mul_conj_prs(A[brev(bin, 11)], prs_q[i]);
-          Bf[(i % 3) * 512 + i / 3] = c;       // decimate by 3 for the 3 x 512 inverse DFT
-        }
-        __syncthreads();
-        dft_dif<9, 3, 3, 3>(Bf, 3, +1.0, tw);
-        float fv = -99999.0f;
-        int fi = 0x7fffffff;
-        for (int kk = tid; kk < kCarriers; kk += kThreads) {
-          const int r = brev(kk & 511, 9);
-          const double2 f0 = Bf[r], f1 = Bf[512 + r], f2 = Bf[1024 + r];
-          const double2 w1 = tw1536[kk], w2 = tw1536[(2 * kk) % 1536];
-          const double xr = f0.x + (f1.x * w1.x - f1.y * w1.y) + (f2.x * w2.x - f2.y * w2.y);
-          const double xi = f0.y + (f1.x * w1.y + f1.y * w1.x) + (f2.x * w2.y + f2.y * w2.x);
-          const float mag = static_cast<float>(sqrt(xr * xr + xi * xi));
-          if (mag > fv) { fv = mag; fi = kk; }     // kk ascending per thread: first maximum kept
-        }
-        float gv;
-        int gi;
-        block_argmax(sh.red, fv, fi, &gv, &gi);
-        const int fine = gi < 768 ? gi * 2 + 16 : (gi - 1536) * 2;
+        const int fine = fine_time_sync(stream, view, nco, A, Bf, tw, tw1536, prs_q, sh.red, pf);   // input_sdr.c:84
         if (tid == 0) sh.st.fine_timeshift = fine;
-
-        // ---- coarse frequency: input_sdr.c:90-109, sdr_sync.c:205-258 ---------------------
-        for (int n = tid; n < 2048; n += kThreads) {
-          const int p = 2 * (kNullSamples + kCpSamples + 1 + fine + n);
-          A[n] = view_sample(stream, view, p, nco);
-        }
-        __syncthreads();
-        dft_dif<11, 3, 3, 3, 2>(A, 1, -1.0, tw);
-        for (int idx = tid; idx < 29 * 128; idx += kThreads) {
-          const int kk = idx / 128 - 14, s = idx % 128;
-          const int shifted = 14 + kk + 256 + s;              // index into the fftshifted spectrum
-          const int bin = (shifted + 1024) & 2047;
-          Bf[idx] = mul_conj_prs(A[brev(bin, 11)], prs_q[14 + s]);
-        }
-        __syncthreads();
-        dft_dif<7, 3, 2, 2>(Bf, 29, +1.0, tw);
-        // per-offset maximum |.|, then first maximum over offsets
-        float cv = -99999.0f;
-        int ci = 0x7fffffff;
-        for (int idx = tid; idx < 29 * 128; idx += kThreads) {
-          const double2 x = Bf[idx];
-          const float mag = static_cast<float>(sqrt(x.x * x.x + x.y * x.y));
-          if (mag > cv) { cv = mag; ci = idx / 128; }        // idx ascending per thread
-        }
-        float hv;
-        int hi;
-        block_argmax(sh.red, cv, ci, &hv, &hi);
-        const int cfs = hi - 14;
-        if (tid == 0) sh.coarse_fs = cfs;
-        if (abs(cfs) > 1) {
-          if (tid == 0) sh.st.force_timesync = 1;
+        if (kChainOnly) {
+          if (tid == 0) sh.status = 2;                    // assumed; sync_verify_kernel checks it
         } else {
-          // ---- fine frequency (estimate only): sdr_sync.c:259-302 -------------------------
-          double acc = 0;
-          for (int n = tid; n < kCpSamples; n += kThreads) {
-            const int pl = 2 * (kNullSamples + 2048 + n), pr = 2 * (kNullSamples + n);
-            const double2 l = view_sample(stream, view, pl, nco), r = view_sample(stream, view, pr, nco);
-            const double lr = l.x, li = l.y, rr = r.x, ri = r.y;
-            acc += atan2(-lr * ri + li * rr, lr * rr + li * ri);
-          }
-          acc = block_sum_double(sh.red, acc);
-          if (tid == 0) {
-            sh.fine_fs = acc / 504 / (2 * M_PI) * 1000;
-            sh.status = 2;
+          const int cfs = coarse_freq_sync(stream, view, nco, fine, A, lds.spec, tw, prs_q, sh.red);   // input_sdr.c:90-104
+          if (tid == 0) sh.coarse_fs = cfs;
+          if (abs(cfs) > 1) {
+            if (tid == 0) sh.st.force_timesync = 1;       // input_sdr.c:105-109
+          } else {
+            const double ffs = fine_freq_corr(stream, view, nco, sh.red);                        // input_sdr.c:112
+            if (tid == 0) {
+              sh.fine_fs = ffs;
+              sh.status = 2;
+            }
           }
         }
       }
@@ -311,23 +440,105 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
   if (tid == 0) { sh.st.fine_freq_shift = sh.fine_fs; states[b] = sh.st; }
 }
 
+// The estimators the chain-only scan left out, for every call it assumed demodulated: grid (max_calls, nstreams).
+// Fills coarse_freq_shift and fine_freq_shift of the call's descriptor; an offset beyond +-1 carrier breaks the assumption:
+// the first such call of a stream is recorded in violation[stream].
+__global__ __launch_bounds__(kThreads) void sync_verify_kernel(const uint8_t* const* __restrict__ iq, CallDesc* __restrict__ descs, int max_calls,
+                                                               int nstreams, const double2* __restrict__ tw2048, const uint8_t* __restrict__ prs_q,
+                                                               int* __restrict__ violation)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int total = max_calls * nstreams;
+  if (static_cast<int>(gridDim.x) == total && descs[blockIdx.x].status != 2) return;   // nothing to do: skip the table fill as well
+  const SyncLds lds = sync_lds(smem, tw2048);
+  Shared& sh = *lds.sh;
+  for (int w = blockIdx.x; w < total; w += gridDim.x) {
+    const int b = w / max_calls;
+    CallDesc& d = descs[w];
+    if (d.status != 2) continue;                           // the same for every thread of the workgroup
+    __syncthreads();                                       // the previous call's readers of sh.st.view are done
+    {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(&d.view);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(&sh.st.view);
+      if (threadIdx.x < sizeof(FrameView) / 4) dst[threadIdx.x] = src[threadIdx.x];
+    }
+    const int fine = d.fine_timeshift;
+    __syncthreads();
+    const uint8_t* stream = iq[b];
+    const int cfs = coarse_freq_sync(stream, sh.st.view, 0, fine, lds.A, lds.spec, lds.tw, prs_q, sh.red);
+    if (abs(cfs) > 1) {
+      if (threadIdx.x == 0) { d.coarse_freq_shift = cfs; atomicMin(violation + b, w % max_calls); }
+      continue;
+    }
+    const double ffs = fine_freq_corr(stream, sh.st.view, 0, sh.red);
+    if (threadIdx.x == 0) { d.coarse_freq_shift = cfs; d.fine_freq_shift = ffs; }
+  }
+}
+
+// fine_freq_shift is only recomputed by calls that demodulate (input_sdr.c:112); every other call still shows the last value
+// (sdr->fine_freq_shift persists).  One thread per stream carries it through the descriptors of a chain-only scan.
+__global__ void sync_carry_kernel(CallDesc* __restrict__ descs, int max_calls, const int64_t* __restrict__ nbytes, const int* __restrict__ calls_before,
+                                  StreamState* __restrict__ states, const int* __restrict__ violation, int nstreams)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nstreams || violation[b] != 0x7f7f7f7f) return;   // streams that broke the assumption are scanned again in full
+  const int ncalls = static_cast<int>(nbytes[b] / kChunkBytes) - calls_before[b];
+  double ffs = states[b].fine_freq_shift;                  // the chain-only scan left the incoming value untouched
+  for (int k = 0; k < ncalls; ++k) {
+    CallDesc& d = descs[static_cast<size_t>(b) * max_calls + k];
+    if (d.status == 2) ffs = d.fine_freq_shift;
+    else d.fine_freq_shift = ffs;
+  }
+  states[b].fine_freq_shift = ffs;
+}
+
 }  // namespace
 
-size_t sync_scan_lds_bytes() { return sizeof(double2) * (2048 + 29 * 128 + 1024) + sizeof(Shared); }
+size_t sync_scan_lds_bytes() { return sizeof(double2) * (2048 + kBatchPoints + 1024 + kSpecBins) + sizeof(Shared); }
+
+static hipError_t sync_attr()
+{
+  static bool attr_set = false;
+  if (attr_set) return hipSuccess;
+  const int lds = static_cast<int>(sync_scan_lds_bytes());
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_scan_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_scan_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_verify_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e == hipSuccess) attr_set = true;
+  return e;
+}
 
 hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, StreamState* states, CallDesc* descs, int2* info,
                             int nstreams, int max_calls, int call_begin, int call_end, const double2* tw2048,
-                            const double2* tw1536, const uint8_t* prs_q, int afc, hipStream_t stream)
+                            const double2* tw1536, const uint8_t* prs_q, int afc, hipStream_t stream, bool chain_only,
+                            const StreamState* states_in, const int* stream_list)
 {
-  static bool attr_set = false;
+  if (nstreams <= 0) return hipSuccess;
+  hipError_t e = sync_attr();
+  if (e != hipSuccess) return e;
   const size_t lds = sync_scan_lds_bytes();
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    if (e != hipSuccess) return e;
-    attr_set = true;
+  if (!states_in) states_in = states;
+  if (chain_only)
+    hipLaunchKernelGGL(sync_scan_kernel<true>, dim3(nstreams), dim3(kThreads), lds, stream, iq, nbytes, states_in, states, stream_list, descs, info,
+                       max_calls, call_begin, call_end, tw2048, tw1536, prs_q, afc);
+  else
+    hipLaunchKernelGGL(sync_scan_kernel<false>, dim3(nstreams), dim3(kThreads), lds, stream, iq, nbytes, states_in, states, stream_list, descs, info,
+                       max_calls, call_begin, call_end, tw2048, tw1536, prs_q, afc);
+  return hipGetLastError();
+}
+
+hipError_t launch_sync_verify(const uint8_t* const* iq, const int64_t* nbytes, const int* calls_before, StreamState* states, CallDesc* descs,
+                              int nstreams, int max_calls, const double2* tw2048, const uint8_t* prs_q, int* violation, bool carry_only, hipStream_t stream)
+{
+  if (nstreams <= 0 || max_calls <= 0) return hipSuccess;
+  hipError_t e = sync_attr();
+  if (e != hipSuccess) return e;
+  if (!carry_only) {
+    const int blocks = max_calls * nstreams;                // one call per workgroup measured better than persistent ones (0.59 vs 0.63 ms)
+    hipLaunchKernelGGL(sync_verify_kernel, dim3(blocks), dim3(kThreads), sync_scan_lds_bytes(), stream, iq, descs, max_calls, nstreams, tw2048, prs_q, violation);
+  } else {
+    hipLaunchKernelGGL(sync_carry_kernel, dim3((nstreams + 63) / 64), dim3(64), 0, stream, descs, max_calls, nbytes, calls_before, states, violation, nstreams);
   }
-  hipLaunchKernelGGL(sync_scan_kernel, dim3(nstreams), dim3(kThreads), lds, stream, iq, nbytes, states, descs, info, max_calls,
-                     call_begin, call_end, tw2048, tw1536, prs_q, afc);
   return hipGetLastError();
 }
 

@@ -10,12 +10,20 @@
 
 namespace dabhip {
 
-// K1: synchronisation scan, one workgroup per stream, calls [call_begin, call_end) (call_end < 0: all)
+// K1: synchronisation scan, one workgroup per stream, calls [call_begin, call_end) (call_end < 0: all).
+// chain_only: FIFO bookkeeping, coarse and fine time only, assuming every frame's coarse frequency offset stays within +-1
+// carrier; launch_sync_verify then computes both frequency estimates for all frames in parallel and records the first call
+// of each stream that breaks the assumption.  states_in (default: states): where the incoming state is read from;
+// stream_list (default: all, block b = stream b): the streams to scan.
 hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, StreamState* states, CallDesc* descs, int2* info,
                             int nstreams, int max_calls, int call_begin, int call_end, const double2* tw2048,
-                            const double2* tw1536, const uint8_t* prs_q, int afc, hipStream_t stream);
+                            const double2* tw1536, const uint8_t* prs_q, int afc, hipStream_t stream, bool chain_only = false,
+                            const StreamState* states_in = nullptr, const int* stream_list = nullptr);
+// carry_only = false: the verification pass (violation[b] = first offending call, untouched otherwise);
+// carry_only = true: fine_freq_shift carried through the calls that did not demodulate, for the streams without a violation
+hipError_t launch_sync_verify(const uint8_t* const* iq, const int64_t* nbytes, const int* calls_before, StreamState* states, CallDesc* descs,
+                              int nstreams, int max_calls, const double2* tw2048, const uint8_t* prs_q, int* violation, bool carry_only, hipStream_t stream);
 
-// K2: 76 x 2048-point DFT of frames[first .. first+nframes) -> spectra[nframes][76][2048]
 // delta != nullptr: the kernel also leaves the guard's per-symbol error bound kGuardC sqrt(sum |x|^2) at delta[(first + j) * 76 + symbol]
 hipError_t launch_ofdm_fft(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first,
                            int nframes, float2* spectra, const float2* tw, hipStream_t stream, float* delta = nullptr);
