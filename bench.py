@@ -32,13 +32,14 @@ sys.path.insert(0, ROOT)
 
 FFT_BYTES_PER_TF = 311296 + 1245184        # cu8 read + complex64 spectra written
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8.0 TB/s spec
-# HBM bytes per TF of ofdm_fft_kernel from rocprofv3 PMC passes (profiles/r01_k2_pmc_traffic.csv; the kernel is unchanged since):
-# (2 x FETCH_SIZE + WRITE_SIZE) KiB per 1024-TF launch = 2 x 165.8k + 1259.5k, FETCH_SIZE doubled as the gfx950 note in
+# HBM bytes per TF of ofdm_fft_kernel from rocprofv3 PMC passes (profiles/r02_k2_pmc_traffic.csv):
+# (2 x FETCH_SIZE + WRITE_SIZE) KiB per 1024-TF launch = 2 x 161,196 + 1,245,184, FETCH_SIZE doubled as the gfx950 note in
 # MI355X_MICROARCH.md (HBM) prescribes.  PMC counters cannot be read from inside this script.
-FFT_PMC_BYTES_PER_TF = (2 * 165800 + 1259500) * 1024 // 1024   # KiB per 1024 TF == bytes per TF: 1,591,100
+FFT_PMC_BYTES_PER_TF = (2 * 161196 + 1245184) * 1024 // 1024   # KiB per 1024 TF == bytes per TF: 1,567,576 = 1.007 x algorithmic
 REALTIME_FPS = 1000.0 / 24.0
 # VALU issue peak: 256 CUs x 4 SIMDs, one wave-instruction per 4 cycles (a quad-cycle) at 2.4 GHz
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 4
+VIT_VALU_PER_STEP = 129.0                  # VALU wave-instructions per trellis step of viterbi_fused_kernel<1> (PMC, see roofline_viterbi)
 
 
 # ---- rank coordination ---------------------------------------------------------------------------------------------
@@ -258,6 +259,8 @@ def run_rank(args, coord):
             eng.set_soft(True)
         if args.two_kernel_ofdm:
             eng.set_fused(False)
+        if args.no_parity_guard:
+            eng.set_parity_guard(False)
         if args.subchannels:
             eng.set_subchannels([int(x) for x in args.subchannels.split(",")])
         eng.decode_device(ptrs[:2], [min(s, 20 * 393216) for s in sizes[:2]])   # loads the code objects (tiny, untimed, part of set-up)
@@ -288,7 +291,26 @@ def run_rank(args, coord):
         fused_off = None
         extra = {}
         if rank == 0:
+            flagged, decisions = eng.guard_stats()
+            extra["parity_guard"] = {"on": not args.no_parity_guard and not args.soft, "decisions_per_step": decisions, "redecided_in_fp64_per_step": flagged,
+                                     "note": "hard decisions whose fp32 margin lies inside the error band are re-decided in fp64 from the int8 samples "
+                                             "(k_parity.hip); raw fp32 disagreement rate without it: profiles/r02_decision_audit.json"}
             fft = eng.fft_roofline(max(3, min(args.steps, 10)))
+            if not args.soft and not args.no_parity_guard and not args.no_variants:
+                # the same job accepting raw fp32 decisions (guard off: the fused kernel without the guard's test)
+                eng.set_parity_guard(False)
+                eng.decode_device(ptrs, sizes)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    f3 = eng.decode_device(ptrs, sizes)
+                torch.cuda.synchronize(dev)
+                e3 = time.perf_counter() - t1
+                extra["parity_guard_off_variant"] = {"value": f3 * args.steps / e3, "unit": "ETI frames/s", "ms_per_step": 1e3 * e3 / args.steps,
+                                                     "stage_ms_per_step": {k: v for k, v in eng.stage_ms().items() if k in ("fft", "demap")},
+                                                     "note": "dabhip_engine_set_parity_guard(0): raw fp32 decisions (disagreement with exact arithmetic: 0 on this "
+                                                             "clean workload, 2.6e-8 of the decisions at 5 dB); this rank only"}
+                eng.set_parity_guard(True)
             if not args.soft and not args.two_kernel_ofdm and not args.no_variants:
                 # the same job with the two-kernel OFDM stage (K2 writes the spectra, K2b reads them back), for comparison
                 eng.set_fused(False)
@@ -345,7 +367,7 @@ def run_rank(args, coord):
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": FFT_PMC_BYTES_PER_TF * tfs / max(launches, 1),
                 "traffic_note": "bytes per launch; per-TF HBM bytes from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                "(profiles/r01_k2_pmc_traffic.csv, FETCH_SIZE x2 gfx950 correction) x TFs per launch",
+                                "(profiles/r02_k2_pmc_traffic.csv, FETCH_SIZE x2 gfx950 correction) x TFs per launch",
                 "how": "dabhip_engine_fft_roofline: K2 alone over the frame list of the timed step (same resident IQ, %d TF per launch), "
                        "HIP events on the engine's stream; the step itself runs the fused transform + demap kernel" % (tfs // max(launches, 1)),
                 "achieved_vs_measured_copy_ceiling": achieved / 6290.0,
@@ -353,6 +375,20 @@ def run_rank(args, coord):
                 "algorithmic_bytes_per_tf": FFT_BYTES_PER_TF}
         if stage:
             out["stage_ms_per_step"] = stage
+            if stage.get("viterbi", 0) > 0 and not args.dry_run and not args.subchannels:
+                # second roofline, for the stage with the most time after the OFDM kernel: the MSC Viterbi is bound by VALU issue and by
+                # the survivor records.  Per trellis step and wave (64 code words): VIT_VALU_PER_STEP wave-instructions (rocprofv3 SQ_INSTS_VALU,
+                # profiles/r01_sq_pmc_summary.csv: 2.77e9 per 2.14e7 wave-steps) and 512 B of records written + read back.
+                steps_per_frame = 27336 if not args.soft else 27336
+                wave_steps = frames_step / world * steps_per_frame / 64.0
+                t = stage["viterbi"] * 1e-3
+                out["roofline_viterbi"] = {
+                    "kernel": "viterbi_fused_kernel", "bound": "valu issue / hbm (survivor records)",
+                    "valu": {"achieved": VIT_VALU_PER_STEP * wave_steps / t / 1e9, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+                             "frac": VIT_VALU_PER_STEP * wave_steps / t / 1e9 / VALU_PEAK_GINST},
+                    "hbm": {"achieved": 1024.0 * wave_steps / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 1024.0 * wave_steps / t / 1e9 / HBM_PEAK_GBS,
+                            "note": "64 B of survivor records per 8 steps and code word, written once and read once"},
+                    "trellis_steps_per_eti_frame": steps_per_frame, "avg_ms": stage["viterbi"]}
         if fused_off:
             out["two_kernel_ofdm_variant"] = fused_off
         if args.subchannels:
@@ -360,7 +396,7 @@ def run_rank(args, coord):
         if args.snr < 100.0:
             out["config"]["snr_db"] = args.snr
             out["config"]["decisions"] = "soft (4-bit)" if args.soft else "hard"
-        for k in ("payload", "cpu_baseline"):
+        for k in ("parity_guard", "parity_guard_off_variant", "payload", "cpu_baseline"):
             if k in extra:
                 out[k] = extra[k]
         print(json.dumps(out))
@@ -382,7 +418,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=6, help="streams of the workload the one-core CPU baseline replays")
     ap.add_argument("--snr", type=float, default=1000.0, help="AWGN SNR in dB over the 2.048 MHz band (BASELINE config 5: 5 dB); default: clean")
     ap.add_argument("--two-kernel-ofdm", action="store_true", help="time the K2 + K2b OFDM stage instead of the fused default")
-    ap.add_argument("--no-variants", action="store_true", help="skip the extra timed pass with the two-kernel OFDM stage")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra timed passes (two-kernel OFDM stage, parity guard off)")
+    ap.add_argument("--no-parity-guard", action="store_true", help="time the pipeline with raw fp32 decisions (dabhip_engine_set_parity_guard(0))")
     ap.add_argument("--subchannels", type=str, default="", help="extension: decode only these SubChIds, e.g. 5 or 1,9 (default: all = reference frames)")
     ap.add_argument("--soft", action="store_true", help="soft-decision decoding (extension; default: hard = reference semantics)")
     args = ap.parse_args()
