@@ -256,3 +256,30 @@ def test_product_tables_match_reference_arrays():
     assert np.array_equal(dab.host_table(1), t["pvec"])
     assert np.array_equal(dab.host_table(2), t["rev_freq_deint_tab"])
     assert np.array_equal(dab.host_table(3), t["prs_quarter_turns"])
+
+
+def test_integration_shims_are_built_against_the_reference_callers():
+    """integration/viterbi_hip.c (S1) and integration/dab_hip.c (S3) compile and link against the reference's own sources /
+    headers (oracle/Makefile) and define exactly the symbols the reference's callers bind: viterbi.h:6-8, viterbi_spiral.h:22,
+    dab.h:91-92.  (Running them needs a GPU: tests/test_gpu_parity_r2.py.)"""
+    import subprocess
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("needs /root/reference at build time")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    want = {"libdabref_hipS1.so": ["viterbi", "init_viterbi", "create_viterbi", "fic_decode", "dab_process_frame"],
+            "libdabref_hipS3.so": ["init_dab_state", "dab_process_frame"]}
+    for so, syms in want.items():
+        path = os.path.join(ROOT, "oracle", "_ref", so)
+        assert os.path.exists(path), so
+        defined = {l.split()[-1] for l in os.popen("nm -D --defined-only %s" % path).read().splitlines() if l.strip()}
+        undefined = {l.split()[-1] for l in os.popen("nm -D --undefined-only %s" % path).read().splitlines() if l.strip()}
+        for sym in syms:
+            assert sym in defined, (so, sym)
+        assert any(u.startswith("dabhip_") for u in undefined), so          # ... and they are bound to libdabhip, not to CPU code
+    # every dabhip_* entry point the shims call is declared in the public header
+    declared = set(_declared_functions())
+    for f in ("viterbi_hip.c", "dab_hip.c", "input_sdr_hip.c"):
+        src = open(os.path.join(ROOT, "integration", f)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        for name in set(re.findall(r"\b(dabhip_[a-z0-9_]+)\s*\(", src)):
+            assert name in declared, (f, name)
