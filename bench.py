@@ -246,6 +246,8 @@ def run_rank(args, coord):
         import torch
         import dabtools_amd as dab
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if os.environ.get("DABHIP_BENCH_ONE_DEVICE") == "1":
+            local_rank = 0                                                 # test knob: all ranks share GPU 0 (exercises the N-rank path on a 1-GPU box)
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         t_gen = time.perf_counter()

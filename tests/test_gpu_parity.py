@@ -85,6 +85,13 @@ def test_ofdm_fft_vs_fp64_dft(engine):
         err = np.abs(got[f].astype(np.float64) - want).max() / scale
         # fp32 radix-8 transform of +-128 integers vs the fp64 DFT: tolerance 2e-6 of full scale
         assert err < 2e-6, err
+        # ... and against numpy.fft (pocketfft, fp64), which shares no code with the oracle: same tolerance
+        x = frames[f].astype(np.int32) - 127
+        x = (((x + 128) & 255) - 128).astype(np.float64).reshape(-1, 2)
+        z = x[:, 0] + 1j * x[:, 1]
+        ref = np.stack([np.fft.fftshift(np.fft.fft(z[2656 + 2552 * i + 504: 2656 + 2552 * i + 504 + 2048])) for i in range(76)])
+        got_c = got[f][..., 0].astype(np.float64) + 1j * got[f][..., 1].astype(np.float64)
+        assert np.abs(got_c - ref).max() / np.abs(ref).max() < 2e-6
 
 
 def test_demap_bits_match_oracle(engine):
