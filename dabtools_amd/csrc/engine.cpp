@@ -72,7 +72,7 @@ Engine::Engine(int device) : device_(device)
   for (auto& e : ev_)
     if (!check(hipEventCreate(&e), "hipEventCreate")) return;
   if (!check(hipEventCreate(&ev_upload_), "hipEventCreate") || !check(hipEventCreate(&ev_fic_), "hipEventCreate") ||
-      !check(hipEventCreate(&ev_fibs_), "hipEventCreate"))
+      !check(hipEventCreate(&ev_fibs_), "hipEventCreate") || !check(hipEventCreate(&ev_part0_), "hipEventCreate"))
     return;
 
   std::vector<double2> tw2048(2048), tw1536(1536);
@@ -136,6 +136,7 @@ Engine::~Engine()
   if (ev_upload_) (void)hipEventDestroy(ev_upload_);
   if (ev_fic_) (void)hipEventDestroy(ev_fic_);
   if (ev_fibs_) (void)hipEventDestroy(ev_fibs_);
+  if (ev_part0_) (void)hipEventDestroy(ev_part0_);
   if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -775,30 +776,51 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     return -1;
 
   times_.frames = since(tfr);
-  // K3 first: a pre-pass transforms only symbols 0..3 of every TF, so the FIC is decoded -- and the host control
-  // plane can run -- while the full OFDM stage (K2 + K2b) still occupies the GPU.
+  // K3 first, so that the FIC is decoded -- and the host control plane can run -- while the bulk of the OFDM stage still
+  // occupies the GPU.  One-kernel OFDM stage: its part 0 (symbols 0..18: the phase reference, the FIC and the first 15 MSC
+  // symbols) of every TF runs now, parts 1..3 after the FIC decode: no transform is done twice.  Two-kernel stage (soft
+  // decisions, set_fused(0)): a pre-pass transforms symbols 0..3 once more.
   std::unique_lock<std::mutex> heavy;
   if (heavy_mu_) heavy = std::unique_lock<std::mutex>(*heavy_mu_);
   const int chunk = std::min(ntf, kFftChunkTfs);
-  if (!d_spectra_.reserve(static_cast<size_t>(chunk) * kSymbolsPerTf * 2048)) return -1;
+  const bool one_kernel = fused_ && soft_bits_ == 0;
+  if (!one_kernel && !d_spectra_.reserve(static_cast<size_t>(chunk) * kSymbolsPerTf * 2048)) return -1;
   if (!h_fibs_.resize(static_cast<size_t>(nslots) * 384) || !h_fib_ok_.resize(static_cast<size_t>(nslots) * 12)) return -1;
   uint8_t* const fibs = h_fibs_.data();
   uint8_t* const ok = h_fib_ok_.data();
   (void)hipEventRecord(ev_[3], stream_);
   const bool guard = guard_active();
   if (guard && !d_delta_.reserve(static_cast<size_t>(ntf) * kSymbolsPerTf)) return -1;
-  for (int first = 0; first < ntf; first += chunk * 19) {       // 4 of 76 symbols: 19 x as many TFs fit the spectra buffer
-    const int n = std::min(chunk * 19, ntf - first);
+  auto fused_parts = [&](int first, int n, int part0, int nparts) -> bool {
     GuardArgs ga{};
-    if (guard && (!guard_begin(n, &ga) ||
-                  !check(launch_symbol_delta(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, 4, d_delta_.get(), kSymbolsPerTf, stream_), "symbol delta launch")))
-      return -1;
-    if (!check(launch_fic_prepass(soft_bits_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(),
-                                  d_frame_slot_.get(), d_qpsk_.get(), d_fic_bits_.get(), ga, stream_),
-               "fic pre-pass launch"))
-      return -1;
-    if (guard && !guard_finish(true)) return -1;
+    if (guard && !guard_begin(n, &ga)) return false;
+    const bool launched =
+        guard ? check(launch_ofdm_demap_fused_guarded(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_twf_.get(), d_frame_slot_.get(),
+                                                      d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_, part0, nparts),
+                      "fused fft/demap launch")
+              : check(launch_ofdm_demap_fused_plain(afc_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_twf_.get(), d_frame_slot_.get(),
+                                                    d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_, part0, nparts),
+                      "fused fft/demap launch");
+    return launched && (!guard || guard_finish(true));
+  };
+  if (one_kernel) {
+    for (int first = 0; first < ntf; first += chunk)
+      if (!fused_parts(first, std::min(chunk, ntf - first), 0, 1)) return -1;
+  } else {
+    for (int first = 0; first < ntf; first += chunk * 19) {       // 4 of 76 symbols: 19 x as many TFs fit the spectra buffer
+      const int n = std::min(chunk * 19, ntf - first);
+      GuardArgs ga{};
+      if (guard && (!guard_begin(n, &ga) ||
+                    !check(launch_symbol_delta(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, 4, d_delta_.get(), kSymbolsPerTf, stream_), "symbol delta launch")))
+        return -1;
+      if (!check(launch_fic_prepass(soft_bits_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(),
+                                    d_frame_slot_.get(), d_qpsk_.get(), d_fic_bits_.get(), ga, stream_),
+                 "fic pre-pass launch"))
+        return -1;
+      if (guard && !guard_finish(true)) return -1;
+    }
   }
+  (void)hipEventRecord(ev_part0_, stream_);
   if (guard) guard_decisions_ += static_cast<int64_t>(ntf) * (kFicBits + kMscBits);
   // FIC decode kernels on the main stream, the FIB download on the side stream: the OFDM stage is queued right behind
   // the FIC kernels and starts without waiting for the download or for the host
@@ -815,30 +837,31 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   }
   for (int c = 0; c < nchunks && gpu_ok; ++c) {
     const int first = c * chunk, n = std::min(chunk, ntf - first);
-    GuardArgs ga{};
-    if (guard && !guard_begin(n, &ga)) { gpu_ok = false; break; }
     (void)hipEventRecord(chunk_ev_[3 * c], stream_);
-    if (fused_ && soft_bits_ == 0) {
-      gpu_ok = guard ? check(launch_ofdm_demap_fused_guarded(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_twf_.get(), d_frame_slot_.get(),
-                                                             d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_),
-                             "fused fft/demap launch")
-                     : check(launch_ofdm_demap_fused_plain(afc_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_twf_.get(), d_frame_slot_.get(),
-                                                           d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_),
-                             "fused fft/demap launch");
+    if (one_kernel) {
+      gpu_ok = fused_parts(first, n, 1, 3);               // parts 1..3: part 0 ran before the FIC decode
       (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
     } else {
+      GuardArgs ga{};
+      if (guard && !guard_begin(n, &ga)) { gpu_ok = false; break; }
       // with the guard on, K2 also leaves the per-symbol error bounds K2b decides with
       gpu_ok = check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(), stream_,
                                      guard ? d_delta_.get() : nullptr),
                      "fft launch");
       (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
       gpu_ok = gpu_ok && check(launch_demap(true, soft_bits_, d_spectra_.get(), first, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_), "demap launch");
+      if (guard) gpu_ok = gpu_ok && guard_finish(true);     // timed with the demapper
     }
-    if (guard) gpu_ok = gpu_ok && guard_finish(true);       // timed with the demapper
     (void)hipEventRecord(chunk_ev_[3 * c + 2], stream_);
   }
   if (!check(hipEventSynchronize(ev_fibs_), "fic decode")) return -1;
-  (void)hipEventElapsedTime(&times_.fic, ev_[3], ev_[0]);
+  {
+    float part0_ms = 0, fic_ms = 0;
+    (void)hipEventElapsedTime(&part0_ms, ev_[3], ev_part0_);
+    (void)hipEventElapsedTime(&fic_ms, ev_part0_, ev_[0]);
+    times_.fic = fic_ms + (one_kernel ? 0.0f : part0_ms);   // the pre-pass of the two-kernel stage is FIC work; part 0 of the fused kernel is OFDM work
+    if (one_kernel) times_.fft += part0_ms;
+  }
 
   // control plane + work lists on a host thread, hidden behind K2 + K2b
   std::vector<ControlPlane>& planes = planes_;

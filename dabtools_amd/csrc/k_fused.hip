@@ -225,7 +225,7 @@ __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t*
   }
 }
 
-// grid = 4 * nframes: workgroup part p of a frame demaps data symbols max(1, 19 p) .. 19 p + 18 (parts 1..3 transform symbol
+// grid = nparts * nframes (parts part0 .. part0 + nparts - 1 of every frame): workgroup part p of a frame demaps data symbols max(1, 19 p) .. 19 p + 18 (parts 1..3 transform symbol
 // 19 p - 1 once more as their differential reference)
 template <bool kNco>
 __global__ __launch_bounds__(kThreads, 3) void ofdm_demap_kernel(const uint8_t* const* __restrict__ iq, const CallDesc* __restrict__ descs,
@@ -233,7 +233,8 @@ __global__ __launch_bounds__(kThreads, 3) void ofdm_demap_kernel(const uint8_t* 
                                                                  const float2* __restrict__ tw_global, const int* __restrict__ frame_slot,
                                                                  const int* __restrict__ frame_cif_row,
                                                                  const uint16_t* __restrict__ qpsk_of_carrier,
-                                                                 uint32_t* __restrict__ fic_bits, uint32_t* __restrict__ msc_bits, const GuardArgs gargs)
+                                                                 uint32_t* __restrict__ fic_bits, uint32_t* __restrict__ msc_bits, const GuardArgs gargs,
+                                                                 int part0, int nparts)
 {
   __shared__ __attribute__((aligned(16))) float2 exA[kExSize];
   __shared__ __attribute__((aligned(16))) float2 exB[kExSize];
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(kThreads, 3) void ofdm_demap_kernel(const uint8_t* 
   __shared__ float2 tw3[4 * 8];
   __shared__ float esum[8];                             // per-wave parts of the symbol energy, two symbols in flight
   const int tid = threadIdx.x;
-  const int j = blockIdx.x >> 2, part = blockIdx.x & 3;
+  const int j = blockIdx.x / nparts, part = part0 + blockIdx.x % nparts;   // the engine launches part 0 of all frames first (FIC), then parts 1..3
   const int2 fr = frames[first + j];
   const CallDesc* desc = descs + static_cast<size_t>(fr.x) * max_calls + fr.y;
   const uint8_t* stream = iq[fr.x];
@@ -300,26 +301,26 @@ __global__ __launch_bounds__(kThreads, 3) void ofdm_demap_kernel(const uint8_t* 
 #if DABHIP_FUSED_GUARD
 hipError_t launch_ofdm_demap_fused_guarded(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
                                            const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
-                                           uint32_t* fic_bits, uint32_t* msc_bits, const GuardArgs& guard, hipStream_t stream)
+                                           uint32_t* fic_bits, uint32_t* msc_bits, const GuardArgs& guard, hipStream_t stream, int part0, int nparts)
 {
-  if (nframes <= 0) return hipSuccess;
-  hipLaunchKernelGGL(ofdm_demap_kernel<false>, dim3(4 * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
-                     frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard);
+  if (nframes <= 0 || nparts <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ofdm_demap_kernel<false>, dim3(nparts * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
+                     frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard, part0, nparts);
   return hipGetLastError();
 }
 #else
 hipError_t launch_ofdm_demap_fused_plain(bool afc, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
                                          const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
-                                         uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream)
+                                         uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream, int part0, int nparts)
 {
-  if (nframes <= 0) return hipSuccess;
+  if (nframes <= 0 || nparts <= 0) return hipSuccess;
   const GuardArgs guard{};
   if (afc)
-    hipLaunchKernelGGL(ofdm_demap_kernel<true>, dim3(4 * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
-                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard);
+    hipLaunchKernelGGL(ofdm_demap_kernel<true>, dim3(nparts * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
+                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard, part0, nparts);
   else
-    hipLaunchKernelGGL(ofdm_demap_kernel<false>, dim3(4 * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
-                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard);
+    hipLaunchKernelGGL(ofdm_demap_kernel<false>, dim3(nparts * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
+                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard, part0, nparts);
   return hipGetLastError();
 }
 #endif
