@@ -70,13 +70,15 @@ __device__ __forceinline__ void fft2048_rest(float2 (&v)[8], float2* bufP, float
 // of the 3072 places is written by exactly one carrier, so the array needs no clearing.  FIC symbols (1..3) leave in natural
 // order (t = i >> 5); MSC symbols as the 16 planes i & 15 of 6 words each (the layout of demap_kernel<true, 1>).
 // Parity guard (k_parity.hip): a decision whose margin is inside the fp32 error band (dc, dp = error bounds of this and of the
-// previous symbol's bins) is listed for the fp64 re-decision that follows this kernel.  The kernel sits at its register limit
-// at three waves per SIMD (two waves cost 40 % of its speed), which makes it touchy: the test below -- inline, per bin, under a
-// run-time flag -- costs 1.6 ms per 16 k TF (5.4 -> 7.0 ms).  Eight arrangements that looked cheaper on paper were built and
-// measured slower (7.6 .. 13 ms; spills or scalar branch ladders in the symbol loop): a symbol-wide threshold in the loop with
-// the exact test in a cold block (inlined, looped over a select chain, as a real call, or on an LDS parking area), a wave-level
-// ballot, v_min3 chains, candidate records filtered by a second kernel, exponent bytes examined at flush time -- and this very
-// code with the flag turned into a template parameter (8.2 ms).  The energy reduction itself is free.
+// previous symbol's bins) is listed for the fp64 re-decision that follows this kernel.  The exact per-bin test runs inline and
+// straight-line, its outcome kept as one bit per bin; the (rare) list append after the loop needs nothing but that mask.
+// Cost: 1.6 ms per 16 k TF (4.9 -> 6.5 ms), all of it the test's nine VALU instructions per bin sitting at the end of every
+// symbol's dependency chain -- the kernel runs at its register limit (168 VGPRs, three waves per SIMD; two waves cost 40 %), so
+// nothing can be carried to a quieter place.  Measured alternatives, all slower (7.0 .. 13 ms): the list append inline per bin;
+// a symbol-wide threshold in the loop with the exact test in a cold block (inlined, looped over a select chain, as a real call,
+// or on an LDS parking area); a wave-level ballot; v_min3 chains; candidate records filtered by a second kernel; exponent bytes
+// examined at flush time; the guard flag as a template parameter; stage-2 twiddles from LDS to free registers.  The energy
+// reduction itself is free.
 struct FusedGuard {
   GuardArgs g;
   unsigned frame;        // index of this TF in the frame list
@@ -84,6 +86,9 @@ struct FusedGuard {
 __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4], const float2 (&px)[4], const float2 (&py)[4],
                                        const int (&qk)[8], bool fic, uint8_t* dec, const FusedGuard& guard, int sym, float dc, float dp)
 {
+#if DABHIP_FUSED_GUARD
+  unsigned hits = 0;
+#endif
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
     const float2 cur = (m & 1) ? y[m >> 1] : x[m >> 1], prev = (m & 1) ? py[m >> 1] : px[m >> 1];
@@ -96,17 +101,24 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
       dec[a0] = (re > 0.0f) ? 0 : 1;                      // input_sdr.c:157
       dec[a1] = (im > 0.0f) ? 1 : 0;                      // input_sdr.c:158
 #if DABHIP_FUSED_GUARD
-      if (guard.g.delta != nullptr) {
+      {                                                   // straight-line: the exact per-bin test, its outcome kept as one bit
         const float n1c = fabsf(cur.x) + fabsf(cur.y), n1p = fabsf(prev.x) + fabsf(prev.y);
-        if (fminf(fabsf(re), fabsf(im)) < n1c * dp + n1p * dc + kGuardProd * n1c * n1p) {
-          const unsigned at = atomicAdd(guard.g.counter, 1u);
-          const unsigned k = 2u * threadIdx.x + 512u * (m >> 1) + (m & 1);      // raw bin
-          if (at < guard.g.cap) guard.g.list[at] = make_uint2(guard.frame, (static_cast<unsigned>(sym) << 16) | k);
-        }
+        hits |= (fminf(fabsf(re), fabsf(im)) < n1c * dp + n1p * dc + kGuardProd * n1c * n1p ? 1u : 0u) << m;
       }
 #endif
     }
   }
+#if DABHIP_FUSED_GUARD
+  if (hits != 0 && guard.g.delta != nullptr) {            // rare; needs nothing but the mask: bin m of thread t is raw bin 2 t + 512 (m >> 1) + (m & 1)
+    do {
+      const unsigned m = __ffs(hits) - 1;
+      hits &= hits - 1;
+      const unsigned at = atomicAdd(guard.g.counter, 1u);
+      const unsigned k = 2u * threadIdx.x + 512u * (m >> 1) + (m & 1u);
+      if (at < guard.g.cap) guard.g.list[at] = make_uint2(guard.frame, (static_cast<unsigned>(sym) << 16) | k);
+    } while (hits);
+  }
+#endif
 }
 
 // sum of |x_n|^2 over the symbol this workgroup is about to transform: every wave leaves its part in esum[0..3] BEFORE the
