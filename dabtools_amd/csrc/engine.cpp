@@ -74,6 +74,8 @@ Engine::Engine(int device) : device_(device)
   if (!check(hipEventCreate(&ev_upload_), "hipEventCreate") || !check(hipEventCreate(&ev_fic_), "hipEventCreate") ||
       !check(hipEventCreate(&ev_fibs_), "hipEventCreate") || !check(hipEventCreate(&ev_part0_), "hipEventCreate"))
     return;
+  for (auto& e : ev_msc_)
+    if (!check(hipEventCreate(&e), "hipEventCreate")) return;
 
   std::vector<double2> tw2048(2048), tw1536(1536);
   std::vector<float2> twf(2048);
@@ -137,6 +139,8 @@ Engine::~Engine()
   if (ev_fic_) (void)hipEventDestroy(ev_fic_);
   if (ev_fibs_) (void)hipEventDestroy(ev_fibs_);
   if (ev_part0_) (void)hipEventDestroy(ev_part0_);
+  for (auto& e : ev_msc_)
+    if (e) (void)hipEventDestroy(e);
   if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -230,17 +234,20 @@ bool Engine::upload_decode_batch(const DecodeBatch& b, const HostList<DecodeJob>
          d_decisions_.reserve(static_cast<size_t>(b.max_dec_rows) * 64) && d_grouped_.reserve(ntiles * row_words * 64);
 }
 
-// regroup + Viterbi over an uploaded batch
+// regroup + Viterbi over an uploaded batch: queued only; ev_msc_[0..2] bracket the two stages
 bool Engine::launch_decode_batch(const DecodeBatch& b, const uint32_t* bits, const int* d_stream_cif_base, const uint32_t* prbs, uint8_t* out,
-                                 int record_stride, float* gather_ms, float* viterbi_ms)
+                                 int record_stride)
 {
+  (void)hipEventRecord(ev_msc_[0], stream_);
+  (void)hipEventRecord(ev_msc_[1], stream_);
+  (void)hipEventRecord(ev_msc_[2], stream_);
   if (b.groups.empty()) return true;
   const int* ids = d_job_ids_.get();
   const int row_words = kCifWords * (soft_bits_ ? 4 : 1);
   const int ntiles = static_cast<int>(b.job_ids.size() / 64);
-  (void)hipEventRecord(ev_[0], stream_);
+  (void)hipEventRecord(ev_msc_[0], stream_);
   if (!check(launch_regroup(soft_bits_, ids, ntiles, d_jobs_.get(), d_stream_cif_base, bits, d_grouped_.get(), stream_), "regroup launch")) return false;
-  (void)hipEventRecord(ev_[1], stream_);
+  (void)hipEventRecord(ev_msc_[1], stream_);
   for (size_t sl = 0; sl + 1 < b.slice_start.size(); ++sl) {
     const int g0 = b.slice_start[sl], n = b.slice_start[sl + 1] - g0;
     if (!check(launch_viterbi_fused(soft_bits_, d_groups_.get() + g0, n, ids, d_plans_.get(), d_grouped_.get(), row_words, d_decisions_.get(), prbs,
@@ -248,11 +255,7 @@ bool Engine::launch_decode_batch(const DecodeBatch& b, const uint32_t* bits, con
                "viterbi launch"))
       return false;
   }
-  (void)hipEventRecord(ev_[2], stream_);
-  if (!check(hipEventSynchronize(ev_[2]), "decode batch")) return false;
-  float ms = 0;
-  if (gather_ms && hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) *gather_ms += ms;
-  if (viterbi_ms && hipEventElapsedTime(&ms, ev_[1], ev_[2]) == hipSuccess) *viterbi_ms += ms;
+  (void)hipEventRecord(ev_msc_[2], stream_);
   return true;
 }
 
@@ -462,23 +465,37 @@ bool Engine::msc_upload(const MscWork& w, hipStream_t s)
          d_stream_cif_base_.upload(w.stream_row_base, s) && upload_decode_batch(w.batch, w.jobs, s);
 }
 
-bool Engine::msc_launch(const MscWork& w)
+// K4 + K5 queued on the main stream (nothing is awaited: the caller does that once, then msc_collect() reads the events)
+bool Engine::msc_launch_async(const MscWork& w)
 {
   const size_t nf = w.nframes;
+  msc_queued_ = false;
   if (nf == 0) return true;
-  std::unique_lock<std::mutex> heavy;
-  if (heavy_mu_) heavy = std::unique_lock<std::mutex>(*heavy_mu_);
   if (!check(hipMemsetAsync(d_eti_.get(), 0x55, nf * kEtiBytes, stream_), "eti memset")) return false;   // padding, misc.c:295
-  if (!launch_decode_batch(w.batch, d_msc_bits_.get(), d_stream_cif_base_.get(), d_prbs_.get(), d_eti_.get(), kEtiBytes, &times_.gather,
-                           &times_.viterbi))
-    return false;
-  (void)hipEventRecord(ev_[0], stream_);
+  if (!launch_decode_batch(w.batch, d_msc_bits_.get(), d_stream_cif_base_.get(), d_prbs_.get(), d_eti_.get(), kEtiBytes)) return false;
   if (!check(launch_eti_finish(d_meta_.get(), static_cast<int>(nf), d_headers_.get(), w.header_stride, d_fibs_.get(), d_crc_tab_.get(), d_crc_shift_.get(), d_eti_.get(), stream_), "eti finish launch"))
     return false;
-  (void)hipEventRecord(ev_[1], stream_);
-  if (!check(hipEventSynchronize(ev_[1]), "eti finish")) return false;
+  (void)hipEventRecord(ev_msc_[3], stream_);
+  msc_queued_ = true;
+  return true;
+}
+
+void Engine::msc_collect()
+{
+  if (!msc_queued_) return;
+  msc_queued_ = false;
   float ms = 0;
-  if (hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) times_.eti += ms;
+  if (hipEventElapsedTime(&ms, ev_msc_[0], ev_msc_[1]) == hipSuccess) times_.gather += ms;
+  if (hipEventElapsedTime(&ms, ev_msc_[1], ev_msc_[2]) == hipSuccess) times_.viterbi += ms;
+  if (hipEventElapsedTime(&ms, ev_msc_[2], ev_msc_[3]) == hipSuccess) times_.eti += ms;
+}
+
+bool Engine::msc_launch(const MscWork& w)
+{
+  std::unique_lock<std::mutex> heavy;
+  if (heavy_mu_) heavy = std::unique_lock<std::mutex>(*heavy_mu_);
+  if (!msc_launch_async(w) || !check(hipStreamSynchronize(stream_), "msc decode")) return false;
+  msc_collect();
   return true;
 }
 
@@ -657,6 +674,7 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
 
   if (!h_descs_.resize(ndesc) || !h_info_.resize(ndesc)) return false;
   sync_rescanned_ = 0;
+  bool split_scan = false;
   (void)hipEventRecord(ev_[0], stream_);
   if (afc_ || full_scan) {
     // the reference's order, call after call: with the software AFC every call's NCO depends on the estimates of the call
@@ -664,10 +682,6 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
     if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), nstreams, max_calls_, -1, -1,
                                 d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), afc_ ? 1 : 0, stream_),
                "sync scan launch"))
-      return false;
-    (void)hipEventRecord(ev_[1], stream_);
-    if (!check(hipStreamWaitEvent(copy_stream_, ev_[1], 0), "desc download") ||
-        !check(hipMemcpyAsync(h_descs_.data(), d_descs_.get(), ndesc * sizeof(CallDesc), hipMemcpyDeviceToHost, copy_stream_), "desc download"))
       return false;
   } else {
     // Split scan: the per-stream chain carries only what the next call depends on (FIFO, coarse and fine time) and assumes the
@@ -686,34 +700,40 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
         !check(launch_sync_verify(d_iq_ptrs_.get(), d_nbytes_.get(), d_calls_before_.get(), d_states_.get(), d_descs_.get(), nstreams, max_calls_,
                                   d_tw2048_.get(), d_prs_.get(), d_viol_.get(), false, stream_),
                "sync verify launch") ||
-        !check(hipMemcpyAsync(h_viol_.data(), d_viol_.get(), nstreams * sizeof(int), hipMemcpyDeviceToHost, stream_), "violation download") ||
-        !check(hipStreamSynchronize(stream_), "sync verify"))
+        // fine_freq_shift carried through the calls that did not demodulate (the kernel skips streams with a violation)
+        !check(launch_sync_verify(d_iq_ptrs_.get(), d_nbytes_.get(), d_calls_before_.get(), d_states_.get(), d_descs_.get(), nstreams, max_calls_,
+                                  d_tw2048_.get(), d_prs_.get(), d_viol_.get(), true, stream_),
+               "sync carry launch") ||
+        !check(hipMemcpyAsync(h_viol_.data(), d_viol_.get(), nstreams * sizeof(int), hipMemcpyDeviceToHost, stream_), "violation download"))
       return false;
+    split_scan = true;
+  }
+  (void)hipEventRecord(ev_[1], stream_);
+  // The host only needs {status, ordinal} of every call to lay the frames out: K1 writes those 8 bytes per call to a
+  // compact array that comes back first; the full descriptors (trace API) follow on the side stream.
+  auto fetch = [&]() {
+    return check(hipMemcpyAsync(h_info_.data(), d_info_.get(), ndesc * sizeof(int2), hipMemcpyDeviceToHost, stream_), "call info download") &&
+           check(hipMemcpyAsync(states, d_states_.get(), nstreams * sizeof(StreamState), hipMemcpyDeviceToHost, stream_), "state download") &&
+           check(hipStreamSynchronize(stream_), "sync scan");
+  };
+  if (!fetch()) return false;
+  if (split_scan) {
     std::vector<int> redo;
     for (int b = 0; b < nstreams; ++b)
       if (h_viol_[b] != 0x7f7f7f7f) redo.push_back(b);
     sync_rescanned_ = static_cast<int>(redo.size());
-    if (!redo.empty() &&
-        (!d_redo_.upload(redo, stream_) ||
-         !check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), static_cast<int>(redo.size()), max_calls_,
-                                 -1, -1, d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), 0, stream_, false, d_states_prev_.get(), d_redo_.get()),
-                "sync rescan launch")))
-      return false;
-    // fine_freq_shift carried through the calls that did not demodulate (streams without a violation), then the descriptors
-    if (!check(launch_sync_verify(d_iq_ptrs_.get(), d_nbytes_.get(), d_calls_before_.get(), d_states_.get(), d_descs_.get(), nstreams, max_calls_,
-                                  d_tw2048_.get(), d_prs_.get(), d_viol_.get(), true, stream_),
-               "sync carry launch"))
-      return false;
-    (void)hipEventRecord(ev_[1], stream_);
-    if (!check(hipStreamWaitEvent(copy_stream_, ev_[1], 0), "desc download") ||
-        !check(hipMemcpyAsync(h_descs_.data(), d_descs_.get(), ndesc * sizeof(CallDesc), hipMemcpyDeviceToHost, copy_stream_), "desc download"))
-      return false;
+    if (!redo.empty()) {                                   // rare: those streams again, in the reference's order, from their incoming state
+      if (!d_redo_.upload(redo, stream_) ||
+          !check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), static_cast<int>(redo.size()), max_calls_,
+                                  -1, -1, d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), 0, stream_, false, d_states_prev_.get(), d_redo_.get()),
+                 "sync rescan launch"))
+        return false;
+      (void)hipEventRecord(ev_[1], stream_);
+      if (!fetch()) return false;
+    }
   }
-  // The host only needs {status, ordinal} of every call to lay the frames out: K1 writes those 8 bytes per call to a
-  // compact array that comes back first; the full descriptors (trace API) follow on a side stream.
-  if (!check(hipMemcpyAsync(h_info_.data(), d_info_.get(), ndesc * sizeof(int2), hipMemcpyDeviceToHost, stream_), "call info download") ||
-      !check(hipMemcpyAsync(states, d_states_.get(), nstreams * sizeof(StreamState), hipMemcpyDeviceToHost, stream_), "state download") ||
-      !check(hipStreamSynchronize(stream_), "sync scan"))
+  if (!check(hipStreamWaitEvent(copy_stream_, ev_[1], 0), "desc download") ||
+      !check(hipMemcpyAsync(h_descs_.data(), d_descs_.get(), ndesc * sizeof(CallDesc), hipMemcpyDeviceToHost, copy_stream_), "desc download"))
     return false;
   (void)hipEventElapsedTime(&times_.sync, ev_[0], ev_[1]);
   for (int b = 0; b < nstreams; ++b)
@@ -900,8 +920,16 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     times_.worklist = since(t1);
   });
 
-  gpu_ok = gpu_ok && check(hipStreamSynchronize(stream_), "fft/demap");
-  for (int c = 0; c < nchunks && gpu_ok; ++c) {
+  // the host thread is done long before the OFDM stage (2 of 5 ms): K4 + K5 are queued right behind it, and the whole
+  // pipeline is awaited ONCE
+  host.join();
+  if (gpu_ok && host_ok)
+    gpu_ok = check(hipStreamWaitEvent(stream_, ev_upload_, 0), "work list wait") && msc_launch_async(work);
+  const bool drained = check(hipStreamSynchronize(stream_), "decode");      // also on the error paths: nothing may stay in flight
+  if (heavy.owns_lock()) heavy.unlock();
+  if (!gpu_ok || !drained) return -1;
+  if (!host_ok) { set_error(host_error); return -1; }
+  for (int c = 0; c < nchunks; ++c) {
     float a = 0, d = 0;
     (void)hipEventElapsedTime(&a, chunk_ev_[3 * c], chunk_ev_[3 * c + 1]);
     (void)hipEventElapsedTime(&d, chunk_ev_[3 * c + 1], chunk_ev_[3 * c + 2]);
@@ -911,14 +939,8 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     fft_launches_ += 1;
     fft_tfs_ += std::min(chunk, ntf - c * chunk);
   }
-  if (heavy.owns_lock()) heavy.unlock();
-  host.join();
-  if (gpu_ok && guard && !guard_check()) return -1;
-  if (!gpu_ok) return -1;
-  if (!host_ok) { set_error(host_error); return -1; }
-
-  // K4 + K5
-  if (!check(hipStreamWaitEvent(stream_, ev_upload_, 0), "work list wait") || !msc_launch(work)) return -1;
+  msc_collect();
+  if (guard && !guard_check()) return -1;
   // what the next segment of a session starts from
   for (int b = 0; b < nstreams; ++b) {
     prev_used_[b] = carry_keep_[b] + nnew[b];

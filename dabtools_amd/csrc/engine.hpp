@@ -242,7 +242,9 @@ class Engine {
   void plan_decode_batch(DecodeBatch& b);
   bool upload_decode_batch(const DecodeBatch& b, const HostList<DecodeJob>& jobs, hipStream_t s);
   bool launch_decode_batch(const DecodeBatch& b, const uint32_t* bits, const int* d_stream_cif_base, const uint32_t* prbs, uint8_t* out,
-                           int record_stride, float* gather_ms, float* viterbi_ms);
+                           int record_stride);
+  bool msc_launch_async(const MscWork& w);   // K4 + K5 queued, nothing awaited
+  void msc_collect();                        // their stage times, once the stream has been awaited
   int plan_id(const CodewordPlan& p);
   bool unpack_tf_slot(int slot, uint8_t* fic_bytes, uint8_t* msc_bytes);
 
@@ -262,6 +264,8 @@ class Engine {
   hipStream_t stream_ = nullptr, copy_stream_ = nullptr;   // copy_stream_: work-list uploads from the control-plane thread
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_upload_ = nullptr, ev_fic_ = nullptr, ev_fibs_ = nullptr, ev_part0_ = nullptr;
+  hipEvent_t ev_msc_[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool msc_queued_ = false;
   std::vector<hipEvent_t> chunk_ev_;
 
   // constant tables
