@@ -77,7 +77,8 @@ __device__ __forceinline__ void fft2048_rest(float2 (&v)[8], float2* bufP, float
 // nothing can be carried to a quieter place.  Measured alternatives, all slower (7.0 .. 13 ms): the list append inline per bin;
 // a symbol-wide threshold in the loop with the exact test in a cold block (inlined, looped over a select chain, as a real call,
 // or on an LDS parking area); a wave-level ballot; v_min3 chains; candidate records filtered by a second kernel; exponent bytes
-// examined at flush time; the guard flag as a template parameter; stage-2 twiddles from LDS to free registers.  The energy
+// examined at flush time; a per-thread threshold (largest component of the thread's own bins) with the exact test in a cold block;
+// the guard flag as a template parameter; stage-2 twiddles from LDS to free registers.  The energy
 // reduction itself is free.
 struct FusedGuard {
   GuardArgs g;
