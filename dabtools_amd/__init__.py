@@ -104,6 +104,9 @@ _SIGNATURES = {
     "dabhip_stream_eti_drain": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dabhip_stream_set_afc": (C.c_int, [C.c_void_p, C.c_int]),
     "dabhip_stream_set_soft": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_device_alloc": (C.c_void_p, [C.c_size_t, C.c_int]),
+    "dabhip_device_free": (None, [C.c_void_p]),
+    "dabhip_device_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "dabhip_host_alloc": (C.c_void_p, [C.c_size_t]),
     "dabhip_host_free": (None, [C.c_void_p]),
     "dabhip_synth_generate_device": (C.c_int, [C.POINTER(SynthCfg), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int]),
@@ -196,6 +199,35 @@ def synth_fibs(cfg, cif_index):
     buf = np.zeros(96, dtype=np.uint8)
     _need(lib().dabhip_synth_fibs(C.byref(cfg), cif_index, _p(buf)) == 96, "synth_fibs")
     return buf
+
+
+class DeviceBuffer:
+    """nbytes of device memory (dabhip_device_alloc): .ptr for the entry points that take device pointers."""
+
+    def __init__(self, nbytes, device=0):
+        self.nbytes = int(nbytes)
+        self.ptr = lib().dabhip_device_alloc(self.nbytes, device)
+        _need(self.ptr, "device_alloc")
+
+    def upload(self, array):
+        a = np.ascontiguousarray(array, dtype=np.uint8)
+        _need(a.size <= self.nbytes and lib().dabhip_device_copy(self.ptr, a.ctypes.data, a.size, 1) == 0, "device_copy")
+
+    def download(self):
+        out = np.empty(self.nbytes, dtype=np.uint8)
+        _need(lib().dabhip_device_copy(out.ctypes.data, self.ptr, self.nbytes, 0) == 0, "device_copy")
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().dabhip_device_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 # ---- host-side control plane (no GPU needed) ----------------------------------------------------

@@ -663,6 +663,21 @@ extern "C" int64_t dabhip_stream_eti_drain(dabhip_stream* s, dabhip_eti_sink sin
   }
   return total;
 }
+// device memory for callers that bring no GPU runtime of their own (the batch entries take device pointers)
+extern "C" void* dabhip_device_alloc(size_t nbytes, int device)
+{
+  void* p = nullptr;
+  if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, nbytes ? nbytes : 1) != hipSuccess) { set_error("device_alloc: hipMalloc of " + std::to_string(nbytes) + " bytes failed"); return nullptr; }
+  return p;
+}
+extern "C" void dabhip_device_free(void* p) { if (p) (void)hipFree(p); }
+extern "C" int dabhip_device_copy(void* dst, const void* src, size_t nbytes, int to_device)
+{
+  if (!dst || !src) { set_error("device_copy: null argument"); return -1; }
+  if (hipMemcpy(dst, src, nbytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost) != hipSuccess) { set_error("device_copy: hipMemcpy failed"); return -1; }
+  return 0;
+}
+
 // page-locked host memory for the segments handed to dabhip_stream_feed (read the next one while this one decodes)
 extern "C" void* dabhip_host_alloc(size_t nbytes)
 {

@@ -86,8 +86,20 @@ struct CopyDesc {
 // Constants: >= 5 x the worst dabhip_stage_decision_audit measured over > 10^10 decisions (profiles/r02_decision_audit.json).
 constexpr float kGuardC = 5.0e-6f;       // bound on |X32 - X| of any bin, relative to sqrt(sum_n |x_n|^2)   (measured worst: 6.3e-7)
 constexpr float kGuardProd = 5.0e-7f;    // rounding of the fp32 product Re/Im(cur conj(prev)), relative to |cur|_1 |prev|_1   (measured worst: 1.0e-7)
+// Soft decisions (extension): value = round(soft_scale x) clamped to +-7, x = Re / Im of cur conj(prev).  The scale is made of
+// the two symbols' sample energies -- on a noise-free Mode-I signal mean |x| = (2048 / 1536) s(l) s(l-1) / sqrt(2), s = sqrt(sum_n
+// |x_n|^2), which the factor below maps to 4.5 -- so it is known before a symbol is transformed (the one-kernel OFDM stage cannot
+// wait for a mean over its own output) and is the same in every kernel that demaps.  dc, dp = kGuardC s of the two symbols.
+constexpr float kSoftGain = 4.5f / 0.94280904f;
+__host__ __device__ inline float soft_scale(float dc, float dp)
+{
+  const float prod = dc * dp;
+  return prod > 0.0f ? kSoftGain * kGuardC * kGuardC / prod : 0.0f;
+}
+
 struct GuardArgs {
-  const float* delta;    // nullptr: guard off (the fused OFDM kernel computes its bounds itself and only tests this for null)
+  const float* delta;    // nullptr: guard off (the fused OFDM kernel computes its bounds itself and only tests this for null); with soft
+                         // decisions: the same array, read for the scale (list == nullptr then)
   int32_t delta_stride;
   uint32_t cap;          // capacity of list
   uint2* list;           // {frame index, symbol << 16 | raw bin}

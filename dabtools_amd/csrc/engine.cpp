@@ -803,15 +803,24 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   std::unique_lock<std::mutex> heavy;
   if (heavy_mu_) heavy = std::unique_lock<std::mutex>(*heavy_mu_);
   const int chunk = std::min(ntf, kFftChunkTfs);
-  const bool one_kernel = fused_ && soft_bits_ == 0;
+  const bool one_kernel = fused_;                        // hard (with or without the guard) and soft decisions alike
   if (!one_kernel && !d_spectra_.reserve(static_cast<size_t>(chunk) * kSymbolsPerTf * 2048)) return -1;
   if (!h_fibs_.resize(static_cast<size_t>(nslots) * 384) || !h_fib_ok_.resize(static_cast<size_t>(nslots) * 12)) return -1;
   uint8_t* const fibs = h_fibs_.data();
   uint8_t* const ok = h_fib_ok_.data();
   (void)hipEventRecord(ev_[3], stream_);
   const bool guard = guard_active();
-  if (guard && !d_delta_.reserve(static_cast<size_t>(ntf) * kSymbolsPerTf)) return -1;
+  const bool soft = soft_bits_ != 0;
+  const bool energies = guard || soft;                    // the per-symbol sample energies: the guard's error bounds, the soft scale
+  if (energies && !d_delta_.reserve(static_cast<size_t>(ntf) * kSymbolsPerTf)) return -1;
+  GuardArgs soft_args{};                                  // soft decisions, two-kernel stage: K2b reads the energies, lists nothing
+  soft_args.delta = d_delta_.get();
+  soft_args.delta_stride = kSymbolsPerTf;
   auto fused_parts = [&](int first, int n, int part0, int nparts) -> bool {
+    if (soft)
+      return check(launch_ofdm_demap_fused_soft(afc_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_twf_.get(), d_frame_slot_.get(),
+                                                d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_, part0, nparts),
+                   "fused fft/demap launch");
     GuardArgs ga{};
     if (guard && !guard_begin(n, &ga)) return false;
     const bool launched =
@@ -829,9 +838,9 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   } else {
     for (int first = 0; first < ntf; first += chunk * 19) {       // 4 of 76 symbols: 19 x as many TFs fit the spectra buffer
       const int n = std::min(chunk * 19, ntf - first);
-      GuardArgs ga{};
-      if (guard && (!guard_begin(n, &ga) ||
-                    !check(launch_symbol_delta(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, 4, d_delta_.get(), kSymbolsPerTf, stream_), "symbol delta launch")))
+      GuardArgs ga = soft ? soft_args : GuardArgs{};   // (hard decisions: a non-null delta switches the guard's listing on)
+      if (guard && !guard_begin(n, &ga)) return -1;
+      if (energies && !check(launch_symbol_delta(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, 4, d_delta_.get(), kSymbolsPerTf, stream_), "symbol delta launch"))
         return -1;
       if (!check(launch_fic_prepass(soft_bits_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(),
                                     d_frame_slot_.get(), d_qpsk_.get(), d_fic_bits_.get(), ga, stream_),
@@ -862,11 +871,11 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
       gpu_ok = fused_parts(first, n, 1, 3);               // parts 1..3: part 0 ran before the FIC decode
       (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
     } else {
-      GuardArgs ga{};
+      GuardArgs ga = soft ? soft_args : GuardArgs{};   // (hard decisions: a non-null delta switches the guard's listing on)
       if (guard && !guard_begin(n, &ga)) { gpu_ok = false; break; }
-      // with the guard on, K2 also leaves the per-symbol error bounds K2b decides with
+      // with the guard on (or soft decisions), K2 also leaves the per-symbol sample energies K2b decides with
       gpu_ok = check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(), stream_,
-                                     guard ? d_delta_.get() : nullptr),
+                                     energies ? d_delta_.get() : nullptr),
                      "fft launch");
       (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
       gpu_ok = gpu_ok && check(launch_demap(true, soft_bits_, d_spectra_.get(), first, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_), "demap launch");

@@ -94,7 +94,9 @@ __device__ __forceinline__ void energy_part(const float2 (&v)[8], float* esum4)
 }
 __device__ __forceinline__ void energy_store(const float* esum4, float* delta_tf, int sym)
 {
-  if (threadIdx.x == 0) delta_tf[sym] = kGuardC * sqrtf(esum4[0] + esum4[1] + esum4[2] + esum4[3]);
+  // the wave parts are exact integers (< 2^24); added up as integers so that every kernel arrives at the very same float
+  if (threadIdx.x == 0)
+    delta_tf[sym] = kGuardC * sqrtf(static_cast<float>(static_cast<int>(esum4[0]) + static_cast<int>(esum4[1]) + static_cast<int>(esum4[2]) + static_cast<int>(esum4[3])));
 }
 
 template <bool kFast, bool kEnergy>
@@ -247,7 +249,6 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
   // alternate from symbol to symbol: one barrier per symbol.
   constexpr int kPer = 32 / kBits;                        // received values per 32-bit word
   __shared__ __attribute__((aligned(16))) uint8_t dec[2][kBitsPerSym];
-  __shared__ float wave_sum[2][kThreads / 64];
   const int tid = threadIdx.x;
   const int j = blockIdx.x / groups_per_tf, grp = blockIdx.x % groups_per_tf;
   const int slot = frame_slot[first + j];                 // TF slot (FIC rows, FIB records)
@@ -284,20 +285,10 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
       }
       prev[m] = cur;
     }
-    float scale = 0.0f;
-    if (kBits != 1) {
-      float acc = 0;
-#pragma unroll
-      for (int m = 0; m < 6; ++m) acc += fabsf(re[m]) + fabsf(im[m]);
-#pragma unroll
-      for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
-      if ((tid & 63) == 0) wave_sum[l & 1][tid >> 6] = acc;
-      __syncthreads();
-      float total = 0;
-#pragma unroll
-      for (int w = 0; w < kThreads / 64; ++w) total += wave_sum[l & 1][w];
-      scale = total > 0.0f ? 4.5f * 3072.0f / total : 0.0f;
-    }
+    // soft decisions: the scale comes from the two symbols' sample energies (soft_scale, device_types.hpp), like in the one-kernel stage
+    const float scale = kBits != 1 ? soft_scale(guard.delta[static_cast<size_t>(first + j) * guard.delta_stride + l],
+                                                guard.delta[static_cast<size_t>(first + j) * guard.delta_stride + l - 1])
+                                   : 0.0f;
 #pragma unroll
     for (int m = 0; m < 6; ++m) {
       // position i of a value inside the symbol -> its byte: natural order i, or plane i & 15, value i >> 4 of that plane

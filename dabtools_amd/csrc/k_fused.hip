@@ -4,13 +4,18 @@
 // written: per TF the kernel reads 311,296 B of IQ and writes 28,800 B of bits, so it is NOT the HBM-roofline stage
 // (reported separately from the K2 roofline number, never instead of it).  Output bits are identical to
 // ofdm_fft_kernel + demap_kernel: same butterflies, same products, same comparisons.
-// This file is compiled twice (Makefile): DABHIP_FUSED_GUARD = 1 (default) -> launch_ofdm_demap_fused_guarded, with the parity
-// guard's test in the symbol loop; = 0 -> launch_ofdm_demap_fused_plain, the kernel without any of it (also the AFC variant).
+// This file is compiled three times (Makefile): DABHIP_FUSED_GUARD = 1 (default) -> launch_ofdm_demap_fused_guarded, with the
+// parity guard's test in the symbol loop; = 0 -> launch_ofdm_demap_fused_plain, the kernel without any of it (also the AFC
+// variant); DABHIP_FUSED_SOFT = 1 -> launch_ofdm_demap_fused_soft: signed 4-bit soft values instead of hard decisions.
 #include <hip/hip_runtime.h>
 
-#ifndef DABHIP_FUSED_GUARD
-#define DABHIP_FUSED_GUARD 1
+#ifndef DABHIP_FUSED_SOFT
+#define DABHIP_FUSED_SOFT 0          // third build: 4-bit soft decisions (launch_ofdm_demap_fused_soft), no guard
 #endif
+#ifndef DABHIP_FUSED_GUARD
+#define DABHIP_FUSED_GUARD (!DABHIP_FUSED_SOFT)
+#endif
+#define DABHIP_FUSED_ENERGY (DABHIP_FUSED_GUARD || DABHIP_FUSED_SOFT)   // the symbol energies are needed by both
 
 #include "dab_tables.hpp"
 #include "device_types.hpp"
@@ -98,6 +103,19 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
     const int p0 = qk[m], p1 = 1536 + qk[m];
     const int a0 = fic ? p0 : (((p0 & 15) * 6 + (p0 >> 9)) * 32 + ((p0 >> 4) & 31));
     const int a1 = fic ? p1 : (((p1 & 15) * 6 + (p1 >> 9)) * 32 + ((p1 >> 4) & 31));
+#if DABHIP_FUSED_SOFT
+    // 4-bit soft values (extension): round(scale x) clamped to +-7, positive = "bit 0"; x = Re for the first
+    // bit and Im(cur conj(prev)) = -im for the second; scale = soft_scale(dc, dp) (device_types.hpp).  One byte per value at
+    // byte 8 w + b = value b of output word w: natural order for the FIC, plane i & 15 / value i >> 4 for the MSC.
+    if (qk[m] >= 0) {
+      const int s0 = fic ? p0 : (p0 & 15) * 192 + (p0 >> 4), s1 = fic ? p1 : (p1 & 15) * 192 + (p1 >> 4);
+      const int q0 = max(-7, min(7, __float2int_rn(re * dc)));          // dc carries the scale in this build
+      const int q1 = max(-7, min(7, __float2int_rn(-im * dc)));
+      dec[s0] = static_cast<uint8_t>(q0 & 15);
+      dec[s1] = static_cast<uint8_t>(q1 & 15);
+    }
+    (void)a0; (void)a1; (void)dp;
+#else
     if (qk[m] >= 0) {                                     // bins without a carrier (DC, guard bands) decide nothing
       dec[a0] = (re > 0.0f) ? 0 : 1;                      // input_sdr.c:157
       dec[a1] = (im > 0.0f) ? 1 : 0;                      // input_sdr.c:158
@@ -108,6 +126,7 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
       }
 #endif
     }
+#endif
   }
 #if DABHIP_FUSED_GUARD
   if (hits != 0 && guard.g.delta != nullptr) {            // rare; needs nothing but the mask: bin m of thread t is raw bin 2 t + 512 (m >> 1) + (m & 1)
@@ -133,8 +152,14 @@ __device__ __forceinline__ void symbol_energy_part(const float2 (&v)[8], float* 
   for (int sft = 32; sft > 0; sft >>= 1) e += __shfl_xor(e, sft);
   if ((threadIdx.x & 63) == 0) esum[threadIdx.x >> 6] = e;
 }
-__device__ __forceinline__ float symbol_bound(const float* esum) { return kGuardC * sqrtf(esum[0] + esum[1] + esum[2] + esum[3]); }
+// the wave parts are exact integers (< 2^24); added up as integers so that every kernel arrives at the very same float
+__device__ __forceinline__ float symbol_bound(const float* esum)
+{
+  const int e = static_cast<int>(esum[0]) + static_cast<int>(esum[1]) + static_cast<int>(esum[2]) + static_cast<int>(esum[3]);
+  return kGuardC * sqrtf(static_cast<float>(e));
+}
 
+#if !DABHIP_FUSED_SOFT
 // 32 decision bytes -> one output word, by thread t < 96
 __device__ __forceinline__ uint32_t pack_word(const uint8_t* dec, int t)
 {
@@ -146,6 +171,7 @@ __device__ __forceinline__ uint32_t pack_word(const uint8_t* dec, int t)
   for (int k = 0; k < 8; ++k) w |= ((d[k] * 0x01020408u) >> 24 & 15u) << (4 * k);   // bytes b0..b3 (0/1) -> b0 | b1<<1 | b2<<2 | b3<<3
   return w;
 }
+#endif
 
 // A symbol whose window reaches into the stale tail of the reference's frame buffer (symbol 75 after a negative timing
 // shift, frames after a coarse resync): its samples come through the view, one at a time, via an LDS staging row, so that
@@ -169,6 +195,25 @@ struct FusedOut {
   int cif_row;
 };
 
+#if DABHIP_FUSED_SOFT
+// 3072 value bytes -> 384 words of eight nibbles (all 256 threads: words t and t + 256); rows are four times as long
+__device__ __forceinline__ void flush_symbol(const uint8_t* dec, int sym, const FusedOut& o)
+{
+  for (int w = threadIdx.x; w < 384; w += kThreads) {
+    const uint2 x = *reinterpret_cast<const uint2*>(dec + 8 * w);
+    const uint32_t y0 = (x.x | (x.x >> 4)) & 0x00ff00ffu, y1 = (x.y | (x.y >> 4)) & 0x00ff00ffu;   // nibbles of bytes 0,1 and 2,3 joined
+    const uint32_t bits = ((y0 | (y0 >> 8)) & 0xffffu) | (((y1 | (y1 >> 8)) & 0xffffu) << 16);
+    if (sym <= 3) {
+      o.fic_row[(sym - 1) * 384 + w] = bits;
+    } else {
+      const int q = (sym - 4) / 18, sidx = (sym - 4) % 18;
+      const int r = w / 24, wq = w % 24;
+      const int delay = static_cast<int>(__brev(static_cast<unsigned>(r)) >> 28);   // map[r], misc.c:32
+      o.msc[static_cast<size_t>(o.cif_row + q - delay) * (1728 * 4) + r * (108 * 4) + sidx * 24 + wq] = bits;
+    }
+  }
+}
+#else
 __device__ __forceinline__ void flush_symbol(const uint8_t* dec, int sym, const FusedOut& o)
 {
   const int tid = threadIdx.x;
@@ -183,6 +228,7 @@ __device__ __forceinline__ void flush_symbol(const uint8_t* dec, int sym, const 
     o.msc[static_cast<size_t>(o.cif_row + q - delay) * 1728 + r * 108 + sidx * 6 + wq] = bits;
   }
 }
+#endif
 
 // symbols [sym_begin, sym_end): transform, and from the second one on demap against the one before
 template <bool kFast, bool kNco>
@@ -192,7 +238,9 @@ __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t*
                                               const FusedGuard& guard, float* esum, float& dprev)
 {
   if (sym_begin >= sym_end) return;
-#if DABHIP_FUSED_GUARD
+#if DABHIP_FUSED_SOFT
+  constexpr bool guarded = true;                        // "energies wanted": the soft scale is made of them
+#elif DABHIP_FUSED_GUARD
   const bool guarded = guard.g.delta != nullptr;
 #else
   constexpr bool guarded = false;
@@ -223,7 +271,11 @@ __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t*
         if (have_out) flush_symbol(h ? decA : decB, s - 1, out);
         if (h) fft2048_rest(v, exB, exA, tw, x, y);
         else fft2048_rest(v, exA, exB, tw, x, y);
+#if DABHIP_FUSED_SOFT
+        if (have_prev) decide(x, y, px, py, qk, s <= 3, h ? decB : decA, guard, s, soft_scale(dcur, dprev), 0.0f);
+#else
         if (have_prev) decide(x, y, px, py, qk, s <= 3, h ? decB : decA, guard, s, dcur, dprev);
+#endif
         dprev = dcur;
         have_out = have_prev;
         have_prev = true;
@@ -282,7 +334,7 @@ __global__ __launch_bounds__(kThreads, 3) void ofdm_demap_kernel(const uint8_t* 
     const int c = (k >= 1 && k <= 768) ? k + 767 : (k >= 1280 ? k - 1280 : -1);
     qk[m] = c >= 0 ? qpsk_of_carrier[c] : -1;
   }
-  const FusedOut out{fic_bits + static_cast<size_t>(frame_slot[first + j]) * 288, msc_bits, frame_cif_row[first + j]};
+  const FusedOut out{fic_bits + static_cast<size_t>(frame_slot[first + j]) * (DABHIP_FUSED_SOFT ? 288 * 4 : 288), msc_bits, frame_cif_row[first + j]};
   const int seg_end0 = desc->view.seg_end[0];
   const int64_t seg_src0 = desc->view.seg_src[0];
   const int nco_hz = desc->nco_hz;
@@ -311,7 +363,22 @@ __global__ __launch_bounds__(kThreads, 3) void ofdm_demap_kernel(const uint8_t* 
 
 }  // namespace
 
-#if DABHIP_FUSED_GUARD
+#if DABHIP_FUSED_SOFT
+hipError_t launch_ofdm_demap_fused_soft(bool afc, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
+                                        const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
+                                        uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream, int part0, int nparts)
+{
+  if (nframes <= 0 || nparts <= 0) return hipSuccess;
+  const GuardArgs guard{};
+  if (afc)
+    hipLaunchKernelGGL(ofdm_demap_kernel<true>, dim3(nparts * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
+                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard, part0, nparts);
+  else
+    hipLaunchKernelGGL(ofdm_demap_kernel<false>, dim3(nparts * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
+                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard, part0, nparts);
+  return hipGetLastError();
+}
+#elif DABHIP_FUSED_GUARD
 hipError_t launch_ofdm_demap_fused_guarded(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
                                            const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
                                            uint32_t* fic_bits, uint32_t* msc_bits, const GuardArgs& guard, hipStream_t stream, int part0, int nparts)

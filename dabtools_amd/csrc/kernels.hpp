@@ -53,11 +53,15 @@ hipError_t launch_viterbi_fused(int soft_bits, const WaveGroup* groups, int ngro
                                 const uint32_t* grouped, int row_words, uint2* decisions, const uint32_t* prbs_words, uint8_t* out,
                                 int record_stride, hipStream_t stream);
 
-// the one-kernel OFDM stage (k_fused.hip, compiled twice): with the parity guard's test in its symbol loop, and without.
+// the one-kernel OFDM stage (k_fused.hip, compiled three times): with the parity guard's test in its symbol loop, without it, and
+// with 4-bit soft values instead of hard decisions.
 // A frame is four parts of 19 symbols; parts part0 .. part0 + nparts - 1 of every frame are launched (part 0 holds the FIC).
 hipError_t launch_ofdm_demap_fused_guarded(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
                                            const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
                                            uint32_t* fic_bits, uint32_t* msc_bits, const GuardArgs& guard, hipStream_t stream, int part0 = 0, int nparts = 4);
+hipError_t launch_ofdm_demap_fused_soft(bool afc, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
+                                        const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
+                                        uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream, int part0 = 0, int nparts = 4);
 hipError_t launch_ofdm_demap_fused_plain(bool afc, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
                                          const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
                                          uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream, int part0 = 0, int nparts = 4);

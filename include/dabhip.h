@@ -163,6 +163,12 @@ int dabhip_stream_set_parity_guard(dabhip_stream *s, int enable);   /* default o
 void *dabhip_host_alloc(size_t nbytes);
 void dabhip_host_free(void *p);
 
+/* Device memory for callers without a GPU runtime of their own: the batch entries (dabhip_engine_decode with on_device,
+ * dabhip_synth_generate_device, the stage entries) take plain device pointers.  copy: to_device != 0: host -> device. */
+void *dabhip_device_alloc(size_t nbytes, int device);
+void dabhip_device_free(void *p);
+int dabhip_device_copy(void *dst, const void *src, size_t nbytes, int to_device);
+
 /* Per sdr_demod call trace of one stream, for parity with the reference's state after each
  * call: {ok, frame_read, coarse_timeshift, fine_timeshift, coarse_freq_shift, fifo_count}
  * as int32[6] per call plus fine_freq_shift as double per call. */

@@ -400,15 +400,17 @@ def test_full_size_batch_properties():
     (a) every ETI frame of sampled streams is well formed (HCRC, EOF CRC, FL, FSYNC/FCT, padding);
     (b) encode -> modulate -> decode returns the payload;  (c) identical inputs give identical outputs;
     (d) one stream is compared byte for byte with the CPU oracle."""
-    import torch
     import eti_check
     ntf, distinct, nstreams = 64, 8, 256
     cfgs = [dab.synth_preset(0, seed=300 + i, cif_count0=(611 * i) % 5000) for i in range(distinct)]
     host = [dab.synth_generate(c, ntf) for c in cfgs]
-    base = [torch.from_numpy(h).cuda() for h in host]
-    tensors = [base[i % distinct] if i < distinct else base[i % distinct].clone() for i in range(nstreams)]
+    tensors = []
+    for i in range(nstreams):                                    # device memory through the library itself (no second GPU runtime in the process)
+        buf = dab.DeviceBuffer(host[i % distinct].size)
+        buf.upload(host[i % distinct])
+        tensors.append(buf)
     eng = dab.Engine(0)
-    total = eng.decode_device([t.data_ptr() for t in tensors], [t.numel() for t in tensors])
+    total = eng.decode_device([t.ptr for t in tensors], [t.nbytes for t in tensors])
     assert total == nstreams * 4 * (ntf - 15)
     ref = {}
     for b in list(range(distinct)) + [distinct + 3, 100, 255]:
@@ -515,15 +517,13 @@ def test_soft_decision_mode():
 def test_device_modulator_matches_host_generator_and_decodes():
     """the GPU modulator emits the host generator's signal (up to fp32-vs-fp64 rounding of a
     sample, one LSB) and what the engine decodes from it equals the oracle on the very same bytes."""
-    import torch
     ntf = 20
     cfgs = [dab.synth_preset(1, seed=7),
             dab.synth_preset(0, seed=8, cif_count0=4990, skip_samples=50001),
             dab.synth_preset(1, seed=9, snr_db=15.0, cfo_hz=130.0, amplitude=0.8)]
-    bufs = [torch.zeros(dab.synth_bytes(c, ntf), dtype=torch.uint8, device="cuda") for c in cfgs]
-    dab.synth_generate_device(cfgs, ntf, [b.data_ptr() for b in bufs])
-    torch.cuda.synchronize()
-    got = [b.cpu().numpy() for b in bufs]
+    bufs = [dab.DeviceBuffer(dab.synth_bytes(c, ntf)) for c in cfgs]
+    dab.synth_generate_device(cfgs, ntf, [b.ptr for b in bufs])
+    got = [b.download() for b in bufs]
     for c, g in zip(cfgs, got):
         want = dab.synth_generate(c, ntf)
         assert g.size == want.size
@@ -531,7 +531,7 @@ def test_device_modulator_matches_host_generator_and_decodes():
         assert diff.max() <= 1
         assert (diff != 0).mean() < 2e-3
     eng = dab.Engine(0)
-    eng.decode_device([b.data_ptr() for b in bufs], [b.numel() for b in bufs])
+    eng.decode_device([b.ptr for b in bufs], [b.nbytes for b in bufs])
     for i, g in enumerate(got):
         want, _ = ol.or_replay(g)
         assert np.array_equal(eng.eti(i), want)

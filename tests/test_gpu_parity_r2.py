@@ -188,7 +188,6 @@ def test_config4_full_size_5db_soft_and_hard():
     """BASELINE configs[4] as written: batch = 256 synthetic streams x 64 TF at 5 dB AWGN, soft-decision Viterbi, on one GPU.
     (a) every ETI frame is well formed; (b) frames-out and payload BER within stated bounds; (c) soft >= hard;
     (d) the HARD decode (reference semantics) of 8 of those streams is byte-identical to the CPU oracle."""
-    import torch
     import eti_check
     from dabtools_amd import shard
     nstreams, ntf, ncheck, noracle = 256, 64, 16, 8
@@ -197,10 +196,9 @@ def test_config4_full_size_5db_soft_and_hard():
         return dab.synth_preset(0, seed=shard.stream_seed(4, g), cif_count0=(97 * g) % 5000, snr_db=snr)
 
     cfgs = [cfg_of(g, 5.0) for g in range(nstreams)]
-    bufs = [torch.empty(dab.synth_bytes(c, ntf), dtype=torch.uint8, device="cuda") for c in cfgs]
-    dab.synth_generate_device(cfgs, ntf, [b.data_ptr() for b in bufs])
-    torch.cuda.synchronize()
-    ptrs, sizes = [b.data_ptr() for b in bufs], [b.numel() for b in bufs]
+    bufs = [dab.DeviceBuffer(dab.synth_bytes(c, ntf)) for c in cfgs]      # device memory through the library itself
+    dab.synth_generate_device(cfgs, ntf, [b.ptr for b in bufs])
+    ptrs, sizes = [b.ptr for b in bufs], [b.nbytes for b in bufs]
     eng = dab.Engine(0)
 
     def stats(b):
@@ -239,7 +237,7 @@ def test_config4_full_size_5db_soft_and_hard():
     assert total_soft >= total_hard and sf >= hf and sb * 3 < hb                # (c)
     # (d) reference semantics, byte for byte, at the SNR where decisions sit closest to zero
     for b in range(noracle):
-        want, trace = ol.or_replay(bufs[b].cpu().numpy())
+        want, trace = ol.or_replay(bufs[b].download())
         got = eng.eti(b)
         assert got.shape == want.shape and np.array_equal(got, want), "stream %d: hard-decision ETI differs from the oracle" % b
     eng.close()
@@ -313,4 +311,33 @@ def test_parity_guard_end_to_end_and_off_switch():
     eng.decode(caps)
     assert eng.guard_stats()[0] == 0
     assert [eng.eti_count(b) for b in range(3)] == [len(w) for w in wants]     # fp32 flips are far too rare to move the lock
+    eng.close()
+
+
+def test_soft_decisions_one_kernel_and_two_kernel_stages_agree():
+    """Soft decisions: the one-kernel OFDM stage (k_fused.hip, DABHIP_FUSED_SOFT build) and K2 + K2b produce the same 4-bit values
+    (the scale comes from the symbols' sample energies, added up as integers in every kernel), hence the same ETI bytes -- on
+    noisy captures where the quantised values matter; and a streaming session gives the one-shot result."""
+    caps = [dab.synth_generate(dab.synth_preset(p, seed=1400 + i, snr_db=snr, skip_samples=sk), 34)
+            for i, (p, snr, sk) in enumerate(((1, 5.5, 0), (0, 6.5, 41000), (1, 8.0, 0), (1, 1000.0, 123)))]
+    eng = dab.Engine(0)
+    eng.set_soft(True)
+    eng.set_fused(False)
+    eng.decode(caps)
+    want = [eng.eti(b) for b in range(len(caps))]
+    assert eng.stage_ms()["demap"] > 0.02
+    eng.set_fused(True)
+    eng.decode(caps)
+    for b, w in enumerate(want):
+        assert len(w) > 40 and np.array_equal(eng.eti(b), w), b
+    st = dab.Stream(len(caps), soft=True)
+    got, pos = [[] for _ in caps], 0
+    for n in (4000000, 262144 * 9, 10 ** 9):
+        st.feed([c[pos:pos + n] for c in caps])
+        for b in range(len(caps)):
+            got[b].append(st.eti(b))
+        pos += n
+    for b, w in enumerate(want):
+        assert np.array_equal(np.concatenate(got[b]), w), b
+    st.close()
     eng.close()
