@@ -86,6 +86,12 @@ struct CopyDesc {
 // Constants: >= 5 x the worst dabhip_stage_decision_audit measured over > 10^10 decisions (profiles/r02_decision_audit.json).
 constexpr float kGuardC = 5.0e-6f;       // bound on |X32 - X| of any bin, relative to sqrt(sum_n |x_n|^2)   (measured worst: 6.3e-7)
 constexpr float kGuardProd = 5.0e-7f;    // rounding of the fp32 product Re/Im(cur conj(prev)), relative to |cur|_1 |prev|_1   (measured worst: 1.0e-7)
+// the guard's test, the same operations in every kernel that applies it (so that they all list the same decisions):
+// |cur|_1 (dp + kGuardProd |prev|_1) + |prev|_1 dc
+__host__ __device__ __forceinline__ float guard_threshold(float n1c, float n1p, float dc, float dp)
+{
+  return fmaf(n1c, fmaf(n1p, kGuardProd, dp), n1p * dc);
+}
 // Soft decisions (extension): value = round(soft_scale x) clamped to +-7, x = Re / Im of cur conj(prev).  The scale is made of
 // the two symbols' sample energies -- on a noise-free Mode-I signal mean |x| = (2048 / 1536) s(l) s(l-1) / sqrt(2), s = sqrt(sum_n
 // |x_n|^2), which the factor below maps to 4.5 -- so it is known before a symbol is transformed (the one-kernel OFDM stage cannot

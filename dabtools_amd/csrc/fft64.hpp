@@ -11,8 +11,16 @@ constexpr int kFft64Threads = 512;   // threads of the workgroup that runs these
 
 __device__ __forceinline__ unsigned brev(unsigned x, int bits) { return __brev(x) >> (32 - bits); }
 
+// Where element i of a transform buffer (or of the twiddle table) sits in LDS.  The later levels of a transform walk the buffer
+// with strides of 4, 32, ... elements of 16 bytes and the twiddle table with strides of 8 .. 128: left in place, the eight lanes
+// that share an LDS cycle would meet in the same banks (two thirds of K1's LDS cycles were bank conflicts).  XOR-ing the low
+// three index bits with bits 3..5 and 6..8 keeps aligned groups of eight together and spreads every one of those strides.
+// Buffers start at multiples of 512 elements, so the swizzle commutes with the buffer offsets.
+__device__ __forceinline__ int lds_at(int i) { return i ^ ((i >> 3) & 7) ^ ((i >> 6) & 7); }
+
 // nbatch independent DFTs of size N = 1 << LOGN stored back to back in LDS, radix-2 decimation in frequency, in
-// place; X[k] ends up at index brev(k).  sign = -1 forward.
+// place; X[k] ends up at index brev(k).  sign = -1 forward.  Element i of buf and of tw2048 (an LDS copy of exp(2 pi i k / 2048),
+// k < 1024) is at lds_at(i).
 // The scan is a chain of dependent LDS round trips with only 2 waves per SIMD to hide them, so L consecutive
 // radix-2 levels are fused: a thread holds the 2^L points it needs in registers, runs the L levels on them (the same
 // butterflies, in the same order of operations as level-by-level radix 2) and meets the others at ONE barrier.
@@ -26,10 +34,10 @@ __device__ __forceinline__ void dif_levels(double2* buf, int nbatch, int s, doub
   for (int idx = threadIdx.x; idx < nbatch * per_batch; idx += kFft64Threads) {
     const int batch = idx / per_batch, w = idx % per_batch;
     const int blk = w / q, k = w % q;
-    double2* x = buf + batch * N + blk * ms + k;
+    const int e0 = batch * N + blk * ms + k;
     double2 r[R];
 #pragma unroll
-    for (int j = 0; j < R; ++j) r[j] = x[j * q];
+    for (int j = 0; j < R; ++j) r[j] = buf[lds_at(e0 + j * q)];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       const int span = R >> (l + 1);             // partner distance in units of q
@@ -40,7 +48,7 @@ __device__ __forceinline__ void dif_levels(double2* buf, int nbatch, int s, doub
         if (j & span) continue;
         const int pos = k + (j & (span - 1)) * q;          // index of the butterfly inside its sub-transform
         const double2 A = r[j], B = r[j + span];
-        double2 tw = tw2048[pos * twstep];
+        double2 tw = tw2048[lds_at(pos * twstep)];
         tw.y *= sign;
         const double dr = A.x - B.x, di = A.y - B.y;
         r[j] = make_double2(A.x + B.x, A.y + B.y);
@@ -48,7 +56,7 @@ __device__ __forceinline__ void dif_levels(double2* buf, int nbatch, int s, doub
       }
     }
 #pragma unroll
-    for (int j = 0; j < R; ++j) x[j * q] = r[j];
+    for (int j = 0; j < R; ++j) buf[lds_at(e0 + j * q)] = r[j];
   }
   __syncthreads();
 }

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
       im[m] = cur.x * prev[m].y - cur.y * prev[m].x;     // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
       if (guarded) {
         const float n1c = fabsf(cur.x) + fabsf(cur.y), n1p = fabsf(prev[m].x) + fabsf(prev[m].y);
-        if (fminf(fabsf(re[m]), fabsf(im[m])) < n1c * dp + n1p * dc + kGuardProd * n1c * n1p) {
+        if (fminf(fabsf(re[m]), fabsf(im[m])) < guard_threshold(n1c, n1p, dc, dp)) {
           const unsigned at = atomicAdd(guard.counter, 1u);
           if (at < guard.cap) guard.list[at] = make_uint2(static_cast<unsigned>(first + j), (static_cast<unsigned>(l) << 16) | static_cast<unsigned>((bin[m] + 1024) & 2047));
         }

@@ -71,75 +71,97 @@ __device__ __forceinline__ void fft2048_rest(float2 (&v)[8], float2* bufP, float
 }
 
 // Hard decisions of one symbol against the previous one, for the 8 bins of this thread (input_sdr.c:132-162), written as
-// 0/1 BYTES into `dec` at the place where the output word wants them: byte 32 t + b = bit b of output word t.  Every one
-// of the 3072 places is written by exactly one carrier, so the array needs no clearing.  FIC symbols (1..3) leave in natural
-// order (t = i >> 5); MSC symbols as the 16 planes i & 15 of 6 words each (the layout of demap_kernel<true, 1>).
+// 0/1 BYTES into `dec` at the place where the output word of an MSC symbol wants them: byte 32 t + b = bit b of word t of the
+// 16 planes i & 15 of 6 words each (the layout of demap_kernel<true, 1>): bit i of the symbol's 3072 sits at
+// A(i) = ((i & 15) 6 + (i >> 9)) 32 + ((i >> 4) & 31), and the second bit of a carrier, i + 1536, at A(i) + 96.  ak[m] = A of
+// the first bit of this thread's bin m, fixed for the kernel's life (-1: no carrier).  Every one of the 3072 places is written
+// by exactly one carrier, so the array needs no clearing.  The three FIC symbols leave in natural order: their flush gathers
+// from the same layout (flush_symbol), so the symbol loop knows only one set of addresses.
 // Parity guard (k_parity.hip): a decision whose margin is inside the fp32 error band (dc, dp = error bounds of this and of the
 // previous symbol's bins) is listed for the fp64 re-decision that follows this kernel.  The exact per-bin test runs inline and
-// straight-line, its outcome kept as one bit per bin; the (rare) list append after the loop needs nothing but that mask.
-// Cost: 1.6 ms per 16 k TF (4.9 -> 6.5 ms), all of it the test's nine VALU instructions per bin sitting at the end of every
-// symbol's dependency chain -- the kernel runs at its register limit (168 VGPRs, three waves per SIMD; two waves cost 40 %), so
-// nothing can be carried to a quieter place.  Measured alternatives, all slower (7.0 .. 13 ms): the list append inline per bin;
-// a symbol-wide threshold in the loop with the exact test in a cold block (inlined, looped over a select chain, as a real call,
-// or on an LDS parking area); a wave-level ballot; v_min3 chains; candidate records filtered by a second kernel; exponent bytes
-// examined at flush time; a per-thread threshold (largest component of the thread's own bins) with the exact test in a cold block;
-// the guard flag as a template parameter; stage-2 twiddles from LDS to free registers.  The energy
-// reduction itself is free.
+// straight-line, its outcome OR-ed into one flag per thread; the (rare) thread with a hit repeats the tests to find the bins.
+// |bin|_1 of the previous symbol is carried (n1p), the test itself is device_types.hpp's guard_threshold.
+// The kernel runs at its register limit (168 VGPRs, three waves per SIMD; two waves cost 40 %).  Measured alternatives, all
+// slower (7.0 .. 13 ms against 6.5): the list append inline per bin; a symbol-wide threshold in the loop with the exact test in a
+// cold block (inlined, looped over a select chain, as a real call, or on an LDS parking area); a wave-level ballot; v_min3
+// chains; candidate records filtered by a second kernel; exponent bytes examined at flush time; a per-thread threshold (largest
+// component of the thread's own bins) with the exact test in a cold block; the guard flag as a template parameter; stage-2
+// twiddles from LDS to free registers.  The energy reduction itself is free.
 struct FusedGuard {
   GuardArgs g;
   unsigned frame;        // index of this TF in the frame list
 };
+#if DABHIP_FUSED_GUARD
+__device__ __forceinline__ float l1norm(const float2 v)
+{
+  float r;
+  asm("v_add_f32_e64 %0, |%1|, |%2|" : "=v"(r) : "v"(v.x), "v"(v.y));   // one instruction (the compiler pairs two of these into v_and x 4 + v_pk_add)
+  return r;
+}
+#endif
+#if !DABHIP_FUSED_SOFT
 __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4], const float2 (&px)[4], const float2 (&py)[4],
-                                       const int (&qk)[8], bool fic, uint8_t* dec, const FusedGuard& guard, int sym, float dc, float dp)
+                                       const int (&ak)[8], uint8_t* dec, const FusedGuard& guard, int sym, float dc, float dp,
+                                       const float (&n1c)[8], const float (&n1p)[8])
 {
 #if DABHIP_FUSED_GUARD
-  unsigned hits = 0;
+  bool any = false;
 #endif
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
     const float2 cur = (m & 1) ? y[m >> 1] : x[m >> 1], prev = (m & 1) ? py[m >> 1] : px[m >> 1];
     const float re = cur.x * prev.x + cur.y * prev.y;     // Re(cur conj(prev))
     const float im = cur.x * prev.y - cur.y * prev.x;     // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
-    const int p0 = qk[m], p1 = 1536 + qk[m];
-    const int a0 = fic ? p0 : (((p0 & 15) * 6 + (p0 >> 9)) * 32 + ((p0 >> 4) & 31));
-    const int a1 = fic ? p1 : (((p1 & 15) * 6 + (p1 >> 9)) * 32 + ((p1 >> 4) & 31));
-#if DABHIP_FUSED_SOFT
-    // 4-bit soft values (extension): round(scale x) clamped to +-7, positive = "bit 0"; x = Re for the first
-    // bit and Im(cur conj(prev)) = -im for the second; scale = soft_scale(dc, dp) (device_types.hpp).  One byte per value at
-    // byte 8 w + b = value b of output word w: natural order for the FIC, plane i & 15 / value i >> 4 for the MSC.
-    if (qk[m] >= 0) {
-      const int s0 = fic ? p0 : (p0 & 15) * 192 + (p0 >> 4), s1 = fic ? p1 : (p1 & 15) * 192 + (p1 >> 4);
-      const int q0 = max(-7, min(7, __float2int_rn(re * dc)));          // dc carries the scale in this build
-      const int q1 = max(-7, min(7, __float2int_rn(-im * dc)));
-      dec[s0] = static_cast<uint8_t>(q0 & 15);
-      dec[s1] = static_cast<uint8_t>(q1 & 15);
-    }
-    (void)a0; (void)a1; (void)dp;
-#else
-    if (qk[m] >= 0) {                                     // bins without a carrier (DC, guard bands) decide nothing
-      dec[a0] = (re > 0.0f) ? 0 : 1;                      // input_sdr.c:157
-      dec[a1] = (im > 0.0f) ? 1 : 0;                      // input_sdr.c:158
+    if (ak[m] >= 0) {                                     // bins without a carrier (DC, guard bands) decide nothing
+      dec[ak[m]] = (re > 0.0f) ? 0 : 1;                   // input_sdr.c:157
+      dec[ak[m] + 96] = (im > 0.0f) ? 1 : 0;              // input_sdr.c:158
 #if DABHIP_FUSED_GUARD
-      {                                                   // straight-line: the exact per-bin test, its outcome kept as one bit
-        const float n1c = fabsf(cur.x) + fabsf(cur.y), n1p = fabsf(prev.x) + fabsf(prev.y);
-        hits |= (fminf(fabsf(re), fabsf(im)) < n1c * dp + n1p * dc + kGuardProd * n1c * n1p ? 1u : 0u) << m;
-      }
+      any |= fminf(fabsf(re), fabsf(im)) < guard_threshold(n1c[m], n1p[m], dc, dp);
 #endif
     }
-#endif
   }
 #if DABHIP_FUSED_GUARD
-  if (hits != 0 && guard.g.delta != nullptr) {            // rare; needs nothing but the mask: bin m of thread t is raw bin 2 t + 512 (m >> 1) + (m & 1)
-    do {
+  if (any && guard.g.delta != nullptr) {                  // rare: which bins?  bin m of thread t is raw bin 2 t + 512 (m >> 1) + (m & 1)
+    unsigned hits = 0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const float2 cur = (m & 1) ? y[m >> 1] : x[m >> 1], prev = (m & 1) ? py[m >> 1] : px[m >> 1];
+      const float re = cur.x * prev.x + cur.y * prev.y, im = cur.x * prev.y - cur.y * prev.x;
+      hits |= (ak[m] >= 0 && fminf(fabsf(re), fabsf(im)) < guard_threshold(n1c[m], n1p[m], dc, dp) ? 1u : 0u) << m;
+    }
+    while (hits) {
       const unsigned m = __ffs(hits) - 1;
       hits &= hits - 1;
       const unsigned at = atomicAdd(guard.g.counter, 1u);
       const unsigned k = 2u * threadIdx.x + 512u * (m >> 1) + (m & 1u);
       if (at < guard.g.cap) guard.g.list[at] = make_uint2(guard.frame, (static_cast<unsigned>(sym) << 16) | k);
-    } while (hits);
+    }
   }
 #endif
 }
+#else
+// 4-bit soft values (extension): round(scale x) clamped to +-7, positive = "bit 0"; x = Re for the first
+// bit and Im(cur conj(prev)) = -im for the second; scale = soft_scale(dc, dp) (device_types.hpp).  One byte per value at
+// byte 8 w + b = value b of output word w: natural order for the FIC, plane i & 15 / value i >> 4 for the MSC.
+__device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4], const float2 (&px)[4], const float2 (&py)[4],
+                                       const int (&qk)[8], bool fic, uint8_t* dec, float scale)
+{
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const float2 cur = (m & 1) ? y[m >> 1] : x[m >> 1], prev = (m & 1) ? py[m >> 1] : px[m >> 1];
+    const float re = cur.x * prev.x + cur.y * prev.y;     // Re(cur conj(prev))
+    const float im = cur.x * prev.y - cur.y * prev.x;     // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
+    const int p0 = qk[m], p1 = 1536 + qk[m];
+    if (qk[m] >= 0) {
+      const int s0 = fic ? p0 : (p0 & 15) * 192 + (p0 >> 4), s1 = fic ? p1 : (p1 & 15) * 192 + (p1 >> 4);
+      const int q0 = max(-7, min(7, __float2int_rn(re * scale)));
+      const int q1 = max(-7, min(7, __float2int_rn(-im * scale)));
+      dec[s0] = static_cast<uint8_t>(q0 & 15);
+      dec[s1] = static_cast<uint8_t>(q1 & 15);
+    }
+  }
+}
+#endif
 
 // sum of |x_n|^2 over the symbol this workgroup is about to transform: every wave leaves its part in esum[0..3] BEFORE the
 // first barrier of the transform; symbol_bound() reads them after it
@@ -214,14 +236,24 @@ __device__ __forceinline__ void flush_symbol(const uint8_t* dec, int sym, const 
   }
 }
 #else
+// 96 output words of 32 decision bytes each.  MSC symbols: word t is bytes 32 t .. 32 t + 31 (plane t / 6, word t % 6).  FIC
+// symbols want natural order: bit b of word t is decision i = 32 t + b, whose byte sits at A(i) (see decide) =
+// (b & 15) 192 + (t >> 4) 32 + (2 t & 31) + (b >> 4): 16 two-byte reads (three symbols per TF, in part 0 only).
 __device__ __forceinline__ void flush_symbol(const uint8_t* dec, int sym, const FusedOut& o)
 {
   const int tid = threadIdx.x;
   if (tid >= 96) return;
-  const uint32_t bits = pack_word(dec, tid);
   if (sym <= 3) {
+    const uint8_t* src = dec + (tid >> 4) * 32 + ((2 * tid) & 31);
+    uint32_t bits = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t u = *reinterpret_cast<const uint16_t*>(src + 192 * j);
+      bits |= ((u & 1u) << j) | ((u >> 8) << (16 + j));
+    }
     o.fic_row[(sym - 1) * 96 + tid] = bits;
   } else {
+    const uint32_t bits = pack_word(dec, tid);
     const int q = (sym - 4) / 18, sidx = (sym - 4) % 18;
     const int r = tid / 6, wq = tid % 6;
     const int delay = static_cast<int>(__brev(static_cast<unsigned>(r)) >> 28);   // map[r], misc.c:32
@@ -235,7 +267,7 @@ template <bool kFast, bool kNco>
 __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t* stream, const FrameView& view, int sym_begin, int sym_end,
                                               bool have_prev, float2 (&px)[4], float2 (&py)[4], float2* exA, float2* exB, uint8_t* decA,
                                               uint8_t* decB, uint16_t* stage, const Twiddles& tw, const int (&qk)[8], uint32_t nco_inc, const FusedOut& out,
-                                              const FusedGuard& guard, float* esum, float& dprev)
+                                              const FusedGuard& guard, float* esum, float& dprev, float (&n1p)[8])
 {
   if (sym_begin >= sym_end) return;
 #if DABHIP_FUSED_SOFT
@@ -272,9 +304,18 @@ __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t*
         if (h) fft2048_rest(v, exB, exA, tw, x, y);
         else fft2048_rest(v, exA, exB, tw, x, y);
 #if DABHIP_FUSED_SOFT
-        if (have_prev) decide(x, y, px, py, qk, s <= 3, h ? decB : decA, guard, s, soft_scale(dcur, dprev), 0.0f);
+        if (have_prev) decide(x, y, px, py, qk, s <= 3, h ? decB : decA, soft_scale(dcur, dprev));
 #else
-        if (have_prev) decide(x, y, px, py, qk, s <= 3, h ? decB : decA, guard, s, dcur, dprev);
+        float n1c[8];
+#if DABHIP_FUSED_GUARD
+#pragma unroll
+        for (int m = 0; m < 8; ++m) n1c[m] = l1norm((m & 1) ? y[m >> 1] : x[m >> 1]);
+#endif
+        if (have_prev) decide(x, y, px, py, qk, h ? decB : decA, guard, s, dcur, dprev, n1c, n1p);
+#if DABHIP_FUSED_GUARD
+#pragma unroll
+        for (int m = 0; m < 8; ++m) n1p[m] = n1c[m];
+#endif
 #endif
         dprev = dcur;
         have_out = have_prev;
@@ -333,6 +374,9 @@ __global__ __launch_bounds__(kThreads, 3) void ofdm_demap_kernel(const uint8_t* 
     const int k = 2 * tid + 512 * (m >> 1) + (m & 1);
     const int c = (k >= 1 && k <= 768) ? k + 767 : (k >= 1280 ? k - 1280 : -1);
     qk[m] = c >= 0 ? qpsk_of_carrier[c] : -1;
+#if !DABHIP_FUSED_SOFT
+    if (c >= 0) qk[m] = ((qk[m] & 15) * 6 + (qk[m] >> 9)) * 32 + ((qk[m] >> 4) & 31);   // where the decision byte goes (decide)
+#endif
   }
   const FusedOut out{fic_bits + static_cast<size_t>(frame_slot[first + j]) * (DABHIP_FUSED_SOFT ? 288 * 4 : 288), msc_bits, frame_cif_row[first + j]};
   const int seg_end0 = desc->view.seg_end[0];
@@ -357,8 +401,9 @@ __global__ __launch_bounds__(kThreads, 3) void ofdm_demap_kernel(const uint8_t* 
   FusedGuard guard{gargs, static_cast<unsigned>(first + j)};
   if (nco_inc) guard.g.delta = nullptr;
   float dprev = 0.0f;                                   // error bound of the previous symbol's bins
-  fused_symbols<true, kNco>(src, stream, view, sym_begin, fast_end, false, px, py, exA, exB, decA, decB, stage, tw, qk, nco_inc, out, guard, esum, dprev);
-  fused_symbols<false, kNco>(src, stream, view, fast_end, sym_end, fast_end > sym_begin, px, py, exA, exB, decA, decB, stage, tw, qk, nco_inc, out, guard, esum, dprev);
+  float n1p[8] = {};                                    // |bin|_1 of the previous symbol's bins (guard)
+  fused_symbols<true, kNco>(src, stream, view, sym_begin, fast_end, false, px, py, exA, exB, decA, decB, stage, tw, qk, nco_inc, out, guard, esum, dprev, n1p);
+  fused_symbols<false, kNco>(src, stream, view, fast_end, sym_end, fast_end > sym_begin, px, py, exA, exB, decA, decB, stage, tw, qk, nco_inc, out, guard, esum, dprev, n1p);
 }
 
 }  // namespace

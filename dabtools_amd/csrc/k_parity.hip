@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kFft64Threads) void decision_audit_kernel(const uin
   const int j = blockIdx.x, tid = threadIdx.x;
   const uint8_t* frame = frames_iq + static_cast<size_t>(j) * kTfBytes;
   const float2* spec = spectra + static_cast<size_t>(j) * (kSymbolsPerTf * 2048);
-  for (int i = tid; i < 1024; i += kFft64Threads) tw[i] = tw2048[i];
+  for (int i = tid; i < 1024; i += kFft64Threads) tw[lds_at(i)] = tw2048[i];
   unsigned long long n_dec = 0, n_dis = 0, n_out = 0, n_flag = 0;
   float m_bin = 0, m_dec = 0, m_prod = 0;
   for (int l = 0; l < kSymbolsPerTf; ++l) {
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kFft64Threads) void decision_audit_kernel(const uin
     int e = 0;
     for (int n = tid; n < 2048; n += kFft64Threads) {
       const int a = prail(frame[start + 2 * n]), b = prail(frame[start + 2 * n + 1]);
-      cur[n] = make_double2(a, b);
+      cur[lds_at(n)] = make_double2(a, b);
       e += a * a + b * b;
     }
     atomicAdd(&s_acc, e);
@@ -188,17 +188,17 @@ __global__ __launch_bounds__(kFft64Threads) void decision_audit_kernel(const uin
     for (int c = tid; c < kCarriers; c += kFft64Threads) {
       const int k = c < 768 ? c + 1280 : c - 767;         // raw bin of carrier c
       const int ks = (k + 1024) & 2047;                   // fftshifted index
-      const double2 x64 = cur[brev(k, 11)];
+      const double2 x64 = cur[lds_at(brev(k, 11))];
       const float2 x32 = spec[l * 2048 + ks];
       if (s_cur > 0) m_bin = fmaxf(m_bin, static_cast<float>(hypot(x32.x - x64.x, x32.y - x64.y)) / s_cur);
       if (l == 0) continue;
-      const double2 p64 = prev[brev(k, 11)];
+      const double2 p64 = prev[lds_at(brev(k, 11))];
       const float2 p32 = spec[(l - 1) * 2048 + ks];
       const double re64 = x64.x * p64.x + x64.y * p64.y, im64 = x64.x * p64.y - x64.y * p64.x;
       const float re32 = x32.x * p32.x + x32.y * p32.y, im32 = x32.x * p32.y - x32.y * p32.x;
       const float n1c = fabsf(x32.x) + fabsf(x32.y), n1p = fabsf(p32.x) + fabsf(p32.y);
       const float unit = n1c * s_prev + n1p * s_cur;
-      const float t = kGuardC * unit + kGuardProd * n1c * n1p;
+      const float t = guard_threshold(n1c, n1p, kGuardC * s_cur, kGuardC * s_prev);   // the kernels' own test
       const bool flagged = fminf(fabsf(re32), fabsf(im32)) < t;
       n_flag += flagged ? 1 : 0;
       const int q = qpsk_of_carrier[c];

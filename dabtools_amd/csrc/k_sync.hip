@@ -81,7 +81,7 @@ __device__ __forceinline__ Prefetched<kCount> prefetch_samples(const uint8_t* st
   }
   return pf;
 }
-// count (a multiple of kThreads) samples starting at buffer byte p0 -> dst[0 .. count)
+// count (a multiple of kThreads) samples starting at buffer byte p0 -> transform buffer dst, elements 0 .. count (fft64.hpp: lds_at)
 template <int kCount>
 __device__ __forceinline__ void load_samples(const uint8_t* stream, const FrameView& view, int p0, int nco, double2* dst)
 {
@@ -93,9 +93,9 @@ __device__ __forceinline__ void load_samples(const uint8_t* stream, const FrameV
 #pragma unroll
     for (int i = 0; i < kCount / kThreads; ++i) w[i] = src[tid + i * kThreads];
 #pragma unroll
-    for (int i = 0; i < kCount / kThreads; ++i) dst[tid + i * kThreads] = sample_of(w[i]);
+    for (int i = 0; i < kCount / kThreads; ++i) dst[lds_at(tid + i * kThreads)] = sample_of(w[i]);
   } else {
-    for (int n = tid; n < kCount; n += kThreads) dst[n] = view_sample(stream, view, p0 + 2 * n, nco);
+    for (int n = tid; n < kCount; n += kThreads) dst[lds_at(n)] = view_sample(stream, view, p0 + 2 * n, nco);
   }
 }
 
@@ -230,7 +230,7 @@ __device__ int fine_time_sync(const uint8_t* stream, const FrameView& view, int 
   const int tid = threadIdx.x;
   if (pf.ok) {
 #pragma unroll
-    for (int i = 0; i < 2048 / kThreads; ++i) A[tid + i * kThreads] = sample_of(pf.w[i]);
+    for (int i = 0; i < 2048 / kThreads; ++i) A[lds_at(tid + i * kThreads)] = sample_of(pf.w[i]);
   } else {
     load_samples<2048>(stream, view, 2 * (kNullSamples + kCpSamples), nco, A);
   }
@@ -238,8 +238,8 @@ __device__ int fine_time_sync(const uint8_t* stream, const FrameView& view, int 
   dft_dif<11, 3, 3, 3, 2>(A, 1, -1.0, tw);
   for (int i = tid; i < kCarriers; i += kThreads) {
     const int bin = i < 768 ? i + 1280 : i - 765;
-    const double2 c = mul_conj_prs(A[brev(bin, 11)], prs_q[i]);
-    Bf[(i % 3) * 512 + i / 3] = c;       // decimate by 3 for the 3 x 512 inverse DFT
+    const double2 c = mul_conj_prs(A[lds_at(brev(bin, 11))], prs_q[i]);
+    Bf[lds_at((i % 3) * 512 + i / 3)] = c;       // decimate by 3 for the 3 x 512 inverse DFT
   }
   __syncthreads();
   dft_dif<9, 3, 3, 3>(Bf, 3, +1.0, tw);
@@ -247,7 +247,7 @@ __device__ int fine_time_sync(const uint8_t* stream, const FrameView& view, int 
   int fi = 0x7fffffff;
   for (int kk = tid; kk < kCarriers; kk += kThreads) {
     const int r = brev(kk & 511, 9);
-    const double2 f0 = Bf[r], f1 = Bf[512 + r], f2 = Bf[1024 + r];
+    const double2 f0 = Bf[lds_at(r)], f1 = Bf[lds_at(512 + r)], f2 = Bf[lds_at(1024 + r)];
     const double2 w1 = tw1536[kk], w2 = tw1536[(2 * kk) % 1536];
     const double xr = f0.x + (f1.x * w1.x - f1.y * w1.y) + (f2.x * w2.x - f2.y * w2.y);
     const double xi = f0.y + (f1.x * w1.y + f1.y * w1.x) + (f2.x * w2.y + f2.y * w2.x);
@@ -269,12 +269,12 @@ __device__ int coarse_freq_sync(const uint8_t* stream, const FrameView& view, in
   __syncthreads();
   dft_dif<11, 3, 3, 3, 2>(A, 1, -1.0, tw);
   // offset kk = -14 .. 14 correlates bins 14 + kk + 256 + s (s < 128) of the fftshifted spectrum: 256 .. 411
-  for (int j = tid; j < kSpecBins; j += kThreads) spec[j] = A[brev((256 + j + 1024) & 2047, 11)];
+  for (int j = tid; j < kSpecBins; j += kThreads) spec[j] = A[lds_at(brev((256 + j + 1024) & 2047, 11))];
   __syncthreads();
   double2* W = A;                                          // 29 x 128 points over A and the batch buffer behind it
   for (int idx = tid; idx < 29 * 128; idx += kThreads) {
     const int o = idx / 128, s = idx % 128;                // o = kk + 14
-    W[idx] = mul_conj_prs(spec[o + s], prs_q[14 + s]);
+    W[lds_at(idx)] = mul_conj_prs(spec[o + s], prs_q[14 + s]);
   }
   __syncthreads();
   dft_dif<7, 3, 2, 2>(W, 29, +1.0, tw);
@@ -282,7 +282,7 @@ __device__ int coarse_freq_sync(const uint8_t* stream, const FrameView& view, in
   float cv = -99999.0f;
   int ci = 0x7fffffff;
   for (int idx = tid; idx < 29 * 128; idx += kThreads) {
-    const double2 x = W[idx];
+    const double2 x = W[lds_at(idx)];
     const float mag = static_cast<float>(sqrt(x.x * x.x + x.y * x.y));
     if (mag > cv) { cv = mag; ci = idx / 128; }            // idx ascending per thread
   }
@@ -330,7 +330,7 @@ __device__ __forceinline__ SyncLds sync_lds(unsigned char* smem, const double2* 
   l.tw = l.Bf + kBatchPoints;                               // 1024: LDS copy of the twiddle table
   l.spec = l.tw + 1024;                                     // kSpecBins
   l.sh = reinterpret_cast<Shared*>(l.spec + kSpecBins);
-  for (int i = threadIdx.x; i < 1024; i += kThreads) l.tw[i] = tw2048[i];
+  for (int i = threadIdx.x; i < 1024; i += kThreads) l.tw[lds_at(i)] = tw2048[i];
   return l;
 }
 
