@@ -12,9 +12,15 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kSymPerBlock = 19;                 // 76 symbols = 4 workgroups x 19
-constexpr int kEx2Stride = 260;                  // [q] stride of exchange 2 (8*32 + 4: bank skew)
-constexpr int kEx3Stride = 520;                  // [t''] stride of exchange 3 (512 + 8)
-constexpr int kExSize = 2080;                    // float2 per exchange buffer
+#ifndef DABHIP_EX2_STRIDE
+#define DABHIP_EX2_STRIDE 258
+#endif
+#ifndef DABHIP_EX3_STRIDE
+#define DABHIP_EX3_STRIDE 520
+#endif
+constexpr int kEx2Stride = DABHIP_EX2_STRIDE;    // [q] stride of exchange 2 (8*32 + 2: the 16 lanes (q, t'' & 1) of a read land in 16 different bank pairs; 260 measured 6.2e8 conflict cycles per 16 launches, 258 none)
+constexpr int kEx3Stride = DABHIP_EX3_STRIDE;    // [t''] stride of exchange 3 (512 + 8)
+constexpr int kExSize = (8 * kEx2Stride > 4 * kEx3Stride ? 8 * kEx2Stride : 4 * kEx3Stride);   // float2 per exchange buffer
 constexpr int kDemapSyms = 5;                    // data symbols per demap workgroup (75 = 5 x 15)
 constexpr int kDemapGroups = 75 / kDemapSyms;
 
