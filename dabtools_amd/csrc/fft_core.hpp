@@ -35,7 +35,28 @@ __device__ __forceinline__ v2f add_mi(v2f b, v2f d) { return vfma(d.yx, v2f{1.0f
 __device__ __forceinline__ v2f sub_mi(v2f b, v2f d) { return vfma(d.yx, v2f{-1.0f, 1.0f}, b); }
 // complex product a b = a.xx b + ((a.yy (-1, 1)) b.yx)
 __device__ __forceinline__ v2f vmul(v2f a, v2f b) { return vfma(a.yy * v2f{-1.0f, 1.0f}, b.yx, a.xx * b); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return F(vmul(V(a), V(b))); }
+// complex product, (fma(a.x, b.x, -(a.y b.y)), fma(a.x, b.y, a.y b.x)), in one of two forms with the SAME roundings (so kernels may
+// differ in the form and still agree bit for bit):
+//   DABHIP_CMUL_SCALAR: two multiplies and two fused multiply-adds of the plain kind (2.6 clocks each per wave on gfx950);
+//   default: two packed instructions (5.0 .. 5.6 clocks each), the swap and the sign riding in op_sel / neg_lo -- the compiler's own
+//   rendering of vmul() spends a third packed instruction on the (-1, 1) factor (tools/ubench/valu_rates.hip for the rates).
+#ifdef DABHIP_CMUL_SCALAR
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+  return make_float2(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
+}
+#elif defined(DABHIP_CMUL_VMUL)
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return F(vmul(V(a), V(b))); }   // probe: different roundings
+#else
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+  const v2f va = V(a), vb = V(b);
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(t) : "v"(va), "v"(vb));        // (-a.y b.y, a.y b.x)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(va), "v"(vb), "v"(t));   // (a.x b.x, a.x b.y) + t
+  return F(r);
+}
+#endif
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return F(V(a) + V(b)); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return F(V(a) - V(b)); }
 __device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // * (-i)
@@ -73,6 +94,17 @@ __device__ __forceinline__ int view_byte(const uint8_t* stream, const FrameView&
   return s < 0 ? 0 : stream[s + p];
 }
 __device__ __forceinline__ float rail(int byte) { return static_cast<float>(static_cast<int8_t>(static_cast<uint8_t>(byte - 127))); }
+// one IQ sample, I in byte 0 and Q in byte 1 of w (upper half clear): (float)(int8)(byte - 127) each (input_sdr.c:60-63).
+// - 127 = + 0x81 mod 256, added without a carry into the byte that is read; the conversion sign-extends that byte itself
+// (two instructions per component: the cast chain above compiles to v_add_u16 + v_bfe_i32 + v_cvt_f32_i32, three of the slower kind)
+__device__ __forceinline__ float2 sample_f32(unsigned w)
+{
+  const unsigned ta = w + 0x81u, tb = w + 0x8100u;
+  float2 v;
+  asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(v.x) : "v"(ta));
+  asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(v.y) : "v"(tb));
+  return v;
+}
 
 // software AFC: de-rotate the 8 samples of this thread by exp(-2 pi i nco n / fs); phase kept as a 32-bit fraction of a
 // turn (inc = nco / fs * 2^32 per sample), so it never loses precision over the 196,608 samples of a frame

@@ -67,6 +67,9 @@ __device__ __forceinline__ void fft2048_store(float2 (&v)[8], float2* bufP, floa
     dft4(y0, y1, y2, y3);
     typedef float __attribute__((ext_vector_type(4))) vfloat4;
     vfloat4* dst = reinterpret_cast<vfloat4*>(out);        // element i holds bins 2i, 2i+1
+#ifdef DABHIP_PROBE_NOSTORE
+    if (x0.x + y1.y != 1.2345e30f) return;                // probe: the transform without its stores
+#endif
     __builtin_nontemporal_store(vfloat4{x0.x, x0.y, y0.x, y0.y}, &dst[(tid + 512) & 1023]);          // k3 = 0: bin p       -> p + 1024
     __builtin_nontemporal_store(vfloat4{x1.x, x1.y, y1.x, y1.y}, &dst[(tid + 256 + 512) & 1023]);    // k3 = 1: bin p + 512
     __builtin_nontemporal_store(vfloat4{x2.x, x2.y, y2.x, y2.y}, &dst[(tid + 512 + 512) & 1023]);    // k3 = 2: bin p + 1024
@@ -110,7 +113,7 @@ __device__ __forceinline__ int transform_symbols(GlobalU16 fast_src, const uint8
   for (int sym = sym_begin; sym < sym_end; ++sym) {
     float2 v[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = make_float2(rail(raw[r] & 0xff), rail(raw[r] >> 8));
+    for (int r = 0; r < 8; ++r) v[r] = sample_f32(raw[r]);
     if (nco_inc) derotate(v, nco_inc, kNullSamples + kSymSamples * sym + kCpSamples + static_cast<int>(threadIdx.x));
     if (sym + 1 < sym_end) load_symbol<kFast>(fast_src, stream, view, sym + 1, raw);   // prefetch under the transform
     if (kEnergy) energy_part(v, eo.esum + 4 * (sym & 1));
@@ -165,7 +168,7 @@ __device__ __forceinline__ void fft_block(const uint8_t* stream, const FrameView
     for (int i = 0; i < kFixed; ++i) {
       float2 v[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = make_float2(rail(raw[r] & 0xff), rail(raw[r] >> 8));
+      for (int r = 0; r < 8; ++r) v[r] = sample_f32(raw[r]);
       if (i + 1 < kFixed) load_symbol<true>(src, stream, view, sym0 + i + 1, raw);
       if (kEnergy) energy_part(v, eo.esum + 4 * ((sym0 + i) & 1));
       if (i & 1) fft2048_store(v, exB, exA, tw, out_tf + static_cast<size_t>(sym0 + i) * 2048);

@@ -143,23 +143,22 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
 }
 #else
 // 4-bit soft values (extension): round(scale x) clamped to +-7, positive = "bit 0"; x = Re for the first
-// bit and Im(cur conj(prev)) = -im for the second; scale = soft_scale(dc, dp) (device_types.hpp).  One byte per value at
-// byte 8 w + b = value b of output word w: natural order for the FIC, plane i & 15 / value i >> 4 for the MSC.
+// bit and Im(cur conj(prev)) = -im for the second; scale = soft_scale(dc, dp) (device_types.hpp).  One byte per value, placed
+// like the hard decisions' bytes: value i of the symbol's 3072 at S(i) = (i & 15) 192 + (i >> 4) (plane i & 15, place i >> 4),
+// the second value of a carrier at S(i) + 96; ak[m] = S of the first value of bin m.  FIC symbols are gathered by their flush.
 __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4], const float2 (&px)[4], const float2 (&py)[4],
-                                       const int (&qk)[8], bool fic, uint8_t* dec, float scale)
+                                       const int (&ak)[8], uint8_t* dec, float scale)
 {
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
     const float2 cur = (m & 1) ? y[m >> 1] : x[m >> 1], prev = (m & 1) ? py[m >> 1] : px[m >> 1];
     const float re = cur.x * prev.x + cur.y * prev.y;     // Re(cur conj(prev))
     const float im = cur.x * prev.y - cur.y * prev.x;     // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
-    const int p0 = qk[m], p1 = 1536 + qk[m];
-    if (qk[m] >= 0) {
-      const int s0 = fic ? p0 : (p0 & 15) * 192 + (p0 >> 4), s1 = fic ? p1 : (p1 & 15) * 192 + (p1 >> 4);
+    if (ak[m] >= 0) {
       const int q0 = max(-7, min(7, __float2int_rn(re * scale)));
       const int q1 = max(-7, min(7, __float2int_rn(-im * scale)));
-      dec[s0] = static_cast<uint8_t>(q0 & 15);
-      dec[s1] = static_cast<uint8_t>(q1 & 15);
+      dec[ak[m]] = static_cast<uint8_t>(q0 & 15);
+      dec[ak[m] + 96] = static_cast<uint8_t>(q1 & 15);
     }
   }
 }
@@ -231,16 +230,22 @@ struct FusedOut {
 };
 
 #if DABHIP_FUSED_SOFT
-// 3072 value bytes -> 384 words of eight nibbles (all 256 threads: words t and t + 256); rows are four times as long
+// 3072 value bytes -> 384 words of eight nibbles (all 256 threads: words t and t + 256); rows are four times as long.
+// MSC symbols: word w is bytes 8 w .. 8 w + 7 (plane w / 24).  FIC symbols want natural order: value b of word w is i = 8 w + b,
+// whose byte sits at S(i) = (8 (w & 1) + b) 192 + (w >> 1): eight single-byte reads (three symbols per TF, in part 0 only).
 __device__ __forceinline__ void flush_symbol(const uint8_t* dec, int sym, const FusedOut& o)
 {
   for (int w = threadIdx.x; w < 384; w += kThreads) {
-    const uint2 x = *reinterpret_cast<const uint2*>(dec + 8 * w);
-    const uint32_t y0 = (x.x | (x.x >> 4)) & 0x00ff00ffu, y1 = (x.y | (x.y >> 4)) & 0x00ff00ffu;   // nibbles of bytes 0,1 and 2,3 joined
-    const uint32_t bits = ((y0 | (y0 >> 8)) & 0xffffu) | (((y1 | (y1 >> 8)) & 0xffffu) << 16);
     if (sym <= 3) {
+      const uint8_t* src = dec + 8 * (w & 1) * 192 + (w >> 1);
+      uint32_t bits = 0;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) bits |= static_cast<uint32_t>(src[192 * b]) << (4 * b);
       o.fic_row[(sym - 1) * 384 + w] = bits;
     } else {
+      const uint2 x = *reinterpret_cast<const uint2*>(dec + 8 * w);
+      const uint32_t y0 = (x.x | (x.x >> 4)) & 0x00ff00ffu, y1 = (x.y | (x.y >> 4)) & 0x00ff00ffu;   // nibbles of bytes 0,1 and 2,3 joined
+      const uint32_t bits = ((y0 | (y0 >> 8)) & 0xffffu) | (((y1 | (y1 >> 8)) & 0xffffu) << 16);
       const int q = (sym - 4) / 18, sidx = (sym - 4) % 18;
       const int r = w / 24, wq = w % 24;
       const int delay = static_cast<int>(__brev(static_cast<unsigned>(r)) >> 28);   // map[r], misc.c:32
@@ -302,7 +307,7 @@ __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t*
       if (s < sym_end) {
         float2 v[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = make_float2(rail(raw[r] & 0xff), rail(raw[r] >> 8));
+        for (int r = 0; r < 8; ++r) v[r] = sample_f32(raw[r]);
         if (kNco && nco_inc) derotate(v, nco_inc, kNullSamples + kSymSamples * s + kCpSamples + static_cast<int>(threadIdx.x));
         // prefetch under the transform; unconditional (a branch here makes the compiler wait for the loads at once)
         if (kFast) load_symbol<true>(fast_src, stream, view, min(s + 1, sym_end - 1), raw);
@@ -323,7 +328,7 @@ __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t*
         if (h) fft2048_rest(v, exB, exA, tw, x, y);
         else fft2048_rest(v, exA, exB, tw, x, y);
 #if DABHIP_FUSED_SOFT
-        if (have_prev) decide(x, y, px, py, qk, s <= 3, h ? decB : decA, soft_scale(dcur, dprev));
+        if (have_prev) decide(x, y, px, py, qk, h ? decB : decA, soft_scale(dcur, dprev));
 #else
         float n1c[8];
 #if DABHIP_FUSED_GUARD
@@ -393,7 +398,9 @@ __global__ __launch_bounds__(kThreads, 3) void ofdm_demap_kernel(const uint8_t* 
     const int k = 2 * tid + 512 * (m >> 1) + (m & 1);
     const int c = (k >= 1 && k <= 768) ? k + 767 : (k >= 1280 ? k - 1280 : -1);
     qk[m] = c >= 0 ? qpsk_of_carrier[c] : -1;
-#if !DABHIP_FUSED_SOFT
+#if DABHIP_FUSED_SOFT
+    if (c >= 0) qk[m] = (qk[m] & 15) * 192 + (qk[m] >> 4);                              // where the value byte goes (decide)
+#else
     if (c >= 0) qk[m] = ((qk[m] & 15) * 6 + (qk[m] >> 9)) * 32 + ((qk[m] >> 4) & 31);   // where the decision byte goes (decide)
 #endif
   }
