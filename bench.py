@@ -40,6 +40,10 @@ REALTIME_FPS = 1000.0 / 24.0
 # VALU issue peak: 256 CUs x 4 SIMDs, one wave-instruction per 4 cycles (a quad-cycle) at 2.4 GHz
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 4
 VIT_VALU_PER_STEP = 129.0                  # VALU wave-instructions per trellis step of viterbi_fused_kernel<1> (PMC, see roofline_viterbi)
+# The same step priced in issue clocks per SIMD (profiles/r02_valu_rates.txt, tools/ubench/valu_rates.hip: wave64 instructions do not all
+# cost a quad-cycle on gfx950): 64 v_add_u32 at 2.56 + 32 v_pk_max_u16 at 4.28 + 13 v_perm_b32 at 4.2 + ~20 others at ~4.2
+VIT_ISSUE_CLOCKS_PER_STEP = 64 * 2.56 + 32 * 4.28 + 13 * 4.2 + 20 * 4.2
+HBM_STREAM_MIX_NOTE = "survivor records are written once and read once: compare with roofline.stream_ceiling.copy, not with the 8 TB/s of the data sheet"
 
 
 # ---- rank coordination ---------------------------------------------------------------------------------------------
@@ -298,6 +302,12 @@ def run_rank(args, coord):
                                      "note": "hard decisions whose fp32 margin lies inside the error band are re-decided in fp64 from the int8 samples "
                                              "(k_parity.hip); raw fp32 disagreement rate without it: profiles/r02_decision_audit.json"}
             fft = eng.fft_roofline(max(3, min(args.steps, 10)))
+            if rank == 0:
+                # what a bare streaming kernel with K2's read/write mix reaches on this device, over a footprint like K2's (untimed part)
+                try:
+                    extra["stream_ceiling"] = dab.stream_ceiling(local_rank, 4 << 30, 3)
+                except dab.DabhipError as e:
+                    extra["stream_ceiling"] = {"error": str(e)}
             if not args.soft and not args.no_parity_guard and not args.no_variants:
                 # the same job accepting raw fp32 decisions (guard off: the fused kernel without the guard's test)
                 eng.set_parity_guard(False)
@@ -373,6 +383,10 @@ def run_rank(args, coord):
                 "how": "dabhip_engine_fft_roofline: K2 alone over the frame list of the timed step (same resident IQ, %d TF per launch), "
                        "HIP events on the engine's stream; the step itself runs the fused transform + demap kernel" % (tfs // max(launches, 1)),
                 "achieved_vs_measured_copy_ceiling": achieved / 6290.0,
+                "stream_ceiling": dict(extra.get("stream_ceiling", {}), unit="GB/s",
+                                       note="bare grid-stride kernels of this library on this device, 4 GiB buffers, best of three grid sizes (k_probe.hip): "
+                                            "fill = write only, copy = 1 read : 1 written, k2_mix = 1 byte read per 4 written with K2's 16-byte nontemporal stores"),
+                "achieved_vs_k2_mix_stream": (achieved / extra["stream_ceiling"]["k2_mix"]) if extra.get("stream_ceiling", {}).get("k2_mix") else None,
                 "launches": launches, "tf_per_launch": tfs / max(launches, 1), "avg_launch_ms": ms / max(launches, 1),
                 "algorithmic_bytes_per_tf": FFT_BYTES_PER_TF}
         if stage:
@@ -388,8 +402,12 @@ def run_rank(args, coord):
                     "kernel": "viterbi_fused_kernel", "bound": "valu issue / hbm (survivor records)",
                     "valu": {"achieved": VIT_VALU_PER_STEP * wave_steps / t / 1e9, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
                              "frac": VIT_VALU_PER_STEP * wave_steps / t / 1e9 / VALU_PEAK_GINST},
+                    "issue_time": {"clocks_per_step": VIT_ISSUE_CLOCKS_PER_STEP, "frac": VIT_ISSUE_CLOCKS_PER_STEP * wave_steps / (256 * 4 * 2.4e9 * t),
+                                   "note": "the step's instructions priced at their measured issue clocks (add 2.56, packed max 4.28, permute 4.2), "
+                                           "over 1024 SIMDs at 2.4 GHz"},
                     "hbm": {"achieved": 1024.0 * wave_steps / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 1024.0 * wave_steps / t / 1e9 / HBM_PEAK_GBS,
-                            "note": "64 B of survivor records per 8 steps and code word, written once and read once"},
+                            "achieved_vs_copy_stream": (1024.0 * wave_steps / t / 1e9 / extra["stream_ceiling"]["copy"]) if extra.get("stream_ceiling", {}).get("copy") else None,
+                            "note": "64 B of survivor records per 8 steps and code word, written once and read once; " + HBM_STREAM_MIX_NOTE},
                     "trellis_steps_per_eti_frame": steps_per_frame, "avg_ms": stage["viterbi"]}
         if fused_off:
             out["two_kernel_ofdm_variant"] = fused_off

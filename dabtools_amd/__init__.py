@@ -104,6 +104,7 @@ _SIGNATURES = {
     "dabhip_stream_eti_drain": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dabhip_stream_set_afc": (C.c_int, [C.c_void_p, C.c_int]),
     "dabhip_stream_set_soft": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_stream_ceiling": (C.c_int, [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "dabhip_device_alloc": (C.c_void_p, [C.c_size_t, C.c_int]),
     "dabhip_device_free": (None, [C.c_void_p]),
     "dabhip_device_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
@@ -199,6 +200,13 @@ def synth_fibs(cfg, cif_index):
     buf = np.zeros(96, dtype=np.uint8)
     _need(lib().dabhip_synth_fibs(C.byref(cfg), cif_index, _p(buf)) == 96, "synth_fibs")
     return buf
+
+
+def stream_ceiling(device=0, nbytes=4 << 30, reps=3):
+    """GB/s a bare streaming kernel reaches on this device: {"fill", "copy", "k2_mix"} (k_probe.hip)."""
+    g = (C.c_double * 3)()
+    _need(lib().dabhip_stream_ceiling(device, nbytes, reps, g) == 0, "stream_ceiling")
+    return {"fill": g[0], "copy": g[1], "k2_mix": g[2]}
 
 
 class DeviceBuffer:

@@ -14,6 +14,7 @@
 #include "../../include/dabhip.h"
 #include "engine.hpp"
 #include "fifo_view.hpp"
+#include "kernels.hpp"
 
 using namespace dabhip;
 
@@ -663,6 +664,13 @@ extern "C" int64_t dabhip_stream_eti_drain(dabhip_stream* s, dabhip_eti_sink sin
   }
   return total;
 }
+extern "C" int dabhip_stream_ceiling(int device, size_t bytes, int reps, double* gbs)
+{
+  if (!gbs) { set_error("stream_ceiling: null argument"); return -1; }
+  if (dabhip::stream_ceiling(device, bytes, reps, gbs) != 0) { set_error("stream_ceiling: allocation or launch failed"); return -1; }
+  return 0;
+}
+
 // device memory for callers that bring no GPU runtime of their own (the batch entries take device pointers)
 extern "C" void* dabhip_device_alloc(size_t nbytes, int device)
 {

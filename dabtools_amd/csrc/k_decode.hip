@@ -466,17 +466,23 @@ __device__ __forceinline__ void chain_back8(const uint4* my_rec, int nsteps, con
   };
   const int nfull = nsteps >> 3, r = nsteps & 7;
   if (r) consume(my_rec[static_cast<size_t>(nfull) * 256].x & 255u, 8 * nfull, r - 1);
-  // records are fetched 2 blocks (16 steps) at a time (their addresses do not depend on the path)
-  for (int b_hi = nfull - 1; b_hi >= 0; b_hi -= 2) {
-    uint4 rec[2][4];
+  // records are fetched kCbBatch blocks at a time (their addresses do not depend on the path): a wave in its chain-back is a
+  // chain of memory round trips (the records of a long code word are 2.4 MB per wave and come back from HBM), and the path
+  // metrics' registers are free by now
+#ifndef DABHIP_CB_BATCH
+#define DABHIP_CB_BATCH 6
+#endif
+  constexpr int kCbBatch = DABHIP_CB_BATCH;
+  for (int b_hi = nfull - 1; b_hi >= 0; b_hi -= kCbBatch) {
+    uint4 rec[kCbBatch][4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < kCbBatch; ++u) {
       const size_t b = static_cast<size_t>(max(b_hi - u, 0));
 #pragma unroll
       for (int j = 0; j < 4; ++j) rec[u][j] = my_rec[b * 256 + 64 * j];
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < kCbBatch; ++u) {
       const int b = b_hi - u;
       if (b >= 0) consume(survivor_byte(rec[u], state), 8 * b, 7);
     }

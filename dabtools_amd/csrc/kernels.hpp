@@ -80,4 +80,7 @@ hipError_t launch_fib_crc(const uint8_t* fibs, int nfib, const uint16_t* crc_tab
 hipError_t launch_eti_finish(const EtiFrameMeta* meta, int nframes, const uint8_t* headers, int header_stride, const uint8_t* fibs,
                              const uint16_t* crc_tab, const uint16_t* shift_cols, uint8_t* eti, hipStream_t stream);
 
+// k_probe.hip: streaming rates of this device (fill, copy, K2's read/write mix) in GB/s -- bench.py's yardstick beside the K2 figure
+int stream_ceiling(int device, size_t bytes, int reps, double* gbs);
+
 }  // namespace dabhip

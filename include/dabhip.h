@@ -163,6 +163,10 @@ int dabhip_stream_set_parity_guard(dabhip_stream *s, int enable);   /* default o
 void *dabhip_host_alloc(size_t nbytes);
 void dabhip_host_free(void *p);
 
+/* Streaming rates of the device, for reading the K2 roofline figure against what a bare kernel reaches (not on the data path):
+ * gbs[0] fill, gbs[1] copy, gbs[2] K2's mix (1 byte read per 4 written), GB/s of bytes moved, over buffers of `bytes` bytes. */
+int dabhip_stream_ceiling(int device, size_t bytes, int reps, double *gbs);
+
 /* Device memory for callers without a GPU runtime of their own: the batch entries (dabhip_engine_decode with on_device,
  * dabhip_synth_generate_device, the stage entries) take plain device pointers.  copy: to_device != 0: host -> device. */
 void *dabhip_device_alloc(size_t nbytes, int device);
