@@ -80,13 +80,15 @@ __device__ __forceinline__ void fft2048_rest(float2 (&v)[8], float2* bufP, float
 // Parity guard (k_parity.hip): a decision whose margin is inside the fp32 error band (dc, dp = error bounds of this and of the
 // previous symbol's bins) is listed for the fp64 re-decision that follows this kernel.  The exact per-bin test runs inline and
 // straight-line, its outcome OR-ed into one flag per thread; the (rare) thread with a hit repeats the tests to find the bins.
-// |bin|_1 of the previous symbol is carried (n1p), the test itself is device_types.hpp's guard_threshold.
-// The kernel runs at its register limit (168 VGPRs, three waves per SIMD; two waves cost 40 %).  Measured alternatives, all
-// slower (7.0 .. 13 ms against 6.5): the list append inline per bin; a symbol-wide threshold in the loop with the exact test in a
-// cold block (inlined, looped over a select chain, as a real call, or on an LDS parking area); a wave-level ballot; v_min3
-// chains; candidate records filtered by a second kernel; exponent bytes examined at flush time; a per-thread threshold (largest
-// component of the thread's own bins) with the exact test in a cold block; the guard flag as a template parameter; stage-2
-// twiddles from LDS to free registers.  The energy reduction itself is free.
+// The test itself is device_types.hpp's guard_threshold; |bin|_1 of both symbols is one instruction each (carrying the previous
+// symbol's costs eight registers, which the kernel does not have).
+// Measured alternatives from the time the kernel ran three waves per SIMD, all slower (7.0 .. 13 ms against 6.5): the list append
+// inline per bin; a symbol-wide threshold in the loop with the exact test in a cold block (inlined, looped over a select chain, as
+// a real call, or on an LDS parking area); a wave-level ballot; v_min3 chains; candidate records filtered by a second kernel;
+// exponent bytes examined at flush time; a per-thread threshold (largest component of the thread's own bins) with the exact test
+// in a cold block; the guard flag as a template parameter; stage-2 twiddles from LDS to free registers.  What did pay (6.5 ->
+// 4.9 ms): one decision layout for FIC and MSC symbols (no per-symbol address selects), the flag instead of a per-bin mask, the
+// symbol energy summed with DPP adds instead of __shfl_xor steps (1 ms by itself), cmul in two packed instructions, four waves.
 struct FusedGuard {
   GuardArgs g;
   unsigned frame;        // index of this TF in the frame list
@@ -101,8 +103,7 @@ __device__ __forceinline__ float l1norm(const float2 v)
 #endif
 #if !DABHIP_FUSED_SOFT
 __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4], const float2 (&px)[4], const float2 (&py)[4],
-                                       const int (&ak)[8], uint8_t* dec, const FusedGuard& guard, int sym, float dc, float dp,
-                                       const float (&n1c)[8], const float (&n1p)[8])
+                                       const int (&ak)[8], uint8_t* dec, const FusedGuard& guard, int sym, float dc, float dp)
 {
 #if DABHIP_FUSED_GUARD
   bool any = false;
@@ -117,7 +118,7 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
       dec[ak[m] + 96] = (im > 0.0f) ? 1 : 0;              // input_sdr.c:158
 #if DABHIP_FUSED_GUARD
 #ifndef DABHIP_PROBE_NOTEST
-      any |= fminf(fabsf(re), fabsf(im)) < guard_threshold(n1c[m], n1p[m], dc, dp);
+      any |= fminf(fabsf(re), fabsf(im)) < guard_threshold(l1norm(cur), l1norm(prev), dc, dp);
 #endif
 #endif
     }
@@ -129,7 +130,7 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
     for (int m = 0; m < 8; ++m) {
       const float2 cur = (m & 1) ? y[m >> 1] : x[m >> 1], prev = (m & 1) ? py[m >> 1] : px[m >> 1];
       const float re = cur.x * prev.x + cur.y * prev.y, im = cur.x * prev.y - cur.y * prev.x;
-      hits |= (ak[m] >= 0 && fminf(fabsf(re), fabsf(im)) < guard_threshold(n1c[m], n1p[m], dc, dp) ? 1u : 0u) << m;
+      hits |= (ak[m] >= 0 && fminf(fabsf(re), fabsf(im)) < guard_threshold(l1norm(cur), l1norm(prev), dc, dp) ? 1u : 0u) << m;
     }
     while (hits) {
       const unsigned m = __ffs(hits) - 1;
@@ -209,18 +210,24 @@ __device__ __forceinline__ uint32_t pack_word(const uint8_t* dec, int t)
 
 // A symbol whose window reaches into the stale tail of the reference's frame buffer (symbol 75 after a negative timing
 // shift, frames after a coarse resync): its samples come through the view, one at a time, via an LDS staging row, so that
-// this rare path adds no register pressure to the symbol loop.
-__device__ __forceinline__ void load_symbol_view(const uint8_t* stream, const FrameView& view, int sym, uint16_t* stage, unsigned (&raw)[8])
+// this rare path adds no register pressure to the symbol loop.  The row is the decision array that is idle at that moment (the
+// one the symbol in flight will fill at its end; its previous content left two barriers ago), used in two halves of 2 KB;
+// every thread reads back only what it wrote itself.
+__device__ __forceinline__ void load_symbol_view(const uint8_t* stream, const FrameView& view, int sym, uint8_t* idle_dec, unsigned (&raw)[8])
 {
   const int tid = threadIdx.x;
   const int start = 2 * (kNullSamples + kSymSamples * sym + kCpSamples);
-#pragma unroll 1
-  for (int r = 0; r < 8; ++r) {
-    const int p = start + 2 * (tid + 256 * r);
-    stage[tid + 256 * r] = static_cast<uint16_t>(view_byte(stream, view, p) | (view_byte(stream, view, p + 1) << 8));
-  }
+  uint16_t* stage = reinterpret_cast<uint16_t*>(idle_dec);
 #pragma unroll
-  for (int r = 0; r < 8; ++r) raw[r] = stage[tid + 256 * r];     // each thread reads back what it wrote: no barrier
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+      const int p = start + 2 * (tid + 256 * (4 * half + r));
+      stage[tid + 256 * r] = static_cast<uint16_t>(view_byte(stream, view, p) | (view_byte(stream, view, p + 1) << 8));
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) raw[4 * half + r] = stage[tid + 256 * r];
+  }
 }
 
 struct FusedOut {
@@ -284,8 +291,8 @@ __device__ __forceinline__ void flush_symbol(const uint8_t* dec, int sym, const 
 template <bool kFast, bool kNco>
 __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t* stream, const FrameView& view, int sym_begin, int sym_end,
                                               bool have_prev, float2 (&px)[4], float2 (&py)[4], float2* exA, float2* exB, uint8_t* decA,
-                                              uint8_t* decB, uint16_t* stage, const Twiddles& tw, const int (&qk)[8], uint32_t nco_inc, const FusedOut& out,
-                                              const FusedGuard& guard, int* esum, float& dprev, float (&n1p)[8])
+                                              uint8_t* decB, const Twiddles& tw, const int (&qk)[8], uint32_t nco_inc, const FusedOut& out,
+                                              const FusedGuard& guard, int* esum, float& dprev)
 {
   if (sym_begin >= sym_end) return;
 #if DABHIP_FUSED_SOFT
@@ -298,7 +305,7 @@ __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t*
   bool have_out = false;                                // decisions of the previous symbol wait in the other dec array
   unsigned raw[8];
   if (kFast) load_symbol<true>(fast_src, stream, view, sym_begin, raw);
-  else load_symbol_view(stream, view, sym_begin, stage, raw);
+  else load_symbol_view(stream, view, sym_begin, decA, raw);
   // two symbols per trip: the LDS buffers swap roles every symbol, so the trip body sees them at fixed places
   for (int sym = sym_begin; sym < sym_end; sym += 2) {
 #pragma unroll
@@ -311,7 +318,7 @@ __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t*
         if (kNco && nco_inc) derotate(v, nco_inc, kNullSamples + kSymSamples * s + kCpSamples + static_cast<int>(threadIdx.x));
         // prefetch under the transform; unconditional (a branch here makes the compiler wait for the loads at once)
         if (kFast) load_symbol<true>(fast_src, stream, view, min(s + 1, sym_end - 1), raw);
-        else load_symbol_view(stream, view, min(s + 1, sym_end - 1), stage, raw);
+        else load_symbol_view(stream, view, min(s + 1, sym_end - 1), h ? decB : decA, raw);
         float2 x[4], y[4];
 #ifndef DABHIP_PROBE_NOENERGY
         if (guarded) symbol_energy_part(v, esum + 4 * h);
@@ -330,16 +337,7 @@ __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t*
 #if DABHIP_FUSED_SOFT
         if (have_prev) decide(x, y, px, py, qk, h ? decB : decA, soft_scale(dcur, dprev));
 #else
-        float n1c[8];
-#if DABHIP_FUSED_GUARD
-#pragma unroll
-        for (int m = 0; m < 8; ++m) n1c[m] = l1norm((m & 1) ? y[m >> 1] : x[m >> 1]);
-#endif
-        if (have_prev) decide(x, y, px, py, qk, h ? decB : decA, guard, s, dcur, dprev, n1c, n1p);
-#if DABHIP_FUSED_GUARD
-#pragma unroll
-        for (int m = 0; m < 8; ++m) n1p[m] = n1c[m];
-#endif
+        if (have_prev) decide(x, y, px, py, qk, h ? decB : decA, guard, s, dcur, dprev);
 #endif
         dprev = dcur;
         have_out = have_prev;
@@ -357,8 +355,14 @@ __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t*
 
 // grid = nparts * nframes (parts part0 .. part0 + nparts - 1 of every frame): workgroup part p of a frame demaps data symbols max(1, 19 p) .. 19 p + 18 (parts 1..3 transform symbol
 // 19 p - 1 once more as their differential reference)
+// Four workgroups per CU (16 waves, 128 VGPRs each, 39.9 KB of LDS each): the symbol loop is a chain of LDS round trips and barriers,
+// and a fourth wave per SIMD hides more of them than the handful of spilled registers costs (guarded 5.3 -> 4.9 ms per 16 k TF, plain
+// 4.5 -> 4.1; measured with three: DABHIP_FUSED_WG_PER_CU=3).
+#ifndef DABHIP_FUSED_WG_PER_CU
+#define DABHIP_FUSED_WG_PER_CU 4
+#endif
 template <bool kNco>
-__global__ __launch_bounds__(kThreads, 3) void ofdm_demap_kernel(const uint8_t* const* __restrict__ iq, const CallDesc* __restrict__ descs,
+__global__ __launch_bounds__(kThreads, DABHIP_FUSED_WG_PER_CU) void ofdm_demap_kernel(const uint8_t* const* __restrict__ iq, const CallDesc* __restrict__ descs,
                                                                  int max_calls, const int2* __restrict__ frames, int first,
                                                                  const float2* __restrict__ tw_global, const int* __restrict__ frame_slot,
                                                                  const int* __restrict__ frame_cif_row,
@@ -368,8 +372,7 @@ __global__ __launch_bounds__(kThreads, 3) void ofdm_demap_kernel(const uint8_t* 
 {
   __shared__ __attribute__((aligned(16))) float2 exA[kExSize];
   __shared__ __attribute__((aligned(16))) float2 exB[kExSize];
-  __shared__ __attribute__((aligned(16))) uint8_t decA[kBitsPerSym], decB[kBitsPerSym];
-  __shared__ uint16_t stage[2048];
+  __shared__ __attribute__((aligned(16))) uint8_t decA[kBitsPerSym], decB[kBitsPerSym];   // 3072 B each
   __shared__ FrameView view;
   __shared__ float2 tw3[4 * 8];
   __shared__ __attribute__((aligned(16))) int esum[8];  // per-wave parts of the symbol energy, two symbols in flight
@@ -427,9 +430,8 @@ __global__ __launch_bounds__(kThreads, 3) void ofdm_demap_kernel(const uint8_t* 
   FusedGuard guard{gargs, static_cast<unsigned>(first + j)};
   if (nco_inc) guard.g.delta = nullptr;
   float dprev = 0.0f;                                   // error bound of the previous symbol's bins
-  float n1p[8] = {};                                    // |bin|_1 of the previous symbol's bins (guard)
-  fused_symbols<true, kNco>(src, stream, view, sym_begin, fast_end, false, px, py, exA, exB, decA, decB, stage, tw, qk, nco_inc, out, guard, esum, dprev, n1p);
-  fused_symbols<false, kNco>(src, stream, view, fast_end, sym_end, fast_end > sym_begin, px, py, exA, exB, decA, decB, stage, tw, qk, nco_inc, out, guard, esum, dprev, n1p);
+  fused_symbols<true, kNco>(src, stream, view, sym_begin, fast_end, false, px, py, exA, exB, decA, decB, tw, qk, nco_inc, out, guard, esum, dprev);
+  fused_symbols<false, kNco>(src, stream, view, fast_end, sym_end, fast_end > sym_begin, px, py, exA, exB, decA, decB, tw, qk, nco_inc, out, guard, esum, dprev);
 }
 
 }  // namespace
