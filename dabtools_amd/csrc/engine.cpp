@@ -71,7 +71,7 @@ Engine::Engine(int device) : device_(device)
   if (!check(hipStreamCreate(&stream_), "hipStreamCreate") || !check(hipStreamCreate(&copy_stream_), "hipStreamCreate")) return;
   for (auto& e : ev_)
     if (!check(hipEventCreate(&e), "hipEventCreate")) return;
-  if (!check(hipEventCreate(&ev_upload_), "hipEventCreate") || !check(hipEventCreate(&ev_fic_), "hipEventCreate") ||
+  if (!check(hipEventCreate(&ev_upload_), "hipEventCreate") || !check(hipEventCreate(&ev_fic_), "hipEventCreate") || !check(hipEventCreate(&ev_fic_done_), "hipEventCreate") ||
       !check(hipEventCreate(&ev_fibs_), "hipEventCreate") || !check(hipEventCreate(&ev_part0_), "hipEventCreate"))
     return;
   for (auto& e : ev_msc_)
@@ -137,6 +137,7 @@ Engine::~Engine()
   for (auto& e : chunk_ev_) (void)hipEventDestroy(e);
   if (ev_upload_) (void)hipEventDestroy(ev_upload_);
   if (ev_fic_) (void)hipEventDestroy(ev_fic_);
+  if (ev_fic_done_) (void)hipEventDestroy(ev_fic_done_);
   if (ev_fibs_) (void)hipEventDestroy(ev_fibs_);
   if (ev_part0_) (void)hipEventDestroy(ev_part0_);
   for (auto& e : ev_msc_)
@@ -347,16 +348,22 @@ bool Engine::fic_decode_slots_async(int first, int n, uint8_t* fibs_host, uint8_
   std::vector<WaveGroup> groups;
   const int64_t dr = (plans_[pid].nsteps + 7) / 8 * 8;
   for (int g = 0; g < ntiles; ++g) groups.push_back(WaveGroup{pid, 64 * g, std::min(64, nblocks - 64 * g), plans_[pid].nsteps, 0, g * dr});
-  if (!d_plans_.upload(plans_, stream_) || !d_groups_.upload(groups, stream_) || !d_job_ids_.upload(ids, stream_) ||
+  // The FIC kernels run on the side stream as well, behind what the main stream has queued so far (the FIC bits): 1008 waves of 774
+  // steps fill a quarter of the chip's wave slots for 0.3 ms, so the main stream goes straight on with the rest of the OFDM stage
+  // and the two share the GPU.  Everything that later touches these buffers on the main stream waits for the side stream
+  // (ev_upload_ in decode_impl, the synchronising callers elsewhere).
+  hipStream_t ks = copy;
+  if (ks != stream_ && (!check(hipEventRecord(ev_fic_, stream_), "fic event") || !check(hipStreamWaitEvent(ks, ev_fic_, 0), "fic event"))) return false;
+  if (!d_plans_.upload(plans_, ks) || !d_groups_.upload(groups, ks) || !d_job_ids_.upload(ids, ks) ||
       !d_grouped_.reserve(static_cast<size_t>(ntiles) * block_words * 64) || !d_decisions_.reserve(static_cast<size_t>(ntiles) * dr * 64))
     return false;
-  if (!check(launch_fic_group(d_fic_bits_.get(), 4 * first, nblocks, block_words, d_grouped_.get(), stream_), "fic group launch") ||
+  if (!check(launch_fic_group(d_fic_bits_.get(), 4 * first, nblocks, block_words, d_grouped_.get(), ks), "fic group launch") ||
       !check(launch_viterbi_fused(soft_bits_, d_groups_.get(), ntiles, d_job_ids_.get(), d_plans_.get(), d_grouped_.get(), block_words,
-                                  d_decisions_.get(), d_prbs_.get(), d_fibs_.get(), 96, stream_),
+                                  d_decisions_.get(), d_prbs_.get(), d_fibs_.get(), 96, ks),
              "fic viterbi launch"))
     return false;
-  if (!check(launch_fib_crc(d_fibs_.get() + static_cast<size_t>(first) * 384, n * 12, d_crc_tab_.get(), d_fib_ok_.get() + static_cast<size_t>(first) * 12, stream_), "fib crc launch")) return false;
-  if (copy != stream_ && (!check(hipEventRecord(ev_fic_, stream_), "fic event") || !check(hipStreamWaitEvent(copy, ev_fic_, 0), "fic event"))) return false;
+  if (!check(launch_fib_crc(d_fibs_.get() + static_cast<size_t>(first) * 384, n * 12, d_crc_tab_.get(), d_fib_ok_.get() + static_cast<size_t>(first) * 12, ks), "fib crc launch")) return false;
+  if (!check(hipEventRecord(ev_fic_done_, ks), "fic event")) return false;
   return check(hipMemcpyAsync(fibs_host, d_fibs_.get() + static_cast<size_t>(first) * 384, static_cast<size_t>(n) * 384, hipMemcpyDeviceToHost, copy), "fib download") &&
          check(hipMemcpyAsync(ok_host, d_fib_ok_.get() + static_cast<size_t>(first) * 12, static_cast<size_t>(n) * 12, hipMemcpyDeviceToHost, copy), "fib flag download") &&
          check(hipEventRecord(ev_fibs_, copy), "fib download event");
@@ -802,8 +809,8 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   // decisions, set_fused(0)): a pre-pass transforms symbols 0..3 once more.
   std::unique_lock<std::mutex> heavy;
   if (heavy_mu_) heavy = std::unique_lock<std::mutex>(*heavy_mu_);
-  const int chunk = std::min(ntf, kFftChunkTfs);
   const bool one_kernel = fused_;                        // hard (with or without the guard) and soft decisions alike
+  const int chunk = one_kernel ? std::max(ntf, 1) : std::min(ntf, kFftChunkTfs);   // only the spectra buffer of the two-kernel stage calls for chunks
   if (!one_kernel && !d_spectra_.reserve(static_cast<size_t>(chunk) * kSymbolsPerTf * 2048)) return -1;
   if (!h_fibs_.resize(static_cast<size_t>(nslots) * 384) || !h_fib_ok_.resize(static_cast<size_t>(nslots) * 12)) return -1;
   uint8_t* const fibs = h_fibs_.data();
@@ -854,7 +861,6 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   // FIC decode kernels on the main stream, the FIB download on the side stream: the OFDM stage is queued right behind
   // the FIC kernels and starts without waiting for the download or for the host
   if (!fic_decode_slots_async(0, nslots, fibs, ok, copy_stream_)) return -1;      // carried slots are decoded again: their FIBs are read by K5
-  (void)hipEventRecord(ev_[0], stream_);
 
   // K2 + K2b in chunks (they share one spectra buffer; stream order keeps them apart), timed with per-chunk events
   bool gpu_ok = true;
@@ -887,7 +893,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   {
     float part0_ms = 0, fic_ms = 0;
     (void)hipEventElapsedTime(&part0_ms, ev_[3], ev_part0_);
-    (void)hipEventElapsedTime(&fic_ms, ev_part0_, ev_[0]);
+    (void)hipEventElapsedTime(&fic_ms, ev_part0_, ev_fic_done_);   // beside the OFDM stage since round 2: no longer a term of the step
     times_.fic = fic_ms + (one_kernel ? 0.0f : part0_ms);   // the pre-pass of the two-kernel stage is FIC work; part 0 of the fused kernel is OFDM work
     if (one_kernel) times_.fft += part0_ms;
   }

@@ -263,7 +263,7 @@ class Engine {
   int device_ = 0;
   hipStream_t stream_ = nullptr, copy_stream_ = nullptr;   // copy_stream_: work-list uploads from the control-plane thread
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_upload_ = nullptr, ev_fic_ = nullptr, ev_fibs_ = nullptr, ev_part0_ = nullptr;
+  hipEvent_t ev_upload_ = nullptr, ev_fic_ = nullptr, ev_fic_done_ = nullptr, ev_fibs_ = nullptr, ev_part0_ = nullptr;
   hipEvent_t ev_msc_[4] = {nullptr, nullptr, nullptr, nullptr};
   bool msc_queued_ = false;
   std::vector<hipEvent_t> chunk_ev_;
