@@ -72,6 +72,7 @@ Engine::Engine(int device) : device_(device)
   for (auto& e : ev_)
     if (!check(hipEventCreate(&e), "hipEventCreate")) return;
   if (!check(hipEventCreate(&ev_upload_), "hipEventCreate") || !check(hipEventCreate(&ev_fic_), "hipEventCreate") || !check(hipEventCreate(&ev_fic_done_), "hipEventCreate") ||
+      !check(hipEventCreate(&ev_chain_), "hipEventCreate") || !check(hipEventCreate(&ev_info_), "hipEventCreate") ||
       !check(hipEventCreate(&ev_fibs_), "hipEventCreate") || !check(hipEventCreate(&ev_part0_), "hipEventCreate"))
     return;
   for (auto& e : ev_msc_)
@@ -138,6 +139,8 @@ Engine::~Engine()
   if (ev_upload_) (void)hipEventDestroy(ev_upload_);
   if (ev_fic_) (void)hipEventDestroy(ev_fic_);
   if (ev_fic_done_) (void)hipEventDestroy(ev_fic_done_);
+  if (ev_chain_) (void)hipEventDestroy(ev_chain_);
+  if (ev_info_) (void)hipEventDestroy(ev_info_);
   if (ev_fibs_) (void)hipEventDestroy(ev_fibs_);
   if (ev_part0_) (void)hipEventDestroy(ev_part0_);
   for (auto& e : ev_msc_)
@@ -628,8 +631,8 @@ bool Engine::begin_decode(int nstreams, bool cont)
   eti_count_.assign(nstreams, 0);
   total_eti_ = 0;
   if (!cont) {
-    planes_.assign(nstreams, ControlPlane());
-    for (ControlPlane& p : planes_) p.set_filter(subch_keep_);
+    planes_.resize(nstreams);                  // re-initialised by the control-plane pass itself (planes_fresh_): 0.2 ms that would otherwise delay K1
+    planes_fresh_ = true;
     carry_keep_.assign(nstreams, 0);
     prev_used_.assign(nstreams, 0);
     calls_done_.assign(nstreams, 0);
@@ -642,7 +645,8 @@ bool Engine::begin_decode(int nstreams, bool cont)
 
 // K1 over the calls that became complete: stages pointers / sizes / states, launches the scan, brings back {status, ordinal}
 // per call and the front-end states (main stream, awaited) and the full descriptors (side stream, awaited by the caller's guard)
-bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont, bool full_scan)
+bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont, bool full_scan,
+                          const std::function<bool()>& layout)
 {
   const auto wall0 = std::chrono::steady_clock::now();
   if (!h_ptrs_.resize(nstreams) || !h_nb_.resize(nstreams)) return false;   // page-locked staging: asynchronous uploads
@@ -704,6 +708,11 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
         !check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), nstreams, max_calls_, -1, -1,
                                 d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), 0, stream_, true),
                "sync chain launch") ||
+        // {status, ordinal} of every call are final once the chain is through (a stream that breaks its assumption is scanned again
+        // below): they come back on the side stream while the verification runs, and the caller lays the frames out beside it
+        !check(hipEventRecord(ev_chain_, stream_), "chain event") || !check(hipStreamWaitEvent(copy_stream_, ev_chain_, 0), "chain event") ||
+        !check(hipMemcpyAsync(h_info_.data(), d_info_.get(), ndesc * sizeof(int2), hipMemcpyDeviceToHost, copy_stream_), "call info download") ||
+        !check(hipEventRecord(ev_info_, copy_stream_), "call info event") ||
         !check(launch_sync_verify(d_iq_ptrs_.get(), d_nbytes_.get(), d_calls_before_.get(), d_states_.get(), d_descs_.get(), nstreams, max_calls_,
                                   d_tw2048_.get(), d_prs_.get(), d_viol_.get(), false, stream_),
                "sync verify launch") ||
@@ -723,7 +732,9 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
            check(hipMemcpyAsync(states, d_states_.get(), nstreams * sizeof(StreamState), hipMemcpyDeviceToHost, stream_), "state download") &&
            check(hipStreamSynchronize(stream_), "sync scan");
   };
+  if (split_scan && (!check(hipEventSynchronize(ev_info_), "call info") || !layout())) return false;
   if (!fetch()) return false;
+  if (!split_scan && !layout()) return false;
   if (split_scan) {
     std::vector<int> redo;
     for (int b = 0; b < nstreams; ++b)
@@ -736,7 +747,7 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
                  "sync rescan launch"))
         return false;
       (void)hipEventRecord(ev_[1], stream_);
-      if (!fetch()) return false;
+      if (!fetch() || !layout()) return false;             // the frames of those streams may have changed
     }
   }
   if (!check(hipStreamWaitEvent(copy_stream_, ev_[1], 0), "desc download") ||
@@ -755,6 +766,8 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   if (!check(hipSetDevice(device_), "hipSetDevice")) return -1;
   const auto wall0 = std::chrono::steady_clock::now();
   auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+  static const bool trace_host = std::getenv("DABHIP_TRACE_HOST") != nullptr;
+  auto mark = [&](const char* what) { if (trace_host) std::fprintf(stderr, "[host] %-18s %8.3f ms\n", what, since(wall0)); };
   times_ = StageTimes{};
   fft_launches_ = fft_tfs_ = 0;
   fft_ms_ = 0;
@@ -765,44 +778,53 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     hipStream_t s;
     ~SideStreamGuard() { (void)hipStreamSynchronize(s); }
   } side_guard{copy_stream_};
-  if (!scan_streams(iq, nbytes, nstreams, on_device, cont, full_scan)) return -1;
-  times_.setup = scan_setup_ms_;
-  const size_t ndesc = static_cast<size_t>(nstreams) * max_calls_;
-
+  mark("begin_decode done");
   // frame list: demodulated TFs, stream-major.  Slots and logical CIF rows of a stream: first the ones carried over from
-  // the previous segment of a session (the last <= 4 TFs), then this segment's.
-  const auto tfr = std::chrono::steady_clock::now();
+  // the previous segment of a session (the last <= 4 TFs), then this segment's.  Built (and uploaded) by the scan as soon as the
+  // calls' {status, ordinal} are known, i.e. while K1's verification kernel still runs.
   std::vector<int> tf_base(nstreams + 1, 0), row_base(nstreams), fib_base(nstreams), nnew(nstreams, 0);
-  if (!h_frames_.resize(ndesc) || !h_frame_slot_.resize(ndesc) || !h_frame_cif_row_.resize(ndesc)) return -1;   // page-locked: uploaded asynchronously
   int next_row = 0, ntf_new = 0;
-  for (int b = 0; b < nstreams; ++b) {
-    const int keep = carry_keep_[b], j0 = ntf_new;
-    const int ncalls = static_cast<int>(nbytes[b] / kChunkBytes) - calls_done_[b];
-    row_base[b] = next_row + kRowLead;      // each stream gets 15 lead-in rows for the scatter of its first CIFs
-    for (int k = 0; k < ncalls; ++k) {
-      const int2 d = h_info_[static_cast<size_t>(b) * max_calls_ + k];     // {status, ordinal}
-      if (d.x == 2) {
-        const int local = keep + (d.y - ord_done_[b]);
-        h_frames_[ntf_new] = make_int2(b, k);
-        h_frame_slot_[ntf_new] = tf_base[b] + local;
-        h_frame_cif_row_[ntf_new] = row_base[b] + 4 * local;
-        ++ntf_new;
+  float frames_ms = 0;
+  auto layout = [&]() -> bool {
+    const auto tfr = std::chrono::steady_clock::now();
+    const size_t nd = static_cast<size_t>(nstreams) * max_calls_;
+    if (!h_frames_.resize(nd) || !h_frame_slot_.resize(nd) || !h_frame_cif_row_.resize(nd)) return false;   // page-locked: uploaded asynchronously
+    next_row = 0;
+    ntf_new = 0;
+    tf_base[0] = 0;
+    for (int b = 0; b < nstreams; ++b) {
+      const int keep = carry_keep_[b], j0 = ntf_new;
+      const int ncalls = static_cast<int>(nbytes[b] / kChunkBytes) - calls_done_[b];
+      row_base[b] = next_row + kRowLead;      // each stream gets 15 lead-in rows for the scatter of its first CIFs
+      for (int k = 0; k < ncalls; ++k) {
+        const int2 d = h_info_[static_cast<size_t>(b) * max_calls_ + k];     // {status, ordinal}
+        if (d.x == 2) {
+          const int local = keep + (d.y - ord_done_[b]);
+          h_frames_[ntf_new] = make_int2(b, k);
+          h_frame_slot_[ntf_new] = tf_base[b] + local;
+          h_frame_cif_row_[ntf_new] = row_base[b] + 4 * local;
+          ++ntf_new;
+        }
       }
+      nnew[b] = ntf_new - j0;
+      tf_base[b + 1] = tf_base[b] + keep + nnew[b];
+      fib_base[b] = 4 * tf_base[b];
+      next_row += kRowLead + 4 * (keep + nnew[b]);
     }
-    nnew[b] = ntf_new - j0;
-    tf_base[b + 1] = tf_base[b] + keep + nnew[b];
-    fib_base[b] = 4 * tf_base[b];
-    next_row += kRowLead + 4 * (keep + nnew[b]);
-  }
+    const bool up = ntf_new == 0 || (d_frames_.upload(h_frames_.data(), ntf_new, stream_) && d_frame_slot_.upload(h_frame_slot_.data(), ntf_new, stream_) &&
+                                     d_frame_cif_row_.upload(h_frame_cif_row_.data(), ntf_new, stream_));
+    frames_ms += since(tfr);
+    return up;
+  };
+  if (!scan_streams(iq, nbytes, nstreams, on_device, cont, full_scan, layout)) return -1;
+  mark("scan done");
+  times_.setup = scan_setup_ms_;
   for (int b = 0; b < nstreams; ++b) calls_done_[b] = std::max(calls_done_[b], static_cast<int>(nbytes[b] / kChunkBytes));
   const int ntf = ntf_new, nslots = tf_base[nstreams];
   last_ntf_ = ntf;
   if (ntf == 0) return 0;                   // nothing demodulated: layout and carried data stay as they are
-  if (!carry_and_reserve(tf_base, row_base, nslots, next_row + 1) || !d_frames_.upload(h_frames_.data(), ntf, stream_) ||
-      !d_frame_slot_.upload(h_frame_slot_.data(), ntf, stream_) || !d_frame_cif_row_.upload(h_frame_cif_row_.data(), ntf, stream_))
-    return -1;
-
-  times_.frames = since(tfr);
+  if (!carry_and_reserve(tf_base, row_base, nslots, next_row + 1)) return -1;
+  times_.frames = frames_ms;
   // K3 first, so that the FIC is decoded -- and the host control plane can run -- while the bulk of the OFDM stage still
   // occupies the GPU.  One-kernel OFDM stage: its part 0 (symbols 0..18: the phase reference, the FIC and the first 15 MSC
   // symbols) of every TF runs now, parts 1..3 after the FIC decode: no transform is done twice.  Two-kernel stage (soft
@@ -910,7 +932,12 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   std::thread host([&]() {
     (void)hipSetDevice(device_);               // the current device is per thread
     const auto t0 = std::chrono::steady_clock::now();
+    const bool fresh = planes_fresh_;
     pool_->parallel_for(nstreams, [&](int b) {
+      if (fresh) {
+        planes[b] = ControlPlane();
+        planes[b].set_filter(subch_keep_);
+      }
       stream_jobs[b].reserve(static_cast<size_t>(4) * nnew[b]);
       planes[b].rebase(4 * (prev_used_[b] - carry_keep_[b]));   // CIF numbering of this segment's layout
       for (int s = tf_base[b] + carry_keep_[b]; s < tf_base[b + 1]; ++s)
@@ -926,6 +953,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
       eti_count_[b] = static_cast<int64_t>(stream_jobs[b].size());
       total_eti_ += eti_count_[b];
     }
+    planes_fresh_ = false;
     times_.control = since(t0);
     const auto t1 = std::chrono::steady_clock::now();
     // the work lists go up on the side stream while the OFDM stage still runs on the main one
@@ -940,7 +968,9 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   host.join();
   if (gpu_ok && host_ok)
     gpu_ok = check(hipStreamWaitEvent(stream_, ev_upload_, 0), "work list wait") && msc_launch_async(work);
+  mark("all queued");
   const bool drained = check(hipStreamSynchronize(stream_), "decode");      // also on the error paths: nothing may stay in flight
+  mark("stream drained");
   if (heavy.owns_lock()) heavy.unlock();
   if (!gpu_ok || !drained) return -1;
   if (!host_ok) { set_error(host_error); return -1; }
@@ -965,6 +995,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   prev_tf_base_ = tf_base;
   prev_row_base_ = row_base;
   times_.wall = since(wall0);
+  mark("return");
   return total_eti_;
 }
 

@@ -14,6 +14,7 @@
 
 #include <cstdint>
 #include <map>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -234,7 +235,9 @@ class Engine {
   bool hard_only(const char* what);
   int64_t decode_impl(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont, bool full_scan = false);
   bool begin_decode(int nstreams, bool cont);
-  bool scan_streams(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont, bool full_scan);
+  // layout: called when the calls' {status, ordinal} are on the host (h_info_) -- early in the split scan, again after a re-scan
+  bool scan_streams(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont, bool full_scan,
+                    const std::function<bool()>& layout);
   bool carry_and_reserve(const std::vector<int>& tf_base, const std::vector<int>& row_base, int nslots, int nrows);
   // plan_jobs[i] = (plan id, job indices decoded with that plan)
   void build_batch(const std::vector<std::pair<int, const std::vector<int>*>>& plan_jobs, DecodeBatch& out);
@@ -263,7 +266,7 @@ class Engine {
   int device_ = 0;
   hipStream_t stream_ = nullptr, copy_stream_ = nullptr;   // copy_stream_: work-list uploads from the control-plane thread
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_upload_ = nullptr, ev_fic_ = nullptr, ev_fic_done_ = nullptr, ev_fibs_ = nullptr, ev_part0_ = nullptr;
+  hipEvent_t ev_upload_ = nullptr, ev_fic_ = nullptr, ev_fic_done_ = nullptr, ev_fibs_ = nullptr, ev_part0_ = nullptr, ev_chain_ = nullptr, ev_info_ = nullptr;
   hipEvent_t ev_msc_[4] = {nullptr, nullptr, nullptr, nullptr};
   bool msc_queued_ = false;
   std::vector<hipEvent_t> chunk_ev_;
@@ -305,6 +308,7 @@ class Engine {
   MscWork work_, work_s3_;
   // session state (decode() resets it, feed() continues it)
   std::vector<ControlPlane> planes_;
+  bool planes_fresh_ = false;      // a new session started: the planes are reset where they are first used
   PinnedBuffer<StreamState> h_states_;
   PinnedBuffer<int2> h_frames_;
   PinnedBuffer<const uint8_t*> h_ptrs_;
