@@ -699,8 +699,10 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
     // coarse frequency offset of every frame within +-1 carrier (input_sdr.c:105-109: otherwise the frame is dropped and a
     // resync forced); both frequency estimates are then computed for all frames in parallel (sync_verify_kernel).  A stream that
     // breaks the assumption (a capture more than a carrier off tune, noise) is scanned again from its incoming state in the
-    // reference's order, so the result is the same in every case.  (Running the verification on a second stream beside the
-    // OFDM stage was tried: both want the CUs' LDS, nothing is gained.)
+    // reference's order, so the result is the same in every case.  (Tried and dropped: the verification on a second stream beside
+    // the OFDM stage, and -- after the LDS bank conflicts were gone -- the chain in 2..16 chunks of calls with each chunk's
+    // verification beside the next chunk: 1.28 -> 1.30..1.40 ms.  A chain workgroup holds half of a CU's LDS, so the verification
+    // beside it runs at half its rate and slows the chain.)
     if (!h_viol_.resize(nstreams) || !d_viol_.reserve(nstreams) || !d_states_prev_.reserve(nstreams) ||
         !d_calls_before_.upload(calls_done_.data(), nstreams, stream_) ||
         !check(hipMemcpyAsync(d_states_prev_.get(), d_states_.get(), nstreams * sizeof(StreamState), hipMemcpyDeviceToDevice, stream_), "state backup") ||
