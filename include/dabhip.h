@@ -135,7 +135,7 @@ int dabhip_engine_set_subchannels(dabhip_engine *e, const int32_t *ids, int n);
 /* OFDM stage variant.  enable != 0 (default): the 2048-point transforms and the DQPSK demap / de-interleave scatter run as
  * ONE kernel that never writes the complex64 spectra (311,296 B read + 28,800 B written per TF).  enable == 0: the two
  * kernels K2 (cu8 -> complex64 spectra, 1,556,480 B per TF: the HBM-roofline stage of SURVEY.md 8(d)) and K2b (spectra ->
- * bits, re-reading the 1.2 MB).  Output bits, hence ETI bytes, are identical.  Soft decisions always use K2 + K2b.
+ * bits, re-reading the 1.2 MB).  Output bits -- and soft values -- hence ETI bytes, are identical in both.
  * dabhip_engine_fft_stats describes whichever kernel ran; dabhip_engine_fft_roofline measures K2 by itself. */
 int dabhip_engine_set_fused(dabhip_engine *e, int enable);
 
