@@ -741,14 +741,26 @@ __device__ __forceinline__ uint16_t crc_shift(uint16_t crc, int nbytes, const ui
 // bytes of the oldest CIF (misc.c:239), EOF CRC over FIC+MST, RFU, TIST (misc.c:281-292).  Each lane takes a
 // slice of the CRC range; the partial CRCs are combined with crc_shift.  The 0x55 padding was laid down by a
 // memset beforehand.
+// The CRC runs four bytes at a time ("slicing by 4": tab[k][x] = CRC of byte x followed by k zero bytes, so that one 32-bit word
+// costs four INDEPENDENT look-ups instead of a chain of four); the range is a multiple of 8 bytes (96 + 8-byte sub-channel units)
+// and starts 4-byte aligned, so a lane's slice is whole words.
 __global__ __launch_bounds__(256) void eti_finish_kernel(const EtiFrameMeta* __restrict__ meta, int nframes,
                                                          const uint8_t* __restrict__ headers, int header_stride,
                                                          const uint8_t* __restrict__ fibs, const uint16_t* __restrict__ crc_tab,
                                                          const uint16_t* __restrict__ shift_cols, uint8_t* __restrict__ eti)
 {
-  __shared__ uint16_t tab[256];                          // CRC table in LDS: the byte loop is a chain of dependent look-ups
-  tab[threadIdx.x] = crc_tab[threadIdx.x];
-  __syncthreads();
+  __shared__ uint16_t tab[4][256];
+  {
+    uint16_t v = crc_tab[threadIdx.x];
+    tab[0][threadIdx.x] = v;
+    __syncthreads();
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {                          // one more zero byte: v <- step(v, 0)
+      v = static_cast<uint16_t>(tab[0][v >> 8] ^ (v << 8));
+      tab[k][threadIdx.x] = v;
+    }
+    __syncthreads();
+  }
   const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (f >= nframes) return;
   const EtiFrameMeta m = meta[f];
@@ -758,22 +770,25 @@ __global__ __launch_bounds__(256) void eti_finish_kernel(const EtiFrameMeta* __r
   for (int i = lane; i < m.header_len; i += 64) e[i] = h[i];
   for (int i = lane; i < 96; i += 64) e[m.header_len + i] = fb[i];
   const int n = 96 + m.mst_bytes;                       // CRC range: FIBs then the decoded sub-channel data
-  const int chunk = (n + 63) / 64;
-  const int lo = min(n, lane * chunk), hi = min(n, lo + chunk);
-  uint16_t crc = lane == 0 ? 0xffff : 0;
-  const uint8_t* mst = e + m.header_len;                // MST bytes were written by the Viterbi kernel
-  for (int i0 = lo; i0 < hi; i0 += 8) {                  // bytes fetched 8 at a time, ahead of the look-up chain
-    uint8_t byte[8];
+  const int nw = n >> 2;                                 // whole words (see above)
+  const int chunk = (nw + 63) / 64;
+  const int lo = min(nw, lane * chunk), hi = min(nw, lo + chunk);
+  unsigned crc = lane == 0 ? 0xffffu : 0u;
+  const uint32_t* fbw = reinterpret_cast<const uint32_t*>(fb);
+  const uint32_t* mstw = reinterpret_cast<const uint32_t*>(e + m.header_len);   // MST bytes were written by the Viterbi kernel
+  for (int i0 = lo; i0 < hi; i0 += 8) {                  // words fetched 8 at a time, ahead of the look-ups
+    uint32_t w[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = min(i0 + u, hi - 1);
-      byte[u] = i < 96 ? fb[i] : mst[i];
+      w[u] = i < 24 ? fbw[i] : mstw[i];
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
-      if (i0 + u < hi) crc = crc16_step(crc, byte[u], tab);
+      if (i0 + u < hi)
+        crc = tab[3][((crc >> 8) ^ w[u]) & 0xff] ^ tab[2][(crc ^ (w[u] >> 8)) & 0xff] ^ tab[1][(w[u] >> 16) & 0xff] ^ tab[0][w[u] >> 24];
   }
-  unsigned acc = crc_shift(crc, n - hi, shift_cols);
+  unsigned acc = crc_shift(static_cast<uint16_t>(crc), n - 4 * hi, shift_cols);
 #pragma unroll
   for (int s = 32; s > 0; s >>= 1) acc ^= __shfl_xor(acc, s);
   if (lane == 0) {
