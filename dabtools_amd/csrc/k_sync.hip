@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "dab_tables.hpp"
 #include "device_types.hpp"
@@ -106,17 +107,35 @@ struct Red {
   double dv[kWaves];
 };
 
+// Wave-level reductions on DPP moves (no LDS round trips: as __shfl_xor steps, i.e. ds_bpermute, the twelve dependent permutes of
+// one arg-max were half a microsecond of every call of the chain).  The value of the lane a DPP control selects; lanes the row mask
+// excludes keep their own.  After the six steps lane 63 holds the wave's result.
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ int dpp_from(int own)
+{
+  return __builtin_amdgcn_update_dpp(own, own, kCtrl, kRowMask, 0xf, false);
+}
+template <typename F>
+__device__ __forceinline__ void wave_reduce_steps(F&& step)
+{
+  step(std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{});    // quad_perm [1,0,3,2]
+  step(std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{});    // quad_perm [2,3,0,1]
+  step(std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});   // row_half_mirror
+  step(std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});   // row_mirror: rows of 16 done
+  step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});   // row_bcast:15 into rows 1 and 3
+  step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});   // row_bcast:31 into rows 2 and 3
+}
+
 // arg-max with the reference's semantics (strict '>' scanning upwards: lowest index wins ties);
-// wave shuffles first, one LDS round across the waves
+// DPP steps inside the wave, one LDS round across the waves
 __device__ void block_argmax(Red& r, float v, int idx, float* out_v, int* out_i)
 {
-#pragma unroll
-  for (int m = 32; m > 0; m >>= 1) {
-    const float ov = __shfl_xor(v, m);
-    const int oi = __shfl_xor(idx, m);
+  wave_reduce_steps([&](auto ctrl, auto mask) {
+    const float ov = __builtin_bit_cast(float, dpp_from<decltype(ctrl)::value, decltype(mask)::value>(__builtin_bit_cast(int, v)));
+    const int oi = dpp_from<decltype(ctrl)::value, decltype(mask)::value>(idx);
     if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-  }
-  if ((threadIdx.x & 63) == 0) { r.fv[threadIdx.x >> 6] = v; r.iv[threadIdx.x >> 6] = idx; }
+  });
+  if ((threadIdx.x & 63) == 63) { r.fv[threadIdx.x >> 6] = v; r.iv[threadIdx.x >> 6] = idx; }
   __syncthreads();
   float bv = r.fv[0];
   int bi = r.iv[0];
@@ -133,9 +152,10 @@ __device__ void block_argmax(Red& r, float v, int idx, float* out_v, int* out_i)
 
 __device__ int block_sum_int(Red& r, int v)
 {
-#pragma unroll
-  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
-  if ((threadIdx.x & 63) == 0) r.iv[threadIdx.x >> 6] = v;
+  wave_reduce_steps([&](auto ctrl, auto mask) {
+    v += __builtin_amdgcn_update_dpp(0, v, decltype(ctrl)::value, decltype(mask)::value, 0xf, false);
+  });
+  if ((threadIdx.x & 63) == 63) r.iv[threadIdx.x >> 6] = v;
   __syncthreads();
   int out = 0;
 #pragma unroll
@@ -144,11 +164,16 @@ __device__ int block_sum_int(Red& r, int v)
   return out;
 }
 
+// (the order of the additions inside a wave is a fixed tree, as it was with the shuffle steps: estimate only, sdr_sync.c:259-302)
 __device__ double block_sum_double(Red& r, double v)
 {
-#pragma unroll
-  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
-  if ((threadIdx.x & 63) == 0) r.dv[threadIdx.x >> 6] = v;
+  wave_reduce_steps([&](auto ctrl, auto mask) {
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(bits), decltype(ctrl)::value, decltype(mask)::value, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(bits >> 32), decltype(ctrl)::value, decltype(mask)::value, 0xf, false);
+    v += __builtin_bit_cast(double, (static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo));   // 0.0 where the row mask excludes the lane
+  });
+  if ((threadIdx.x & 63) == 63) r.dv[threadIdx.x >> 6] = v;
   __syncthreads();
   double out = 0;
 #pragma unroll
