@@ -847,19 +847,19 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   GuardArgs soft_args{};                                  // soft decisions, two-kernel stage: K2b reads the energies, lists nothing
   soft_args.delta = d_delta_.get();
   soft_args.delta_stride = kSymbolsPerTf;
-  auto fused_parts = [&](int first, int n, int part0, int nparts) -> bool {
+  auto fused_parts = [&](int first, int n, int part0, int nparts, int span = 1) -> bool {
     if (soft)
       return check(launch_ofdm_demap_fused_soft(afc_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_twf_.get(), d_frame_slot_.get(),
-                                                d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_, part0, nparts),
+                                                d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_, part0, nparts, span),
                    "fused fft/demap launch");
     GuardArgs ga{};
     if (guard && !guard_begin(n, &ga)) return false;
     const bool launched =
         guard ? check(launch_ofdm_demap_fused_guarded(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_twf_.get(), d_frame_slot_.get(),
-                                                      d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_, part0, nparts),
+                                                      d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_, part0, nparts, span),
                       "fused fft/demap launch")
               : check(launch_ofdm_demap_fused_plain(afc_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_twf_.get(), d_frame_slot_.get(),
-                                                    d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_, part0, nparts),
+                                                    d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_, part0, nparts, span),
                       "fused fft/demap launch");
     return launched && (!guard || guard_finish(true));
   };
@@ -898,7 +898,9 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     const int first = c * chunk, n = std::min(chunk, ntf - first);
     (void)hipEventRecord(chunk_ev_[3 * c], stream_);
     if (one_kernel) {
-      gpu_ok = fused_parts(first, n, 1, 3);               // parts 1..3: part 0 ran before the FIC decode
+      // parts 1..3 (part 0 ran before the FIC decode) as ONE workgroup per frame: one reference symbol transformed again instead of three
+      static const bool split3 = std::getenv("DABHIP_FUSED_SPLIT3") != nullptr;   // measurement knob: three workgroups of 19 symbols
+      gpu_ok = split3 ? fused_parts(first, n, 1, 3) : fused_parts(first, n, 1, 1, 3);
       (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
     } else {
       GuardArgs ga = soft ? soft_args : GuardArgs{};   // (hard decisions: a non-null delta switches the guard's listing on)
