@@ -828,9 +828,10 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   if (!carry_and_reserve(tf_base, row_base, nslots, next_row + 1)) return -1;
   times_.frames = frames_ms;
   // K3 first, so that the FIC is decoded -- and the host control plane can run -- while the bulk of the OFDM stage still
-  // occupies the GPU.  One-kernel OFDM stage: its part 0 (symbols 0..18: the phase reference, the FIC and the first 15 MSC
-  // symbols) of every TF runs now, parts 1..3 after the FIC decode: no transform is done twice.  Two-kernel stage (soft
-  // decisions, set_fused(0)): a pre-pass transforms symbols 0..3 once more.
+  // occupies the GPU.  One-kernel OFDM stage: the FIC symbols (0..3) of every TF run now, a launch of 4 / 76 of the work, so that the
+  // FIBs reach the host 2 ms before the MSC symbols are through and the control plane stays hidden behind them (with the first 19
+  // symbols in this launch the host finished 0.4 ms AFTER the OFDM stage).  Two-kernel stage (set_fused(0)): a pre-pass over the
+  // same four symbols.
   std::unique_lock<std::mutex> heavy;
   if (heavy_mu_) heavy = std::unique_lock<std::mutex>(*heavy_mu_);
   const bool one_kernel = fused_;                        // hard (with or without the guard) and soft decisions alike
@@ -847,25 +848,25 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   GuardArgs soft_args{};                                  // soft decisions, two-kernel stage: K2b reads the energies, lists nothing
   soft_args.delta = d_delta_.get();
   soft_args.delta_stride = kSymbolsPerTf;
-  auto fused_parts = [&](int first, int n, int part0, int nparts, int span = 1) -> bool {
+  auto fused_parts = [&](int first, int n, int sym_a, int sym_b, int nparts) -> bool {
     if (soft)
       return check(launch_ofdm_demap_fused_soft(afc_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_twf_.get(), d_frame_slot_.get(),
-                                                d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_, part0, nparts, span),
+                                                d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_, sym_a, sym_b, nparts),
                    "fused fft/demap launch");
     GuardArgs ga{};
     if (guard && !guard_begin(n, &ga)) return false;
     const bool launched =
         guard ? check(launch_ofdm_demap_fused_guarded(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_twf_.get(), d_frame_slot_.get(),
-                                                      d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_, part0, nparts, span),
+                                                      d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_, sym_a, sym_b, nparts),
                       "fused fft/demap launch")
               : check(launch_ofdm_demap_fused_plain(afc_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_twf_.get(), d_frame_slot_.get(),
-                                                    d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_, part0, nparts, span),
+                                                    d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_, sym_a, sym_b, nparts),
                       "fused fft/demap launch");
     return launched && (!guard || guard_finish(true));
   };
   if (one_kernel) {
     for (int first = 0; first < ntf; first += chunk)
-      if (!fused_parts(first, std::min(chunk, ntf - first), 0, 1)) return -1;
+      if (!fused_parts(first, std::min(chunk, ntf - first), 1, 4, 1)) return -1;      // the three FIC symbols (and symbol 0, their reference)
   } else {
     for (int first = 0; first < ntf; first += chunk * 19) {       // 4 of 76 symbols: 19 x as many TFs fit the spectra buffer
       const int n = std::min(chunk * 19, ntf - first);
@@ -898,9 +899,9 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     const int first = c * chunk, n = std::min(chunk, ntf - first);
     (void)hipEventRecord(chunk_ev_[3 * c], stream_);
     if (one_kernel) {
-      // parts 1..3 (part 0 ran before the FIC decode) as ONE workgroup per frame: one reference symbol transformed again instead of three
-      static const bool split3 = std::getenv("DABHIP_FUSED_SPLIT3") != nullptr;   // measurement knob: three workgroups of 19 symbols
-      gpu_ok = split3 ? fused_parts(first, n, 1, 3) : fused_parts(first, n, 1, 1, 3);
+      // the 72 MSC symbols (the FIC symbols ran before the FIC decode was queued); workgroups per frame: measurement knob
+      static const int msc_wgs = std::getenv("DABHIP_FUSED_MSC_WGS") ? std::max(1, std::min(8, std::atoi(std::getenv("DABHIP_FUSED_MSC_WGS")))) : 1;
+      gpu_ok = fused_parts(first, n, 4, 76, msc_wgs);
       (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
     } else {
       GuardArgs ga = soft ? soft_args : GuardArgs{};   // (hard decisions: a non-null delta switches the guard's listing on)
@@ -915,7 +916,9 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     }
     (void)hipEventRecord(chunk_ev_[3 * c + 2], stream_);
   }
+  mark("ofdm queued");
   if (!check(hipEventSynchronize(ev_fibs_), "fic decode")) return -1;
+  mark("fibs on host");
   {
     float part0_ms = 0, fic_ms = 0;
     (void)hipEventElapsedTime(&part0_ms, ev_[3], ev_part0_);
@@ -959,10 +962,13 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     }
     planes_fresh_ = false;
     times_.control = since(t0);
+    mark("control plane done");
     const auto t1 = std::chrono::steady_clock::now();
     // the work lists go up on the side stream while the OFDM stage still runs on the main one
-    host_ok = msc_prepare(job_ptrs, plane_ptrs, row_base, fib_base, work) && msc_upload(work, copy_stream_) &&
-              check(hipEventRecord(ev_upload_, copy_stream_), "work list upload");
+    host_ok = msc_prepare(job_ptrs, plane_ptrs, row_base, fib_base, work);
+    mark("work lists built");
+    host_ok = host_ok && msc_upload(work, copy_stream_) && check(hipEventRecord(ev_upload_, copy_stream_), "work list upload");
+    mark("work lists queued");
     if (!host_ok) host_error = dabhip_last_error();
     times_.worklist = since(t1);
   });

@@ -353,8 +353,8 @@ __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t*
   }
 }
 
-// grid = nparts * nframes: a workgroup covers `span` consecutive parts of 19 symbols of its frame, starting at part p = part0 + span * (index % nparts): data symbols max(1, 19 p) .. 19 (p + span) - 1 (p > 0: it transforms symbol
-// 19 p - 1 once more as their differential reference)
+// grid = nparts * nframes: the data symbols [sym_a, sym_b) of every frame (1 <= sym_a: symbol 0 is the phase reference only), split over
+// nparts workgroups per frame; a workgroup transforms the symbol before its first data symbol once more as differential reference.
 // Four workgroups per CU (16 waves, 128 VGPRs each, 39.9 KB of LDS each): the symbol loop is a chain of LDS round trips and barriers,
 // and a fourth wave per SIMD hides more of them than the handful of spilled registers costs (guarded 5.3 -> 4.9 ms per 16 k TF, plain
 // 4.5 -> 4.1; measured with three: DABHIP_FUSED_WG_PER_CU=3).
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kThreads, DABHIP_FUSED_WG_PER_CU) void ofdm_demap_k
                                                                  const int* __restrict__ frame_cif_row,
                                                                  const uint16_t* __restrict__ qpsk_of_carrier,
                                                                  uint32_t* __restrict__ fic_bits, uint32_t* __restrict__ msc_bits, const GuardArgs gargs,
-                                                                 int part0, int nparts, int span)
+                                                                 int sym_a, int sym_b, int nparts)
 {
   __shared__ __attribute__((aligned(16))) float2 exA[kExSize];
   __shared__ __attribute__((aligned(16))) float2 exB[kExSize];
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kThreads, DABHIP_FUSED_WG_PER_CU) void ofdm_demap_k
   __shared__ float2 tw3[4 * 8];
   __shared__ __attribute__((aligned(16))) int esum[8];  // per-wave parts of the symbol energy, two symbols in flight
   const int tid = threadIdx.x;
-  const int j = blockIdx.x / nparts, part = part0 + (blockIdx.x % nparts) * span;   // the engine launches part 0 of all frames first (FIC), then parts 1..3 as one span
+  const int j = blockIdx.x / nparts, part = blockIdx.x % nparts;   // the engine launches the FIC symbols of all frames first, then the MSC symbols
   const int2 fr = frames[first + j];
   const CallDesc* desc = descs + static_cast<size_t>(fr.x) * max_calls + fr.y;
   const uint8_t* stream = iq[fr.x];
@@ -421,7 +421,8 @@ __global__ __launch_bounds__(kThreads, DABHIP_FUSED_WG_PER_CU) void ofdm_demap_k
   GlobalU16 src = reinterpret_cast<GlobalU16>(reinterpret_cast<uintptr_t>(stream + (seg_src0 >= 0 ? seg_src0 : 0)));
   const uint32_t nco_inc = nco_hz ? static_cast<uint32_t>(static_cast<int64_t>(llrint(nco_hz * (4294967296.0 / 2048000.0)))) : 0u;
 
-  const int sym_begin = part ? part * kSymPerBlock - 1 : 0, sym_end = (part + span) * kSymPerBlock;
+  const int per = (sym_b - sym_a + nparts - 1) / nparts;             // data symbols per workgroup
+  const int sym_begin = sym_a + part * per - 1, sym_end = min(sym_b, sym_a + (part + 1) * per);   // the symbol before the first one is its reference
   // fast run (an even number of symbols, so that the LDS buffers end where they started), then the rest through the view
   int fast_end = max(sym_begin, min(sym_end, nfast));
   fast_end -= (fast_end - sym_begin) & 1;
@@ -439,41 +440,41 @@ __global__ __launch_bounds__(kThreads, DABHIP_FUSED_WG_PER_CU) void ofdm_demap_k
 #if DABHIP_FUSED_SOFT
 hipError_t launch_ofdm_demap_fused_soft(bool afc, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
                                         const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
-                                        uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream, int part0, int nparts, int span)
+                                        uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream, int sym_a, int sym_b, int nparts)
 {
   if (nframes <= 0 || nparts <= 0) return hipSuccess;
   const GuardArgs guard{};
   if (afc)
     hipLaunchKernelGGL(ofdm_demap_kernel<true>, dim3(nparts * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
-                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard, part0, nparts, span);
+                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard, sym_a, sym_b, nparts);
   else
     hipLaunchKernelGGL(ofdm_demap_kernel<false>, dim3(nparts * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
-                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard, part0, nparts, span);
+                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard, sym_a, sym_b, nparts);
   return hipGetLastError();
 }
 #elif DABHIP_FUSED_GUARD
 hipError_t launch_ofdm_demap_fused_guarded(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
                                            const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
-                                           uint32_t* fic_bits, uint32_t* msc_bits, const GuardArgs& guard, hipStream_t stream, int part0, int nparts, int span)
+                                           uint32_t* fic_bits, uint32_t* msc_bits, const GuardArgs& guard, hipStream_t stream, int sym_a, int sym_b, int nparts)
 {
   if (nframes <= 0 || nparts <= 0) return hipSuccess;
   hipLaunchKernelGGL(ofdm_demap_kernel<false>, dim3(nparts * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
-                     frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard, part0, nparts, span);
+                     frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard, sym_a, sym_b, nparts);
   return hipGetLastError();
 }
 #else
 hipError_t launch_ofdm_demap_fused_plain(bool afc, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
                                          const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
-                                         uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream, int part0, int nparts, int span)
+                                         uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream, int sym_a, int sym_b, int nparts)
 {
   if (nframes <= 0 || nparts <= 0) return hipSuccess;
   const GuardArgs guard{};
   if (afc)
     hipLaunchKernelGGL(ofdm_demap_kernel<true>, dim3(nparts * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
-                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard, part0, nparts, span);
+                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard, sym_a, sym_b, nparts);
   else
     hipLaunchKernelGGL(ofdm_demap_kernel<false>, dim3(nparts * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
-                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard, part0, nparts, span);
+                       frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard, sym_a, sym_b, nparts);
   return hipGetLastError();
 }
 #endif

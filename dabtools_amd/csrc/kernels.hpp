@@ -55,17 +55,17 @@ hipError_t launch_viterbi_fused(int soft_bits, const WaveGroup* groups, int ngro
 
 // the one-kernel OFDM stage (k_fused.hip, compiled three times): with the parity guard's test in its symbol loop, without it, and
 // with 4-bit soft values instead of hard decisions.
-// A frame is four parts of 19 symbols; nparts workgroups per frame are launched, each covering `span` consecutive parts, from part0 on
-// (part 0 holds the FIC; a workgroup that does not start at symbol 0 transforms the symbol before its first one once more as reference).
+// Data symbols [sym_a, sym_b) of every frame (1..3 = FIC, 4..75 = MSC), nparts workgroups per frame; each transforms the symbol before
+// its first data symbol as differential reference.
 hipError_t launch_ofdm_demap_fused_guarded(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
                                            const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
-                                           uint32_t* fic_bits, uint32_t* msc_bits, const GuardArgs& guard, hipStream_t stream, int part0 = 0, int nparts = 4, int span = 1);
+                                           uint32_t* fic_bits, uint32_t* msc_bits, const GuardArgs& guard, hipStream_t stream, int sym_a = 1, int sym_b = 76, int nparts = 4);
 hipError_t launch_ofdm_demap_fused_soft(bool afc, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
                                         const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
-                                        uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream, int part0 = 0, int nparts = 4, int span = 1);
+                                        uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream, int sym_a = 1, int sym_b = 76, int nparts = 4);
 hipError_t launch_ofdm_demap_fused_plain(bool afc, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
                                          const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
-                                         uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream, int part0 = 0, int nparts = 4, int span = 1);
+                                         uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream, int sym_a = 1, int sym_b = 76, int nparts = 4);
 // parity guard (k_parity.hip): per-symbol error bounds, fp64 re-decision of the flagged carriers, and the audit
 hipError_t launch_symbol_delta(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
                                int nsym, float* delta, int delta_stride, hipStream_t stream);
