@@ -729,10 +729,13 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
   (void)hipEventRecord(ev_[1], stream_);
   // The host only needs {status, ordinal} of every call to lay the frames out: K1 writes those 8 bytes per call to a
   // compact array that comes back first; the full descriptors (trace API) follow on the side stream.
+  // (on the side stream, behind the scan's last kernel: what the layout callback may have queued on the main stream meanwhile -- the
+  // first OFDM launch -- is not waited for)
   auto fetch = [&]() {
-    return check(hipMemcpyAsync(h_info_.data(), d_info_.get(), ndesc * sizeof(int2), hipMemcpyDeviceToHost, stream_), "call info download") &&
-           check(hipMemcpyAsync(states, d_states_.get(), nstreams * sizeof(StreamState), hipMemcpyDeviceToHost, stream_), "state download") &&
-           check(hipStreamSynchronize(stream_), "sync scan");
+    return check(hipStreamWaitEvent(copy_stream_, ev_[1], 0), "scan event") &&
+           check(hipMemcpyAsync(h_info_.data(), d_info_.get(), ndesc * sizeof(int2), hipMemcpyDeviceToHost, copy_stream_), "call info download") &&
+           check(hipMemcpyAsync(states, d_states_.get(), nstreams * sizeof(StreamState), hipMemcpyDeviceToHost, copy_stream_), "state download") &&
+           check(hipStreamSynchronize(copy_stream_), "sync scan");
   };
   if (split_scan && (!check(hipEventSynchronize(ev_info_), "call info") || !layout())) return false;
   if (!fetch()) return false;
@@ -818,36 +821,23 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     frames_ms += since(tfr);
     return up;
   };
-  if (!scan_streams(iq, nbytes, nstreams, on_device, cont, full_scan, layout)) return -1;
-  mark("scan done");
-  times_.setup = scan_setup_ms_;
-  for (int b = 0; b < nstreams; ++b) calls_done_[b] = std::max(calls_done_[b], static_cast<int>(nbytes[b] / kChunkBytes));
-  const int ntf = ntf_new, nslots = tf_base[nstreams];
-  last_ntf_ = ntf;
-  if (ntf == 0) return 0;                   // nothing demodulated: layout and carried data stay as they are
-  if (!carry_and_reserve(tf_base, row_base, nslots, next_row + 1)) return -1;
-  times_.frames = frames_ms;
-  // K3 first, so that the FIC is decoded -- and the host control plane can run -- while the bulk of the OFDM stage still
-  // occupies the GPU.  One-kernel OFDM stage: the FIC symbols (0..3) of every TF run now, a launch of 4 / 76 of the work, so that the
-  // FIBs reach the host 2 ms before the MSC symbols are through and the control plane stays hidden behind them (with the first 19
-  // symbols in this launch the host finished 0.4 ms AFTER the OFDM stage).  Two-kernel stage (set_fused(0)): a pre-pass over the
-  // same four symbols.
+  // Stage A: everything between the layout and the FIC decode -- buffers for the layout, then the FIC symbols (0..3) of every TF
+  // through the OFDM stage.  K3 comes first so that the FIC is decoded, and the host control plane can run, while the bulk of the
+  // OFDM stage still occupies the GPU: a launch of 4 / 76 of the work, so that the FIBs reach the host 2 ms before the MSC
+  // symbols are through (with the first 19 symbols in this launch the host finished 0.4 ms AFTER the OFDM stage).  Two-kernel stage
+  // (set_fused(0)): a pre-pass over the same four symbols.
+  // A fresh decode runs stage A from the layout callback, i.e. queued right behind K1 while the host still waits for K1's last
+  // downloads (0.19 ms of idle GPU otherwise); if a stream is scanned again afterwards (rare), the layout and stage A simply run
+  // again for the new frame list.  A session's further segments run it after the scan: their carry-over copies must happen once.
   std::unique_lock<std::mutex> heavy;
-  if (heavy_mu_) heavy = std::unique_lock<std::mutex>(*heavy_mu_);
   const bool one_kernel = fused_;                        // hard (with or without the guard) and soft decisions alike
-  const int chunk = one_kernel ? std::max(ntf, 1) : std::min(ntf, kFftChunkTfs);   // only the spectra buffer of the two-kernel stage calls for chunks
-  if (!one_kernel && !d_spectra_.reserve(static_cast<size_t>(chunk) * kSymbolsPerTf * 2048)) return -1;
-  if (!h_fibs_.resize(static_cast<size_t>(nslots) * 384) || !h_fib_ok_.resize(static_cast<size_t>(nslots) * 12)) return -1;
-  uint8_t* const fibs = h_fibs_.data();
-  uint8_t* const ok = h_fib_ok_.data();
-  (void)hipEventRecord(ev_[3], stream_);
   const bool guard = guard_active();
   const bool soft = soft_bits_ != 0;
   const bool energies = guard || soft;                    // the per-symbol sample energies: the guard's error bounds, the soft scale
-  if (energies && !d_delta_.reserve(static_cast<size_t>(ntf) * kSymbolsPerTf)) return -1;
+  int ntf = 0, nslots = 0, chunk = 1;
+  uint8_t* fibs = nullptr;
+  uint8_t* ok = nullptr;
   GuardArgs soft_args{};                                  // soft decisions, two-kernel stage: K2b reads the energies, lists nothing
-  soft_args.delta = d_delta_.get();
-  soft_args.delta_stride = kSymbolsPerTf;
   auto fused_parts = [&](int first, int n, int sym_a, int sym_b, int nparts) -> bool {
     if (soft)
       return check(launch_ofdm_demap_fused_soft(afc_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_twf_.get(), d_frame_slot_.get(),
@@ -864,24 +854,51 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
                       "fused fft/demap launch");
     return launched && (!guard || guard_finish(true));
   };
-  if (one_kernel) {
-    for (int first = 0; first < ntf; first += chunk)
-      if (!fused_parts(first, std::min(chunk, ntf - first), 1, 4, 1)) return -1;      // the three FIC symbols (and symbol 0, their reference)
-  } else {
-    for (int first = 0; first < ntf; first += chunk * 19) {       // 4 of 76 symbols: 19 x as many TFs fit the spectra buffer
-      const int n = std::min(chunk * 19, ntf - first);
-      GuardArgs ga = soft ? soft_args : GuardArgs{};   // (hard decisions: a non-null delta switches the guard's listing on)
-      if (guard && !guard_begin(n, &ga)) return -1;
-      if (energies && !check(launch_symbol_delta(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, 4, d_delta_.get(), kSymbolsPerTf, stream_), "symbol delta launch"))
-        return -1;
-      if (!check(launch_fic_prepass(soft_bits_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(),
-                                    d_frame_slot_.get(), d_qpsk_.get(), d_fic_bits_.get(), ga, stream_),
-                 "fic pre-pass launch"))
-        return -1;
-      if (guard && !guard_finish(true)) return -1;
+  auto stage_a = [&]() -> bool {
+    ntf = ntf_new;
+    nslots = tf_base[nstreams];
+    if (ntf == 0) return true;
+    if (!carry_and_reserve(tf_base, row_base, nslots, next_row + 1)) return false;
+    if (heavy_mu_ && !heavy.owns_lock()) heavy = std::unique_lock<std::mutex>(*heavy_mu_);
+    chunk = one_kernel ? std::max(ntf, 1) : std::min(ntf, kFftChunkTfs);   // only the spectra buffer of the two-kernel stage calls for chunks
+    if (!one_kernel && !d_spectra_.reserve(static_cast<size_t>(chunk) * kSymbolsPerTf * 2048)) return false;
+    if (!h_fibs_.resize(static_cast<size_t>(nslots) * 384) || !h_fib_ok_.resize(static_cast<size_t>(nslots) * 12)) return false;
+    fibs = h_fibs_.data();
+    ok = h_fib_ok_.data();
+    (void)hipEventRecord(ev_[3], stream_);
+    if (energies && !d_delta_.reserve(static_cast<size_t>(ntf) * kSymbolsPerTf)) return false;
+    soft_args.delta = d_delta_.get();
+    soft_args.delta_stride = kSymbolsPerTf;
+    if (one_kernel) {
+      for (int first = 0; first < ntf; first += chunk)
+        if (!fused_parts(first, std::min(chunk, ntf - first), 1, 4, 1)) return false;      // the three FIC symbols (and symbol 0, their reference)
+    } else {
+      for (int first = 0; first < ntf; first += chunk * 19) {       // 4 of 76 symbols: 19 x as many TFs fit the spectra buffer
+        const int n = std::min(chunk * 19, ntf - first);
+        GuardArgs ga = soft ? soft_args : GuardArgs{};   // (hard decisions: a non-null delta switches the guard's listing on)
+        if (guard && !guard_begin(n, &ga)) return false;
+        if (energies && !check(launch_symbol_delta(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, 4, d_delta_.get(), kSymbolsPerTf, stream_), "symbol delta launch"))
+          return false;
+        if (!check(launch_fic_prepass(soft_bits_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(),
+                                      d_frame_slot_.get(), d_qpsk_.get(), d_fic_bits_.get(), ga, stream_),
+                   "fic pre-pass launch"))
+          return false;
+        if (guard && !guard_finish(true)) return false;
+      }
     }
-  }
-  (void)hipEventRecord(ev_part0_, stream_);
+    (void)hipEventRecord(ev_part0_, stream_);
+    return true;
+  };
+  const bool early_a = !cont;
+  auto layout_and_a = [&]() -> bool { return layout() && (!early_a || stage_a()); };
+  if (!scan_streams(iq, nbytes, nstreams, on_device, cont, full_scan, layout_and_a)) return -1;
+  mark("scan done");
+  times_.setup = scan_setup_ms_;
+  for (int b = 0; b < nstreams; ++b) calls_done_[b] = std::max(calls_done_[b], static_cast<int>(nbytes[b] / kChunkBytes));
+  if (!early_a && !stage_a()) return -1;
+  last_ntf_ = ntf;
+  if (ntf == 0) return 0;                   // nothing demodulated: layout and carried data stay as they are
+  times_.frames = frames_ms;
   if (guard) guard_decisions_ += static_cast<int64_t>(ntf) * (kFicBits + kMscBits);
   // FIC decode kernels on the main stream, the FIB download on the side stream: the OFDM stage is queued right behind
   // the FIC kernels and starts without waiting for the download or for the host
