@@ -375,6 +375,11 @@ bool Engine::fic_decode_slots_async(int first, int n, uint8_t* fibs_host, uint8_
 bool Engine::msc_prepare(const std::vector<const std::vector<EtiJob>*>& stream_jobs, const std::vector<const ControlPlane*>& planes,
                          const std::vector<int>& stream_row_base, const std::vector<int>& stream_fib_base, MscWork& out)
 {
+  static const bool trace_host = std::getenv("DABHIP_TRACE_HOST") != nullptr;
+  const auto t_in = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (trace_host) std::fprintf(stderr, "[host]   msc_prepare %-14s %8.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_in).count());
+  };
   size_t nf = 0;
   for (const auto* v : stream_jobs) nf += v->size();
   out.nframes = nf;
@@ -391,17 +396,35 @@ bool Engine::msc_prepare(const std::vector<const std::vector<EtiJob>*>& stream_j
   std::vector<std::vector<int>> layout_frames;
   HostList<DecodeJob>& jobs = out.jobs;
   HostList<EtiFrameMeta>& meta = out.meta;
-  jobs.assign(nf, DecodeJob{0, 0});
-  meta.assign(nf, EtiFrameMeta{0, 0, 0, 0});
+  const size_t nstreams = stream_jobs.size();
+  // pass 0 (parallel over streams; the job lists are ~15 MB, walked once here): the longest header and the layouts a stream uses
+  // (layouts change rarely: one entry per run), with the header length of the first job of each
+  std::vector<int> stream_max_header(nstreams, 0);
+  std::vector<std::vector<std::pair<int, int>>> used(nstreams);   // (local layout, header_len)
+  pool_->parallel_for(static_cast<int>(nstreams), [&](int b) {
+    int mh = 0, prev = -1;
+    for (const EtiJob& j : *stream_jobs[b]) {
+      mh = std::max(mh, j.header_len);
+      if (j.layout != prev) {
+        prev = j.layout;
+        bool seen = false;
+        for (const auto& u : used[b]) seen = seen || u.first == j.layout;
+        if (!seen) used[b].push_back({j.layout, j.header_len});
+      }
+    }
+    stream_max_header[b] = mh;
+  });
   int max_header = 0;
-  for (const auto* v : stream_jobs)
-    for (const EtiJob& j : *v) max_header = std::max(max_header, j.header_len);
+  for (int mh : stream_max_header) max_header = std::max(max_header, mh);
   const int header_stride = (max_header + 15) & ~15;
   out.header_stride = header_stride;
   HostList<uint8_t>& headers = out.headers;
-  headers.assign(nf * static_cast<size_t>(header_stride), 0);
+  // every record is written in full by pass 2 (a header row up to its own length, which is all K5 reads): no fill
+  jobs.resize(nf);
+  meta.resize(nf);
+  headers.resize(nf * static_cast<size_t>(header_stride));
+  mark("lists sized");
   // pass 1 (serial, cheap): global layout id of every (stream, local layout)
-  const size_t nstreams = stream_jobs.size();
   std::vector<std::vector<int>> local_to_global(nstreams);
   std::vector<size_t> frame_base(nstreams + 1, 0);
   for (size_t b = 0; b < nstreams; ++b) {
@@ -409,13 +432,10 @@ bool Engine::msc_prepare(const std::vector<const std::vector<EtiJob>*>& stream_j
     if (stream_jobs[b]->empty()) continue;
     const auto& lays = planes[b]->layouts();
     local_to_global[b].assign(lays.size(), -1);
-    int prev = -1;
-    for (const EtiJob& job : *stream_jobs[b]) {
-      if (job.layout == prev) continue;       // layouts change rarely: one lookup per run
-      prev = job.layout;
-      if (local_to_global[b][job.layout] >= 0) continue;
-      const std::vector<SubChannel>& subs = lays[job.layout];
-      std::vector<int32_t> key = {job.header_len};
+    for (const auto& u : used[b]) {
+      const int layout = u.first, job_header_len = u.second;
+      const std::vector<SubChannel>& subs = lays[layout];
+      std::vector<int32_t> key = {job_header_len};
       for (const SubChannel& sc : subs) {
         const int32_t fields[] = {sc.slform, sc.uep_index, sc.start_cu, sc.size_cu, sc.bitrate, sc.protlev};
         key.insert(key.end(), fields, fields + 6);
@@ -423,21 +443,22 @@ bool Engine::msc_prepare(const std::vector<const std::vector<EtiJob>*>& stream_j
       auto it = layout_index.find(key);
       if (it == layout_index.end()) {
         Layout lay;
-        int off = job.header_len + 96;
+        int off = job_header_len + 96;
         for (const SubChannel& sc : subs) {
           CodewordPlan cp = make_plan(puncture_plan(sc), sc.start_cu * 64, off);
           lay.plan_ids.push_back(plan_id(cp));
           off += (cp.out_bytes + 7) & 0xfff8;          // misc.c:259-260: obytes = ((bits/8)+7) & 0xfff8
         }
-        lay.mst_bytes = off - job.header_len - 96;
+        lay.mst_bytes = off - job_header_len - 96;
         if (off + 8 > kEtiBytes) { set_error("ETI frame overflow: sub-channels exceed 6144 bytes"); return false; }
         it = layout_index.emplace(std::move(key), static_cast<int>(layouts.size())).first;
         layouts.push_back(std::move(lay));
         layout_frames.emplace_back();
       }
-      local_to_global[b][job.layout] = it->second;
+      local_to_global[b][layout] = it->second;
     }
   }
+  mark("layouts");
   // pass 2 (parallel over streams): per-frame records
   std::vector<std::vector<std::pair<int, std::pair<int, int>>>> runs(nstreams);   // per stream: (layout, [first, last) frame)
   pool_->parallel_for(static_cast<int>(nstreams), [&](int b) {
@@ -456,14 +477,17 @@ bool Engine::msc_prepare(const std::vector<const std::vector<EtiJob>*>& stream_j
       ++f;
     }
   });
+  mark("frame records");
   for (size_t b = 0; b < nstreams; ++b)
     for (const auto& r : runs[b])
       for (int f = r.second.first; f < r.second.second; ++f) layout_frames[r.first].push_back(f);
+  mark("layout frames");
   std::vector<std::pair<int, const std::vector<int>*>> plan_jobs;
   for (size_t l = 0; l < layouts.size(); ++l)
     for (int pid : layouts[l].plan_ids) plan_jobs.emplace_back(pid, &layout_frames[l]);
   build_batch(plan_jobs, out.batch);
   plan_decode_batch(out.batch);
+  mark("batch");
   return true;
 }
 
