@@ -488,7 +488,21 @@ __device__ __forceinline__ void chain_back8(const uint4* my_rec, int nsteps, con
 #pragma unroll
     for (int u = 0; u < kCbBatch; ++u) {
       const int b = b_hi - u;
-      if (b >= 0) consume(survivor_byte(rec[u], state), 8 * b, 7);
+      if (b >= 1) {
+        // A whole block in one go.  Its decisions d_k = !tag_k (k = 0 .. 7, step 8 b + k), bit-reversed: r8 = d_0 .. d_7 from the top.
+        // Walking back from step 8 b + 7 to 8 b leaves state (d_0 .. d_5) = r8 >> 2; data bit i = step - 6 goes MSB-first into byte
+        // i >> 3: d_6, d_7 are the top two bits of byte b, d_0 .. d_5 the low six bits of byte b - 1 -- the new state itself.
+        const unsigned r8 = __brev(~survivor_byte(rec[u], state) & 0xffu) >> 24;
+        state = r8 >> 2;
+        acc |= ((r8 & 3u) << 6) << (8 * (b & 3));
+        if ((b & 3) == 0) {
+          dst[b >> 2] = acc ^ prbs_words[b >> 2];
+          acc = 0;
+        }
+        acc |= state << (8 * ((b - 1) & 3));
+      } else if (b == 0) {
+        consume(survivor_byte(rec[u], state), 0, 7);       // steps 0..5 only flush the encoder's initial zeros
+      }
     }
   }
 }
