@@ -11,8 +11,10 @@ python3 $R/bench.py --steps 10 --snr 7 --no-cpu-baseline > $O/bench_hard7db.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --no-cpu-baseline --steps 10 > $O/bench_under_rocprof.json 2>> $O/bench.err
 cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
 cp $(find $O/trace -name "*domain_stats.csv" | head -1) $O/bench_domain_stats.csv 2>/dev/null
-python3 $R/tools/timeline.py $O/trace > $O/step_timeline.txt
 rm -rf $O/trace
+rocprofv3 --kernel-trace --output-format csv -d $O/trace2 -- python3 $R/bench.py --no-cpu-baseline --no-variants --steps 5 > /dev/null 2>> $O/bench.err
+python3 $R/tools/timeline.py $O/trace2 > $O/step_timeline.txt      # the default step (no variants after it)
+rm -rf $O/trace2
 C1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAVE_CYCLES"
 C2="SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAVES"
 rocprofv3 --pmc $C1 --output-format csv -d $O/pmc_f1 -- python3 $R/bench.py --no-cpu-baseline --no-variants --steps 2 --warmup 1 > /dev/null 2>&1

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel timeline of the last full decode in a rocprofv3 --kernel-trace csv: start, duration, gap to the previous kernel's end."""
-import csv, glob, sys
-f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
+import csv, glob, os, sys
+f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)[-1]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'sync_scan_kernel' in r['Kernel_Name']]
 start, stop = idx[-3], idx[-2]
