@@ -924,8 +924,8 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   if (ntf == 0) return 0;                   // nothing demodulated: layout and carried data stay as they are
   times_.frames = frames_ms;
   if (guard) guard_decisions_ += static_cast<int64_t>(ntf) * (kFicBits + kMscBits);
-  // FIC decode kernels on the main stream, the FIB download on the side stream: the OFDM stage is queued right behind
-  // the FIC kernels and starts without waiting for the download or for the host
+  // FIC decode kernels and the FIB download on the side stream: the rest of the OFDM stage is queued on the main stream right
+  // away and shares the GPU with them, waiting neither for the download nor for the host
   if (!fic_decode_slots_async(0, nslots, fibs, ok, copy_stream_)) return -1;      // carried slots are decoded again: their FIBs are read by K5
 
   // K2 + K2b in chunks (they share one spectra buffer; stream order keeps them apart), timed with per-chunk events
@@ -964,11 +964,11 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     float part0_ms = 0, fic_ms = 0;
     (void)hipEventElapsedTime(&part0_ms, ev_[3], ev_part0_);
     (void)hipEventElapsedTime(&fic_ms, ev_part0_, ev_fic_done_);   // beside the OFDM stage since round 2: no longer a term of the step
-    times_.fic = fic_ms + (one_kernel ? 0.0f : part0_ms);   // the pre-pass of the two-kernel stage is FIC work; part 0 of the fused kernel is OFDM work
+    times_.fic = fic_ms + (one_kernel ? 0.0f : part0_ms);   // the pre-pass of the two-kernel stage is FIC work; the FIC symbols' launch of the fused kernel is OFDM work
     if (one_kernel) times_.fft += part0_ms;
   }
 
-  // control plane + work lists on a host thread, hidden behind K2 + K2b
+  // control plane + work lists on a host thread, hidden behind the MSC symbols' part of the OFDM stage
   std::vector<ControlPlane>& planes = planes_;
   // host work lists live in the engine: ~35 MB per step at the benchmark size, reused instead of re-allocated
   std::vector<std::vector<EtiJob>>& stream_jobs = stream_jobs_;
@@ -1014,8 +1014,8 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     times_.worklist = since(t1);
   });
 
-  // the host thread is done long before the OFDM stage (2 of 5 ms): K4 + K5 are queued right behind it, and the whole
-  // pipeline is awaited ONCE
+  // the host thread is done before the OFDM stage (at 4.5 of 5.8 ms into the step with 24 threads): K4 + K5 are queued right
+  // behind it, and the whole pipeline is awaited ONCE
   host.join();
   if (gpu_ok && host_ok)
     gpu_ok = check(hipStreamWaitEvent(stream_, ev_upload_, 0), "work list wait") && msc_launch_async(work);
