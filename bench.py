@@ -43,7 +43,8 @@ VIT_VALU_PER_STEP = 129.0                  # VALU wave-instructions per trellis 
 # The same step priced in issue clocks per SIMD (profiles/r02_valu_rates.txt, tools/ubench/valu_rates.hip: wave64 instructions do not all
 # cost a quad-cycle on gfx950): 64 v_add_u32 at 2.56 + 32 v_pk_max_u16 at 4.28 + 13 v_perm_b32 at 4.2 + ~20 others at ~4.2
 VIT_ISSUE_CLOCKS_PER_STEP = 64 * 2.56 + 32 * 4.28 + 13 * 4.2 + 20 * 4.2
-HBM_STREAM_MIX_NOTE = "survivor records are written once and read once: compare with roofline.stream_ceiling.copy, not with the 8 TB/s of the data sheet"
+VIT_REC_BYTES_PER_WAVE_STEP = 512.0 * 1.45   # 64 lanes x 8 B written per step; read back: 16 of 64 bytes per lane and block = ~45 % of the sectors
+HBM_STREAM_MIX_NOTE = "compare with roofline.stream_ceiling.copy, not with the 8 TB/s of the data sheet"
 
 
 # ---- rank coordination ---------------------------------------------------------------------------------------------
@@ -405,9 +406,11 @@ def run_rank(args, coord):
                     "issue_time": {"clocks_per_step": VIT_ISSUE_CLOCKS_PER_STEP, "frac": VIT_ISSUE_CLOCKS_PER_STEP * wave_steps / (256 * 4 * 2.4e9 * t),
                                    "note": "the step's instructions priced at their measured issue clocks (add 2.56, packed max 4.28, permute 4.2), "
                                            "over 1024 SIMDs at 2.4 GHz"},
-                    "hbm": {"achieved": 1024.0 * wave_steps / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 1024.0 * wave_steps / t / 1e9 / HBM_PEAK_GBS,
-                            "achieved_vs_copy_stream": (1024.0 * wave_steps / t / 1e9 / extra["stream_ceiling"]["copy"]) if extra.get("stream_ceiling", {}).get("copy") else None,
-                            "note": "64 B of survivor records per 8 steps and code word, written once and read once; " + HBM_STREAM_MIX_NOTE},
+                    "hbm": {"achieved": VIT_REC_BYTES_PER_WAVE_STEP * wave_steps / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": VIT_REC_BYTES_PER_WAVE_STEP * wave_steps / t / 1e9 / HBM_PEAK_GBS,
+                            "achieved_vs_copy_stream": (VIT_REC_BYTES_PER_WAVE_STEP * wave_steps / t / 1e9 / extra["stream_ceiling"]["copy"]) if extra.get("stream_ceiling", {}).get("copy") else None,
+                            "note": "64 B of survivor records per 8 steps and code word, written once; the chain-back reads the 16-byte part that holds its "
+                                    "state's byte (about 45 % of the 32-byte sectors); " + HBM_STREAM_MIX_NOTE},
                     "trellis_steps_per_eti_frame": steps_per_frame, "avg_ms": stage["viterbi"]}
         if fused_off:
             out["two_kernel_ofdm_variant"] = fused_off

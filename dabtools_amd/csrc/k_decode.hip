@@ -265,17 +265,6 @@ __device__ __forceinline__ uint32_t in_vgpr(uint32_t x)
   asm volatile("" : "+v"(x));   // keeps the 8-way select below a v_cndmask tree (the optimiser would index a scratch copy instead)
   return x;
 }
-__device__ __forceinline__ unsigned survivor_nibble(const uint4& lo, const uint4& hi, unsigned state)
-{
-  const unsigned r = ((state >> 5) << 4) | (state & 15u), half = (state >> 4) & 1u;
-  const unsigned i = r >> 2, nib = 4u * (r & 1u) + 2u * half + ((r >> 1) & 1u);
-  const bool i0 = i & 1u, i1 = i & 2u, i2 = i & 4u;
-  const uint32_t a = i0 ? in_vgpr(lo.y) : in_vgpr(lo.x), b = i0 ? in_vgpr(lo.w) : in_vgpr(lo.z);
-  const uint32_t c = i0 ? in_vgpr(hi.y) : in_vgpr(hi.x), d = i0 ? in_vgpr(hi.w) : in_vgpr(hi.z);
-  const uint32_t ab = i1 ? b : a, cd = i1 ? d : c;
-  return ((i2 ? cd : ab) >> (4u * nib)) & 15u;
-}
-
 // ---------------------------------------------------------------------------------------
 // regroup: logical CIF rows (16 planes of 108 x kBits words each, one row per ETI frame) ->
 // de-interleaved natural bit order, 64 frames interleaved word by word:
@@ -403,20 +392,6 @@ __device__ __forceinline__ void survivor_record8(const pk16 (&n)[32], uint4* rec
 #pragma unroll
   for (int j = 0; j < 4; ++j) rec_store(rec + 64 * j, d[4 * j], d[4 * j + 1], d[4 * j + 2], d[4 * j + 3]);
 }
-__device__ __forceinline__ unsigned survivor_byte(const uint4 (&r)[4], unsigned state)
-{
-  const unsigned reg = ((state >> 5) << 4) | (state & 15u), half = (state >> 4) & 1u;
-  const unsigned i = reg >> 1, byte = 2u * (reg & 1u) + half;
-  uint32_t w[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {                          // word i & 3 of each of the four 16-byte parts, then part i >> 2
-    const uint32_t a = (i & 1u) ? in_vgpr(r[j].y) : in_vgpr(r[j].x), b = (i & 1u) ? in_vgpr(r[j].w) : in_vgpr(r[j].z);
-    w[j] = (i & 2u) ? b : a;
-  }
-  const uint32_t lo = (i & 4u) ? w[1] : w[0], hi = (i & 4u) ? w[3] : w[2];
-  return (((i & 8u) ? hi : lo) >> (8u * byte)) & 255u;
-}
-
 // 8 trellis steps from 8 table rows (one byte each): two passes through the register layouts, one survivor record
 __device__ __forceinline__ void acs8_lut(uint32_t rows0, uint32_t rows1, const MetricLut* lut, pk16 (&pm)[32], pk16 (&pn)[32],
                                          pk16 (&pl4)[32], uint4* rec)
@@ -483,39 +458,29 @@ __device__ __forceinline__ void chain_back8(const uint4* my_rec, int nsteps, con
   };
   const int nfull = nsteps >> 3, r = nsteps & 7;
   if (r) consume(my_rec[static_cast<size_t>(nfull) * 256].x & 255u, 8 * nfull, r - 1);
-  // records are fetched kCbBatch blocks at a time (their addresses do not depend on the path): a wave in its chain-back is a
-  // chain of memory round trips (the records of a long code word are 2.4 MB per wave and come back from HBM), and the path
-  // metrics' registers are free by now
-#ifndef DABHIP_CB_BATCH
-#define DABHIP_CB_BATCH 6
-#endif
-  constexpr int kCbBatch = DABHIP_CB_BATCH;
-  for (int b_hi = nfull - 1; b_hi >= 0; b_hi -= kCbBatch) {
-    uint4 rec[kCbBatch][4];
-#pragma unroll
-    for (int u = 0; u < kCbBatch; ++u) {
-      const size_t b = static_cast<size_t>(max(b_hi - u, 0));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) rec[u][j] = rec_load(my_rec + b * 256 + 64 * j);
-    }
-#pragma unroll
-    for (int u = 0; u < kCbBatch; ++u) {
-      const int b = b_hi - u;
-      if (b >= 1) {
-        // A whole block in one go.  Its decisions d_k = !tag_k (k = 0 .. 7, step 8 b + k), bit-reversed: r8 = d_0 .. d_7 from the top.
-        // Walking back from step 8 b + 7 to 8 b leaves state (d_0 .. d_5) = r8 >> 2; data bit i = step - 6 goes MSB-first into byte
-        // i >> 3: d_6, d_7 are the top two bits of byte b, d_0 .. d_5 the low six bits of byte b - 1 -- the new state itself.
-        const unsigned r8 = __brev(~survivor_byte(rec[u], state) & 0xffu) >> 24;
-        state = r8 >> 2;
-        acc |= ((r8 & 3u) << 6) << (8 * (b & 3));
-        if ((b & 3) == 0) {
-          dst[b >> 2] = acc ^ prbs_words[b >> 2];
-          acc = 0;
-        }
-        acc |= state << (8 * ((b - 1) & 3));
-      } else if (b == 0) {
-        consume(survivor_byte(rec[u], state), 0, 7);       // steps 0..5 only flush the encoder's initial zeros
+  // Only the 16-byte part of a record that holds the current state's byte is fetched (part = state bits 5 and 3): a chain of
+  // dependent loads, one memory round trip per 8 steps, but 45 % of the records' sectors instead of all of them -- the stage is
+  // bound by the record traffic, and a wave that waits here leaves the SIMD to the forward passes of the others (5.42 -> 5.06 ms;
+  // fetching whole records 2 .. 8 blocks ahead, which hides the latency instead, made no difference at all).
+  // A whole block per step: its decisions d_k = !tag_k (k = 0 .. 7, step 8 b + k), bit-reversed: r8 = d_0 .. d_7 from the top.  Walking
+  // back from step 8 b + 7 to 8 b leaves state (d_0 .. d_5) = r8 >> 2; data bit i = step - 6 goes MSB-first into byte i >> 3: d_6, d_7
+  // are the top two bits of byte b, d_0 .. d_5 the low six bits of byte b - 1 -- the new state itself.
+  for (int b = nfull - 1; b >= 0; --b) {
+    const unsigned reg = ((state >> 5) << 4) | (state & 15u), half = (state >> 4) & 1u, i = reg >> 1, byte = 2u * (reg & 1u) + half;   // survivor_record8's layout
+    const uint4 r = rec_load(my_rec + static_cast<size_t>(b) * 256 + 64 * (i >> 2));
+    const uint32_t lo = (i & 1u) ? in_vgpr(r.y) : in_vgpr(r.x), hi = (i & 1u) ? in_vgpr(r.w) : in_vgpr(r.z);
+    const unsigned tags = (((i & 2u) ? hi : lo) >> (8u * byte)) & 255u;
+    if (b >= 1) {
+      const unsigned r8 = __brev(~tags & 0xffu) >> 24;
+      state = r8 >> 2;
+      acc |= ((r8 & 3u) << 6) << (8 * (b & 3));
+      if ((b & 3) == 0) {
+        dst[b >> 2] = acc ^ prbs_words[b >> 2];
+        acc = 0;
       }
+      acc |= state << (8 * ((b - 1) & 3));
+    } else {
+      consume(tags, 0, 7);                                 // steps 0..5 only flush the encoder's initial zeros
     }
   }
 }
@@ -544,20 +509,14 @@ __device__ __forceinline__ void chain_back(const uint4* my_rec, int nsteps, cons
   };
   const int nfull = nsteps >> 2, r = nsteps & 3;
   if (r) consume(my_rec[static_cast<size_t>(nfull) * 128].x & 15u, 4 * nfull, r - 1);
-  // records are fetched 4 blocks at a time (their addresses do not depend on the path)
-  for (int b_hi = nfull - 1; b_hi >= 1; b_hi -= 4) {
-    uint4 lo[4], hi[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const size_t b = static_cast<size_t>(max(b_hi - u, 0));
-      lo[u] = rec_load(my_rec + b * 128);
-      hi[u] = rec_load(my_rec + b * 128 + 64);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int b = b_hi - u;
-      if (b >= 1) consume(survivor_nibble(lo[u], hi[u], state), 4 * b, 3);
-    }
+  // as in chain_back8: only the 16-byte half of a record that holds the state's nibble is fetched (half = word index >> 2).
+  // Block 0 (steps 0..3) only flushes the encoder's initial zeros: nothing to read.
+  for (int b = nfull - 1; b >= 1; --b) {
+    const unsigned reg = ((state >> 5) << 4) | (state & 15u), half = (state >> 4) & 1u;
+    const unsigned i = reg >> 2, nib = 4u * (reg & 1u) + 2u * half + ((reg >> 1) & 1u);     // survivor_record's layout
+    const uint4 v = rec_load(my_rec + static_cast<size_t>(b) * 128 + 64 * (i >> 2));
+    const uint32_t lo = (i & 1u) ? in_vgpr(v.y) : in_vgpr(v.x), hi = (i & 1u) ? in_vgpr(v.w) : in_vgpr(v.z);
+    consume((((i & 2u) ? hi : lo) >> (4u * nib)) & 15u, 4 * b, 3);
   }
 }
 
