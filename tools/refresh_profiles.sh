@@ -30,6 +30,6 @@ done
 ( echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --no-cpu-baseline --no-variants --steps 1 --warmup 1; sums per kernel, KiB"
   python3 $R/tools/sq_pmc_summary.py fetch=$O/pmc_FETCH_SIZE write=$O/pmc_WRITE_SIZE | grep -E "pass,|ofdm_fft|ofdm_demap|viterbi_fused" ) > $O/k2_pmc_traffic.csv
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
-$R/variants/valu_rates > $O/valu_rates.txt 2>&1
-$R/variants/hbm_rates > $O/hbm_rates.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w $R/tools/ubench/valu_rates.hip -o /tmp/valu_rates && /tmp/valu_rates > $O/valu_rates.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w $R/tools/ubench/hbm_rates.hip -o /tmp/hbm_rates && /tmp/hbm_rates > $O/hbm_rates.txt 2>&1
 ls -la $O
