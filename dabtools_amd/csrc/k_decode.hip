@@ -458,7 +458,7 @@ __device__ __forceinline__ void chain_back8(const uint4* my_rec, int nsteps, con
   };
   const int nfull = nsteps >> 3, r = nsteps & 7;
   if (r) consume(my_rec[static_cast<size_t>(nfull) * 256].x & 255u, 8 * nfull, r - 1);
-  // Only the 16-byte part of a record that holds the current state's byte is fetched (part = state bits 5 and 3): a chain of
+  // Only the word of a record that holds the current state's byte is fetched (its 16-byte part = state bits 5 and 3): a chain of
   // dependent loads, one memory round trip per 8 steps, but 45 % of the records' sectors instead of all of them -- the stage is
   // bound by the record traffic, and a wave that waits here leaves the SIMD to the forward passes of the others (5.42 -> 5.06 ms;
   // fetching whole records 2 .. 8 blocks ahead, which hides the latency instead, made no difference at all).
@@ -467,9 +467,8 @@ __device__ __forceinline__ void chain_back8(const uint4* my_rec, int nsteps, con
   // are the top two bits of byte b, d_0 .. d_5 the low six bits of byte b - 1 -- the new state itself.
   for (int b = nfull - 1; b >= 0; --b) {
     const unsigned reg = ((state >> 5) << 4) | (state & 15u), half = (state >> 4) & 1u, i = reg >> 1, byte = 2u * (reg & 1u) + half;   // survivor_record8's layout
-    const uint4 r = rec_load(my_rec + static_cast<size_t>(b) * 256 + 64 * (i >> 2));
-    const uint32_t lo = (i & 1u) ? in_vgpr(r.y) : in_vgpr(r.x), hi = (i & 1u) ? in_vgpr(r.w) : in_vgpr(r.z);
-    const unsigned tags = (((i & 2u) ? hi : lo) >> (8u * byte)) & 255u;
+    const uint32_t w = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(my_rec + static_cast<size_t>(b) * 256 + 64 * (i >> 2)) + (i & 3u));
+    const unsigned tags = (w >> (8u * byte)) & 255u;
     if (b >= 1) {
       const unsigned r8 = __brev(~tags & 0xffu) >> 24;
       state = r8 >> 2;
