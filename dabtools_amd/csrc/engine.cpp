@@ -505,7 +505,6 @@ bool Engine::msc_launch_async(const MscWork& w)
   const size_t nf = w.nframes;
   msc_queued_ = false;
   if (nf == 0) return true;
-  if (!check(hipMemsetAsync(d_eti_.get(), 0x55, nf * kEtiBytes, stream_), "eti memset")) return false;   // padding, misc.c:295
   if (!launch_decode_batch(w.batch, d_msc_bits_.get(), d_stream_cif_base_.get(), d_prbs_.get(), d_eti_.get(), kEtiBytes)) return false;
   if (!check(launch_eti_finish(d_meta_.get(), static_cast<int>(nf), d_headers_.get(), w.header_stride, d_fibs_.get(), d_crc_tab_.get(), d_crc_shift_.get(), d_eti_.get(), stream_), "eti finish launch"))
     return false;

@@ -728,8 +728,7 @@ __device__ __forceinline__ uint16_t crc_shift(uint16_t crc, int nbytes, const ui
 
 // one WAVE per ETI frame: header bytes (built by the host control plane, init_eti misc.c:153-213), the 96 FIB
 // bytes of the oldest CIF (misc.c:239), EOF CRC over FIC+MST, RFU, TIST (misc.c:281-292).  Each lane takes a
-// slice of the CRC range; the partial CRCs are combined with crc_shift.  The 0x55 padding was laid down by a
-// memset beforehand.
+// slice of the CRC range; the partial CRCs are combined with crc_shift.  The 0x55 padding behind the trailer is written here too.
 // The CRC runs four bytes at a time ("slicing by 4": tab[k][x] = CRC of byte x followed by k zero bytes, so that one 32-bit word
 // costs four INDEPENDENT look-ups instead of a chain of four); the range is a multiple of 8 bytes (96 + 8-byte sub-channel units)
 // and starts 4-byte aligned, so a lane's slice is whole words.
@@ -787,6 +786,10 @@ __global__ __launch_bounds__(256) void eti_finish_kernel(const EtiFrameMeta* __r
     e[pos++] = static_cast<uint8_t>(out & 0xff);
     for (int i = 0; i < 6; ++i) e[pos++] = 0xff;
   }
+  // the rest of the frame is padding (misc.c:295): header, FIBs, every sub-channel's bytes (multiples of 8) and the trailer above are
+  // all written by someone, so the frame needs no fill beforehand
+  uint32_t* ew = reinterpret_cast<uint32_t*>(e);
+  for (int i = (m.header_len + n + 8) / 4 + lane; i < kEtiBytes / 4; i += 64) ew[i] = 0x55555555u;
 }
 
 }  // namespace
