@@ -349,6 +349,7 @@ def run_rank(args, coord):
             if not args.no_cpu_baseline and world == 1:
                 extra["cpu_baseline"] = cpu_baseline(tensors, args.tfs, args.cpu_sample)
 
+    rank_info["host_ms_per_step"] = {k: round(stage[k], 4) for k in ("control", "host_worklist", "host_setup", "host_frames", "wall") if k in stage}
     rows = coord.gather({"info": rank_info, "elapsed": elapsed, "frames": frames})
     if rank == 0:
         elapsed_max = max(r["elapsed"] for r in rows)

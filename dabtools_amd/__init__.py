@@ -62,7 +62,24 @@ _SIGNATURES = {
     "dabhip_dab_locked": (C.c_int, [C.c_void_p]),
     "dabhip_dab_last_fibs": (C.c_int, [C.c_void_p, u8p, u8p]),
     "dabhip_engine_create": (C.c_void_p, [C.c_int]),
+    "dabhip_engine_create_ex": (C.c_void_p, [C.c_int, C.c_int]),
     "dabhip_engine_destroy": (None, [C.c_void_p]),
+    "dabhip_multi_create": (C.c_void_p, [C.POINTER(C.c_int), C.c_int]),
+    "dabhip_multi_destroy": (None, [C.c_void_p]),
+    "dabhip_multi_slices": (C.c_int, [C.c_void_p]),
+    "dabhip_multi_slice_of": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "dabhip_multi_decode": (C.c_int64, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int]),
+    "dabhip_multi_eti_count": (C.c_int64, [C.c_void_p, C.c_int]),
+    "dabhip_multi_eti_read": (C.c_int64, [C.c_void_p, C.c_int, u8p, C.c_int64]),
+    "dabhip_multi_eti_drain": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dabhip_multi_trace": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int]),
+    "dabhip_multi_engine": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "dabhip_multi_wall_ms": (C.c_float, [C.c_void_p, C.c_int]),
+    "dabhip_multi_set_afc": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_multi_set_soft": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_multi_set_parity_guard": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_multi_set_fused": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_multi_set_subchannels": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
     "dabhip_engine_decode": (C.c_int64, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int]),
     "dabhip_engine_eti_count": (C.c_int64, [C.c_void_p, C.c_int]),
     "dabhip_engine_eti_read": (C.c_int64, [C.c_void_p, C.c_int, u8p, C.c_int64]),
@@ -99,6 +116,7 @@ _SIGNATURES = {
     "dabhip_stream_create": (C.c_void_p, [C.c_int, C.c_int]),
     "dabhip_stream_destroy": (None, [C.c_void_p]),
     "dabhip_stream_feed": (C.c_int64, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int]),
+    "dabhip_stream_prefetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int]),
     "dabhip_stream_eti_count": (C.c_int64, [C.c_void_p, C.c_int]),
     "dabhip_stream_eti_read": (C.c_int64, [C.c_void_p, C.c_int, u8p, C.c_int64]),
     "dabhip_stream_eti_drain": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -207,6 +225,29 @@ def stream_ceiling(device=0, nbytes=4 << 30, reps=3):
     g = (C.c_double * 3)()
     _need(lib().dabhip_stream_ceiling(device, nbytes, reps, g) == 0, "stream_ceiling")
     return {"fill": g[0], "copy": g[1], "k2_mix": g[2]}
+
+
+class HostBuffer:
+    """nbytes of page-locked host memory (dabhip_host_alloc): .array is a numpy view, .ptr its address.  Uploads from it are
+    plain asynchronous DMA at the PCIe rate; pageable memory goes through the engine's staging ring instead."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self.ptr = lib().dabhip_host_alloc(max(self.nbytes, 1))
+        _need(self.ptr, "host_alloc")
+        self.array = np.ctypeslib.as_array(C.cast(self.ptr, u8p), (self.nbytes,))
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib().dabhip_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class DeviceBuffer:
@@ -408,8 +449,9 @@ class Dab:
 
 # ---- batch engine -------------------------------------------------------------------------------
 class Engine:
-    def __init__(self, device=0):
-        self._h = lib().dabhip_engine_create(device)
+    def __init__(self, device=0, host_threads=0, _borrowed=None):
+        self._owned = _borrowed is None
+        self._h = _borrowed or lib().dabhip_engine_create_ex(device, host_threads)
         _need(self._h, "engine_create")
         self.nstreams = 0
 
@@ -464,6 +506,15 @@ class Engine:
         self.nstreams = len(arrs)
         return n
 
+    def decode_host_ptrs(self, ptrs, sizes):
+        """ptrs: HOST addresses (ints; page-locked memory from HostBuffer uploads at the PCIe rate), sizes: byte counts."""
+        p = (C.c_void_p * len(ptrs))(*ptrs)
+        s = (C.c_size_t * len(sizes))(*sizes)
+        n = lib().dabhip_engine_decode(self._h, p, s, len(ptrs), 0)
+        _need(n >= 0, "engine_decode")
+        self.nstreams = len(ptrs)
+        return n
+
     def decode_device(self, ptrs, sizes):
         """ptrs: device addresses (ints, e.g. torch tensor.data_ptr()), sizes: byte counts."""
         p = (C.c_void_p * len(ptrs))(*ptrs)
@@ -498,9 +549,9 @@ class Engine:
         return ints[:n], ffs[:n]
 
     def stage_ms(self):
-        names = (C.c_char_p * 12)()
-        ms = (C.c_float * 12)()
-        n = lib().dabhip_engine_stage_ms(self._h, names, ms, 12)
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = lib().dabhip_engine_stage_ms(self._h, names, ms, 16)
         return {names[i].decode(): ms[i] for i in range(n)}
 
     def fft_stats(self):
@@ -545,12 +596,116 @@ class Engine:
         return fibs, ok
 
     def close(self):
-        if self._h:
+        if self._h and self._owned:
             lib().dabhip_engine_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):
         try:                       # at interpreter shutdown the module globals may already be gone
+            self.close()
+        except Exception:
+            pass
+
+
+class Multi:
+    """The batch engine over several devices of one node (dabhip_multi_*): streams dealt to the devices in contiguous slices
+    (2048 on 8 = stream s on device s // 256), all slices decoding at once, no exchange between them.  A device may be listed
+    several times (every entry is its own slice)."""
+
+    def __init__(self, devices):
+        devs = list(devices)
+        self._h = lib().dabhip_multi_create((C.c_int * len(devs))(*devs), len(devs))
+        _need(self._h, "multi_create")
+        self.devices = devs
+        self.nstreams = 0
+
+    def _set(self, fn, enable):
+        _need(fn(self._h, 1 if enable else 0) == 0, "multi_set")
+
+    def set_afc(self, enable):
+        self._set(lib().dabhip_multi_set_afc, enable)
+
+    def set_soft(self, enable):
+        self._set(lib().dabhip_multi_set_soft, enable)
+
+    def set_parity_guard(self, enable):
+        self._set(lib().dabhip_multi_set_parity_guard, enable)
+
+    def set_fused(self, enable):
+        self._set(lib().dabhip_multi_set_fused, enable)
+
+    def set_subchannels(self, ids):
+        ids = list(ids or [])
+        _need(lib().dabhip_multi_set_subchannels(self._h, (C.c_int32 * max(len(ids), 1))(*ids), len(ids)) == 0, "multi_set_subchannels")
+
+    def decode(self, streams):
+        """streams: list of numpy uint8 arrays (host) -> total ETI frames."""
+        arrs = [np.ascontiguousarray(s, dtype=np.uint8) for s in streams]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        sizes = (C.c_size_t * len(arrs))(*[a.size for a in arrs])
+        n = lib().dabhip_multi_decode(self._h, ptrs, sizes, len(arrs), 0)
+        _need(n >= 0, "multi_decode")
+        self.nstreams = len(arrs)
+        return n
+
+    def decode_device(self, ptrs, sizes):
+        """ptrs[b]: device address on the device of stream b's slice (slice_of)."""
+        p = (C.c_void_p * len(ptrs))(*ptrs)
+        s = (C.c_size_t * len(sizes))(*sizes)
+        n = lib().dabhip_multi_decode(self._h, p, s, len(ptrs), 1)
+        _need(n >= 0, "multi_decode")
+        self.nstreams = len(ptrs)
+        return n
+
+    def slice_of(self, stream):
+        """(slice, device) of a stream in a decode of the last decode's size."""
+        dev = C.c_int(0)
+        sl = lib().dabhip_multi_slice_of(self._h, stream, C.byref(dev))
+        _need(sl >= 0, "multi_slice_of")
+        return sl, dev.value
+
+    def eti_count(self, stream):
+        return lib().dabhip_multi_eti_count(self._h, stream)
+
+    def eti(self, stream):
+        n = lib().dabhip_multi_eti_count(self._h, stream)
+        _need(n >= 0, "multi_eti_count")
+        out = np.zeros((n, ETI_BYTES), dtype=np.uint8)
+        if n:
+            _need(lib().dabhip_multi_eti_read(self._h, stream, _p(out), n) == n, "multi_eti_read")
+        return out
+
+    def drain(self):
+        """All frames through dabhip_multi_eti_drain -> [(stream, frame bytes)] in emission order."""
+        got = []
+        sink = C.CFUNCTYPE(None, u8p, C.c_int, C.c_void_p)(lambda p, b, _u: got.append((b, bytes(np.ctypeslib.as_array(p, (ETI_BYTES,))))))
+        n = lib().dabhip_multi_eti_drain(self._h, C.cast(sink, C.c_void_p), None)
+        _need(n == len(got), "multi_eti_drain")
+        return got
+
+    def trace(self, stream, ncalls):
+        ints = np.zeros((ncalls, 6), dtype=np.int32)
+        ffs = np.zeros(ncalls, dtype=np.float64)
+        n = lib().dabhip_multi_trace(self._h, stream, ints.ctypes.data_as(C.POINTER(C.c_int32)), ffs.ctypes.data_as(C.POINTER(C.c_double)), ncalls)
+        _need(n >= 0, "multi_trace")
+        return ints[:n], ffs[:n]
+
+    def engine(self, slice_index):
+        """The slice's engine (borrowed: stage_ms(), guard_stats(), ...)."""
+        h = lib().dabhip_multi_engine(self._h, slice_index)
+        _need(h, "multi_engine")
+        return Engine(_borrowed=h)
+
+    def wall_ms(self, slice_index=-1):
+        return lib().dabhip_multi_wall_ms(self._h, slice_index)
+
+    def close(self):
+        if self._h:
+            lib().dabhip_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
             self.close()
         except Exception:
             pass
@@ -581,6 +736,20 @@ class Stream:
         n = lib().dabhip_stream_feed(self._h, ptrs, sizes, 0)
         _need(n >= 0, "stream_feed")
         return n
+
+    def feed_ptrs(self, ptrs, sizes, on_device=False):
+        """feed() over raw addresses (page-locked host memory from host_alloc(), or device memory)."""
+        p = (C.c_void_p * len(ptrs))(*ptrs)
+        s = (C.c_size_t * len(sizes))(*sizes)
+        n = lib().dabhip_stream_feed(self._h, p, s, 1 if on_device else 0)
+        _need(n >= 0, "stream_feed")
+        return n
+
+    def prefetch_ptrs(self, ptrs, sizes, on_device=False):
+        """dabhip_stream_prefetch: start uploading the segment a later feed_ptrs() with the same arguments will consume."""
+        p = (C.c_void_p * len(ptrs))(*ptrs)
+        s = (C.c_size_t * len(sizes))(*sizes)
+        _need(lib().dabhip_stream_prefetch(self._h, p, s, 1 if on_device else 0) == 0, "stream_prefetch")
 
     def eti(self, stream):
         n = lib().dabhip_stream_eti_count(self._h, stream)

@@ -30,12 +30,12 @@ struct dabhip_engine {
   float wall_ms = 0;
   int device = 0;
 
-  explicit dabhip_engine(int dev) : device(dev)
+  explicit dabhip_engine(int dev, int host_threads = 0) : device(dev)
   {
     int nl = 1;   // measured on MI355X: splitting the batch costs more (two shorter Viterbi launches, two scans) than the overlap wins
     if (const char* env = std::getenv("DABHIP_LANES")) nl = std::max(1, std::min(4, std::atoi(env)));
     for (int l = 0; l < nl; ++l) {
-      lanes.emplace_back(new Engine(dev));
+      lanes.emplace_back(new Engine(dev, host_threads));
       if (!lanes.back()->ok()) break;
     }
     for (auto& l : lanes) l->set_heavy_lock(lanes.size() > 1 ? &heavy : nullptr);
@@ -108,6 +108,12 @@ dabhip_engine* dabhip_engine_create(int device)
   if (e && !e->ok()) { delete e; return nullptr; }
   return e;
 }
+dabhip_engine* dabhip_engine_create_ex(int device, int host_threads)
+{
+  dabhip_engine* e = new (std::nothrow) dabhip_engine(device, host_threads);
+  if (e && !e->ok()) { delete e; return nullptr; }
+  return e;
+}
 void dabhip_engine_destroy(dabhip_engine* e) { delete e; }
 
 int64_t dabhip_engine_decode(dabhip_engine* e, const uint8_t* const* iq, const size_t* nbytes, int nstreams, int on_device)
@@ -175,17 +181,22 @@ int dabhip_engine_trace(const dabhip_engine* e, int stream, int32_t* ints6, doub
 int dabhip_engine_stage_ms(const dabhip_engine* e, const char** names, float* ms, int cap)
 {
   if (!e) return -1;
-  static const char* kNames[12] = {"sync", "fft", "demap", "fic", "control", "gather", "viterbi", "eti", "host_setup", "host_frames", "host_worklist", "wall"};
-  float v[12] = {0};
+  constexpr int kN = 15;
+  static const char* kNames[kN] = {"sync", "fft", "demap", "fic", "control", "gather", "viterbi", "eti", "host_setup", "host_frames", "host_worklist", "wall",
+                                   "h2d", "h2d_mbytes", "h2d_pinned_mbytes"};
+  float v[kN] = {0};
   for (size_t l = 0; l < e->lanes.size(); ++l) {
     if (e->lane_frames.empty() || (l > 0 && e->lane_frames[l] == 0 && e->lane_of.size() < 64)) continue;
     const StageTimes& t = e->lanes[l]->stage_times();
     const float x[11] = {t.sync, t.fft, t.demap, t.fic, t.control, t.gather, t.viterbi, t.eti, t.setup, t.frames, t.worklist};
     for (int i = 0; i < 11; ++i) v[i] += x[i];     // lanes overlap in time: the sum is device/host work, not wall time
+    v[12] += t.h2d;
+    v[13] += static_cast<float>(t.h2d_bytes * 1e-6);
+    v[14] += static_cast<float>(t.h2d_pinned_bytes * 1e-6);
   }
   v[11] = e->wall_ms;
   int n = 0;
-  for (; n < 12 && n < cap; ++n) {
+  for (; n < kN && n < cap; ++n) {
     if (names) names[n] = kNames[n];
     if (ms) ms[n] = v[n];
   }
@@ -577,20 +588,54 @@ extern "C" int dabhip_synth_generate_device(const dabhip_synth_cfg* cfgs, int ns
 }
 
 // ---- streaming sessions -----------------------------------------------
-// B parallel unbounded streams decoded segment by segment.  Per stream the session keeps a device window holding the
-// bytes the front end may still read (FIFO backlog and stale-tail sources, Engine::stream_need_from) followed by the
-// new segment; windows ping-pong between two allocations so that the kept bytes never overlap their destination.
+// B parallel unbounded streams decoded segment by segment.  Per stream the session keeps device windows: segment k lives in
+// window k % 3 behind a reserve of kWindowReserve bytes, and the bytes of earlier segments the front end may still read (FIFO
+// backlog and stale-tail sources, Engine::stream_need_from) are copied in front of it from window (k - 1) % 3 when segment k is
+// fed.  Three windows so that the NEXT segment (k + 1) can be uploading into its window -- which holds segment k - 2, dead since
+// feed(k - 1) -- on a stream of its own while segment k decodes (dabhip_stream_prefetch).
+namespace {
+constexpr size_t kWindowReserve = size_t(8) << 20;    // > FIFO capacity (1.5 MiB) + 12 nested stale tails of one TF each
+}
 struct dabhip_stream {
   Engine eng;
   int n = 0;
   bool first = true;
-  std::vector<std::unique_ptr<DeviceBuffer<uint8_t>>> win[2];
-  std::vector<int> cur;
-  std::vector<int64_t> base, avail;
-  dabhip_stream(int device, int nstreams) : eng(device), n(nstreams), cur(nstreams, 0), base(nstreams, 0), avail(nstreams, 0)
+  std::vector<std::unique_ptr<DeviceBuffer<uint8_t>>> win[3];
+  std::vector<int64_t> base, avail;            // per stream: first stream byte still held, bytes received (fed) so far
+  std::vector<size_t> org;                     // per stream: offset, in the newest fed window, of stream byte base[b]
+  uint64_t fed = 0, queued = 0;                // segments fed / handed over (fed <= queued <= fed + 2)
+  hipStream_t up_stream = nullptr;             // prefetch uploads
+  hipEvent_t up_done[3] = {nullptr, nullptr, nullptr};
+  struct Pending { std::vector<const uint8_t*> iq; std::vector<size_t> nbytes; };
+  Pending pending[3];                          // what was prefetched into window i (checked against the feed that consumes it)
+  dabhip_stream(int device, int nstreams) : eng(device), n(nstreams), base(nstreams, 0), avail(nstreams, 0), org(nstreams, 0)
   {
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 3; ++s)
       for (int b = 0; b < nstreams; ++b) win[s].emplace_back(new DeviceBuffer<uint8_t>());
+    if (eng.ok()) {
+      (void)hipStreamCreateWithFlags(&up_stream, hipStreamNonBlocking);
+      for (auto& e : up_done) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    }
+  }
+  ~dabhip_stream()
+  {
+    if (up_stream) (void)hipStreamSynchronize(up_stream);
+    for (auto& e : up_done)
+      if (e) (void)hipEventDestroy(e);
+    if (up_stream) (void)hipStreamDestroy(up_stream);
+  }
+  // segment -> window w of every stream, behind the reserve, on stream `st`
+  bool upload(int w, const uint8_t* const* iq, const size_t* nbytes, bool on_device, hipStream_t st)
+  {
+    for (int b = 0; b < n; ++b) {
+      DeviceBuffer<uint8_t>& to = *win[w][b];
+      if (!to.reserve(kWindowReserve + std::max<size_t>(nbytes[b], 16))) return false;
+      if (nbytes[b] && hipMemcpyAsync(to.get() + kWindowReserve, iq[b], nbytes[b], on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st) != hipSuccess) {
+        set_error("stream_feed: segment upload failed");
+        return false;
+      }
+    }
+    return true;
   }
 };
 
@@ -598,7 +643,7 @@ extern "C" dabhip_stream* dabhip_stream_create(int device, int nstreams)
 {
   if (nstreams <= 0) { set_error("stream_create: no streams"); return nullptr; }
   dabhip_stream* s = new dabhip_stream(device, nstreams);
-  if (!s->eng.ok()) { delete s; return nullptr; }
+  if (!s->eng.ok() || !s->up_stream) { delete s; return nullptr; }
   return s;
 }
 extern "C" void dabhip_stream_destroy(dabhip_stream* s) { delete s; }
@@ -619,26 +664,68 @@ extern "C" int dabhip_stream_set_soft(dabhip_stream* s, int on)
   return 0;
 }
 
+// Start uploading a segment that a LATER dabhip_stream_feed will consume, and return at once.  Host segments must live in
+// page-locked memory (dabhip_host_alloc) for the copy to be a true asynchronous DMA; they must stay untouched until the feed
+// that consumes them has returned.
+extern "C" int dabhip_stream_prefetch(dabhip_stream* s, const uint8_t* const* iq, const size_t* nbytes, int on_device)
+{
+  if (!s || !iq || !nbytes) { set_error("stream_prefetch: null argument"); return -1; }
+  if (s->queued - s->fed >= 2) { set_error("stream_prefetch: two segments are already waiting to be fed"); return -1; }
+  if (hipSetDevice(s->eng.device()) != hipSuccess) { set_error("stream_prefetch: hipSetDevice failed"); return -1; }
+  const int w = static_cast<int>(s->queued % 3);
+  if (!s->upload(w, iq, nbytes, on_device != 0, s->up_stream)) return -1;
+  if (hipEventRecord(s->up_done[w], s->up_stream) != hipSuccess) { set_error("stream_prefetch: event record failed"); return -1; }
+  s->pending[w].iq.assign(iq, iq + s->n);
+  s->pending[w].nbytes.assign(nbytes, nbytes + s->n);
+  ++s->queued;
+  return 0;
+}
+
 extern "C" int64_t dabhip_stream_feed(dabhip_stream* s, const uint8_t* const* iq, const size_t* nbytes, int on_device)
 {
   if (!s || !iq || !nbytes) { set_error("stream_feed: null argument"); return -1; }
   if (hipSetDevice(s->eng.device()) != hipSuccess) { set_error("stream_feed: hipSetDevice failed"); return -1; }
+  const int w = static_cast<int>(s->fed % 3), wprev = static_cast<int>((s->fed + 2) % 3);
+  hipStream_t st = s->eng.stream();
+  if (s->queued > s->fed) {                    // this segment was prefetched: it must be the one handed over first
+    const dabhip_stream::Pending& p = s->pending[w];
+    for (int b = 0; b < s->n; ++b)
+      if (p.iq[b] != iq[b] || p.nbytes[b] != nbytes[b]) { set_error("stream_feed: not the segment that was prefetched first"); return -1; }
+    if (hipStreamWaitEvent(st, s->up_done[w], 0) != hipSuccess) { set_error("stream_feed: event wait failed"); return -1; }
+  } else {
+    if (!s->upload(w, iq, nbytes, on_device != 0, st)) return -1;
+    ++s->queued;
+  }
   std::vector<const uint8_t*> virt(s->n);
   std::vector<size_t> avail(s->n);
   for (int b = 0; b < s->n; ++b) {
     const int64_t need = s->first ? 0 : std::min(s->eng.stream_need_from(b), s->avail[b]);
-    const size_t kept = static_cast<size_t>(s->avail[b] - need), total = kept + nbytes[b];
-    DeviceBuffer<uint8_t>& from = *s->win[s->cur[b]][b];
-    DeviceBuffer<uint8_t>& to = *s->win[s->cur[b] ^ 1][b];
-    if (!to.reserve(std::max<size_t>(total, 16))) return -1;
-    if (kept && hipMemcpyAsync(to.get(), from.get() + (need - s->base[b]), kept, hipMemcpyDeviceToDevice, s->eng.stream()) != hipSuccess) { set_error("stream_feed: window move failed"); return -1; }
-    if (nbytes[b] && hipMemcpyAsync(to.get() + kept, iq[b], nbytes[b], on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->eng.stream()) != hipSuccess) { set_error("stream_feed: segment upload failed"); return -1; }
-    s->cur[b] ^= 1;
+    const size_t kept = static_cast<size_t>(s->avail[b] - need);
+    DeviceBuffer<uint8_t>& from = *s->win[wprev][b];
+    DeviceBuffer<uint8_t>* to = s->win[w][b].get();
+    size_t at = kWindowReserve;                 // where the segment starts in `to`
+    if (kept > kWindowReserve) {
+      // more history than the reserve holds (not seen in practice): move the segment into a larger window
+      std::unique_ptr<DeviceBuffer<uint8_t>> big(new DeviceBuffer<uint8_t>());
+      if (!big->reserve(kept + std::max<size_t>(nbytes[b], 16))) return -1;
+      if (nbytes[b] && hipMemcpyAsync(big->get() + kept, to->get() + kWindowReserve, nbytes[b], hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("stream_feed: window move failed"); return -1; }
+      if (hipStreamSynchronize(st) != hipSuccess) { set_error("stream_feed: window move failed"); return -1; }
+      s->win[w][b] = std::move(big);
+      to = s->win[w][b].get();
+      at = kept;
+    }
+    // stream byte x of the bytes still held lives at from + org + (x - base)
+    if (kept && hipMemcpyAsync(to->get() + at - kept, from.get() + s->org[b] + (need - s->base[b]), kept, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+      set_error("stream_feed: window move failed");
+      return -1;
+    }
+    s->org[b] = at - kept;
     s->base[b] = need;
     s->avail[b] += static_cast<int64_t>(nbytes[b]);
-    virt[b] = to.get() - need;           // byte x of the stream lives at virt[b][x]
+    virt[b] = to->get() + at - kept - need;    // byte x of the stream lives at virt[b][x]
     avail[b] = static_cast<size_t>(s->avail[b]);
   }
+  ++s->fed;
   const int64_t frames = s->eng.feed(virt.data(), avail.data(), s->n, s->first);
   if (frames >= 0) s->first = false;
   return frames;

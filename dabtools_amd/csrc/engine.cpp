@@ -62,7 +62,7 @@ bool Engine::check(hipError_t e, const char* what)
   return false;
 }
 
-Engine::Engine(int device) : device_(device)
+Engine::Engine(int device, int host_threads) : device_(device)
 {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device: libdabhip has no CPU fallback"); return; }
@@ -77,6 +77,10 @@ Engine::Engine(int device) : device_(device)
     return;
   for (auto& e : ev_msc_)
     if (!check(hipEventCreate(&e), "hipEventCreate")) return;
+  for (auto& e : ev_h2d_)
+    if (!check(hipEventCreate(&e), "hipEventCreate")) return;
+  for (auto& e : stage_ev_)
+    if (!check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) return;
 
   std::vector<double2> tw2048(2048), tw1536(1536);
   std::vector<float2> twf(2048);
@@ -125,9 +129,10 @@ Engine::Engine(int device) : device_(device)
   // host threads for the per-stream control plane: half the cores, at most 24; DABHIP_HOST_THREADS overrides it (bench.py
   // gives each of N ranks on a node cores / N, so that 8 ranks do not start 8 x 24 busy threads)
   const int hw = static_cast<int>(std::thread::hardware_concurrency());
-  int nthreads = std::min(hw / 2, 24);
+  int nthreads = host_threads > 0 ? std::min(host_threads, 64) : std::min(hw / 2, 24);
   if (const char* env = std::getenv("DABHIP_HOST_THREADS")) nthreads = std::max(1, std::min(64, std::atoi(env)));
   pool_.reset(new ThreadPool(std::max(0, nthreads - 1)));
+  host_lane_.reset(new AsyncLane());
   ok_ = true;
 }
 
@@ -144,6 +149,10 @@ Engine::~Engine()
   if (ev_fibs_) (void)hipEventDestroy(ev_fibs_);
   if (ev_part0_) (void)hipEventDestroy(ev_part0_);
   for (auto& e : ev_msc_)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : ev_h2d_)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : stage_ev_)
     if (e) (void)hipEventDestroy(e);
   if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
   if (stream_) (void)hipStreamDestroy(stream_);
@@ -537,6 +546,7 @@ bool Engine::msc_run(MscWork& w) { return msc_upload(w, stream_) && msc_launch(w
 bool Engine::read_eti(int64_t first, int64_t n, uint8_t* dst)
 {
   if (n <= 0) return true;
+  if (!check(hipSetDevice(device_), "hipSetDevice")) return false;   // callers may sit on another device's thread (dabhip_multi)
   return check(hipMemcpy(dst, d_eti_.get() + first * kEtiBytes, static_cast<size_t>(n) * kEtiBytes, hipMemcpyDeviceToHost), "eti download");
 }
 
@@ -666,6 +676,70 @@ bool Engine::begin_decode(int nstreams, bool cont)
   return true;
 }
 
+// Host-fed decode (the reference's input arrives in host buffers: dab2eti.c:117-130,238).  Streams that live in page-locked memory
+// (dabhip_host_alloc, hipHostMalloc / hipHostRegister of the caller's own) go up as plain asynchronous DMA, one copy per stream,
+// back to back on the main stream.  Pageable memory cannot be DMA'd from: it is copied into a ring of page-locked staging buffers
+// by the engine's host pool (all threads on one piece: a single core's memcpy is slower than the PCIe link) and each piece leaves
+// as its own asynchronous copy, so the pool fills one buffer while up to three others drain.  K1 follows in stream order.
+bool Engine::upload_iq(const uint8_t* const* iq, const size_t* nbytes, int nstreams, const uint8_t** ptrs)
+{
+  constexpr size_t kStageBytes = size_t(32) << 20, kPiece = size_t(1) << 20;
+  (void)hipEventRecord(ev_h2d_[0], stream_);
+  size_t off = 0;
+  int next_buf = 0;
+  size_t fill = 0;                             // bytes staged in the current buffer, not yet queued
+  size_t fill_dst = 0;                         // device offset the current buffer's bytes go to (streams are laid out back to back)
+  auto flush = [&]() -> bool {
+    if (fill == 0) return true;
+    const bool ok = check(hipMemcpyAsync(d_iq_own_.get() + fill_dst, stage_buf_[next_buf].data(), fill, hipMemcpyHostToDevice, stream_), "IQ upload") &&
+                    check(hipEventRecord(stage_ev_[next_buf], stream_), "IQ upload");
+    next_buf = (next_buf + 1) % kStageBufs;
+    fill = 0;
+    return ok;
+  };
+  for (int b = 0; b < nstreams; ++b) {
+    uint8_t* const dst = d_iq_own_.get() + off;
+    ptrs[b] = dst;
+    const size_t n = nbytes[b], padded = (n + 15) & ~size_t(15);
+    hipPointerAttribute_t attr;
+    const bool pinned = n && hipPointerGetAttributes(&attr, iq[b]) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (!pinned) (void)hipGetLastError();      // an unregistered pointer is reported as an error: that is the answer, not a failure
+    times_.h2d_bytes += static_cast<double>(n);
+    if (pinned) {
+      if (!flush()) return false;              // keeps the copies in stream order (cheap: at most one partly filled buffer)
+      times_.h2d_pinned_bytes += static_cast<double>(n);
+      if (!check(hipMemcpyAsync(dst, iq[b], n, hipMemcpyHostToDevice, stream_), "IQ upload")) return false;
+    } else {
+      // staged: a stream's bytes continue in the buffer where the previous stream's ended only when they are adjacent on the device
+      // (they are, up to the 16-byte padding: a buffer is flushed at a stream boundary when the padding is not zero)
+      size_t done = 0;
+      while (done < n) {
+        if (fill == 0) {
+          if (!stage_buf_[next_buf].resize(kStageBytes)) return false;
+          if (!check(hipEventSynchronize(stage_ev_[next_buf]), "IQ staging")) return false;   // its previous copy has left (never recorded: returns at once)
+          fill_dst = off + done;
+        }
+        const size_t take = std::min(n - done, kStageBytes - fill);
+        const uint8_t* src = iq[b] + done;
+        uint8_t* stage = stage_buf_[next_buf].data() + fill;
+        const int pieces = static_cast<int>((take + kPiece - 1) / kPiece);
+        pool_->parallel_for(pieces, [&](int i) {
+          const size_t a = static_cast<size_t>(i) * kPiece;
+          std::memcpy(stage + a, src + a, std::min(kPiece, take - a));
+        });
+        fill += take;
+        done += take;
+        if (fill == kStageBytes && !flush()) return false;
+      }
+      if (padded != n && !flush()) return false;
+    }
+    off += padded;
+  }
+  if (!flush()) return false;
+  (void)hipEventRecord(ev_h2d_[1], stream_);
+  return true;
+}
+
 // K1 over the calls that became complete: stages pointers / sizes / states, launches the scan, brings back {status, ordinal}
 // per call and the front-end states (main stream, awaited) and the full descriptors (side stream, awaited by the caller's guard)
 bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont, bool full_scan,
@@ -685,13 +759,7 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
   if (on_device) {
     for (int b = 0; b < nstreams; ++b) ptrs[b] = iq[b];
   } else {
-    if (!d_iq_own_.reserve(total)) return false;
-    size_t off = 0;
-    for (int b = 0; b < nstreams; ++b) {
-      if (!check(hipMemcpyAsync(d_iq_own_.get() + off, iq[b], nbytes[b], hipMemcpyHostToDevice, stream_), "IQ upload")) return false;
-      ptrs[b] = d_iq_own_.get() + off;
-      off += (nbytes[b] + 15) & ~size_t(15);
-    }
+    if (!d_iq_own_.reserve(total) || !upload_iq(iq, nbytes, nstreams, ptrs)) return false;
   }
   if (!h_states_.resize(nstreams)) return false;
   StreamState* const states = h_states_.data();
@@ -976,7 +1044,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   MscWork& work = work_;
   bool host_ok = true;
   std::string host_error;
-  std::thread host([&]() {
+  host_lane_->post([&]() {
     (void)hipSetDevice(device_);               // the current device is per thread
     const auto t0 = std::chrono::steady_clock::now();
     const bool fresh = planes_fresh_;
@@ -1015,7 +1083,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
 
   // the host thread is done before the OFDM stage (at 4.5 of 5.8 ms into the step with 24 threads): K4 + K5 are queued right
   // behind it, and the whole pipeline is awaited ONCE
-  host.join();
+  host_lane_->wait();
   if (gpu_ok && host_ok)
     gpu_ok = check(hipStreamWaitEvent(stream_, ev_upload_, 0), "work list wait") && msc_launch_async(work);
   mark("all queued");
@@ -1035,6 +1103,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     fft_tfs_ += std::min(chunk, ntf - c * chunk);
   }
   msc_collect();
+  if (!on_device && times_.h2d_bytes > 0) (void)hipEventElapsedTime(&times_.h2d, ev_h2d_[0], ev_h2d_[1]);
   if (guard && !guard_check()) return -1;
   // what the next segment of a session starts from
   for (int b = 0; b < nstreams; ++b) {

@@ -129,6 +129,8 @@ class PinnedBuffer {
 struct StageTimes {
   float sync = 0, fft = 0, demap = 0, fic = 0, control = 0, gather = 0, viterbi = 0, eti = 0;
   float setup = 0, frames = 0, worklist = 0, wall = 0;   // host-side phases (wall clock)
+  float h2d = 0;                                         // host-fed decode: upload of the IQ (HIP events; 0 when the IQ was resident)
+  double h2d_bytes = 0, h2d_pinned_bytes = 0;            // bytes uploaded, and how many of them came from page-locked memory
 };
 
 // Work list for gather + Viterbi launches: wave-groups of <= 64 equal-length code words.
@@ -152,7 +154,8 @@ struct MscWork {
 
 class Engine {
  public:
-  explicit Engine(int device);
+  // host_threads: threads of the per-stream control-plane pool (0 = half the cores, at most 24; DABHIP_HOST_THREADS overrides)
+  explicit Engine(int device, int host_threads = 0);
   ~Engine();
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
@@ -238,6 +241,8 @@ class Engine {
   // layout: called when the calls' {status, ordinal} are on the host (h_info_) -- early in the split scan, again after a re-scan
   bool scan_streams(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont, bool full_scan,
                     const std::function<bool()>& layout);
+  // host-fed decode: the streams' bytes into d_iq_own_ (ptrs[b] = where stream b landed), queued on the main stream
+  bool upload_iq(const uint8_t* const* iq, const size_t* nbytes, int nstreams, const uint8_t** ptrs);
   bool carry_and_reserve(const std::vector<int>& tf_base, const std::vector<int>& row_base, int nslots, int nrows);
   // plan_jobs[i] = (plan id, job indices decoded with that plan)
   void build_batch(const std::vector<std::pair<int, const std::vector<int>*>>& plan_jobs, DecodeBatch& out);
@@ -263,11 +268,18 @@ class Engine {
   int soft_bits_ = 0;
   std::mutex* heavy_mu_ = nullptr;
   std::unique_ptr<ThreadPool> pool_;   // host threads for per-stream control-plane work
+  std::unique_ptr<AsyncLane> host_lane_;   // the control-plane pass of a decode, beside its GPU work
   int device_ = 0;
   hipStream_t stream_ = nullptr, copy_stream_ = nullptr;   // copy_stream_: work-list uploads from the control-plane thread
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_upload_ = nullptr, ev_fic_ = nullptr, ev_fic_done_ = nullptr, ev_fibs_ = nullptr, ev_part0_ = nullptr, ev_chain_ = nullptr, ev_info_ = nullptr;
   hipEvent_t ev_msc_[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_h2d_[2] = {nullptr, nullptr};
+  // page-locked staging ring for uploads from pageable memory: the host pool copies piece n + 1 into one buffer while the DMA of
+  // piece n drains another
+  static constexpr int kStageBufs = 4;
+  PinnedBuffer<uint8_t> stage_buf_[kStageBufs];
+  hipEvent_t stage_ev_[kStageBufs] = {nullptr, nullptr, nullptr, nullptr};
   bool msc_queued_ = false;
   std::vector<hipEvent_t> chunk_ev_;
 

@@ -269,9 +269,12 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
   for (int l = group_syms * grp + 1; l <= group_syms * grp + group_syms; ++l) {
     uint8_t* d = dec[l & 1];
     const bool natural = l <= 3 || !kPlanar;
+    // Batch path (kPlanar): the FIC symbols were demapped -- and guarded -- by the pre-pass, and the FIC decode may be reading
+    // those rows on the side stream right now (Engine::fic_decode_slots_async), so this launch neither stores nor lists them.
+    const bool fic_done = kPlanar && l <= 3;
     float re[6], im[6];
     // parity guard (k_parity.hip; hard decisions only): error bounds of this symbol's and the previous symbol's bins
-    const bool guarded = kBits == 1 && guard.delta != nullptr;
+    const bool guarded = kBits == 1 && guard.delta != nullptr && !fic_done;
     const float dc = guarded ? guard.delta[static_cast<size_t>(first + j) * guard.delta_stride + l] : 0.0f;
     const float dp = guarded ? guard.delta[static_cast<size_t>(first + j) * guard.delta_stride + l - 1] : 0.0f;
 #pragma unroll
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
         w = ((y0 | (y0 >> 8)) & 0xffffu) | (((y1 | (y1 >> 8)) & 0xffffu) << 16);
       }
       if (natural) {
-        if (l <= 3) fic_bits[static_cast<size_t>(slot) * (288 * kBits) + (l - 1) * (96 * kBits) + t] = w;
+        if (l <= 3) { if (!fic_done) fic_bits[static_cast<size_t>(slot) * (288 * kBits) + (l - 1) * (96 * kBits) + t] = w; }
         else msc_bits[static_cast<size_t>(cif_row) * (1728 * kBits) + (l - 4) * (96 * kBits) + t] = w;
       } else {
         const int q = (l - 4) / 18, sidx = (l - 4) % 18;          // CIF within the TF, symbol within the CIF

@@ -1,0 +1,198 @@
+// multi.cpp — the batch engine over several MI355X of one node (include/dabhip.h: dabhip_multi_*).
+//
+// Ensembles are independent end to end, so a batch shards by stream with no data-path exchange: the
+// streams are dealt to the listed devices in contiguous slices (stream s of B on n devices -> slice s / ceil(B / n), the
+// low slices taking the remainder: 2048 streams on 8 devices = 256 each, stream s on device s / 256), every slice is one
+// complete batch engine with its own persistent host thread, HIP streams and control-plane pool, and the slices run
+// concurrently.  No collective, no peer access, no RCCL.  The ETI frames come back in stream order whatever device made
+// them.  This is the single-process form of what bench.py does with one process per GPU; dab2eti.c:237,279-302 (one demod
+// thread, one device) is what it stands in for.
+//
+// A device may be listed more than once: every entry is a slice of its own (tests map all eight slices of a node onto GPU 0).
+#include <algorithm>
+#include <chrono>
+#include <memory>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/dabhip.h"
+#include "thread_pool.hpp"
+
+namespace dabhip {
+void set_error(const std::string& msg);
+}
+using dabhip::AsyncLane;
+using dabhip::set_error;
+
+struct dabhip_multi {
+  struct Slice {
+    int device = 0;
+    dabhip_engine* eng = nullptr;
+    std::unique_ptr<AsyncLane> lane;     // the slice's host thread: its decode calls run here
+    int first = 0, count = 0;            // streams [first, first + count) of the last decode
+    int64_t frames = 0;
+    float wall_ms = 0;
+    std::string error;
+  };
+  std::vector<Slice> slices;
+  int nstreams = 0;
+  float wall_ms = 0;
+
+  ~dabhip_multi()
+  {
+    for (Slice& s : slices) {
+      s.lane.reset();
+      if (s.eng) dabhip_engine_destroy(s.eng);
+    }
+  }
+  const Slice* slice_of(int stream) const
+  {
+    if (stream < 0 || stream >= nstreams) return nullptr;
+    for (const Slice& s : slices)
+      if (stream >= s.first && stream < s.first + s.count) return &s;
+    return nullptr;
+  }
+};
+
+extern "C" {
+
+dabhip_multi* dabhip_multi_create(const int* devices, int n)
+{
+  if (!devices || n <= 0 || n > 64) { set_error("multi_create: need 1..64 devices"); return nullptr; }
+  std::unique_ptr<dabhip_multi> m(new (std::nothrow) dabhip_multi);
+  if (!m) return nullptr;
+  // host threads per slice: the slices share the host, so that eight of them do not start 8 x 24 busy threads
+  const int hw = static_cast<int>(std::thread::hardware_concurrency());
+  const int host_threads = std::max(2, std::min(24, hw / (2 * n)));
+  m->slices.resize(n);
+  for (int i = 0; i < n; ++i) {
+    dabhip_multi::Slice& s = m->slices[i];
+    s.device = devices[i];
+    s.eng = dabhip_engine_create_ex(devices[i], host_threads);
+    if (!s.eng) return nullptr;            // dabhip_last_error() says why (bad index, no GPU: there is no CPU fallback)
+    s.lane.reset(new AsyncLane());
+  }
+  return m.release();
+}
+
+void dabhip_multi_destroy(dabhip_multi* m) { delete m; }
+
+int dabhip_multi_slices(const dabhip_multi* m) { return m ? static_cast<int>(m->slices.size()) : -1; }
+
+int dabhip_multi_slice_of(const dabhip_multi* m, int stream, int* device)
+{
+  if (!m) return -1;
+  const dabhip_multi::Slice* s = m->slice_of(stream);
+  if (!s) return -1;
+  if (device) *device = s->device;
+  return static_cast<int>(s - m->slices.data());
+}
+
+int64_t dabhip_multi_decode(dabhip_multi* m, const uint8_t* const* iq, const size_t* nbytes, int nstreams, int on_device)
+{
+  if (!m || !iq || !nbytes) { set_error("multi_decode: null argument"); return -1; }
+  if (nstreams <= 0) { set_error("multi_decode: no streams"); return -1; }
+  const auto t0 = std::chrono::steady_clock::now();
+  const int n = static_cast<int>(m->slices.size());
+  const int base = nstreams / n, rem = nstreams % n;
+  int next = 0;
+  for (int i = 0; i < n; ++i) {
+    dabhip_multi::Slice& s = m->slices[i];
+    s.first = next;
+    s.count = base + (i < rem ? 1 : 0);
+    next += s.count;
+    s.frames = 0;
+    s.wall_ms = 0;
+    s.error.clear();
+  }
+  m->nstreams = nstreams;
+  for (dabhip_multi::Slice& s : m->slices) {
+    if (s.count == 0) continue;
+    dabhip_multi::Slice* sp = &s;
+    s.lane->post([sp, iq, nbytes, on_device]() {
+      const auto t = std::chrono::steady_clock::now();
+      sp->frames = dabhip_engine_decode(sp->eng, iq + sp->first, nbytes + sp->first, sp->count, on_device);
+      if (sp->frames < 0) sp->error = dabhip_last_error();      // thread-local text: carried to the caller's thread below
+      sp->wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t).count();
+    });
+  }
+  for (dabhip_multi::Slice& s : m->slices)
+    if (s.count) s.lane->wait();           // every slice is awaited, also after a failure: nothing may stay in flight
+  int64_t total = 0;
+  for (size_t i = 0; i < m->slices.size(); ++i) {
+    const dabhip_multi::Slice& s = m->slices[i];
+    if (s.frames < 0) { set_error("slice " + std::to_string(i) + " (device " + std::to_string(s.device) + "): " + s.error); return -1; }
+    total += s.frames;
+  }
+  m->wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return total;
+}
+
+int64_t dabhip_multi_eti_count(const dabhip_multi* m, int stream)
+{
+  const dabhip_multi::Slice* s = m ? m->slice_of(stream) : nullptr;
+  return s ? dabhip_engine_eti_count(s->eng, stream - s->first) : -1;
+}
+
+int64_t dabhip_multi_eti_read(dabhip_multi* m, int stream, uint8_t* dst, int64_t cap_frames)
+{
+  if (!m || !dst) { set_error("multi_eti_read: null argument"); return -1; }
+  const dabhip_multi::Slice* s = m->slice_of(stream);
+  if (!s) { set_error("multi_eti_read: bad stream"); return -1; }
+  return dabhip_engine_eti_read(s->eng, stream - s->first, dst, cap_frames);
+}
+
+int64_t dabhip_multi_eti_drain(dabhip_multi* m, dabhip_eti_sink sink, void* user)
+{
+  if (!m || !sink) { set_error("multi_eti_drain: null argument"); return -1; }
+  int64_t total = 0;
+  std::vector<uint8_t> buf;
+  for (int b = 0; b < m->nstreams; ++b) {   // stream order = slice order: the slices are contiguous
+    const int64_t n = dabhip_multi_eti_count(m, b);
+    if (n < 0) return -1;
+    buf.resize(static_cast<size_t>(n) * DABHIP_ETI_BYTES);
+    if (n && dabhip_multi_eti_read(m, b, buf.data(), n) != n) return -1;
+    for (int64_t f = 0; f < n; ++f) sink(buf.data() + f * DABHIP_ETI_BYTES, b, user);
+    total += n;
+  }
+  return total;
+}
+
+int dabhip_multi_trace(const dabhip_multi* m, int stream, int32_t* ints6, double* ffs, int cap_calls)
+{
+  const dabhip_multi::Slice* s = m ? m->slice_of(stream) : nullptr;
+  return s ? dabhip_engine_trace(s->eng, stream - s->first, ints6, ffs, cap_calls) : -1;
+}
+
+dabhip_engine* dabhip_multi_engine(dabhip_multi* m, int slice)
+{
+  if (!m || slice < 0 || slice >= static_cast<int>(m->slices.size())) return nullptr;
+  return m->slices[slice].eng;
+}
+
+// wall clock of the last decode: the whole call, and one slice's own decode (slice >= 0)
+float dabhip_multi_wall_ms(const dabhip_multi* m, int slice)
+{
+  if (!m) return -1.0f;
+  if (slice < 0) return m->wall_ms;
+  return slice < static_cast<int>(m->slices.size()) ? m->slices[slice].wall_ms : -1.0f;
+}
+
+#define DABHIP_MULTI_FORWARD(name, call)                       \
+  int name                                                     \
+  {                                                            \
+    if (!m) return -1;                                         \
+    for (auto& s : m->slices)                                  \
+      if (call != 0) return -1;                                \
+    return 0;                                                  \
+  }
+DABHIP_MULTI_FORWARD(dabhip_multi_set_afc(dabhip_multi* m, int enable), dabhip_engine_set_afc(s.eng, enable))
+DABHIP_MULTI_FORWARD(dabhip_multi_set_soft(dabhip_multi* m, int enable), dabhip_engine_set_soft(s.eng, enable))
+DABHIP_MULTI_FORWARD(dabhip_multi_set_parity_guard(dabhip_multi* m, int enable), dabhip_engine_set_parity_guard(s.eng, enable))
+DABHIP_MULTI_FORWARD(dabhip_multi_set_fused(dabhip_multi* m, int enable), dabhip_engine_set_fused(s.eng, enable))
+DABHIP_MULTI_FORWARD(dabhip_multi_set_subchannels(dabhip_multi* m, const int32_t* ids, int n), dabhip_engine_set_subchannels(s.eng, ids, n))
+#undef DABHIP_MULTI_FORWARD
+
+}  // extern "C"

@@ -100,4 +100,68 @@ class ThreadPool {
   bool stop_ = false;
 };
 
+// One persistent host thread that runs posted closures in order: the engine's control-plane pass runs here beside the GPU
+// work of the same decode (it used to be a std::thread created and joined per decode).
+class AsyncLane {
+ public:
+  AsyncLane() : worker_([this] { loop(); }) {}
+  ~AsyncLane()
+  {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    worker_.join();
+  }
+  AsyncLane(const AsyncLane&) = delete;
+  AsyncLane& operator=(const AsyncLane&) = delete;
+
+  // fn runs on the lane's thread; everything it references must stay alive until wait() has returned
+  void post(std::function<void()> fn)
+  {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      queue_.push_back(std::move(fn));
+      ++posted_;
+    }
+    cv_.notify_all();
+  }
+  // returns when everything posted so far has run
+  void wait()
+  {
+    std::unique_lock<std::mutex> lk(mu_);
+    const uint64_t target = posted_;
+    idle_.wait(lk, [&] { return finished_ >= target; });
+  }
+
+ private:
+  void loop()
+  {
+    for (;;) {
+      std::function<void()> fn;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return stop_ || !queue_.empty(); });
+        if (queue_.empty()) return;          // stop requested and nothing left to run
+        fn = std::move(queue_.front());
+        queue_.erase(queue_.begin());
+      }
+      fn();
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        ++finished_;
+      }
+      idle_.notify_all();
+    }
+  }
+
+  std::mutex mu_;
+  std::condition_variable cv_, idle_;
+  std::vector<std::function<void()>> queue_;
+  uint64_t posted_ = 0, finished_ = 0;
+  bool stop_ = false;
+  std::thread worker_;                       // last member: starts after the state it uses exists
+};
+
 }  // namespace dabhip

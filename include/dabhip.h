@@ -88,6 +88,9 @@ int dabhip_dab_last_fibs(const dabhip_dab *d, uint8_t *fibs, uint8_t *crc_ok);
 /* ---- batch engine ---------------------------------------------------------------------- */
 typedef struct dabhip_engine dabhip_engine;
 dabhip_engine *dabhip_engine_create(int device);
+/* The same with an explicit size for the engine's host thread pool (per-stream control plane, work lists, staging copies);
+ * 0 = automatic (half the cores, at most 24).  Several engines in one process should share the host between them. */
+dabhip_engine *dabhip_engine_create_ex(int device, int host_threads);
 void dabhip_engine_destroy(dabhip_engine *e);
 
 /* Decode B independent cu8 streams (the replay loop of dab2eti.c:60-130 per stream, in
@@ -139,6 +142,35 @@ int dabhip_engine_set_subchannels(dabhip_engine *e, const int32_t *ids, int n);
  * dabhip_engine_fft_stats describes whichever kernel ran; dabhip_engine_fft_roofline measures K2 by itself. */
 int dabhip_engine_set_fused(dabhip_engine *e, int enable);
 
+/* ---- several devices of one node (BASELINE configs[3]: 2048 streams = 256 per GPU x 8) --------------
+ * dab2eti.c:237,279-302 drives ONE device from one demod thread.  A batch of independent ensembles shards by stream with no
+ * data exchange at all: the streams of a decode are dealt to the listed devices in contiguous slices (stream s of B on n
+ * devices belongs to slice s / ceil(B / n), the low slices taking the remainder -- 2048 on 8 = stream s on device s / 256),
+ * every slice is a complete batch engine with its own persistent host thread and HIP streams, and all slices decode at
+ * once.  No collective, no peer access.  Frames are read back per GLOBAL stream index, or drained in stream order.
+ * A device may be listed more than once (each entry is its own slice).  iq[b]: host pointers, or -- on_device != 0 --
+ * device pointers that live on the device of stream b's slice (dabhip_multi_slice_of). */
+typedef struct dabhip_multi dabhip_multi;
+dabhip_multi *dabhip_multi_create(const int *devices, int n);
+void dabhip_multi_destroy(dabhip_multi *m);
+int dabhip_multi_slices(const dabhip_multi *m);
+/* Slice (and its device) that decodes `stream` in a decode of the size of the LAST dabhip_multi_decode. */
+int dabhip_multi_slice_of(const dabhip_multi *m, int stream, int *device);
+int64_t dabhip_multi_decode(dabhip_multi *m, const uint8_t *const *iq, const size_t *nbytes, int nstreams, int on_device);
+int64_t dabhip_multi_eti_count(const dabhip_multi *m, int stream);
+int64_t dabhip_multi_eti_read(dabhip_multi *m, int stream, uint8_t *dst, int64_t cap_frames);
+int64_t dabhip_multi_eti_drain(dabhip_multi *m, dabhip_eti_sink sink, void *user);   /* all frames, global stream order */
+int dabhip_multi_trace(const dabhip_multi *m, int stream, int32_t *ints6, double *ffs, int cap_calls);
+/* The engine of one slice, for the per-engine queries (stage times, guard statistics); owned by the multi object. */
+dabhip_engine *dabhip_multi_engine(dabhip_multi *m, int slice);
+/* Wall clock (ms) of the last decode: the whole call (slice < 0) or one slice's own decode on its host thread. */
+float dabhip_multi_wall_ms(const dabhip_multi *m, int slice);
+int dabhip_multi_set_afc(dabhip_multi *m, int enable);
+int dabhip_multi_set_soft(dabhip_multi *m, int enable);
+int dabhip_multi_set_parity_guard(dabhip_multi *m, int enable);
+int dabhip_multi_set_fused(dabhip_multi *m, int enable);
+int dabhip_multi_set_subchannels(dabhip_multi *m, const int32_t *ids, int n);
+
 /* ---- streaming sessions ---------------------------------------------
  * The batch engine over UNBOUNDED streams: B parallel captures fed segment by segment (stdin, a socket, a file too
  * large for the device).  The state dab2eti keeps between calls -- FIFO backlog and stale frame tail (sdr_fifo.c),
@@ -152,6 +184,12 @@ void dabhip_stream_destroy(dabhip_stream *s);
 /* Append nbytes[b] bytes to stream b (host pointers, or device pointers when on_device != 0) and decode every
  * 262144-byte call that became complete.  Returns the ETI frames produced by this segment, <0 on error. */
 int64_t dabhip_stream_feed(dabhip_stream *s, const uint8_t *const *iq, const size_t *nbytes, int on_device);
+/* Overlap of upload and decode: hand over the segment AFTER the one about to be fed.  Its upload starts at once on a stream
+ * of its own and runs while dabhip_stream_feed decodes the segment before it; a later dabhip_stream_feed with the SAME
+ * pointers and sizes consumes it.  Order of calls: prefetch(0) feed(0)  -or-  feed(0); then prefetch(k+1) feed(k) ...; at most
+ * two segments may be waiting.  Host segments must be page-locked (dabhip_host_alloc) for the copy to run asynchronously and must
+ * stay untouched until the feed that consumes them has returned.  Returns 0, <0 on error. */
+int dabhip_stream_prefetch(dabhip_stream *s, const uint8_t *const *iq, const size_t *nbytes, int on_device);
 int64_t dabhip_stream_eti_count(const dabhip_stream *s, int stream);
 int64_t dabhip_stream_eti_read(dabhip_stream *s, int stream, uint8_t *dst, int64_t cap_frames);
 int64_t dabhip_stream_eti_drain(dabhip_stream *s, dabhip_eti_sink sink, void *user);
@@ -180,7 +218,9 @@ int dabhip_engine_trace(const dabhip_engine *e, int stream, int32_t *ints6, doub
 
 /* Timing of the stages of the last decode (milliseconds, HIP events on the engine's stream).
  * names: "sync", "fft", "demap", "fic", "control", "gather", "viterbi", "eti", then host wall-clock
- * phases "host_setup", "host_frames", "host_worklist" and the total "wall".  Returns number of entries written. */
+ * phases "host_setup", "host_frames", "host_worklist" and the total "wall"; then, for a host-fed decode (on_device == 0),
+ * "h2d" (ms of the IQ upload, HIP events), "h2d_mbytes" (10^6 bytes uploaded) and "h2d_pinned_mbytes" (how much of that came
+ * straight from page-locked memory; the rest went through the engine's staging ring).  Returns number of entries written. */
 int dabhip_engine_stage_ms(const dabhip_engine *e, const char **names, float *ms, int cap);
 /* Per-launch statistics of the OFDM FFT kernel in the last decode: number of launches,
  * transmission frames transformed, total kernel milliseconds (HIP events). */

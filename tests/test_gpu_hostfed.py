@@ -1,0 +1,114 @@
+"""GPU tests of the host-fed paths: the reference's input arrives in host buffers (dab2eti.c:117-130,238), so the batch entry
+and the streaming sessions take host memory -- page-locked (plain asynchronous DMA) or pageable (through the engine's staging
+ring) -- and must produce the ETI bytes of the device-resident decode."""
+import numpy as np
+import pytest
+
+import dabtools_amd as dab
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def _caps():
+    caps = []
+    for i in range(7):
+        cfg = dab.synth_preset(i % 2, seed=4100 + i, cif_count0=333 * i, skip_samples=(0, 9001, 150000)[i % 3], snr_db=(1000.0, 11.0)[i % 2])
+        iq = dab.synth_generate(cfg, 19 + i % 2)
+        if i in (2, 5):
+            iq = iq[: iq.size - (1237 + 16 * i)]           # ragged: neither whole calls nor a multiple of 16 bytes
+        caps.append(iq)
+    caps.append(np.zeros(0, np.uint8))                     # an empty stream in the batch
+    return caps
+
+
+def test_host_fed_decode_pinned_pageable_and_mixed_equal_resident_decode():
+    caps = _caps()
+    eng = dab.Engine(0)
+    total = eng.decode(caps)                               # pageable numpy arrays: staging ring
+    st = eng.stage_ms()
+    assert abs(st["h2d_mbytes"] - sum(c.size for c in caps) * 1e-6) < 1e-2 and st["h2d_pinned_mbytes"] == 0 and st["h2d"] > 0
+    want = [eng.eti(b) for b in range(len(caps))]
+    assert total == sum(len(w) for w in want) > 7 * 8
+    for b in (0, 2, 5):
+        assert np.array_equal(want[b], ol.or_replay(caps[b])[0]), b
+    # the same bytes resident on the device
+    bufs = [dab.DeviceBuffer(max(c.size, 16)) for c in caps]
+    for buf, c in zip(bufs, caps):
+        if c.size:
+            buf.upload(c)
+    assert eng.decode_device([b.ptr for b in bufs], [c.size for c in caps]) == total
+    assert eng.stage_ms()["h2d_mbytes"] == 0
+    for b, w in enumerate(want):
+        assert np.array_equal(eng.eti(b), w), b
+    # page-locked host memory (all streams), then a mix of page-locked and pageable streams in one batch
+    pinned = [dab.HostBuffer(max(c.size, 16)) for c in caps]
+    for hb, c in zip(pinned, caps):
+        hb.array[: c.size] = c
+    assert eng.decode_host_ptrs([hb.ptr for hb in pinned], [c.size for c in caps]) == total
+    st = eng.stage_ms()
+    assert abs(st["h2d_pinned_mbytes"] - st["h2d_mbytes"]) < 1e-3 and st["h2d_mbytes"] > 50
+    for b, w in enumerate(want):
+        assert np.array_equal(eng.eti(b), w), b
+    mixed = [pinned[b].ptr if b % 2 else caps[b].ctypes.data for b in range(len(caps))]
+    assert eng.decode_host_ptrs(mixed, [c.size for c in caps]) == total
+    st = eng.stage_ms()
+    assert 0 < st["h2d_pinned_mbytes"] < st["h2d_mbytes"]
+    for b, w in enumerate(want):
+        assert np.array_equal(eng.eti(b), w), b
+    for x in bufs + pinned:
+        x.free()
+    eng.close()
+
+
+def test_stream_session_with_prefetched_segments_equals_one_shot_decode():
+    """dabhip_stream_prefetch: segment k + 1 uploads on its own stream while segment k decodes (three device windows per
+    stream).  Segments of unrelated sizes in page-locked memory; order prefetch(0) feed(0) / prefetch(k+1) feed(k), with one
+    plain feed in between; the concatenated frames equal the one-shot decode; misuse is refused."""
+    caps = _caps()[:6]
+    eng = dab.Engine(0)
+    eng.decode(caps)
+    want = [eng.eti(b) for b in range(len(caps))]
+    eng.close()
+    cuts = [0, 3000000, 3000000 + 262144 * 5, 5500000, 5500001, 6900000, 10 ** 9]
+    segs = []                                              # per segment: (HostBuffers, sizes)
+    for a, z in zip(cuts, cuts[1:]):
+        parts = [c[a:z] for c in caps]
+        hbs = [dab.HostBuffer(max(p.size, 16)) for p in parts]
+        for hb, p in zip(hbs, parts):
+            hb.array[: p.size] = p
+        segs.append(([hb.ptr for hb in hbs], [p.size for p in parts], hbs))
+    st = dab.Stream(len(caps))
+    got = [[] for _ in caps]
+
+    def collect():
+        for b in range(len(caps)):
+            got[b].append(st.eti(b))
+
+    st.prefetch_ptrs(*segs[0][:2])
+    for k in range(len(segs)):
+        if k == 3:                                         # a segment that was not prefetched: plain feed (nothing may be waiting)
+            st.feed_ptrs(*segs[k][:2])
+            collect()
+            if k + 1 < len(segs):
+                st.prefetch_ptrs(*segs[k + 1][:2])
+            continue
+        if k + 1 < len(segs) and k + 1 != 3:
+            st.prefetch_ptrs(*segs[k + 1][:2])             # uploads while segment k decodes
+        st.feed_ptrs(*segs[k][:2])
+        collect()
+    for b, w in enumerate(want):
+        assert np.array_equal(np.concatenate(got[b]), w), b
+    st.close()
+    # misuse: feeding something else than the segment handed over first; three segments waiting
+    st = dab.Stream(len(caps))
+    st.prefetch_ptrs(*segs[0][:2])
+    with pytest.raises(dab.DabhipError, match="prefetched first"):
+        st.feed_ptrs(*segs[1][:2])
+    st.prefetch_ptrs(*segs[1][:2])
+    with pytest.raises(dab.DabhipError, match="already waiting"):
+        st.prefetch_ptrs(*segs[2][:2])
+    st.close()
+    for _, _, hbs in segs:
+        for hb in hbs:
+            hb.free()

@@ -1,0 +1,95 @@
+"""GPU tests of the multi-device batch entry (dabhip_multi_*; BASELINE configs[3] = 2048 streams as
+256 per GPU x 8).  The boxes of this pool have ONE GPU, so the eight slices of a node are all mapped onto device 0 (a device
+may be listed more than once; every entry is a slice with its own engine, host thread and HIP streams): what is proven here
+is the sharding rule, the concurrency of the slices' host sides and byte-equality with the single-engine decode and the
+oracle -- not a scaling figure."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import dabtools_amd as dab
+import oracle_lib as ol
+from dabtools_amd import shard
+
+pytestmark = pytest.mark.gpu
+
+
+def _captures(n, ntf=19):
+    caps = []
+    for i in range(n):
+        cfg = dab.synth_preset(i % 2, seed=3100 + i, cif_count0=(611 * i) % 5000, skip_samples=(0, 77001, 0, 1234)[i % 4],
+                               snr_db=(1000.0, 1000.0, 12.0)[i % 3])
+        caps.append(dab.synth_generate(cfg, ntf + i % 3))
+    return caps
+
+
+def test_eight_slices_on_one_gpu_equal_single_engine_and_oracle():
+    """19 streams dealt to 8 slices (3,3,3,2,2,2,2,2 -- the remainder goes to the low slices, shard.shard_streams' rule), all
+    slices decoding concurrently on GPU 0: every stream's ETI bytes and per-call trace equal the single-engine decode of the same
+    batch; six streams are also held against the oracle; the drain delivers the frames in global stream order."""
+    caps = _captures(19)
+    single = dab.Engine(0)
+    total_single = single.decode(caps)
+    multi = dab.Multi([0] * 8)
+    total = multi.decode(caps)
+    assert total == total_single > 19 * 8
+    for rank in range(8):
+        for s in shard.shard_streams(len(caps), 8, rank):
+            assert multi.slice_of(s) == (rank, 0)
+    for b, iq in enumerate(caps):
+        want = single.eti(b)
+        got = multi.eti(b)
+        assert got.shape == want.shape and np.array_equal(got, want), b
+        ncalls = iq.size // dab.CHUNK_BYTES
+        ti, tf = single.trace(b, ncalls)
+        mi, mf = multi.trace(b, ncalls)
+        assert np.array_equal(ti, mi) and np.array_equal(tf, mf), b
+    for b in (0, 3, 7, 8, 13, 18):
+        assert np.array_equal(multi.eti(b), ol.or_replay(caps[b])[0]), b
+    drained = multi.drain()
+    assert [b for b, _ in drained] == [b for b in range(len(caps)) for _ in range(multi.eti_count(b))]
+    assert b"".join(f for _, f in drained) == b"".join(single.eti(b).tobytes() for b in range(len(caps)))
+    # the slices really ran side by side: the call took less than the sum of the slices' own wall clocks
+    walls = [multi.wall_ms(i) for i in range(8)]
+    assert all(w > 0 for w in walls) and multi.wall_ms() < sum(walls)
+    # a second decode with fewer streams than slices: the empty slices stay idle
+    assert multi.decode(caps[:3]) == sum(single.eti_count(b) for b in range(3))
+    assert [multi.slice_of(b)[0] for b in range(3)] == [0, 1, 2]
+    for b in range(3):
+        assert np.array_equal(multi.eti(b), single.eti(b))
+    # settings reach every slice
+    multi.set_subchannels([2])
+    single.set_subchannels([2])
+    multi.decode(caps[:9])
+    single.decode(caps[:9])
+    for b in range(9):
+        assert np.array_equal(multi.eti(b), single.eti(b)), b
+    multi.close()
+    single.close()
+
+
+def test_multi_rejects_bad_devices():
+    with pytest.raises(dab.DabhipError):
+        dab.Multi([0, 99])
+    with pytest.raises(dab.DabhipError):
+        dab.Multi([])
+
+
+def test_cli_devices_flag_equals_single_device_output(tmp_path):
+    """`dab2eti-hip --devices 0,0,0 f0 .. f4` (three slices on GPU 0) writes the bytes of `dab2eti-hip f0 .. f4`."""
+    exe = os.path.join(os.path.dirname(dab.LIB_PATH), "dab2eti-hip")
+    names = []
+    for i, iq in enumerate(_captures(5, ntf=18)):
+        p = tmp_path / ("cap%d.cu8" % i)
+        iq.tofile(p)
+        names.append(str(p))
+    one = subprocess.run([exe] + names, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    three = subprocess.run([exe, "--devices", "0,0,0"] + names, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    assert len(one.stdout) > 5 * 8 * dab.ETI_BYTES and one.stdout == three.stdout
+    assert b"(device 0)" in three.stderr
+    rng = subprocess.run([exe, "--devices", "0-0"] + names[:2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    assert rng.stdout == subprocess.run([exe] + names[:2], stdout=subprocess.PIPE, check=True).stdout
+    bad = subprocess.run([exe, "--devices", "0,x"] + names[:1], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert bad.returncode == 1

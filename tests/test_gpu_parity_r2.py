@@ -298,13 +298,16 @@ def test_parity_guard_end_to_end_and_off_switch():
     """Guard on (default) vs off on noisy captures: same frames out; the guard re-decides a small, non-zero number of
     decisions; with it on, fused and two-kernel OFDM stages and the oracle agree byte for byte."""
     caps = [dab.synth_generate(dab.synth_preset(1, seed=1300 + i, snr_db=snr), 30) for i, snr in enumerate((5.0, 6.0, 9.0))]
-    wants = [ol.or_replay(c)[0] for c in caps]
+    replays = [ol.or_replay(c) for c in caps]
+    wants = [r[0] for r in replays]
+    demodulated = sum(t.ok for _, trace in replays for t in trace)            # sdr_demod calls that returned 1: one TF of decisions each
     eng = dab.Engine(0)
     for fused in (True, False):
         eng.set_fused(fused)
         eng.decode(caps)
         flagged, decisions = eng.guard_stats()
-        assert 0 < flagged < 1e-3 * decisions and decisions == sum(c.size // dab.TF_BYTES - 1 for c in caps) * 230400 or decisions > 0
+        assert 0 < flagged < 1e-3 * decisions, (fused, flagged, decisions)
+        assert decisions == demodulated * 230400, (fused, decisions, demodulated)
         for b, w in enumerate(wants):
             assert np.array_equal(eng.eti(b), w), (fused, b)
     eng.set_parity_guard(False)
