@@ -159,91 +159,13 @@ Engine::~Engine()
 }
 
 // ---------------------------------------------------------------------------------------------
-int Engine::plan_id(const CodewordPlan& p)
-{
-  std::vector<int32_t> key = {p.blocks[0], p.blocks[1], p.blocks[2], p.blocks[3],
-                              static_cast<int32_t>(p.mask[0]), static_cast<int32_t>(p.mask[1]), static_cast<int32_t>(p.mask[2]),
-                              static_cast<int32_t>(p.mask[3]), p.nsteps, p.start_bit, p.out_offset, p.out_bytes};
-  auto it = plan_index_.find(key);
-  if (it != plan_index_.end()) return it->second;
-  const int id = static_cast<int>(plans_.size());
-  plans_.push_back(p);
-  plan_index_.emplace(std::move(key), id);
-  return id;
-}
-
-static CodewordPlan make_plan(const PuncturePlan& pp, int start_bit, int out_offset)
-{
-  CodewordPlan p;
-  for (int s = 0; s < 4; ++s) { p.blocks[s] = pp.blocks[s]; p.mask[s] = puncture_mask(pp.pi[s]); }
-  p.nsteps = pp.trellis_steps();
-  p.start_bit = start_bit;
-  p.out_offset = out_offset;
-  p.out_bytes = (p.nsteps - 6) / 8;
-  return p;
-}
-
-// wave-groups of <= 64 jobs per plan, longest code words first
-void Engine::build_batch(const std::vector<std::pair<int, const std::vector<int>*>>& plan_jobs, DecodeBatch& out)
-{
-  out.groups.clear();
-  out.job_ids.clear();
-  out.slice_start.clear();
-  out.max_dec_rows = 0;
-  std::vector<std::pair<int, size_t>> order;   // (nsteps, index into plan_jobs)
-  size_t total = 0;
-  for (size_t i = 0; i < plan_jobs.size(); ++i) {
-    order.emplace_back(plans_[plan_jobs[i].first].nsteps, i);
-    total += plan_jobs[i].second->size();
-  }
-  std::stable_sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
-  (void)total;
-  std::map<const std::vector<int>*, int> placed;   // plans of one layout share the same job list
-  for (const auto& o : order) {
-    const int plan = plan_jobs[o.second].first;
-    const std::vector<int>& ids = *plan_jobs[o.second].second;
-    auto it = placed.find(&ids);
-    if (it == placed.end()) {
-      out.job_ids.resize((out.job_ids.size() + 63) / 64 * 64, -1);        // lists start on a tile of 64 (regroup_kernel)
-      it = placed.emplace(&ids, static_cast<int>(out.job_ids.size())).first;
-      out.job_ids.insert(out.job_ids.end(), ids.begin(), ids.end());
-    }
-    const int first = it->second;
-    for (size_t g = 0; g < ids.size(); g += 64)
-      out.groups.push_back(WaveGroup{plan, first + static_cast<int>(g), static_cast<int>(std::min<size_t>(64, ids.size() - g)), o.first, 0, 0});
-  }
-}
-
-// slices of wave-groups whose survivor records fit the cap; record offsets are per slice
-void Engine::plan_decode_batch(DecodeBatch& b)
-{
-  b.slice_start = {0};
-  b.max_dec_rows = 0;
-  int64_t dec_rows = 0;
-  const int ng = static_cast<int>(b.groups.size());
-  for (int g = 0; g < ng; ++g) {
-    const int64_t dr = (b.groups[g].nsteps + 7) / 8 * 8;
-    if (g > b.slice_start.back() && dec_rows + dr > kMaxDecisionRows) {
-      b.slice_start.push_back(g);
-      b.max_dec_rows = std::max(b.max_dec_rows, dec_rows);
-      dec_rows = 0;
-    }
-    b.groups[g].step_base = 0;
-    b.groups[g].dec_base = dec_rows;
-    dec_rows += dr;
-  }
-  b.slice_start.push_back(ng);
-  b.max_dec_rows = std::max(b.max_dec_rows, dec_rows);
-  b.job_ids.resize((b.job_ids.size() + 63) / 64 * 64, -1);     // tiles of 64 records
-}
-
 // work lists of a batch to the device (any stream: only the launches below consume them)
 bool Engine::upload_decode_batch(const DecodeBatch& b, const HostList<DecodeJob>& jobs, hipStream_t s)
 {
   if (b.groups.empty()) return true;
   const int row_words = kCifWords * (soft_bits_ ? 4 : 1);
   const size_t ntiles = b.job_ids.size() / 64;
-  return d_plans_.upload(plans_, s) && d_groups_.upload(b.groups, s) && d_job_ids_.upload(b.job_ids, s) && d_jobs_.upload(jobs, s) &&
+  return d_plans_.upload(plan_table_.plans(), s) && d_groups_.upload(b.groups, s) && d_job_ids_.upload(b.job_ids, s) && d_jobs_.upload(jobs, s) &&
          d_decisions_.reserve(static_cast<size_t>(b.max_dec_rows) * 64) && d_grouped_.reserve(ntiles * row_words * 64);
 }
 
@@ -352,21 +274,21 @@ bool Engine::fic_decode_slots_async(int first, int n, uint8_t* fibs_host, uint8_
 {
   if (n <= 0) return true;
   const int bits = soft_bits_ ? 4 : 1;
-  const int pid = plan_id(make_plan(fic_plan(), 0, 0));
+  const int pid = plan_table_.id(make_codeword_plan(fic_plan(), 0, 0));
   // record i of this call = FIC block 4 * first + i; 64 blocks per wave, interleaved word by word by fic_group_kernel
   const int nblocks = 4 * n, ntiles = (nblocks + 63) / 64, block_words = 72 * bits;
   std::vector<int> ids(static_cast<size_t>(ntiles) * 64, -1);
   for (int i = 0; i < nblocks; ++i) ids[i] = 4 * first + i;
   std::vector<WaveGroup> groups;
-  const int64_t dr = (plans_[pid].nsteps + 7) / 8 * 8;
-  for (int g = 0; g < ntiles; ++g) groups.push_back(WaveGroup{pid, 64 * g, std::min(64, nblocks - 64 * g), plans_[pid].nsteps, 0, g * dr});
+  const int64_t dr = (plan_table_[pid].nsteps + 7) / 8 * 8;
+  for (int g = 0; g < ntiles; ++g) groups.push_back(WaveGroup{pid, 64 * g, std::min(64, nblocks - 64 * g), plan_table_[pid].nsteps, 0, g * dr});
   // The FIC kernels run on the side stream as well, behind what the main stream has queued so far (the FIC bits): 1008 waves of 774
   // steps fill a quarter of the chip's wave slots for 0.3 ms, so the main stream goes straight on with the rest of the OFDM stage
   // and the two share the GPU.  Everything that later touches these buffers on the main stream waits for the side stream
   // (ev_upload_ in decode_impl, the synchronising callers elsewhere).
   hipStream_t ks = copy;
   if (ks != stream_ && (!check(hipEventRecord(ev_fic_, stream_), "fic event") || !check(hipStreamWaitEvent(ks, ev_fic_, 0), "fic event"))) return false;
-  if (!d_plans_.upload(plans_, ks) || !d_groups_.upload(groups, ks) || !d_job_ids_.upload(ids, ks) ||
+  if (!d_plans_.upload(plan_table_.plans(), ks) || !d_groups_.upload(groups, ks) || !d_job_ids_.upload(ids, ks) ||
       !d_grouped_.reserve(static_cast<size_t>(ntiles) * block_words * 64) || !d_decisions_.reserve(static_cast<size_t>(ntiles) * dr * 64))
     return false;
   if (!check(launch_fic_group(d_fic_bits_.get(), 4 * first, nblocks, block_words, d_grouped_.get(), ks), "fic group launch") ||
@@ -389,115 +311,10 @@ bool Engine::msc_prepare(const std::vector<const std::vector<EtiJob>*>& stream_j
   auto mark = [&](const char* what) {
     if (trace_host) std::fprintf(stderr, "[host]   msc_prepare %-14s %8.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_in).count());
   };
-  size_t nf = 0;
-  for (const auto* v : stream_jobs) nf += v->size();
-  out.nframes = nf;
-  out.stream_row_base = stream_row_base;
-  if (nf == 0) return true;
-  // An ensemble layout (the active sub-channels in SubChId order) fixes the code word plans and their offsets in
-  // the ETI frame.  Layouts are identified by content so that streams carrying the same multiplex share plans.
-  struct Layout {
-    std::vector<int> plan_ids;
-    int mst_bytes = 0;
-  };
-  std::map<std::vector<int32_t>, int> layout_index;
-  std::vector<Layout> layouts;
-  std::vector<std::vector<int>> layout_frames;
-  HostList<DecodeJob>& jobs = out.jobs;
-  HostList<EtiFrameMeta>& meta = out.meta;
-  const size_t nstreams = stream_jobs.size();
-  // pass 0 (parallel over streams; the job lists are ~15 MB, walked once here): the longest header and the layouts a stream uses
-  // (layouts change rarely: one entry per run), with the header length of the first job of each
-  std::vector<int> stream_max_header(nstreams, 0);
-  std::vector<std::vector<std::pair<int, int>>> used(nstreams);   // (local layout, header_len)
-  pool_->parallel_for(static_cast<int>(nstreams), [&](int b) {
-    int mh = 0, prev = -1;
-    for (const EtiJob& j : *stream_jobs[b]) {
-      mh = std::max(mh, j.header_len);
-      if (j.layout != prev) {
-        prev = j.layout;
-        bool seen = false;
-        for (const auto& u : used[b]) seen = seen || u.first == j.layout;
-        if (!seen) used[b].push_back({j.layout, j.header_len});
-      }
-    }
-    stream_max_header[b] = mh;
-  });
-  int max_header = 0;
-  for (int mh : stream_max_header) max_header = std::max(max_header, mh);
-  const int header_stride = (max_header + 15) & ~15;
-  out.header_stride = header_stride;
-  HostList<uint8_t>& headers = out.headers;
-  // every record is written in full by pass 2 (a header row up to its own length, which is all K5 reads): no fill
-  jobs.resize(nf);
-  meta.resize(nf);
-  headers.resize(nf * static_cast<size_t>(header_stride));
-  mark("lists sized");
-  // pass 1 (serial, cheap): global layout id of every (stream, local layout)
-  std::vector<std::vector<int>> local_to_global(nstreams);
-  std::vector<size_t> frame_base(nstreams + 1, 0);
-  for (size_t b = 0; b < nstreams; ++b) {
-    frame_base[b + 1] = frame_base[b] + stream_jobs[b]->size();
-    if (stream_jobs[b]->empty()) continue;
-    const auto& lays = planes[b]->layouts();
-    local_to_global[b].assign(lays.size(), -1);
-    for (const auto& u : used[b]) {
-      const int layout = u.first, job_header_len = u.second;
-      const std::vector<SubChannel>& subs = lays[layout];
-      std::vector<int32_t> key = {job_header_len};
-      for (const SubChannel& sc : subs) {
-        const int32_t fields[] = {sc.slform, sc.uep_index, sc.start_cu, sc.size_cu, sc.bitrate, sc.protlev};
-        key.insert(key.end(), fields, fields + 6);
-      }
-      auto it = layout_index.find(key);
-      if (it == layout_index.end()) {
-        Layout lay;
-        int off = job_header_len + 96;
-        for (const SubChannel& sc : subs) {
-          CodewordPlan cp = make_plan(puncture_plan(sc), sc.start_cu * 64, off);
-          lay.plan_ids.push_back(plan_id(cp));
-          off += (cp.out_bytes + 7) & 0xfff8;          // misc.c:259-260: obytes = ((bits/8)+7) & 0xfff8
-        }
-        lay.mst_bytes = off - job_header_len - 96;
-        if (off + 8 > kEtiBytes) { set_error("ETI frame overflow: sub-channels exceed 6144 bytes"); return false; }
-        it = layout_index.emplace(std::move(key), static_cast<int>(layouts.size())).first;
-        layouts.push_back(std::move(lay));
-        layout_frames.emplace_back();
-      }
-      local_to_global[b][layout] = it->second;
-    }
-  }
-  mark("layouts");
-  // pass 2 (parallel over streams): per-frame records
-  std::vector<std::vector<std::pair<int, std::pair<int, int>>>> runs(nstreams);   // per stream: (layout, [first, last) frame)
-  pool_->parallel_for(static_cast<int>(nstreams), [&](int b) {
-    size_t f = frame_base[b];
-    int run_gid = -1;
-    for (const EtiJob& job : *stream_jobs[b]) {
-      const int gid = local_to_global[b][job.layout];
-      if (gid != run_gid) {
-        runs[b].push_back({gid, {static_cast<int>(f), static_cast<int>(f)}});
-        run_gid = gid;
-      }
-      runs[b].back().second.second = static_cast<int>(f) + 1;
-      jobs[f] = DecodeJob{static_cast<int32_t>(b), job.first_cif};
-      meta[f] = EtiFrameMeta{job.header_len, layouts[gid].mst_bytes, stream_fib_base[b] + job.first_cif, 0};
-      std::memcpy(headers.data() + f * header_stride, job.header, static_cast<size_t>(job.header_len));
-      ++f;
-    }
-  });
-  mark("frame records");
-  for (size_t b = 0; b < nstreams; ++b)
-    for (const auto& r : runs[b])
-      for (int f = r.second.first; f < r.second.second; ++f) layout_frames[r.first].push_back(f);
-  mark("layout frames");
-  std::vector<std::pair<int, const std::vector<int>*>> plan_jobs;
-  for (size_t l = 0; l < layouts.size(); ++l)
-    for (int pid : layouts[l].plan_ids) plan_jobs.emplace_back(pid, &layout_frames[l]);
-  build_batch(plan_jobs, out.batch);
-  plan_decode_batch(out.batch);
-  mark("batch");
-  return true;
+  std::string error;
+  if (prepare_msc_work(plan_table_, *pool_, stream_jobs, planes, stream_row_base, stream_fib_base, kMaxDecisionRows, out, &error, mark)) return true;
+  set_error(error);
+  return false;
 }
 
 // work lists, ETI header bytes and frame records of a prepared batch to the device; `s` may be a side stream
@@ -1044,7 +861,8 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   MscWork& work = work_;
   bool host_ok = true;
   std::string host_error;
-  host_lane_->post([&]() {
+  static const bool fresh_thread = std::getenv("DABHIP_HOST_FRESH_THREAD") != nullptr;   // measurement knob: a std::thread per decode, as before round 3
+  auto host_work = [&]() {
     (void)hipSetDevice(device_);               // the current device is per thread
     const auto t0 = std::chrono::steady_clock::now();
     const bool fresh = planes_fresh_;
@@ -1079,11 +897,15 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     mark("work lists queued");
     if (!host_ok) host_error = dabhip_last_error();
     times_.worklist = since(t1);
-  });
+  };
+  std::thread fresh_host;
+  if (fresh_thread) fresh_host = std::thread(host_work);
+  else host_lane_->post(host_work);
 
   // the host thread is done before the OFDM stage (at 4.5 of 5.8 ms into the step with 24 threads): K4 + K5 are queued right
   // behind it, and the whole pipeline is awaited ONCE
-  host_lane_->wait();
+  if (fresh_thread) fresh_host.join();
+  else host_lane_->wait();
   if (gpu_ok && host_ok)
     gpu_ok = check(hipStreamWaitEvent(stream_, ev_upload_, 0), "work list wait") && msc_launch_async(work);
   mark("all queued");
@@ -1331,7 +1153,7 @@ int Engine::viterbi_batch(const uint8_t* symbols, uint8_t* data, int framebits, 
   std::memset(&plan, 0, sizeof plan);
   plan.nsteps = nsteps;
   plan.out_bytes = framebits / 8;
-  const int pid = plan_id(plan);
+  const int pid = plan_table_.id(plan);
   std::vector<WaveGroup> groups;
   const int64_t dr = (nsteps + 7) / 8 * 8;
   std::vector<uint4> steps(static_cast<size_t>(ngroups) * n16 * 64, make_uint4(0, 0, 0, 0));
@@ -1356,7 +1178,7 @@ int Engine::viterbi_batch(const uint8_t* symbols, uint8_t* data, int framebits, 
   // no gather: upload the step rows directly, then run the decoder with an all-zero scrambler
   const size_t out_bytes = static_cast<size_t>(n) * (framebits / 8);
   if (framebits / 32 > 1024) { set_error("viterbi: code word too long"); return -1; }
-  if (!d_plans_.upload(plans_, stream_) || !d_groups_.upload(groups, stream_) || !d_steps_.upload(steps, stream_) ||
+  if (!d_plans_.upload(plan_table_.plans(), stream_) || !d_groups_.upload(groups, stream_) || !d_steps_.upload(steps, stream_) ||
       !d_decisions_.reserve(static_cast<size_t>(ngroups) * dr * 64) || !d_bytes_.reserve(out_bytes))
     return -1;
   if (!check(launch_viterbi(d_groups_.get(), ngroups, nullptr, d_plans_.get(), d_steps_.get(), d_decisions_.get(), d_zero_words_.get(),

@@ -24,6 +24,7 @@
 #include "control_plane.hpp"
 #include "device_types.hpp"
 #include "thread_pool.hpp"
+#include "worklist.hpp"
 
 namespace dabhip {
 
@@ -133,24 +134,9 @@ struct StageTimes {
   double h2d_bytes = 0, h2d_pinned_bytes = 0;            // bytes uploaded, and how many of them came from page-locked memory
 };
 
-// Work list for gather + Viterbi launches: wave-groups of <= 64 equal-length code words.
-struct DecodeBatch {
-  HostList<WaveGroup> groups;      // longest code words first
-  HostList<int> job_ids;           // lanes of group g decode jobs job_ids[g.first .. g.first + g.count); padded to tiles of 64
-  std::vector<int> slice_start;    // launches: groups [slice_start[i], slice_start[i+1]) share the survivor-record buffer
-  int64_t max_dec_rows = 0;
-};
-
-// Everything the MSC decode of a set of ETI frames needs, prepared on the host (no GPU work)
-struct MscWork {
-  HostList<DecodeJob> jobs;
-  HostList<EtiFrameMeta> meta;
-  HostList<uint8_t> headers;
-  int header_stride = 0;
-  DecodeBatch batch;
-  std::vector<int> stream_row_base;
-  size_t nframes = 0;
-};
+// the MSC decode's work lists (worklist.hpp) in page-locked memory: they go to the device as plain asynchronous DMA
+using DecodeBatch = DecodeBatchT<PinnedAllocator>;
+using MscWork = MscWorkT<PinnedAllocator>;
 
 class Engine {
  public:
@@ -244,16 +230,12 @@ class Engine {
   // host-fed decode: the streams' bytes into d_iq_own_ (ptrs[b] = where stream b landed), queued on the main stream
   bool upload_iq(const uint8_t* const* iq, const size_t* nbytes, int nstreams, const uint8_t** ptrs);
   bool carry_and_reserve(const std::vector<int>& tf_base, const std::vector<int>& row_base, int nslots, int nrows);
-  // plan_jobs[i] = (plan id, job indices decoded with that plan)
-  void build_batch(const std::vector<std::pair<int, const std::vector<int>*>>& plan_jobs, DecodeBatch& out);
-  // MSC decode batch: slices and record offsets (host), work lists to the device, regroup + fused Viterbi launches
-  void plan_decode_batch(DecodeBatch& b);
+  // MSC decode batch: work lists to the device, regroup + fused Viterbi launches
   bool upload_decode_batch(const DecodeBatch& b, const HostList<DecodeJob>& jobs, hipStream_t s);
   bool launch_decode_batch(const DecodeBatch& b, const uint32_t* bits, const int* d_stream_cif_base, const uint32_t* prbs, uint8_t* out,
                            int record_stride);
   bool msc_launch_async(const MscWork& w);   // K4 + K5 queued, nothing awaited
   void msc_collect();                        // their stage times, once the stream has been awaited
-  int plan_id(const CodewordPlan& p);
   bool unpack_tf_slot(int slot, uint8_t* fic_bytes, uint8_t* msc_bytes);
 
   // parity guard plumbing: list + counter for one launch, fix-up after it, entry count to the host (checked at the end)
@@ -337,8 +319,7 @@ class Engine {
   DeviceBuffer<uint8_t> d_carry_;
   DeviceBuffer<CopyDesc> d_copy_descs_;
 
-  std::vector<CodewordPlan> plans_;
-  std::map<std::vector<int32_t>, int> plan_index_;
+  PlanTable plan_table_;
 
   PinnedBuffer<CallDesc> h_descs_;
   PinnedBuffer<int2> h_info_;

@@ -1,0 +1,271 @@
+// host_units.cpp — the host-only units of the product (no GPU call in any of them), compiled by tests/host_sanitize/Makefile with
+// g++ -fsanitize=thread and -fsanitize=address,undefined and run by the CPU suite (tests/test_host_sanitize.py).
+//
+//   thread_pool.hpp    ThreadPool (per-stream control-plane pool) and AsyncLane (the decode's host lane), used the way the engine
+//                      uses them: a lane task that calls parallel_for while the posting thread waits; several engines' worth at once
+//   control_plane.hpp  FIG parse, lock rule, CIF ring, ETI headers over the FIBs of synthetic ensembles, streams in parallel
+//   worklist.hpp       frame records, header rows, wave-groups and slices of the MSC decode (with plain std::allocator lists)
+//   fifo_view.hpp      the closed-form FIFO / stale-tail views under random timing corrections, against a byte-level replay of
+//                      cbWrite / sdr_read_fifo's copying rule (sdr_fifo.c:26-61)
+//   synth.cpp          the modulator's bit content and sample generation (bounds, UB)
+// The reference's own data race (rtlsdr_callback writing sdr->input_buffer while the demod thread reads it, dab2eti.c:117-130)
+// has no counterpart here: segments are handed over by value of their pointers and never written while a decode runs.
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "../../include/dabhip.h"
+#include "../../dabtools_amd/csrc/control_plane.hpp"
+#include "../../dabtools_amd/csrc/fifo_view.hpp"
+#include "../../dabtools_amd/csrc/thread_pool.hpp"
+#include "../../dabtools_amd/csrc/worklist.hpp"
+
+using namespace dabhip;
+
+namespace dabhip {
+void set_error(const std::string&) {}      // error.cpp's thread-local text is not linked into this binary
+}
+
+#define CHECK(cond)                                                                     \
+  do {                                                                                  \
+    if (!(cond)) { std::fprintf(stderr, "%s:%d: CHECK failed: %s\n", __FILE__, __LINE__, #cond); std::exit(1); } \
+  } while (0)
+
+template <class T>
+using StdAlloc = std::allocator<T>;
+
+static void test_pool_and_lane()
+{
+  ThreadPool pool(5);
+  for (int round = 0; round < 400; ++round) {
+    const int n = 1 + (round * 37) % 301;
+    std::vector<int> hits(static_cast<size_t>(n), 0);
+    pool.parallel_for(n, [&](int i) { hits[static_cast<size_t>(i)] += 1; });      // every index exactly once, visible after the call
+    for (int h : hits) CHECK(h == 1);
+  }
+  pool.parallel_for(0, [&](int) { CHECK(false); });
+  // the engine's pattern: the decode thread posts the control-plane pass to the lane and waits; the pass fans out over the pool
+  AsyncLane lane;
+  long total = 0;
+  for (int round = 0; round < 200; ++round) {
+    std::vector<long> part(64, 0);
+    lane.post([&]() {
+      pool.parallel_for(64, [&](int i) { part[static_cast<size_t>(i)] = i + round; });
+      for (long p : part) total += p;
+    });
+    lane.wait();
+    CHECK(part[63] == 63 + round);
+  }
+  CHECK(total == 200L * (63 * 64 / 2) + 64L * (199 * 200 / 2));
+  // several posts before one wait run in order
+  std::vector<int> order;
+  for (int i = 0; i < 50; ++i) lane.post([&order, i]() { order.push_back(i); });
+  lane.wait();
+  CHECK(order.size() == 50);
+  for (int i = 0; i < 50; ++i) CHECK(order[static_cast<size_t>(i)] == i);
+  // a pool without workers: the caller does everything
+  ThreadPool solo(0);
+  int sum = 0;
+  solo.parallel_for(10, [&](int i) { sum += i; });
+  CHECK(sum == 45);
+}
+
+// the FIBs and CRC flags of `ntf` transmission frames of one synthetic ensemble, as the FIC decode hands them to the control plane
+static void make_fibs(int preset, uint64_t seed, int cif0, int ntf, std::vector<uint8_t>& fibs, std::vector<uint8_t>& ok)
+{
+  dabhip_synth_cfg cfg;
+  CHECK(dabhip_synth_preset(preset, &cfg) == 0);
+  cfg.seed = seed;
+  cfg.cif_count0 = cif0;
+  fibs.assign(static_cast<size_t>(ntf) * 384, 0);
+  ok.assign(static_cast<size_t>(ntf) * 12, 1);
+  for (int c = 0; c < 4 * ntf; ++c) CHECK(dabhip_synth_fibs(&cfg, c, fibs.data() + static_cast<size_t>(c) * 96) == 96);
+}
+
+// one engine's host side for a batch: control plane over the pool, then the work lists -- checked for internal consistency
+static void control_and_worklist(int nstreams, int ntf, int64_t max_rows, unsigned salt)
+{
+  ThreadPool pool(3);
+  std::vector<std::vector<uint8_t>> fibs(static_cast<size_t>(nstreams)), ok(static_cast<size_t>(nstreams));
+  for (int b = 0; b < nstreams; ++b) {
+    make_fibs(b % 2, 100 + salt + static_cast<unsigned>(b), (977 * b + static_cast<int>(salt)) % 5000, ntf, fibs[static_cast<size_t>(b)], ok[static_cast<size_t>(b)]);
+    if (b % 5 == 3)                       // a stream that loses lock four TFs before its end: one TF with a failed FIB CRC (dab.c:55-61)
+      ok[static_cast<size_t>(b)][static_cast<size_t>(12 * (ntf - 4) + 4)] = 0;
+  }
+  std::vector<ControlPlane> planes(static_cast<size_t>(nstreams));
+  std::vector<std::vector<EtiJob>> jobs(static_cast<size_t>(nstreams));
+  pool.parallel_for(nstreams, [&](int b) {
+    const size_t sb = static_cast<size_t>(b);
+    planes[sb] = ControlPlane();
+    if (b % 7 == 6) planes[sb].set_filter(0x6ull);                 // sub-channel filter: SubChIds 1 and 2 only
+    for (int t = 0; t < ntf; ++t) planes[sb].on_tf(t, fibs[sb].data() + static_cast<size_t>(t) * 384, ok[sb].data() + static_cast<size_t>(t) * 12, jobs[sb]);
+  });
+  std::vector<const ControlPlane*> plane_ptrs;
+  std::vector<const std::vector<EtiJob>*> job_ptrs;
+  std::vector<int> row_base, fib_base;
+  size_t nf = 0;
+  for (int b = 0; b < nstreams; ++b) {
+    const size_t sb = static_cast<size_t>(b);
+    plane_ptrs.push_back(&planes[sb]);
+    job_ptrs.push_back(&jobs[sb]);
+    row_base.push_back(15 + b * (4 * ntf + 15));
+    fib_base.push_back(4 * ntf * b);
+    if (b % 5 != 3) CHECK(static_cast<int>(jobs[sb].size()) == 4 * (ntf - 13));      // 10 TFs to lock (dab.c:50-53), 16 CIFs in the ring before the first frame
+    else CHECK(static_cast<int>(jobs[sb].size()) == 4 * (ntf - 4 - 13));
+    nf += jobs[sb].size();
+  }
+  PlanTable plans;
+  MscWorkT<StdAlloc> work;
+  std::string error;
+  CHECK(prepare_msc_work(plans, pool, job_ptrs, plane_ptrs, row_base, fib_base, max_rows, work, &error));
+  CHECK(work.nframes == nf && work.jobs.size() == nf && work.meta.size() == nf);
+  CHECK(work.header_stride % 16 == 0 && work.headers.size() == nf * static_cast<size_t>(work.header_stride));
+  // frame records are stream-major and carry the stream's own jobs
+  size_t f = 0;
+  for (int b = 0; b < nstreams; ++b)
+    for (const EtiJob& j : jobs[static_cast<size_t>(b)]) {
+      CHECK(work.jobs[f].stream == b && work.jobs[f].cif == j.first_cif);
+      CHECK(work.meta[f].header_len == j.header_len && work.meta[f].fib_block == fib_base[static_cast<size_t>(b)] + j.first_cif);
+      CHECK(std::memcmp(work.headers.data() + f * static_cast<size_t>(work.header_stride), j.header, static_cast<size_t>(j.header_len)) == 0);
+      CHECK(12 + 96 + work.meta[f].mst_bytes + 8 <= 6144 + 12);
+      ++f;
+    }
+  // wave-groups: longest first, lanes name valid frames, every (frame, sub-channel of its layout) exactly once
+  const auto& batch = work.batch;
+  CHECK(batch.job_ids.size() % 64 == 0 && !batch.groups.empty());
+  std::vector<int> decoded_bytes(nf, 0);
+  int prev_steps = 1 << 30;
+  for (const WaveGroup& g : batch.groups) {
+    CHECK(g.nsteps <= prev_steps);
+    prev_steps = g.nsteps;
+    CHECK(g.count >= 1 && g.count <= 64 && g.first >= 0 && static_cast<size_t>(g.first + g.count) <= batch.job_ids.size());
+    const CodewordPlan& p = plans[g.plan];
+    CHECK(p.nsteps == g.nsteps && p.out_bytes == (p.nsteps - 6) / 8);
+    for (int l = 0; l < g.count; ++l) {
+      const int id = batch.job_ids[static_cast<size_t>(g.first + l)];
+      CHECK(id >= 0 && static_cast<size_t>(id) < nf);
+      CHECK(p.out_offset >= work.meta[static_cast<size_t>(id)].header_len + 96);
+      CHECK(p.out_offset + p.out_bytes <= work.meta[static_cast<size_t>(id)].header_len + 96 + work.meta[static_cast<size_t>(id)].mst_bytes);
+      decoded_bytes[static_cast<size_t>(id)] += (p.out_bytes + 7) & 0xfff8;
+    }
+  }
+  for (size_t i = 0; i < nf; ++i) CHECK(decoded_bytes[i] == work.meta[i].mst_bytes);   // the sub-channels tile the MST exactly (misc.c:259-260)
+  // slices partition the groups; record rows fit the cap (a single group may exceed it on its own)
+  CHECK(batch.slice_start.front() == 0 && batch.slice_start.back() == static_cast<int>(batch.groups.size()));
+  for (size_t s = 0; s + 1 < batch.slice_start.size(); ++s) {
+    CHECK(batch.slice_start[s] < batch.slice_start[s + 1]);
+    int64_t rows = 0;
+    for (int g = batch.slice_start[s]; g < batch.slice_start[s + 1]; ++g) {
+      CHECK(batch.groups[static_cast<size_t>(g)].dec_base == rows);
+      rows += (batch.groups[static_cast<size_t>(g)].nsteps + 7) / 8 * 8;
+    }
+    CHECK(rows <= batch.max_dec_rows);
+    CHECK(rows <= max_rows || batch.slice_start[s + 1] - batch.slice_start[s] == 1);
+  }
+}
+
+static void test_control_and_worklist()
+{
+  control_and_worklist(24, 30, int64_t(48) << 20, 0);
+  control_and_worklist(9, 22, 20000, 1);                 // a small record cap: many slices
+  // several engines' host sides at once in one process (dabhip_multi: one lane + one pool per slice)
+  std::vector<std::unique_ptr<AsyncLane>> lanes;
+  for (int i = 0; i < 4; ++i) lanes.emplace_back(new AsyncLane());
+  for (int i = 0; i < 4; ++i) lanes[static_cast<size_t>(i)]->post([i]() { control_and_worklist(10 + i, 24, int64_t(1) << 20, 10u * static_cast<unsigned>(i)); });
+  for (auto& l : lanes) l->wait();
+}
+
+// byte-level replay of what sdr_read_fifo does to the 393216-byte frame buffer (sdr_fifo.c:43-61), on a stream whose byte at
+// offset x is the tag x itself (64-bit), so a view can be compared position by position
+static void test_fifo_views()
+{
+  std::mt19937 rng(7);
+  for (int trial = 0; trial < 30; ++trial) {
+    StreamState st;
+    std::memset(&st, 0, sizeof st);
+    fifo_reset(st);
+    std::vector<int64_t> buffer(kTfBytes, -1);            // stream offset held at each buffer position (-1: calloc'ed zero)
+    int64_t rd = 0, fed = 0;
+    bool overflowed = false;
+    for (int call = 0; call < 120 && !overflowed; ++call) {
+      const int r = static_cast<int>(rng() % 10);
+      st.coarse_timeshift = r == 0 ? static_cast<int>(rng() % 380000) : 0;               // a coarse resync now and then
+      st.fine_timeshift = r < 7 ? static_cast<int>(rng() % 61) - 30 : -static_cast<int>(rng() % 3000);
+      const int shift = st.coarse_timeshift + st.fine_timeshift;
+      fed += kChunkBytes;
+      int64_t count = fed - rd;
+      bool read = false;
+      if (count >= 3 * kTfSamples) {
+        read = true;
+        if (shift > 0) {
+          for (int p = 0; p < shift && p < kTfBytes; ++p) buffer[static_cast<size_t>(p)] = rd + p;      // the skipped bytes pass through the buffer
+          rd += shift;
+          count -= shift;
+          const int len = count < kTfBytes ? static_cast<int>(count) : kTfBytes;
+          for (int p = 0; p < len; ++p) buffer[static_cast<size_t>(p)] = rd + p;
+          rd += len;
+        } else {
+          const int len = kTfBytes + shift;
+          for (int p = 0; p < len; ++p) buffer[static_cast<size_t>(p)] = rd + p;
+          rd += len;
+        }
+      }
+      const FifoCall c = fifo_call(st);
+      if (st.overflow) { overflowed = true; break; }       // more than kMaxSeg nested short reads: the engine reports it
+      CHECK((c.status != 0) == read);
+      CHECK(c.fifo_count == static_cast<int>(fed - rd));
+      CHECK(st.consumed == rd && st.fed == fed);
+      if (!read) continue;
+      CHECK(st.view.nseg >= 1 && st.view.nseg <= kMaxSeg);
+      int lo = 0;
+      for (int i = 0; i < st.view.nseg; ++i) {
+        CHECK(st.view.seg_end[i] > lo || (i == 0 && st.view.seg_end[0] >= 0));
+        for (int p = lo; p < st.view.seg_end[i]; p += 997)                                // sampled positions plus both ends
+          CHECK(buffer[static_cast<size_t>(p)] == (st.view.seg_src[i] < 0 ? -1 : st.view.seg_src[i] + p));
+        if (st.view.seg_end[i] > lo) {
+          const int p = st.view.seg_end[i] - 1;
+          CHECK(buffer[static_cast<size_t>(p)] == (st.view.seg_src[i] < 0 ? -1 : st.view.seg_src[i] + p));
+        }
+        lo = st.view.seg_end[i];
+      }
+      CHECK(lo == kTfBytes);
+    }
+  }
+}
+
+static void test_synth()
+{
+  for (int preset = 0; preset < 2; ++preset) {
+    dabhip_synth_cfg cfg;
+    CHECK(dabhip_synth_preset(preset, &cfg) == 0);
+    cfg.seed = 5 + static_cast<uint64_t>(preset);
+    cfg.skip_samples = preset ? 4321 : 0;
+    cfg.snr_db = preset ? 9.0 : 1000.0;
+    cfg.cfo_hz = preset ? 123.0 : 0.0;
+    const size_t n = dabhip_synth_bytes(&cfg, 2);
+    std::vector<uint8_t> iq(n + 64, 0xAA);
+    CHECK(dabhip_synth_generate(&cfg, 2, iq.data(), n) == static_cast<int64_t>(n));
+    for (size_t i = n; i < n + 64; ++i) CHECK(iq[i] == 0xAA);
+    CHECK(dabhip_synth_generate(&cfg, 2, iq.data(), n - 1) < 0);                           // too small a buffer is refused
+    std::vector<uint8_t> pay(4096);
+    for (int k = 0; k < cfg.nsub; ++k) CHECK(dabhip_synth_payload(&cfg, 3, k, pay.data(), static_cast<int>(pay.size())) > 0);
+  }
+}
+
+int main(int argc, char** argv)
+{
+  const char* only = argc > 1 ? argv[1] : "";
+  struct { const char* name; void (*fn)(); } tests[] = {
+      {"pool", test_pool_and_lane}, {"worklist", test_control_and_worklist}, {"fifo", test_fifo_views}, {"synth", test_synth}};
+  for (const auto& t : tests) {
+    if (*only && std::strcmp(only, t.name) != 0) continue;
+    t.fn();
+    std::printf("ok %s\n", t.name);
+  }
+  return 0;
+}

@@ -93,3 +93,29 @@ def test_cli_devices_flag_equals_single_device_output(tmp_path):
     assert rng.stdout == subprocess.run([exe] + names[:2], stdout=subprocess.PIPE, check=True).stdout
     bad = subprocess.run([exe, "--devices", "0,x"] + names[:1], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert bad.returncode == 1
+
+
+def test_eti_consumer_pipe_against_the_reference_eti2mpa(tmp_path):
+    """`dab2eti-hip capture.cu8 | eti2mpa N` with the REFERENCE's own eti2mpa.c (oracle/_ref/eti2mpa_ref, compiled unmodified) as the
+    consumer of GPU-made ETI: its output equals our eti2mpa's and the payload the modulator sent, for three SubChIds."""
+    ref_exe = os.path.join(os.path.dirname(os.path.dirname(dab.LIB_PATH)), "oracle", "_ref", "eti2mpa_ref")
+    assert os.path.exists(ref_exe), "oracle/_ref/eti2mpa_ref missing: __graft_entry__.build() makes it where the reference is present"
+    here = os.path.dirname(dab.LIB_PATH)
+    cfg = dab.synth_preset(0, seed=77, cif_count0=4990)            # the 12 sub-channel mix; the CIF counter wraps inside the capture
+    cap = tmp_path / "cap.cu8"
+    dab.synth_generate(cfg, 22).tofile(cap)
+    eti = subprocess.run([os.path.join(here, "dab2eti-hip"), str(cap)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    assert len(eti) == 4 * (22 - 15) * dab.ETI_BYTES
+    frames = np.frombuffer(eti, np.uint8).reshape(-1, dab.ETI_BYTES)
+    eti_file = tmp_path / "out.eti"             # a regular file: the reference's single read() per frame (eti2mpa.c:32) comes back short on a pipe
+    eti_file.write_bytes(eti)
+    fib_index = {dab.synth_fibs(cfg, c).tobytes(): c for c in range(4 * 22)}
+    for slot, scid in ((0, 1), (5, 6), (10, 11)):                  # UEP 128k, UEP 192k, the EEP 2-A 8 kbit/s special case
+        with open(eti_file, "rb") as f:
+            ref = subprocess.run([ref_exe, str(scid)], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        ours = subprocess.run([os.path.join(here, "eti2mpa"), str(scid)], input=eti, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+        assert ref.returncode == 1 and b"Extracting channel: SCID=%d" % scid in ref.stderr      # eti2mpa.c:33-36,49
+        assert ref.stdout == ours.stdout and len(ref.stdout) > 0
+        sent = b"".join(dab.synth_payload(cfg, fib_index[f[12 + 4 * (f[5] & 0x7f):][:96].tobytes()], slot).tobytes() for f in frames)
+        # STL counts 64-bit words: the 8 kbit/s sub-channel's 24 payload bytes sit in 3 words exactly, the others likewise
+        assert ref.stdout == sent, scid

@@ -168,6 +168,18 @@ def test_eti2mpa_extracts_subchannel_from_reference_eti(tmp_path):
         assert out == want
     r = subprocess.run([exe, "33"], input=eti.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 4 and r.stdout == b""
+    # ... and next to the reference's own eti2mpa.c, compiled unmodified by oracle/Makefile (it ends with "Read error", exit 1, at
+    # the end of its input: eti2mpa.c:33-36)
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "eti2mpa_ref")
+    if not os.path.exists(ref_exe):
+        pytest.skip("oracle/_ref/eti2mpa_ref not built (reference sources absent)")
+    eti_file = tmp_path / "golden.eti"            # a regular file: the reference's single read() per frame (eti2mpa.c:32) comes back short on a pipe
+    eti.tofile(eti_file)
+    for scid in (1, 2, 5, 9):
+        ours = subprocess.run([exe, str(scid)], input=eti.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+        with open(eti_file, "rb") as f:
+            ref = subprocess.run([ref_exe, str(scid)], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert ref.returncode == 1 and len(ref.stdout) > 0 and ref.stdout == ours, scid
 
 
 def _fifo_view_matches_oracle(iq):
