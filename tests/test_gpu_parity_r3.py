@@ -1,0 +1,67 @@
+"""GPU parity tests, third batch: a randomised sweep against the oracle inside the suite, and BASELINE configs[2] on exactly the
+workload bench.py times (256 DISTINCT device-modulated ensembles x 64 TF)."""
+import hashlib
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import dabtools_amd as dab
+import oracle_lib as ol
+from dabtools_amd import shard
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_randomised_sweep_against_the_oracle():
+    """A one-minute cut of tools/stress_parity.py: captures with random ensembles (12 / 4 sub-channels), seeds, CIF counters, start
+    offsets, amplitudes, noise (clean ... 9 dB), carrier offsets up to +-400 Hz and ragged lengths, decoded by the batch engine in
+    parity mode; ETI bytes AND the per-call front-end trace of every capture equal or_replay's.  >= 3000 ETI frames."""
+    spec = importlib.util.spec_from_file_location("stress_parity", os.path.join(ROOT, "tools", "stress_parity.py"))
+    sp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sp)
+    seed = int.from_bytes(os.urandom(4), "little")          # a fresh sweep every run; the seed is in the failure message
+    res = sp.run(rounds=2, streams=48, tfs=22, workers=min(32, os.cpu_count() or 1), seed=seed)
+    assert res["differences"] == [], (seed, res["differences"][:5])
+    assert res["eti_frames_compared"] >= 3000 and res["calls_compared"] >= 2500, res
+    cases = res["cases"]
+    assert any(c["snr_db"] < 10 for c in cases) and any(c["bytes_cut"] for c in cases) and any(c["cfo_hz"] for c in cases)
+    assert any(c["skip_samples"] for c in cases) and {c["preset"] for c in cases} == {0, 1}
+
+
+def test_config2_the_benchmark_workload_itself():
+    """BASELINE configs[2] as bench.py builds it: 256 distinct ensembles (seed = 2000 + stream, CIF counter 97 * stream mod 5000),
+    modulated on the device, 64 TF each, resident in HBM.  (a) 16 streams spread over the batch are byte-equal to the CPU oracle's
+    replay of the very bytes the device modulator wrote; (b) all 256 streams' frames are identical between the fused OFDM stage
+    (default) and the two-kernel stage; (c) every stream yields 4 * (64 - 15) frames."""
+    nstreams, ntf = 256, 64
+    cfgs = [dab.synth_preset(0, seed=shard.stream_seed(2, g), cif_count0=(97 * g) % 5000) for g in range(nstreams)]
+    nbytes = dab.synth_bytes(cfgs[0], ntf)
+    bufs = [dab.DeviceBuffer(nbytes) for _ in range(nstreams)]
+    dab.synth_generate_device(cfgs, ntf, [b.ptr for b in bufs], 0)
+    eng = dab.Engine(0)
+    ptrs, sizes = [b.ptr for b in bufs], [nbytes] * nstreams
+    assert eng.decode_device(ptrs, sizes) == nstreams * 4 * (ntf - 15)
+    digests = []
+    sample = list(range(0, nstreams, 17))[:15] + [255]                     # 16 streams
+    kept = {}
+    for b in range(nstreams):
+        eti = eng.eti(b)
+        assert eti.shape == (4 * (ntf - 15), dab.ETI_BYTES), b                # (c)
+        digests.append(hashlib.sha256(eti.tobytes()).digest())
+        if b in sample:
+            kept[b] = eti
+    assert len(set(digests)) == nstreams                                     # the ensembles really are distinct
+    for b in sample:                                                         # (a)
+        want, _ = ol.or_replay(bufs[b].download())
+        assert np.array_equal(kept[b], want), b
+    eng.set_fused(False)                                                     # (b)
+    assert eng.decode_device(ptrs, sizes) == nstreams * 4 * (ntf - 15)
+    for b in range(nstreams):
+        assert hashlib.sha256(eng.eti(b).tobytes()).digest() == digests[b], b
+    eng.close()
+    for b in bufs:
+        b.free()

@@ -4,7 +4,8 @@ amplitudes, noise levels and small carrier offsets, decoded by the batch engine 
 stream, by the CPU oracle (oracle/or_replay, a process pool over the host cores): ETI bytes and per-call traces must be equal.
 
   python tools/stress_parity.py [--rounds 6] [--streams 48] [--tfs 24] [--workers 32]
-Prints one JSON line; exit code 1 on any difference.  Checker use of oracle/ only (like tests/)."""
+Prints one JSON line (totals plus one record per capture: its parameters, calls, frames, resyncs, equal or not); exit code 1 on any
+difference.  tests/test_gpu_parity_r3.py runs a one-minute cut of it under -m gpu.  Checker use of oracle/ only (like tests/)."""
 import argparse
 import json
 import multiprocessing as mp
@@ -27,37 +28,34 @@ def oracle_job(args):
     return eti, [(t.ok, t.read_frame, t.coarse_timeshift, t.fine_timeshift, t.coarse_freq_shift, t.fifo_count) for t in trace]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--rounds", type=int, default=6)
-    ap.add_argument("--streams", type=int, default=48)
-    ap.add_argument("--tfs", type=int, default=24)
-    ap.add_argument("--workers", type=int, default=min(32, os.cpu_count() or 1))
-    ap.add_argument("--seed", type=int, default=20261002)
-    args = ap.parse_args()
+def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None):
+    """The sweep itself -> result dict (one record per capture under "cases")."""
     import dabtools_amd as dab
-    rng = np.random.default_rng(args.seed)
+    workers = workers or min(32, os.cpu_count() or 1)
+    rng = np.random.default_rng(seed)
     tmp = "/tmp/stress_parity_%d" % os.getpid()
     os.makedirs(tmp, exist_ok=True)
     eng = dab.Engine(0)
     total_frames = total_calls = 0
-    bad = []
+    bad, cases = [], []
     t0 = time.time()
-    with mp.get_context("spawn").Pool(args.workers) as pool:
-        for r in range(args.rounds):
-            cfgs, paths, iqs = [], [], []
-            for i in range(args.streams):
+    with mp.get_context("spawn").Pool(workers) as pool:
+        for r in range(rounds):
+            cfgs, paths, iqs, ragged = [], [], [], []
+            for i in range(streams):
                 snr = float(rng.choice([1000.0, 1000.0, 20.0, 14.0, 11.0, 9.0]))
                 cfg = dab.synth_preset(int(rng.integers(0, 2)), seed=int(rng.integers(1, 1 << 30)), cif_count0=int(rng.integers(0, 5000)),
                                        skip_samples=int(rng.choice([0, 0, int(rng.integers(1, 196608))])), snr_db=snr,
                                        amplitude=float(rng.choice([1.0, 0.8, 0.5, 0.35])), cfo_hz=float(rng.choice([0.0, 0.0, rng.uniform(-400, 400)])))
-                ntf = int(args.tfs + rng.integers(0, 5))
+                ntf = int(tfs + rng.integers(0, 5))
                 iq = dab.synth_generate(cfg, ntf)
+                cut = 0
                 if rng.integers(0, 4) == 0:                                   # ragged: not a whole number of 262144-byte calls
-                    iq = iq[: iq.size - int(rng.integers(1, 262144))]
+                    cut = int(rng.integers(1, 262144))
+                    iq = iq[: iq.size - cut]
                 p = os.path.join(tmp, "s%d.npy" % i)
                 np.save(p, iq)
-                cfgs.append(cfg); paths.append(p); iqs.append(iq)
+                cfgs.append(cfg); paths.append(p); iqs.append(iq); ragged.append(cut)
             pending = pool.map_async(oracle_job, [(p,) for p in paths], chunksize=1)
             eng.decode(iqs)
             got = [(eng.eti(b), eng.trace(b, iqs[b].size // 262144)[0]) for b in range(len(iqs))]
@@ -68,16 +66,35 @@ def main():
                 gtrace = [tuple(int(x) for x in t) for t in trace]
                 total_frames += len(weti)
                 total_calls += len(wtrace)
-                if eti.shape != weti.shape or not np.array_equal(eti, weti) or gtrace != wtrace:
+                equal = eti.shape == weti.shape and np.array_equal(eti, weti) and gtrace == wtrace
+                cases.append({"round": r, "stream": b, "preset": 0 if cfgs[b].nsub == 12 else 1, "seed": int(cfgs[b].seed), "cif_count0": int(cfgs[b].cif_count0),
+                              "skip_samples": int(cfgs[b].skip_samples), "snr_db": float(cfgs[b].snr_db), "amplitude": float(cfgs[b].amplitude),
+                              "cfo_hz": round(float(cfgs[b].cfo_hz), 2), "bytes_cut": ragged[b], "calls": len(wtrace), "eti_frames": int(len(weti)),
+                              "resyncs": int(sum(1 for t in wtrace[2:] if t[2] != 0)), "equal": bool(equal)})
+                if not equal:
                     bad.append({"round": r, "stream": b, "seed": int(cfgs[b].seed), "snr_db": float(cfgs[b].snr_db), "frames": [int(len(eti)), int(len(weti))],
                                 "trace_equal": gtrace == wtrace})
-            print("round %d: %d streams, %d ETI frames so far, %d differences" % (r, len(iqs), total_frames, len(bad)), file=sys.stderr, flush=True)
+            if log:
+                print("round %d: %d streams, %d ETI frames so far, %d differences" % (r, len(iqs), total_frames, len(bad)), file=log, flush=True)
+    eng.close()
     for f in os.listdir(tmp):
         os.remove(os.path.join(tmp, f))
     os.rmdir(tmp)
-    print(json.dumps({"rounds": args.rounds, "streams_per_round": args.streams, "eti_frames_compared": total_frames, "calls_compared": total_calls,
-                      "differences": bad, "seconds": round(time.time() - t0, 1), "seed": args.seed}))
-    sys.exit(1 if bad else 0)
+    return {"rounds": rounds, "streams_per_round": streams, "eti_frames_compared": total_frames, "calls_compared": total_calls,
+            "differences": bad, "seconds": round(time.time() - t0, 1), "seed": seed, "cases": cases}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=6)
+    ap.add_argument("--streams", type=int, default=48)
+    ap.add_argument("--tfs", type=int, default=24)
+    ap.add_argument("--workers", type=int, default=min(32, os.cpu_count() or 1))
+    ap.add_argument("--seed", type=int, default=20261002)
+    args = ap.parse_args()
+    res = run(args.rounds, args.streams, args.tfs, args.workers, args.seed, log=sys.stderr)
+    print(json.dumps(res))
+    sys.exit(1 if res["differences"] else 0)
 
 
 if __name__ == "__main__":
