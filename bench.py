@@ -31,20 +31,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FFT_BYTES_PER_TF = 311296 + 1245184        # cu8 read + complex64 spectra written
+FUSED_BYTES_PER_TF = 311296 + 28800        # the fused OFDM stage: cu8 read + bit-packed decisions written
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8.0 TB/s spec
-# HBM bytes per TF of ofdm_fft_kernel from rocprofv3 PMC passes (profiles/r02_k2_pmc_traffic.csv):
-# (2 x FETCH_SIZE + WRITE_SIZE) KiB per 1024-TF launch = 2 x 161,196 + 1,245,184, FETCH_SIZE doubled as the gfx950 note in
-# MI355X_MICROARCH.md (HBM) prescribes.  PMC counters cannot be read from inside this script.
-FFT_PMC_BYTES_PER_TF = (2 * 161196 + 1245184) * 1024 // 1024   # KiB per 1024 TF == bytes per TF: 1,567,576 = 1.007 x algorithmic
 REALTIME_FPS = 1000.0 / 24.0
-# VALU issue peak: 256 CUs x 4 SIMDs, one wave-instruction per 4 cycles (a quad-cycle) at 2.4 GHz
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 4
-VIT_VALU_PER_STEP = 129.0                  # VALU wave-instructions per trellis step of viterbi_fused_kernel<1> (PMC, see roofline_viterbi)
-# The same step priced in issue clocks per SIMD (profiles/r02_valu_rates.txt, tools/ubench/valu_rates.hip: wave64 instructions do not all
-# cost a quad-cycle on gfx950): 64 v_add_u32 at 2.56 + 32 v_pk_max_u16 at 4.28 + 13 v_perm_b32 at 4.2 + ~20 others at ~4.2
-VIT_ISSUE_CLOCKS_PER_STEP = 64 * 2.56 + 32 * 4.28 + 13 * 4.2 + 20 * 4.2
-VIT_REC_BYTES_PER_WAVE_STEP = 512.0 * 1.45   # 64 lanes x 8 B written per step; read back: 16 of 64 bytes per lane and block = ~45 % of the sectors
-HBM_STREAM_MIX_NOTE = "compare with roofline.stream_ceiling.copy, not with the 8 TB/s of the data sheet"
+SIMDS, XCDS = 256 * 4, 8
+# Every roofline input that cannot be measured from inside this script (PMC counters, the effective clock) is read from the tracked
+# profile of the round, produced by tools/refresh_profiles.sh (rocprofv3 passes over THIS script) -- never baked in here.
+PROFILE_PMC = os.path.join(ROOT, "profiles", "r03_pmc_summary.csv")
+# issue cost of a wave64 VALU instruction on gfx950 (MI355X_MICROARCH.md, per-instruction table: v_fma_f32 2 cycles; tools/ubench/valu_rates.hip,
+# profiles/r03_valu_rates.txt: plain 32-bit VOP1/VOP2 2, every VOP3 / VOP3P / DPP / 64-bit form 4)
+CYC_SIMPLE, CYC_VOP3 = 2.0, 4.0
+VIT_ADDS_PER_STEP = 64                     # the v_add_u32 of one trellis step (k_decode.hip butterfly_pair: 4 per register pair x 16), all 2-cycle
+MSC_STEPS_PER_FRAME = 4 * 3078 + 2 * 4614 + 3 * 1542 + 774 + 2 * 198      # 27,336: trellis steps of the 12 sub-channels of the canonical mix
+FIC_STEPS = 774
 
 
 # ---- rank coordination ---------------------------------------------------------------------------------------------
@@ -154,6 +153,52 @@ def launch_ranks(args, argv):
     return 1 if failed or any(p.returncode for p in procs) else 0
 
 
+# ---- tracked profile inputs ---------------------------------------------------------------------------------------------
+class Profile:
+    """profiles/rNN_pmc_summary.csv (tools/sq_pmc_summary.py): cell(pass, kernel, counter) = counter summed over the kernel's dispatches
+    in that rocprofv3 pass; meta(key) = what the profiled command was."""
+
+    def __init__(self, path):
+        self.path = os.path.relpath(path, ROOT)
+        self.cells, self.metas = {}, {}
+        with open(path) as f:
+            for line in f:
+                if line.startswith("#") or line.startswith("pass,"):
+                    continue
+                pas, rest = line.rstrip("\n").split(",", 1)
+                kernel, ndisp, counter, value = rest.rsplit(",", 3)     # kernel names may hold commas (template arguments)
+                if pas == "meta":
+                    self.metas[kernel] = float(value)
+                else:
+                    self.cells[(pas, kernel, counter)] = float(value)
+
+    def cell(self, pas, kernel, counter):
+        key = (pas, kernel, counter)
+        if key not in self.cells:
+            raise SystemExit("bench.py: %s has no cell (%s, %s, %s): re-run tools/refresh_profiles.sh" % ((self.path,) + key))
+        return self.cells[key]
+
+    def meta(self, key):
+        if key not in self.metas:
+            raise SystemExit("bench.py: %s has no meta row %s: re-run tools/refresh_profiles.sh" % (self.path, key))
+        return self.metas[key]
+
+    def ref(self, pas, kernel, counter):
+        return "%s: %s / %s / %s" % (self.path, pas, kernel, counter)
+
+
+def load_profile():
+    if not os.path.exists(PROFILE_PMC):
+        raise SystemExit("bench.py: %s is missing.  The roofline objects are computed from the tracked rocprofv3 profile of this round; produce it "
+                         "on a GPU box with tools/refresh_profiles.sh (its own passes run with --profile-pass)." % os.path.relpath(PROFILE_PMC, ROOT))
+    return Profile(PROFILE_PMC)
+
+
+def wave_steps(frames, tf_slots):
+    """Trellis steps x waves of one decode: every wave = 64 code words of one length (12 sub-channels per ETI frame, 4 FIC blocks per TF)."""
+    return -(-frames // 64) * MSC_STEPS_PER_FRAME + -(-4 * tf_slots // 64) * FIC_STEPS
+
+
 # ---- workload -----------------------------------------------------------------------------------------------------
 def make_streams(torch, dev, nstreams, ntf, ndistinct, rank, snr_db=1000.0, host_synth=False):
     """nstreams synthetic ensembles resident on the device.  Default: every stream its own ensemble (payload, CIF
@@ -179,44 +224,27 @@ def make_streams(torch, dev, nstreams, ntf, ndistinct, rank, snr_db=1000.0, host
 
 def payload_stats(dab, eng, first_global_stream, nstreams, ntf):
     """Decoded payload vs what the modulator sent, over the first streams of this rank (noisy configs)."""
-    import numpy as np
-    from dabtools_amd import shard
-    frames = good = bit_err = bits = 0
-    expected = nstreams * 4 * (ntf - 15)
+    from dabtools_amd import payload
+    chk = payload.PayloadCheck()
     for b in range(nstreams):
-        g = first_global_stream + b
-        cfg = dab.synth_preset(0, seed=shard.stream_seed(2, g), cif_count0=(97 * g) % 5000)
-        fib_index = {dab.synth_fibs(cfg, c).tobytes(): c for c in range(4 * ntf)}
-        for e in eng.eti(b):
-            frames += 1
-            nst = int(e[5]) & 0x7f
-            pos = 12 + 4 * nst
-            cif = fib_index.get(e[pos:pos + 96].tobytes())
-            if cif is None or nst != cfg.nsub:
-                continue
-            pos += 96
-            wrong = 0
-            for k in range(nst):
-                want = dab.synth_payload(cfg, cif, k)
-                wrong += int(np.unpackbits(np.bitwise_xor(e[pos:pos + want.size], want)).sum())
-                bits += 8 * want.size
-                pos += want.size
-            bit_err += wrong
-            good += int(wrong == 0)
-    return {"streams_checked": nstreams, "frames_expected_if_locked": expected, "frames_out": frames, "error_free_frames": good,
-            "payload_ber": (bit_err / bits) if bits else None}
+        chk.add_stream(dab, payload.bench_cfg(dab, first_global_stream + b), ntf, eng.eti(b))
+    return chk.result()
 
 
-def cpu_baseline(tensors, ntf, nsample):
+def cpu_baseline(tensors, ntf, nsample, ber_first_stream=-1, snr=1000.0):
     """tools/cpu_baseline.py on the first streams of this very workload, as a CHILD process (one process per core needs
-    fork, which a process that has initialised the GPU must not do)."""
+    fork, which a process that has initialised the GPU must not do).  ber_first_stream >= 0: also the payload BER of the real
+    reference back ends (scalar and ENABLE_SPIRAL_VITERBI SSE) on those captures' hard decisions (BASELINE configs[4])."""
     with tempfile.TemporaryDirectory(prefix="dabhip_bench_") as tmp:
         files = []
         for i, t in enumerate(tensors[:nsample]):
             path = os.path.join(tmp, "s%d.cu8" % i)
             t.cpu().numpy().tofile(path)
             files.append(path)
-        cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--tfs", str(ntf), "--iq"] + files
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--tfs", str(ntf)]
+        if ber_first_stream >= 0:
+            cmd += ["--ber-first-stream", str(ber_first_stream), "--snr", str(snr)]
+        cmd += ["--iq"] + files
         res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     if res.returncode != 0:
         return {"error": res.stderr[-400:]}
@@ -232,13 +260,169 @@ def workload_text(args):
 
 
 # ---- one rank -----------------------------------------------------------------------------------------------------
+def h2d_inclusive(dab, device, tensors, sizes, frames_resident, args):
+    """The same workload with the IQ in HOST memory, PCIe included (never `value`): page-locked buffers (dabhip_host_alloc) through
+    (a) one dabhip_engine_decode(on_device = 0): upload, then decode; (b) a dabhip_stream session in segments of --h2d-segment-tfs TF
+    with dabhip_stream_prefetch: segment k + 1 uploads while segment k decodes; plus (c) pageable memory through the staging ring."""
+    import numpy as np
+    B, nbytes = len(tensors), sizes[0]
+    pinned = [dab.HostBuffer(nbytes) for _ in range(B)]
+    for hb, t in zip(pinned, tensors):
+        assert dab.lib().dabhip_device_copy(hb.ptr, t.data_ptr(), nbytes, 0) == 0
+    out = {"pinned": True, "unit": "ETI frames/s", "workload_bytes": B * nbytes,
+           "note": "IQ starts in page-locked HOST memory (dabhip_host_alloc); PCIe-bound: 128,394 B of IQ per ETI frame for a 64-TF capture "
+                   "(98,304 in the steady state of a session); never `value`"}
+    eng = dab.Engine(device)
+
+    def one_shot(ptrs, nb, reps=3):
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            n = eng.decode_host_ptrs(ptrs, nb)
+            dt = time.perf_counter() - t0
+            st = eng.stage_ms()
+            rec = {"value": n / dt, "ms": 1e3 * dt, "eti_frames": n, "h2d_ms": st["h2d"], "h2d_GBps": st["h2d_mbytes"] / max(st["h2d"], 1e-9),
+                   "end_to_end_GBps": sum(nb) / dt / 1e9, "pinned_fraction": st["h2d_pinned_mbytes"] / max(st["h2d_mbytes"], 1e-9)}
+            if best is None or rec["value"] > best["value"]:
+                best = rec
+        return best
+
+    out["one_shot"] = one_shot([hb.ptr for hb in pinned], sizes)
+    out["one_shot"]["identical_frame_count"] = out["one_shot"]["eti_frames"] == frames_resident
+    npage = min(B, 32)                                       # pageable memory: a sample (the copies are made here, 0.8 GB)
+    pageable = [np.array(hb.array[:nbytes], copy=True) for hb in pinned[:npage]]
+    out["one_shot_pageable"] = dict(one_shot([a.ctypes.data for a in pageable], sizes[:npage], reps=2), streams=npage,
+                                    note="pageable host memory: copied into a ring of page-locked staging buffers by the engine's host pool, piece by piece")
+    del pageable
+    eng.close()
+    seg = args.h2d_segment_tfs * dab.TF_BYTES
+    cuts = list(range(0, nbytes, seg)) + [nbytes]
+    segs = [([hb.ptr + a for hb in pinned], [z - a] * B) for a, z in zip(cuts, cuts[1:])]
+    best = None
+    for _ in range(2):
+        st = dab.Stream(B, device=device)
+        per_seg = []
+        t0 = time.perf_counter()
+        st.prefetch_ptrs(*segs[0])
+        for k in range(len(segs)):
+            tk = time.perf_counter()                        # an iteration = hand over segment k + 1, decode segment k
+            if k + 1 < len(segs):
+                st.prefetch_ptrs(*segs[k + 1])
+            n = st.feed_ptrs(*segs[k])
+            per_seg.append((n, time.perf_counter() - tk))
+        dt = time.perf_counter() - t0
+        st.close()
+        total = sum(n for n, _ in per_seg)
+        first = max(3, -(-16 // args.h2d_segment_tfs) + 1)   # after lock-in, and with an upload running beside the decode (not the last)
+        steady = [(n, t) for n, t in per_seg[first:-1] if n > 0]
+        rec = {"value": total / dt, "ms": 1e3 * dt, "eti_frames": total, "end_to_end_GBps": B * nbytes / dt / 1e9, "segments": len(segs),
+               "segment_tfs": args.h2d_segment_tfs, "identical_frame_count": total == frames_resident,
+               "steady_state": ({"value": sum(n for n, _ in steady) / sum(t for _, t in steady), "ms_per_segment": 1e3 * sum(t for _, t in steady) / len(steady),
+                                 "GBps": len(steady) * B * seg / sum(t for _, t in steady) / 1e9, "segments_counted": len(steady)} if steady else None)}
+        if best is None or rec["value"] > best["value"]:
+            best = rec
+    out["session_prefetch"] = best
+    # the headline of this object: the sustained host-fed rate (steady state of the session), with the one-shot figure beside it
+    out["value"] = (best["steady_state"] or best)["value"]
+    out["GBps"] = (best["steady_state"] or best).get("GBps", best["end_to_end_GBps"])
+    for hb in pinned:
+        hb.free()
+    return out
+
+
+def rooflines(prof, args, world, frames_rank, ntf_rank, stage, fft, stream_ceiling):
+    """roofline (K2, HBM), roofline_viterbi (VALU issue), roofline_ofdm_fused (VALU issue / LDS): live times of this run x per-unit figures
+    read from the tracked profile; every input names the CSV cells it comes from."""
+    out = {}
+    decodes = prof.meta("full_decodes")
+    same = prof.meta("streams_per_gpu") == args.streams and prof.meta("tf_per_stream") == args.tfs
+    K2, VIT, FUSED = "ofdm_fft_kernel<false>", "viterbi_fused_kernel<1>", "ofdm_demap_kernel<false>"
+    if fft:
+        launches, tfs, ms = fft
+        achieved = FFT_BYTES_PER_TF * tfs / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        k2_tfs = prof.meta("k2_roofline_tfs")                  # TFs ofdm_fft_kernel<false> transformed in the profiled run
+        traffic_per_tf = (2.0 * prof.cell("fetch", K2, "FETCH_SIZE") + prof.cell("write", K2, "WRITE_SIZE")) * 1024.0 / k2_tfs
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "ofdm_fft_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic_per_tf * tfs / max(launches, 1),
+            "traffic_note": "HBM bytes per launch FROM THE TRACKED PROFILE, not from this run: (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 / TFs "
+                            "(FETCH_SIZE doubled: gfx950 note in MI355X_MICROARCH.md) = %.0f B per TF = %.3f x algorithmic; cells %s, %s, meta k2_roofline_tfs"
+                            % (traffic_per_tf, traffic_per_tf / FFT_BYTES_PER_TF, prof.ref("fetch", K2, "FETCH_SIZE"), prof.ref("write", K2, "WRITE_SIZE")),
+            "measured_outside_the_timed_step": True,
+            "how": "dabhip_engine_fft_roofline: K2 ALONE over the frame list of the timed step (same resident IQ, %d TF per launch), HIP events on the "
+                   "engine's stream around every launch.  The timed step itself runs the fused transform + demap kernel (roofline_ofdm_fused), which "
+                   "never writes the spectra; `frac` is this kernel's figure, not the pipeline's" % (tfs // max(launches, 1)),
+            "stream_ceiling": dict(stream_ceiling or {}, unit="GB/s",
+                                   note="bare grid-stride kernels of this library on this device, measured in this run, 4 GiB buffers (k_probe.hip): "
+                                        "fill = write only, copy = 1 read : 1 written, k2_mix = 1 byte read per 4 written with K2's 16-byte nontemporal stores"),
+            "achieved_vs_measured_copy_ceiling": (achieved / stream_ceiling["copy"]) if (stream_ceiling or {}).get("copy") else None,
+            "achieved_vs_k2_mix_stream": (achieved / stream_ceiling["k2_mix"]) if (stream_ceiling or {}).get("k2_mix") else None,
+            "launches": launches, "tf_per_launch": tfs / max(launches, 1), "avg_launch_ms": ms / max(launches, 1),
+            "algorithmic_bytes_per_tf": FFT_BYTES_PER_TF}
+    if stage.get("viterbi", 0) > 0 and not args.subchannels and not args.soft:
+        # MSC Viterbi (hard decisions): bound by VALU issue.  Per wave (64 code words) and trellis step: insts = SQ_INSTS_VALU / wave-steps of the
+        # profiled run (FIC and MSC launches of all its decodes); 64 of them are 2-cycle v_add_u32, the rest 4-cycle forms; the SIMDs' clock
+        # under this kernel = GRBM_GUI_ACTIVE / 8 XCDs / kernel time of the same pass.
+        ws_prof = decodes * prof.meta("viterbi_wave_steps_per_decode") + prof.meta("viterbi_wave_steps_setup")
+        insts = prof.cell("clk", VIT, "SQ_INSTS_VALU") / ws_prof
+        clock = prof.cell("clk", VIT, "GRBM_GUI_ACTIVE") / XCDS / prof.cell("clk", VIT, "DURATION_NS")       # GHz
+        cycles = CYC_SIMPLE * VIT_ADDS_PER_STEP + CYC_VOP3 * (insts - VIT_ADDS_PER_STEP)
+        ws = wave_steps(frames_rank, 0)                                                   # the MSC launch of one step on this rank
+        t = stage["viterbi"] * 1e-3
+        rec_bytes = (2.0 * prof.cell("fetch", VIT, "FETCH_SIZE") + prof.cell("write", VIT, "WRITE_SIZE")) * 1024.0 / decodes
+        io_bytes = frames_rank * (1728 * 4 + 27264 // 8)                                  # grouped received bits in, decoded sub-channel bytes out
+        out["roofline_viterbi"] = {
+            "kernel": VIT, "bound": "valu issue", "achieved": cycles * ws / t / 1e9, "peak": SIMDS * clock, "unit": "G issue cycles/s",
+            "frac": cycles * ws / t / 1e9 / (SIMDS * clock),
+            "inputs": {
+                "valu_insts_per_wave_step": {"value": insts, "from": prof.ref("clk", VIT, "SQ_INSTS_VALU") + " / (meta full_decodes x viterbi_wave_steps_per_decode + viterbi_wave_steps_setup)"},
+                "effective_clock_ghz": {"value": clock, "from": prof.ref("clk", VIT, "GRBM_GUI_ACTIVE") + " / 8 XCDs / DURATION_NS of the same pass (dense VALU: the chip clocks below its 2.4 GHz)"},
+                "issue_cycles_per_wave_step": {"value": cycles, "from": "%d v_add_u32 x %.0f cycles + the other instructions x %.0f cycles" % (VIT_ADDS_PER_STEP, CYC_SIMPLE, CYC_VOP3)},
+                "wave_steps_per_launch": ws, "simds": SIMDS, "avg_ms": stage["viterbi"], "profile_matches_this_workload": same},
+            "survivor_traffic": {"bytes_per_step": rec_bytes, "x_stage_io": rec_bytes / io_bytes, "GBps": rec_bytes / t / 1e9, "frac_of_hbm_peak": rec_bytes / t / 1e9 / HBM_PEAK_GBS,
+                                 "from": "%s, %s (x2, + WRITE_SIZE) / meta full_decodes" % (prof.ref("fetch", VIT, "FETCH_SIZE"), prof.ref("write", VIT, "WRITE_SIZE")),
+                                 "note": "one lane per code word with a full traceback: 64 B of survivor records per 8 steps and code word written, the 16-byte part "
+                                         "holding the path's state read back; the stage's own input + output is %.2f GB per step.  Measured with the records kept in L2 "
+                                         "(build DABHIP_VIT_NOSTORE): the HBM traffic costs 0.3 of the 5.0 ms, the chain-back 0.15" % (io_bytes / 1e9)}}
+    if stage.get("fft", 0) > 0 and not args.two_kernel_ofdm and not args.soft and not args.no_parity_guard:
+        # the default OFDM stage: ofdm_demap_kernel (guarded build): not HBM-bound -- VALU issue with LDS round trips and barriers per symbol
+        tr_prof = decodes * prof.meta("ofdm_transforms_per_decode") + prof.meta("ofdm_transforms_setup")
+        insts = prof.cell("clk", FUSED, "SQ_INSTS_VALU") / (4.0 * tr_prof)                   # per wave (4 per transform)
+        clock = prof.cell("clk", FUSED, "GRBM_GUI_ACTIVE") / XCDS / prof.cell("clk", FUSED, "DURATION_NS")
+        transforms = 77 * ntf_rank                                                           # symbols 0..3 (FIC launch) + 3..75 (MSC launch) per TF
+        t = stage["fft"] * 1e-3
+        hbm = FUSED_BYTES_PER_TF * ntf_rank / t / 1e9
+        tfs_prof = decodes * prof.meta("tf_per_decode") + prof.meta("tf_setup")
+        out["roofline_ofdm_fused"] = {
+            "kernel": FUSED + " (transform + DQPSK + demap + de-interleave scatter, parity guard's test inline)", "bound": "valu issue / lds",
+            "achieved": 4.0 * insts * transforms / t / 1e9, "unit": "G wave-instructions/s",
+            "valu_issue": {"insts_per_wave_per_transform": insts, "from": prof.ref("clk", FUSED, "SQ_INSTS_VALU") + " / 4 waves / transforms of the profiled run",
+                           "effective_clock_ghz": clock, "clock_from": prof.ref("clk", FUSED, "GRBM_GUI_ACTIVE") + " / 8 / DURATION_NS",
+                           "frac_if_all_4_cycle": 4.0 * insts * transforms * CYC_VOP3 / t / 1e9 / (SIMDS * clock),
+                           "frac_if_all_2_cycle": 4.0 * insts * transforms * CYC_SIMPLE / t / 1e9 / (SIMDS * clock),
+                           "note": "the mix of 2- and 4-cycle forms is not counted separately: the issue-time fraction lies between the two figures"},
+            "lds": {"bank_conflict_pct": 100.0 * prof.cell("f2", FUSED, "SQ_LDS_BANK_CONFLICT") / prof.cell("f2", FUSED, "SQ_LDS_IDX_ACTIVE"),
+                    "from": prof.ref("f2", FUSED, "SQ_LDS_BANK_CONFLICT") + " / SQ_LDS_IDX_ACTIVE",
+                    "wait_inst_lds_pct_of_wave_cycles": 100.0 * prof.cell("f1", FUSED, "SQ_WAIT_INST_LDS") / prof.cell("clk", FUSED, "SQ_WAVE_CYCLES")},
+            "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS, "algorithmic_bytes_per_tf": FUSED_BYTES_PER_TF,
+                    "write_amplification": prof.cell("write", FUSED, "WRITE_SIZE") * 1024.0 / (28800.0 * tfs_prof),
+                    "from": prof.ref("write", FUSED, "WRITE_SIZE") + " x 1024 / (28,800 B x TFs of the profiled run)",
+                    "note": "NOT the bound of this kernel (it never writes the spectra): stated so that nobody reads it as one"},
+            "transforms_per_step": transforms, "avg_ms": stage["fft"], "profile_matches_this_workload": same}
+    return out
+
+
 def run_rank(args, coord):
     rank, world = coord.rank, coord.world
     from dabtools_amd import shard
     mine = shard.shard_streams(world * args.streams, world, rank)          # global stream indices of this rank
     rank_info = {"rank": rank, "first_stream": mine[0], "last_stream": mine[-1], "streams": len(mine),
                  "first_seed": shard.stream_seed(2, mine[0]), "host_threads": os.environ.get("DABHIP_HOST_THREADS", "auto")}
+    prof = None
+    if rank == 0 and not args.dry_run and not args.profile_pass:
+        prof = load_profile()                                              # fails loudly BEFORE any GPU time is spent
 
+    ntf_rank = 0
     if args.dry_run:
         coord.barrier()
         t0 = time.perf_counter()
@@ -270,7 +454,8 @@ def run_rank(args, coord):
             eng.set_parity_guard(False)
         if args.subchannels:
             eng.set_subchannels([int(x) for x in args.subchannels.split(",")])
-        eng.decode_device(ptrs[:2], [min(s, 20 * 393216) for s in sizes[:2]])   # loads the code objects (tiny, untimed, part of set-up)
+        setup_tf = 20
+        setup_frames = eng.decode_device(ptrs[:2], [min(s, setup_tf * 393216) for s in sizes[:2]])   # loads the code objects (tiny, untimed, part of set-up)
 
         def barrier():
             torch.cuda.synchronize(dev)
@@ -289,11 +474,9 @@ def run_rank(args, coord):
                 stage[k] = stage.get(k, 0.0) + v
         barrier()
         elapsed = time.perf_counter() - t0
-        stage = {k: v / args.steps for k, v in stage.items()}
+        stage = {k: v / args.steps for k, v in stage.items() if not k.startswith("h2d")}
+        ntf_rank = eng.guard_stats()[1] // 230400 if not (args.soft or args.no_parity_guard) else 0
 
-        # Roofline: K2 = ofdm_fft_kernel by itself, on the same resident IQ and the frame list of the step just
-        # timed, HIP events on the engine's stream around every launch.  The pipeline's default OFDM stage fuses K2 with the
-        # demapper and never writes the spectra; that kernel is not HBM-bound and carries no roofline figure.
         fft = None
         fused_off = None
         extra = {}
@@ -302,13 +485,21 @@ def run_rank(args, coord):
             extra["parity_guard"] = {"on": not args.no_parity_guard and not args.soft, "decisions_per_step": decisions, "redecided_in_fp64_per_step": flagged,
                                      "note": "hard decisions whose fp32 margin lies inside the error band are re-decided in fp64 from the int8 samples "
                                              "(k_parity.hip); raw fp32 disagreement rate without it: profiles/r02_decision_audit.json"}
+            # K2 = ofdm_fft_kernel by itself, on the same resident IQ and the frame list of the step just timed
             fft = eng.fft_roofline(max(3, min(args.steps, 10)))
-            if rank == 0:
-                # what a bare streaming kernel with K2's read/write mix reaches on this device, over a footprint like K2's (untimed part)
-                try:
-                    extra["stream_ceiling"] = dab.stream_ceiling(local_rank, 4 << 30, 3)
-                except dab.DabhipError as e:
-                    extra["stream_ceiling"] = {"error": str(e)}
+            try:
+                extra["stream_ceiling"] = dab.stream_ceiling(local_rank, 4 << 30, 3)
+            except dab.DabhipError as e:
+                extra["stream_ceiling"] = {"error": str(e)}
+            # what the profile passes of tools/refresh_profiles.sh need to know about this run (see rooflines())
+            k2_launches, k2_tfs, _ = fft
+            reps = max(3, min(args.steps, 10)) + 1                                         # fft_roofline: one untimed pass first
+            tf_step = k2_tfs // max(reps - 1, 1)
+            extra["profile_meta"] = {"full_decodes": args.warmup + args.steps, "streams_per_gpu": args.streams, "tf_per_stream": args.tfs,
+                                     "viterbi_wave_steps_per_decode": wave_steps(frames, tf_step), "viterbi_wave_steps_setup": wave_steps(setup_frames, 2 * (setup_tf - 1)),
+                                     "ofdm_transforms_per_decode": 77 * tf_step, "ofdm_transforms_setup": 77 * 2 * (setup_tf - 1),
+                                     "tf_per_decode": tf_step, "tf_setup": 2 * (setup_tf - 1), "k2_roofline_tfs": tf_step * reps}
+            ntf_rank = tf_step
             if not args.soft and not args.no_parity_guard and not args.no_variants:
                 # the same job accepting raw fp32 decisions (guard off: the fused kernel without the guard's test)
                 eng.set_parity_guard(False)
@@ -346,8 +537,15 @@ def run_rank(args, coord):
             if args.snr < 100.0:
                 eng.decode_device(ptrs, sizes)
                 extra["payload"] = payload_stats(dab, eng, rank * args.streams, min(16, args.streams), args.tfs)
+            if not args.no_h2d and world == 1 and not args.soft and not args.subchannels and not args.host_synth:
+                eng.close()                                                   # its buffers (survivor records ...) make room for the session's windows
+                eng = None
+                extra["h2d_inclusive"] = h2d_inclusive(dab, local_rank, tensors, sizes, frames, args)
             if not args.no_cpu_baseline and world == 1:
-                extra["cpu_baseline"] = cpu_baseline(tensors, args.tfs, args.cpu_sample)
+                if args.snr < 100.0:                                          # configs[4]: CPU BER on the 16 streams the GPU payload was checked on
+                    extra["cpu_baseline"] = cpu_baseline(tensors, args.tfs, min(16, args.streams), ber_first_stream=rank * args.streams, snr=args.snr)
+                else:
+                    extra["cpu_baseline"] = cpu_baseline(tensors, args.tfs, args.cpu_sample)
 
     rank_info["host_ms_per_step"] = {k: round(stage[k], 4) for k in ("control", "host_worklist", "host_setup", "host_frames", "wall") if k in stage}
     rows = coord.gather({"info": rank_info, "elapsed": elapsed, "frames": frames})
@@ -355,6 +553,10 @@ def run_rank(args, coord):
         elapsed_max = max(r["elapsed"] for r in rows)
         frames_step = sum(r["frames"] for r in rows)
         value = frames_step * args.steps / elapsed_max
+        if args.soft:
+            ofdm_stage = "K2 + K2b (two kernels), soft values" if args.two_kernel_ofdm else "fused transform + demap, 4-bit soft values (k_fused.hip, DABHIP_FUSED_SOFT build)"
+        else:
+            ofdm_stage = "K2 + K2b (two kernels)" if args.two_kernel_ofdm else "fused transform + demap (default)"
         out = {
             "metric": "ETI frames/s (24 ms each), Mode-I batch, synthetic IQ resident in HBM",
             "value": value, "unit": "ETI frames/s", "x_realtime": value / REALTIME_FPS,
@@ -366,53 +568,22 @@ def run_rank(args, coord):
             "dtype": "f64 sync / f32 OFDM / u16 ACS / u8 ETI",
             "data": extra.get("data", "none (dry run)"),
             "config": {"workload": workload_text(args), "streams_per_gpu": args.streams, "tf_per_stream": args.tfs,
-                       "eti_frames_per_step": frames_step,
-                       "ofdm_stage": "K2 + K2b (two kernels)" if (args.two_kernel_ofdm or args.soft) else "fused transform + demap (default)",
+                       "eti_frames_per_step": frames_step, "ofdm_stage": ofdm_stage,
                        "sharding": "independent ensembles, %d per GPU, stream s on rank s // %d, no collective" % (args.streams, args.streams)},
             "ranks": [dict(r["info"], elapsed_s=r["elapsed"], eti_frames_per_step=r["frames"]) for r in rows],
         }
         if args.dry_run:
             out["dry_run"] = True
-        if fft:
-            launches, tfs, ms = fft
-            achieved = FFT_BYTES_PER_TF * tfs / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            out["roofline"] = {
-                "bound": "hbm", "kernel": "ofdm_fft_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": FFT_PMC_BYTES_PER_TF * tfs / max(launches, 1),
-                "traffic_note": "bytes per launch; per-TF HBM bytes from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                "(profiles/r02_k2_pmc_traffic.csv, FETCH_SIZE x2 gfx950 correction) x TFs per launch",
-                "how": "dabhip_engine_fft_roofline: K2 alone over the frame list of the timed step (same resident IQ, %d TF per launch), "
-                       "HIP events on the engine's stream; the step itself runs the fused transform + demap kernel" % (tfs // max(launches, 1)),
-                "achieved_vs_measured_copy_ceiling": achieved / 6290.0,
-                "stream_ceiling": dict(extra.get("stream_ceiling", {}), unit="GB/s",
-                                       note="bare grid-stride kernels of this library on this device, 4 GiB buffers, best of three grid sizes (k_probe.hip): "
-                                            "fill = write only, copy = 1 read : 1 written, k2_mix = 1 byte read per 4 written with K2's 16-byte nontemporal stores"),
-                "achieved_vs_k2_mix_stream": (achieved / extra["stream_ceiling"]["k2_mix"]) if extra.get("stream_ceiling", {}).get("k2_mix") else None,
-                "launches": launches, "tf_per_launch": tfs / max(launches, 1), "avg_launch_ms": ms / max(launches, 1),
-                "algorithmic_bytes_per_tf": FFT_BYTES_PER_TF}
         if stage:
             out["stage_ms_per_step"] = stage
-            if stage.get("viterbi", 0) > 0 and not args.dry_run and not args.subchannels:
-                # second roofline, for the stage with the most time after the OFDM kernel: the MSC Viterbi is bound by VALU issue and by
-                # the survivor records.  Per trellis step and wave (64 code words): VIT_VALU_PER_STEP wave-instructions (rocprofv3 SQ_INSTS_VALU,
-                # profiles/r01_sq_pmc_summary.csv: 2.77e9 per 2.14e7 wave-steps) and 512 B of records written + read back.
-                steps_per_frame = 27336 if not args.soft else 27336
-                wave_steps = frames_step / world * steps_per_frame / 64.0
-                t = stage["viterbi"] * 1e-3
-                out["roofline_viterbi"] = {
-                    "kernel": "viterbi_fused_kernel", "bound": "valu issue / hbm (survivor records)",
-                    "valu": {"achieved": VIT_VALU_PER_STEP * wave_steps / t / 1e9, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
-                             "frac": VIT_VALU_PER_STEP * wave_steps / t / 1e9 / VALU_PEAK_GINST},
-                    "issue_time": {"clocks_per_step": VIT_ISSUE_CLOCKS_PER_STEP, "frac": VIT_ISSUE_CLOCKS_PER_STEP * wave_steps / (256 * 4 * 2.4e9 * t),
-                                   "note": "the step's instructions priced at their measured issue clocks (add 2.56, packed max 4.28, permute 4.2), "
-                                           "over 1024 SIMDs at 2.4 GHz"},
-                    "hbm": {"achieved": VIT_REC_BYTES_PER_WAVE_STEP * wave_steps / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": VIT_REC_BYTES_PER_WAVE_STEP * wave_steps / t / 1e9 / HBM_PEAK_GBS,
-                            "achieved_vs_copy_stream": (VIT_REC_BYTES_PER_WAVE_STEP * wave_steps / t / 1e9 / extra["stream_ceiling"]["copy"]) if extra.get("stream_ceiling", {}).get("copy") else None,
-                            "note": "64 B of survivor records per 8 steps and code word, written once; the chain-back reads the 16-byte part that holds its "
-                                    "state's byte (about 45 % of the 32-byte sectors); " + HBM_STREAM_MIX_NOTE},
-                    "trellis_steps_per_eti_frame": steps_per_frame, "avg_ms": stage["viterbi"]}
+        if prof is not None:
+            out.update(rooflines(prof, args, world, frames, ntf_rank, stage, fft, extra.get("stream_ceiling")))
+        elif fft:
+            launches, tfs, ms = fft                       # --profile-pass: the K2 figure that needs no profile input
+            achieved = FFT_BYTES_PER_TF * tfs / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            out["roofline"] = {"bound": "hbm", "kernel": "ofdm_fft_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                               "traffic": None, "launches": launches, "tf_per_launch": tfs / max(launches, 1), "avg_launch_ms": ms / max(launches, 1),
+                               "note": "--profile-pass: no profile-derived inputs"}
         if fused_off:
             out["two_kernel_ofdm_variant"] = fused_off
         if args.subchannels:
@@ -420,7 +591,7 @@ def run_rank(args, coord):
         if args.snr < 100.0:
             out["config"]["snr_db"] = args.snr
             out["config"]["decisions"] = "soft (4-bit)" if args.soft else "hard"
-        for k in ("parity_guard", "parity_guard_off_variant", "payload", "cpu_baseline"):
+        for k in ("parity_guard", "parity_guard_off_variant", "payload", "h2d_inclusive", "cpu_baseline", "profile_meta"):
             if k in extra:
                 out[k] = extra[k]
         print(json.dumps(out))
@@ -446,6 +617,9 @@ def main():
     ap.add_argument("--no-parity-guard", action="store_true", help="time the pipeline with raw fp32 decisions (dabhip_engine_set_parity_guard(0))")
     ap.add_argument("--subchannels", type=str, default="", help="extension: decode only these SubChIds, e.g. 5 or 1,9 (default: all = reference frames)")
     ap.add_argument("--soft", action="store_true", help="soft-decision decoding (extension; default: hard = reference semantics)")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the host-fed measurement (h2d_inclusive: 6.4 GB of page-locked host memory at the default size)")
+    ap.add_argument("--h2d-segment-tfs", type=int, default=8, help="segment length of the host-fed streaming session, in transmission frames")
+    ap.add_argument("--profile-pass", action="store_true", help="run under tools/refresh_profiles.sh: no profile-derived objects (they are being produced), emit profile_meta")
     args = ap.parse_args()
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))

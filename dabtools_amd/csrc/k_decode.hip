@@ -68,7 +68,16 @@ __host__ __device__ constexpr unsigned branch_code3(unsigned i)   // bits 0..2 o
 typedef short __attribute__((ext_vector_type(2))) pk16;
 typedef unsigned __attribute__((ext_vector_type(4))) vuint4;
 // Survivor records are written once and read once, megabytes apart in time: nontemporal both ways (Viterbi stage 5.5 -> 5.25 ms)
-__device__ __forceinline__ void rec_store(uint4* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { __builtin_nontemporal_store(vuint4{a, b, c, d}, reinterpret_cast<vuint4*>(p)); }
+#ifndef DABHIP_VIT_NOSTORE      // measurement builds only (tools/build_variant_decode.sh): the forward pass without its record traffic
+#define DABHIP_VIT_NOSTORE 0
+#endif
+#ifndef DABHIP_VIT_WAVES        // waves per SIMD the fused decoder is compiled for (register budget 512 / waves)
+#define DABHIP_VIT_WAVES 4
+#endif
+__device__ __forceinline__ void rec_store(uint4* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+  __builtin_nontemporal_store(vuint4{a, b, c, d}, reinterpret_cast<vuint4*>(p));
+}
 __device__ __forceinline__ uint4 rec_load(const uint4* p) { return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const vuint4*>(p))); }
 typedef unsigned short __attribute__((ext_vector_type(2))) upk16;
 
@@ -594,7 +603,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(const WaveGroup* __restrict
 // received values of the stream; n is wave-uniform.  kBits = 1: hard bits (the reference's behaviour);
 // kBits = 4: signed 4-bit soft values (extension).
 template <int kBits>
-__global__ __launch_bounds__(256, 4) void viterbi_fused_kernel(const WaveGroup* __restrict__ groups, int ngroups, const int* __restrict__ job_ids,
+__global__ __launch_bounds__(256, DABHIP_VIT_WAVES) void viterbi_fused_kernel(const WaveGroup* __restrict__ groups, int ngroups, const int* __restrict__ job_ids,
                                                                const CodewordPlan* __restrict__ plans,
                                                                const uint32_t* __restrict__ grouped, int row_words,
                                                                uint2* __restrict__ decisions, const uint32_t* __restrict__ prbs_words,
@@ -649,8 +658,11 @@ __global__ __launch_bounds__(256, 4) void viterbi_fused_kernel(const WaveGroup* 
           ww[g >> 2] |= row << (8 * (g & 3));
         }
         have -= need;
-        if (t + 8 <= nsteps) acs8_lut(ww[0], ww[1], lut, pm, pn, pl4, my_rec + static_cast<size_t>(t >> 3) * 256);
-        else if (t < nsteps) acs8_tail_lut(ww[0], ww[1], nsteps - t, lut, pm, pn, pl4, my_rec + static_cast<size_t>(t >> 3) * 256);
+        // (measurement build DABHIP_VIT_NOSTORE: the MSC code words' records all land on the same four blocks, i.e. stay in L2 --
+        // the forward pass without its HBM traffic; the decoded MSC bytes are garbage then, the FIC is untouched)
+        const size_t blk = (DABHIP_VIT_NOSTORE && nsteps > 800) ? static_cast<size_t>((t >> 3) & 3) : static_cast<size_t>(t >> 3);
+        if (t + 8 <= nsteps) acs8_lut(ww[0], ww[1], lut, pm, pn, pl4, my_rec + blk * 256);
+        else if (t < nsteps) acs8_tail_lut(ww[0], ww[1], nsteps - t, lut, pm, pn, pl4, my_rec + blk * 256);
       } else {
         uint64_t nibs[2];
 #pragma unroll
@@ -677,6 +689,7 @@ __global__ __launch_bounds__(256, 4) void viterbi_fused_kernel(const WaveGroup* 
   if (lane >= grp.count) return;
   const int record = job_ids ? job_ids[grp.first + lane] : grp.first + lane;
   uint32_t* dst = reinterpret_cast<uint32_t*>(out + static_cast<size_t>(record) * record_stride + pl.out_offset);
+  if (kBits == 1 && DABHIP_VIT_NOSTORE == 2 && nsteps > 800) return;     // ... and without the chain-back
   if (kBits == 1) chain_back8(my_rec, nsteps, prbs_words, dst);
   else chain_back(my_rec, nsteps, prbs_words, dst);
 }

@@ -13,6 +13,8 @@
 // symbol on the GPU (fft64.hpp), compared bin by bin and decision by decision with what the fp32 stage produced.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "dab_tables.hpp"
 #include "device_types.hpp"
 #include "fft64.hpp"
@@ -141,6 +143,76 @@ __global__ __launch_bounds__(256) void exact_decide_kernel(const uint2* __restri
   }
 }
 
+// ---- list overflow: every decision of the launch again, in fp64 ------------------------------------------------------------
+// More decisions inside the fp32 error band than the list holds (input that synchronises but has many near-zero products: strongly
+// notched, narrowband or near-DC frames) used to make the decode fail.  Now the launch's frames are simply decided again in full, by
+// fp64 transforms of their symbols (the audit's transform): slow -- 76 double-precision 2048-point transforms per frame -- but only ever
+// run for a launch whose list overflowed, and the bits are then those of exact arithmetic like everywhere else.  A fixed small grid:
+// the normal case (no overflow) costs one counter read per workgroup.  One workgroup per frame at a time, symbols [sym_a - 1, sym_b)
+// in order (the previous symbol's bins stay in LDS as the differential reference), the symbol's 96 output words built in LDS.
+__global__ __launch_bounds__(kFft64Threads) void exact_decide_all_kernel(const unsigned* __restrict__ counter, unsigned cap, const uint8_t* const* __restrict__ iq,
+                                                                        const CallDesc* __restrict__ descs, int max_calls, const int2* __restrict__ frames,
+                                                                        int first, int nframes, int sym_a, int sym_b, const double2* __restrict__ tw2048,
+                                                                        const uint16_t* __restrict__ qpsk_of_carrier, const int* __restrict__ frame_slot,
+                                                                        const int* __restrict__ frame_cif_row, int planar, int skip_fic,
+                                                                        uint32_t* __restrict__ fic_bits, uint32_t* __restrict__ msc_bits)
+{
+  if (counter[0] <= cap) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double2* A = reinterpret_cast<double2*>(smem);
+  double2* P = A + 2048;
+  double2* tw = P + 2048;                                  // 1024 twiddles
+  __shared__ uint32_t words[96];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 1024; i += kFft64Threads) tw[lds_at(i)] = tw2048[i];
+  for (int j = blockIdx.x; j < nframes; j += gridDim.x) {
+    const int f = first + j;
+    const int2 fr = frames[f];
+    const CallDesc* desc = descs + static_cast<size_t>(fr.x) * max_calls + fr.y;
+    const uint8_t* stream = iq[fr.x];
+    for (int l = sym_a - 1; l < sym_b; ++l) {
+      double2* cur = (l & 1) ? P : A;
+      const double2* prev = (l & 1) ? A : P;
+      if (tid < 96) words[tid] = 0u;
+      __syncthreads();
+      const int start = 2 * (kNullSamples + kSymSamples * l + kCpSamples);
+      for (int n = tid; n < 2048; n += kFft64Threads)
+        cur[lds_at(n)] = make_double2(prail(pview_byte(stream, desc->view, start + 2 * n)), prail(pview_byte(stream, desc->view, start + 2 * n + 1)));
+      __syncthreads();
+      dft_dif<11, 3, 3, 3, 2>(cur, 1, -1.0, tw);            // ends with a barrier
+      if (l < sym_a || (skip_fic && l <= 3)) continue;      // the reference symbol of the run; FIC symbols another launch owns
+      for (int c = tid; c < kCarriers; c += kFft64Threads) {
+        const int k = c < 768 ? c + 1280 : c - 767;         // raw bin of carrier c
+        const double2 x = cur[lds_at(brev(k, 11))], p = prev[lds_at(brev(k, 11))];
+        const double re = x.x * p.x + x.y * p.y, im = x.x * p.y - x.y * p.x;      // input_sdr.c:135-143
+        const unsigned b0 = (re > 0.0) ? 0u : 1u, b1 = (im > 0.0) ? 1u : 0u;      // input_sdr.c:157-158
+        const int q = qpsk_of_carrier[c];
+        const int pos[2] = {q, 1536 + q};
+        const unsigned bit[2] = {b0, b1};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int i = pos[h];
+          // word index inside the symbol's 96 output words: natural order, or plane i & 15, bit i >> 4 of that plane (demap_kernel<true, 1>)
+          const int w = (l <= 3 || !planar) ? (i >> 5) : (i & 15) * 6 + (i >> 9), sh = (l <= 3 || !planar) ? (i & 31) : ((i >> 4) & 31);
+          if (bit[h]) atomicOr(&words[w], 1u << sh);
+        }
+      }
+      __syncthreads();
+      if (tid < 96) {
+        if (l <= 3) fic_bits[static_cast<size_t>(frame_slot[f]) * 288 + (l - 1) * 96 + tid] = words[tid];
+        else if (planar) {
+          const int qc = (l - 4) / 18, sidx = (l - 4) % 18, r = tid / 6, wq = tid % 6;
+          const int delay = static_cast<int>(__brev(static_cast<unsigned>(r)) >> 28);
+          msc_bits[static_cast<size_t>(frame_cif_row[f] + qc - delay) * 1728 + r * 108 + sidx * 6 + wq] = words[tid];
+        } else {
+          msc_bits[static_cast<size_t>(frame_cif_row[f]) * 1728 + (l - 4) * 96 + tid] = words[tid];
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // ---- audit: fp64 transforms of every symbol vs the fp32 stage ---------------------------------------------------------
 // One 512-thread workgroup per frame (contiguous 393216-byte frames).  out[]: see dabhip_stage_decision_audit.
 struct AuditOut {
@@ -247,6 +319,24 @@ hipError_t launch_exact_decide(const uint2* list, const unsigned* counter, unsig
 {
   hipLaunchKernelGGL(exact_decide_kernel, dim3(2048), dim3(256), 0, stream, list, counter, cap, iq, descs, max_calls, frames, tw2048,
                      qpsk_of_carrier, carrier_of_qpsk, frame_slot, frame_cif_row, planar ? 1 : 0, fic_bits, msc_bits);
+  return hipGetLastError();
+}
+
+hipError_t launch_exact_decide_all(const unsigned* counter, unsigned cap, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames,
+                                   int first, int nframes, int sym_a, int sym_b, const double2* tw2048, const uint16_t* qpsk_of_carrier,
+                                   const int* frame_slot, const int* frame_cif_row, bool planar, bool skip_fic, uint32_t* fic_bits, uint32_t* msc_bits,
+                                   hipStream_t stream)
+{
+  if (nframes <= 0) return hipSuccess;
+  static bool attr_set = false;
+  const size_t lds = sizeof(double2) * (2048 + 2048 + 1024);
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(exact_decide_all_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(exact_decide_all_kernel, dim3(std::min(nframes, 512)), dim3(kFft64Threads), lds, stream, counter, cap, iq, descs, max_calls, frames, first,
+                     nframes, sym_a, sym_b, tw2048, qpsk_of_carrier, frame_slot, frame_cif_row, planar ? 1 : 0, skip_fic ? 1 : 0, fic_bits, msc_bits);
   return hipGetLastError();
 }
 

@@ -82,7 +82,9 @@ class PlanTable {
   std::map<std::vector<int32_t>, int> index_;
 };
 
-// wave-groups of <= 64 jobs per plan, longest code words first; plan_jobs[i] = (plan id, job indices decoded with that plan)
+// wave-groups of <= 64 jobs per plan, longest code words first; plan_jobs[i] = (plan id, job indices decoded with that plan).
+// (Measured in round 3 with an order knob: dealing the 3078- and 1542-step classes -- or the short ones -- proportionally into one
+// another, or short words beside the longest, costs 6.1 .. 7.1 ms against 5.45 on the same box: longest-first stays.)
 template <template <class> class Alloc>
 void build_decode_batch(const PlanTable& plans, const std::vector<std::pair<int, const std::vector<int>*>>& plan_jobs, DecodeBatchT<Alloc>& out)
 {

@@ -62,6 +62,29 @@ def _backend_pass(sse, reps):
     return n, dt
 
 
+def _backend_payload(sse, args):
+    """ETI frames of the real reference back end over every capture's demapped frames -> payload statistics vs the modulator."""
+    sys.path.insert(0, ROOT)
+    import dabtools_amd as dab          # host-only entry points (dabhip_synth_*): no GPU call
+    from dabtools_amd import payload
+    R = oracle_lib.ref(sse=sse)
+    chk = payload.PayloadCheck()
+    tok = _silence_stderr()
+    try:
+        for i, tfs in enumerate(_TFS):
+            H = R.refh_new()
+            for f, m in tfs:
+                C.memmove(R.refh_tf_fic(H), oracle_lib._ptr(f), f.size)
+                C.memmove(R.refh_tf_msc(H), oracle_lib._ptr(m), m.size)
+                R.refh_process(H)
+            n = R.refh_neti(H)
+            eti = np.ctypeslib.as_array(R.refh_eti(H), (max(n, 1), 6144))[:n].copy()
+            chk.add_stream(dab, payload.bench_cfg(dab, args.ber_first_stream + i, args.snr), args.tfs, eti)
+    finally:
+        _restore_stderr(*tok)
+    return chk.result()
+
+
 def _noop(_):
     time.sleep(0.01)
 
@@ -82,6 +105,9 @@ def main():
     ap.add_argument("--tfs", type=int, default=64)
     ap.add_argument("--cores", type=int, default=0, help="processes for the per-core runs (0: min(host cores, 32))")
     ap.add_argument("--backend-streams", type=int, default=2)
+    ap.add_argument("--ber-first-stream", type=int, default=-1, help="global index of the first capture: also report the reference back ends' payload BER "
+                    "(hard decisions of the oracle front end on these very captures) against what bench.py's modulator sent")
+    ap.add_argument("--snr", type=float, default=1000.0)
     args = ap.parse_args()
     ncores = os.cpu_count() or 1
     k = args.cores or min(ncores, 32)
@@ -104,7 +130,8 @@ def main():
     fic = np.zeros(9216, np.uint8)
     msc = np.zeros(221184, np.uint8)
     _TFS = []
-    for iq in caps[: args.backend_streams]:
+    nback = len(caps) if args.ber_first_stream >= 0 else args.backend_streams
+    for iq in caps[:nback]:
         S, tfs = O.or_sdr_new(), []
         for off in range(0, iq.size - 262144 + 1, 262144):
             if O.or_sdr_demod(S, oracle_lib._ptr(iq[off:off + 262144]), 262144, oracle_lib._ptr(fic), oracle_lib._ptr(msc)):
@@ -126,6 +153,10 @@ def main():
     for key, sse in (("reference_backend_scalar", False), ("reference_backend_sse", True)):
         if oracle_lib.ref(sse=sse) is None:
             continue
+        if args.ber_first_stream >= 0:
+            # BASELINE configs[4]: the CPU back end's own decoding quality on the same noisy input (its hard decisions; the SSE decoder's
+            # tie rule and metrics differ from the scalar one, viterbi_spiral_sse16.c:130-133, depuncture.c:36-43)
+            rec_ber = _backend_payload(sse, args)
         reps = 4 if sse else 1
         n, dt = _backend_pass(sse, reps)
         rec = {"value": n / dt, "unit": "ETI frames/s", "cores": 1, "kind": "reference",
@@ -157,6 +188,8 @@ def main():
         for _ in range(vreps):
             R.refh_viterbi(H, oracle_lib._ptr(sym), oracle_lib._ptr(data), nbits)
         rec["viterbi_mbit_s"] = vreps * nbits / (time.perf_counter() - t0) / 1e6
+        if args.ber_first_stream >= 0:
+            rec["payload"] = rec_ber
         out[key] = rec
     print(json.dumps(out))
 

@@ -1,10 +1,11 @@
 # kernel-trace statistics of the default bench step: gpurun_out/prof_stats/*kernel_stats.csv
+set -euo pipefail
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-rm -rf $R/gpurun_out/prof_stats
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python3 $R/bench.py --no-cpu-baseline --no-variants --steps 10 $BENCH_EXTRA > $R/gpurun_out/prof_stats_bench.json 2>/dev/null
-F=$(find $R/gpurun_out/prof_stats -name "*kernel_stats.csv" | head -1)
-cp $F $R/gpurun_out/kernel_stats.csv
+rm -rf "$R/gpurun_out/prof_stats"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_stats" -- python3 "$R/bench.py" --no-cpu-baseline --no-variants --steps 10 ${BENCH_EXTRA:-} > "$R/gpurun_out/prof_stats_bench.json" 2>/dev/null
+F=$(find "$R/gpurun_out/prof_stats" -name "*kernel_stats.csv" | head -1)
+cp $F "$R/gpurun_out/kernel_stats.csv"
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("$R/gpurun_out/kernel_stats.csv")))
