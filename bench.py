@@ -369,7 +369,9 @@ def rooflines(prof, args, world, frames_rank, ntf_rank, stage, fft, stream_ceili
         cycles = CYC_SIMPLE * VIT_ADDS_PER_STEP + CYC_VOP3 * (insts - VIT_ADDS_PER_STEP)
         ws = wave_steps(frames_rank, 0)                                                   # the MSC launch of one step on this rank
         t = stage["viterbi"] * 1e-3
-        rec_bytes = (2.0 * prof.cell("fetch", VIT, "FETCH_SIZE") + prof.cell("write", VIT, "WRITE_SIZE")) * 1024.0 / decodes
+        rec_read = 2.0 * prof.cell("fetch", VIT, "FETCH_SIZE") * 1024.0 / decodes          # FETCH_SIZE doubled: gfx950 note in MI355X_MICROARCH.md
+        rec_written = prof.cell("write", VIT, "WRITE_SIZE") * 1024.0 / decodes
+        rec_bytes = rec_read + rec_written
         io_bytes = frames_rank * (1728 * 4 + 27264 // 8)                                  # grouped received bits in, decoded sub-channel bytes out
         out["roofline_viterbi"] = {
             "kernel": VIT, "bound": "valu issue", "achieved": cycles * ws / t / 1e9, "peak": SIMDS * clock, "unit": "G issue cycles/s",
@@ -379,7 +381,7 @@ def rooflines(prof, args, world, frames_rank, ntf_rank, stage, fft, stream_ceili
                 "effective_clock_ghz": {"value": clock, "from": prof.ref("clk", VIT, "GRBM_GUI_ACTIVE") + " / 8 XCDs / DURATION_NS of the same pass (dense VALU: the chip clocks below its 2.4 GHz)"},
                 "issue_cycles_per_wave_step": {"value": cycles, "from": "%d v_add_u32 x %.0f cycles + the other instructions x %.0f cycles" % (VIT_ADDS_PER_STEP, CYC_SIMPLE, CYC_VOP3)},
                 "wave_steps_per_launch": ws, "simds": SIMDS, "avg_ms": stage["viterbi"], "profile_matches_this_workload": same},
-            "survivor_traffic": {"bytes_per_step": rec_bytes, "x_stage_io": rec_bytes / io_bytes, "GBps": rec_bytes / t / 1e9, "frac_of_hbm_peak": rec_bytes / t / 1e9 / HBM_PEAK_GBS,
+            "survivor_traffic": {"bytes_per_step": rec_bytes, "written": rec_written, "read_back": rec_read, "x_stage_io": rec_bytes / io_bytes, "GBps": rec_bytes / t / 1e9, "frac_of_hbm_peak": rec_bytes / t / 1e9 / HBM_PEAK_GBS,
                                  "from": "%s, %s (x2, + WRITE_SIZE) / meta full_decodes" % (prof.ref("fetch", VIT, "FETCH_SIZE"), prof.ref("write", VIT, "WRITE_SIZE")),
                                  "note": "one lane per code word with a full traceback: 64 B of survivor records per 8 steps and code word written, the 16-byte part "
                                          "holding the path's state read back; the stage's own input + output is %.2f GB per step.  Measured with the records kept in L2 "

@@ -109,6 +109,8 @@ _SIGNATURES = {
     "dabhip_engine_set_fused": (C.c_int, [C.c_void_p, C.c_int]),
     "dabhip_engine_set_parity_guard": (C.c_int, [C.c_void_p, C.c_int]),
     "dabhip_engine_guard_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "dabhip_engine_guard_overflows": (C.c_int, [C.c_void_p]),
+    "dabhip_engine_set_guard_list_cap": (C.c_int, [C.c_void_p, C.c_uint32]),
     "dabhip_stream_set_parity_guard": (C.c_int, [C.c_void_p, C.c_int]),
     "dabhip_stage_decision_audit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "dabhip_engine_set_subchannels": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
@@ -482,6 +484,14 @@ class Engine:
         a, b = C.c_int64(0), C.c_int64(0)
         _need(lib().dabhip_engine_guard_stats(self._h, C.byref(a), C.byref(b)) == 0, "guard_stats")
         return a.value, b.value
+
+    def guard_overflows(self):
+        """Launches of the last decode whose guard list overflowed (their frames were decided again in full, in fp64)."""
+        return lib().dabhip_engine_guard_overflows(self._h)
+
+    def set_guard_list_cap(self, cap):
+        """Test knob: capacity of the guard's list per launch (0 = automatic)."""
+        _need(lib().dabhip_engine_set_guard_list_cap(self._h, cap) == 0, "set_guard_list_cap")
 
     def decision_audit(self, frames=None, device_ptr=None, nframes=None, guard=False):
         """fp32 OFDM stage vs fp64 on contiguous cu8 frames -> dict (see dabhip_stage_decision_audit)."""

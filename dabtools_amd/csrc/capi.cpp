@@ -248,6 +248,20 @@ int dabhip_engine_guard_stats(const dabhip_engine* e, int64_t* flagged, int64_t*
   if (decisions) *decisions = b;
   return 0;
 }
+int dabhip_engine_guard_overflows(const dabhip_engine* e)
+{
+  if (!e) return -1;
+  int n = 0;
+  const int nl = e->lane_of.size() >= 64 ? static_cast<int>(e->lanes.size()) : 1;
+  for (int l = 0; l < nl; ++l) n += e->lanes[l]->guard_overflows();
+  return n;
+}
+int dabhip_engine_set_guard_list_cap(dabhip_engine* e, uint32_t cap)
+{
+  if (!e) return -1;
+  for (auto& l : e->lanes) l->set_guard_list_cap(cap);
+  return 0;
+}
 int dabhip_engine_set_fused(dabhip_engine* e, int enable)
 {
   if (!e) return -1;
@@ -604,11 +618,15 @@ struct dabhip_stream {
   std::vector<int64_t> base, avail;            // per stream: first stream byte still held, bytes received (fed) so far
   std::vector<size_t> org;                     // per stream: offset, in the newest fed window, of stream byte base[b]
   uint64_t fed = 0, queued = 0;                // segments fed / handed over (fed <= queued <= fed + 2)
-  // prefetch uploads: a few streams side by side, so that one copy's set-up hides behind another copy's transfer (one stream: 256
-  // copies of 3 MB reached 48 GB/s, 25 MB copies 55.5)
-  static constexpr int kUpStreams = 4;
-  hipStream_t up_stream[kUpStreams] = {nullptr, nullptr, nullptr, nullptr};
+  // prefetch uploads run on a stream of their own.  Measured on the 256-stream workload, 8-TF segments (805 MB each): one gather kernel
+  // per segment 56.5 GB/s, 256 copy commands on one stream 54.0, dealt to two / four streams 25 / 36 (they get in each other's way)
+  static constexpr int kUpStreams = 1;
+  hipStream_t up_stream[kUpStreams] = {nullptr};
   hipEvent_t up_done[3][kUpStreams] = {};
+  // upload by a gather kernel that reads the page-locked host segments over PCIe (one launch per segment instead of one copy command
+  // per stream): descriptor lists, one per window, page-locked so that they go up asynchronously
+  HostList<CopyDesc> gather_descs[3];
+  DeviceBuffer<CopyDesc> d_gather_descs[3];
   struct Pending { std::vector<const uint8_t*> iq; std::vector<size_t> nbytes; };
   Pending pending[3];                          // what was prefetched into window i (checked against the feed that consumes it)
   dabhip_stream(int device, int nstreams) : eng(device), n(nstreams), base(nstreams, 0), avail(nstreams, 0), org(nstreams, 0)
@@ -637,9 +655,34 @@ struct dabhip_stream {
       if (!st) return false;
     return true;
   }
+  // the same by ONE kernel launch on the upload stream, when every non-empty host segment is page-locked (device-visible): a small
+  // persistent grid reads the host memory over PCIe (64 workgroups: 56.5 GB/s; 16: 54.5; 256: 43.8 -- and they would take CUs from the
+  // decode running beside it).  DABHIP_PREFETCH_KERNEL=0 selects the copy engine instead, = N > 1 another grid size.
+  bool upload_by_kernel(int w, const uint8_t* const* iq, const size_t* nbytes)
+  {
+    static const int mode = std::getenv("DABHIP_PREFETCH_KERNEL") ? std::atoi(std::getenv("DABHIP_PREFETCH_KERNEL")) : 1;
+    if (mode <= 0) return false;
+    HostList<CopyDesc>& descs = gather_descs[w];
+    descs.clear();
+    for (int b = 0; b < n; ++b) {
+      if (nbytes[b] == 0) continue;
+      if (nbytes[b] >= (size_t(1) << 32)) return false;
+      hipPointerAttribute_t attr;
+      if (hipPointerGetAttributes(&attr, iq[b]) != hipSuccess || attr.type != hipMemoryTypeHost || !attr.devicePointer) { (void)hipGetLastError(); return false; }
+      DeviceBuffer<uint8_t>& to = *win[w][b];
+      if (!to.reserve(kWindowReserve + std::max<size_t>(nbytes[b], 16))) return false;
+      const uint8_t* dev_view = static_cast<const uint8_t*>(attr.devicePointer) + (iq[b] - static_cast<const uint8_t*>(attr.hostPointer));
+      descs.push_back(CopyDesc{dev_view, to.get() + kWindowReserve, static_cast<uint32_t>(nbytes[b]), 0});
+    }
+    if (descs.empty()) return true;
+    const int wgs = mode > 1 ? mode : 64;
+    return d_gather_descs[w].upload(descs, up_stream[0]) &&
+           launch_host_gather(d_gather_descs[w].get(), static_cast<int>(descs.size()), wgs, up_stream[0]) == hipSuccess;
+  }
   // segment -> window w of every stream, behind the reserve; on stream `one`, or dealt round-robin to the upload streams
   bool upload(int w, const uint8_t* const* iq, const size_t* nbytes, bool on_device, hipStream_t one)
   {
+    if (!one && !on_device && upload_by_kernel(w, iq, nbytes)) return true;
     for (int b = 0; b < n; ++b) {
       DeviceBuffer<uint8_t>& to = *win[w][b];
       hipStream_t st = one ? one : up_stream[b % kUpStreams];

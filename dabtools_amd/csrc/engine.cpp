@@ -415,32 +415,35 @@ bool Engine::carry_and_reserve(const std::vector<int>& tf_base, const std::vecto
 // Parity guard around one demapping launch: guard_begin() clears the counter and hands the kernel its list; guard_finish()
 // queues the fp64 re-decision of what was listed and the copy of the entry count to the host; guard_check() (after the
 // stream has been awaited) adds the counts up and refuses a result whose list overflowed.
-constexpr int kGuardMaxLaunches = 64;
+constexpr int kGuardMinLaunches = 64;
 bool Engine::guard_begin(int ntf_in_launch, GuardArgs* out)
 {
-  const uint32_t cap = static_cast<uint32_t>(std::max<int64_t>(int64_t(1) << 20, static_cast<int64_t>(ntf_in_launch) * 4096));   // 1.8 % of a TF's decisions
-  if (!d_guard_list_.reserve(cap) || !d_guard_counter_.reserve(4) || !h_guard_counts_.resize(kGuardMaxLaunches)) return false;
-  guard_cap_ = static_cast<uint32_t>(std::min<size_t>(d_guard_list_.capacity(), 0xffffffffu));
+  // the list: flag rates measured on noisy input are a few decisions per TF (7e-6 of 230,400 at 5 dB); 64 entries per TF, at least
+  // 256 K, and a launch that overflows it is decided again in full (exact_decide_all_kernel) instead of failing
+  uint32_t cap = static_cast<uint32_t>(std::max<int64_t>(int64_t(1) << 18, static_cast<int64_t>(ntf_in_launch) * 64));
+  if (guard_cap_override_) cap = guard_cap_override_;
+  if (!d_guard_list_.reserve(cap) || !d_guard_counter_.reserve(4)) return false;
+  if (guard_launches_ == 0 && h_guard_counts_.size() < static_cast<size_t>(kGuardMinLaunches) && !h_guard_counts_.resize(kGuardMinLaunches)) return false;
+  guard_cap_ = guard_cap_override_ ? guard_cap_override_ : static_cast<uint32_t>(std::min<size_t>(d_guard_list_.capacity(), 0xffffffffu));
   if (!check(hipMemsetAsync(d_guard_counter_.get(), 0, 4 * sizeof(uint32_t), stream_), "guard counter")) return false;
   *out = GuardArgs{d_delta_.get(), kSymbolsPerTf, guard_cap_, d_guard_list_.get(), d_guard_counter_.get()};
   return true;
 }
-bool Engine::guard_finish(bool planar)
+bool Engine::guard_finish(bool planar, int first, int n, int sym_a, int sym_b, bool skip_fic)
 {
-  if (guard_launches_ >= kGuardMaxLaunches) { set_error("parity guard: too many launches in one decode"); return false; }
+  if (static_cast<size_t>(guard_launches_) >= h_guard_counts_.size()) { set_error("parity guard: more guarded launches than planned for in one decode"); return false; }
   return check(launch_exact_decide(d_guard_list_.get(), d_guard_counter_.get(), guard_cap_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(),
                                    d_tw2048_.get(), d_qpsk_.get(), d_qpsk_inv_.get(), d_frame_slot_.get(), d_frame_cif_row_.get(), planar, d_fic_bits_.get(), d_msc_bits_.get(), stream_),
                "exact decide launch") &&
+         check(launch_exact_decide_all(d_guard_counter_.get(), guard_cap_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, sym_a, sym_b,
+                                       d_tw2048_.get(), d_qpsk_.get(), d_frame_slot_.get(), d_frame_cif_row_.get(), planar, skip_fic, d_fic_bits_.get(), d_msc_bits_.get(), stream_),
+               "exact decide (overflow) launch") &&
          check(hipMemcpyAsync(h_guard_counts_.data() + guard_launches_++, d_guard_counter_.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, stream_), "guard count download");
 }
 bool Engine::guard_check()
 {
   for (int i = 0; i < guard_launches_; ++i) {
-    if (h_guard_counts_[i] > guard_cap_) {
-      set_error("parity guard: more than " + std::to_string(guard_cap_) + " decisions inside the fp32 error band in one launch (list overflow); "
-                "decode again with dabhip_engine_set_parity_guard(e, 0) to accept fp32 decisions");
-      return false;
-    }
+    if (h_guard_counts_[i] > guard_cap_) ++guard_overflows_;       // that launch was decided again in full: still exact, only slow
     guard_flagged_ += h_guard_counts_[i];
   }
   guard_launches_ = 0;
@@ -686,6 +689,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   fft_ms_ = 0;
   guard_flagged_ = guard_decisions_ = 0;
   guard_launches_ = 0;
+  guard_overflows_ = 0;
   if (!begin_decode(nstreams, cont)) return -1;
   struct SideStreamGuard {                   // whatever was queued on the side stream is awaited before returning
     hipStream_t s;
@@ -760,7 +764,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
               : check(launch_ofdm_demap_fused_plain(afc_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_twf_.get(), d_frame_slot_.get(),
                                                     d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), stream_, sym_a, sym_b, nparts),
                       "fused fft/demap launch");
-    return launched && (!guard || guard_finish(true));
+    return launched && (!guard || guard_finish(true, first, n, sym_a, sym_b, false));
   };
   auto stage_a = [&]() -> bool {
     ntf = ntf_new;
@@ -775,6 +779,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     ok = h_fib_ok_.data();
     (void)hipEventRecord(ev_[3], stream_);
     if (energies && !d_delta_.reserve(static_cast<size_t>(ntf) * kSymbolsPerTf)) return false;
+    if (guard && guard_launches_ == 0 && !h_guard_counts_.resize(static_cast<size_t>(kGuardMinLaunches) + 2 * static_cast<size_t>(ntf / kFftChunkTfs + 1))) return false;
     soft_args.delta = d_delta_.get();
     soft_args.delta_stride = kSymbolsPerTf;
     if (one_kernel) {
@@ -791,7 +796,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
                                       d_frame_slot_.get(), d_qpsk_.get(), d_fic_bits_.get(), ga, stream_),
                    "fic pre-pass launch"))
           return false;
-        if (guard && !guard_finish(true)) return false;
+        if (guard && !guard_finish(true, first, n, 1, 4, false)) return false;
       }
     }
     (void)hipEventRecord(ev_part0_, stream_);
@@ -837,7 +842,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
                      "fft launch");
       (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
       gpu_ok = gpu_ok && check(launch_demap(true, soft_bits_, d_spectra_.get(), first, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_), "demap launch");
-      if (guard) gpu_ok = gpu_ok && guard_finish(true);     // timed with the demapper
+      if (guard) gpu_ok = gpu_ok && guard_finish(true, first, n, 1, kSymbolsPerTf, true);     // timed with the demapper; the FIC symbols belong to the pre-pass
     }
     (void)hipEventRecord(chunk_ev_[3 * c + 2], stream_);
   }
@@ -1124,7 +1129,7 @@ int Engine::stage_decision_audit(const uint8_t* frames, int nframes, bool on_dev
       return -1;
     if (!check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), n, d_frames_.get(), 0, n, d_spectra_.get(), d_twf_.get(), stream_), "fft launch") ||
         !check(launch_demap(false, 0, d_spectra_.get(), 0, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_), "demap launch") ||
-        (guard_on && !guard_finish(false)) ||
+        (guard_on && !guard_finish(false, 0, n, 1, kSymbolsPerTf, false)) ||
         !check(launch_decision_audit(d_in + static_cast<size_t>(first) * kTfBytes, n, d_spectra_.get(), d_fic_bits_.get(), d_msc_bits_.get(), d_tw2048_.get(), d_qpsk_.get(), d_out.get(), stream_), "audit launch") ||
         !check(hipStreamSynchronize(stream_), "audit") || (guard_on && !guard_check()))
       return -1;
@@ -1222,7 +1227,7 @@ bool Engine::demod_one_frame(const uint8_t* iq_virtual_base, const CallDesc& des
     return false;
   if (!check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), 1, d_frames_.get(), 0, 1, d_spectra_.get(), d_twf_.get(), stream_), "fft launch") ||
       !check(launch_demap(false, 0, d_spectra_.get(), 0, 1, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_), "demap launch") ||
-      (guard && !guard_finish(false)) ||
+      (guard && !guard_finish(false, 0, 1, 1, kSymbolsPerTf, false)) ||
       !check(hipStreamSynchronize(stream_), "demod") || (guard && !guard_check()))
     return false;
   return unpack_tf_slot(0, fic_bytes, msc_bytes);

@@ -168,6 +168,8 @@ class Engine {
   void set_parity_guard(bool on) { parity_guard_ = on; }
   // decisions flagged and re-decided by the guard in the last decode (FIC pre-pass + OFDM stage), and decisions taken
   void guard_stats(int64_t* flagged, int64_t* decisions) const { if (flagged) *flagged = guard_flagged_; if (decisions) *decisions = guard_decisions_; }
+  int guard_overflows() const { return guard_overflows_; }
+  void set_guard_list_cap(uint32_t cap) { guard_cap_override_ = cap; }   // test knob: a tiny list makes the overflow path run
 
   // -- batch path ---------------------------------------------------------------------------
   int64_t decode(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device);
@@ -241,7 +243,8 @@ class Engine {
   // parity guard plumbing: list + counter for one launch, fix-up after it, entry count to the host (checked at the end)
   bool guard_active() const { return parity_guard_ && soft_bits_ == 0 && !afc_; }
   bool guard_begin(int ntf_in_launch, GuardArgs* out);
-  bool guard_finish(bool planar);
+  // the launch just queued covered frames [first, first + n) of the frame list, data symbols [sym_a, sym_b); skip_fic: another launch owns symbols 1..3
+  bool guard_finish(bool planar, int first, int n, int sym_a, int sym_b, bool skip_fic);
   bool guard_check();
 
   bool ok_ = false;
@@ -314,8 +317,9 @@ class Engine {
   DeviceBuffer<uint32_t> d_guard_counter_;
   PinnedBuffer<uint32_t> h_guard_counts_;
   int guard_launches_ = 0;
-  uint32_t guard_cap_ = 0;
+  uint32_t guard_cap_ = 0, guard_cap_override_ = 0;
   int64_t guard_flagged_ = 0, guard_decisions_ = 0;
+  int guard_overflows_ = 0;          // launches of the last decode whose list overflowed (decided again in full, fp64)
   DeviceBuffer<uint8_t> d_carry_;
   DeviceBuffer<CopyDesc> d_copy_descs_;
 

@@ -602,6 +602,13 @@ __global__ __launch_bounds__(64) void viterbi_kernel(const WaveGroup* __restrict
 // Puncturing vectors keep the FIRST n bits of every group of four (n = 1..4), so a step's input is simply the next n
 // received values of the stream; n is wave-uniform.  kBits = 1: hard bits (the reference's behaviour);
 // kBits = 4: signed 4-bit soft values (extension).
+#ifndef DABHIP_VIT_TIMES         // measurement build only (tools/vit_tail.py): start / end / chain-back time stamps of every wave
+#define DABHIP_VIT_TIMES 0
+#endif
+#if DABHIP_VIT_TIMES
+__device__ unsigned long long g_vit_times[4 * 32768];     // {start, forward pass done, end, nsteps << 8 | XCC} per wave-group of the LAST big launch
+#endif
+
 template <int kBits>
 __global__ __launch_bounds__(256, DABHIP_VIT_WAVES) void viterbi_fused_kernel(const WaveGroup* __restrict__ groups, int ngroups, const int* __restrict__ job_ids,
                                                                const CodewordPlan* __restrict__ plans,
@@ -617,6 +624,15 @@ __global__ __launch_bounds__(256, DABHIP_VIT_WAVES) void viterbi_fused_kernel(co
   const WaveGroup grp = groups[g];
   const CodewordPlan pl = plans[grp.plan];
   const int nsteps = grp.nsteps;             // 32 x blocks + 6: the tail unit holds 6 steps
+#if DABHIP_VIT_TIMES
+  const bool stamp = ngroups > 2048 && g < 32768 && lane == 0;
+  if (stamp) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_vit_times[4 * g] = wall_clock64();
+    g_vit_times[4 * g + 3] = (static_cast<unsigned long long>(nsteps) << 8) | (xcc & 15u);
+  }
+#endif
   uint4* my_rec = reinterpret_cast<uint4*>(decisions + grp.dec_base * 64) + lane;
 
   // received words of this lane's record: tile = grp.first / 64 (job lists are padded to tiles of 64)
@@ -686,13 +702,30 @@ __global__ __launch_bounds__(256, DABHIP_VIT_WAVES) void viterbi_fused_kernel(co
       if ((t & (MetricScale<kScale>::kRebaseSteps - 1)) == 0 && t < nsteps) rebase_metrics<kScale>(pm);
     }
   }
-  if (lane >= grp.count) return;
-  const int record = job_ids ? job_ids[grp.first + lane] : grp.first + lane;
-  uint32_t* dst = reinterpret_cast<uint32_t*>(out + static_cast<size_t>(record) * record_stride + pl.out_offset);
-  if (kBits == 1 && DABHIP_VIT_NOSTORE == 2 && nsteps > 800) return;     // ... and without the chain-back
-  if (kBits == 1) chain_back8(my_rec, nsteps, prbs_words, dst);
-  else chain_back(my_rec, nsteps, prbs_words, dst);
+#if DABHIP_VIT_TIMES
+  if (stamp) g_vit_times[4 * g + 1] = wall_clock64();
+#endif
+  if (lane < grp.count && !(kBits == 1 && DABHIP_VIT_NOSTORE == 2 && nsteps > 800)) {     // (NOSTORE == 2: ... and without the chain-back)
+    const int record = job_ids ? job_ids[grp.first + lane] : grp.first + lane;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out + static_cast<size_t>(record) * record_stride + pl.out_offset);
+    if (kBits == 1) chain_back8(my_rec, nsteps, prbs_words, dst);
+    else chain_back(my_rec, nsteps, prbs_words, dst);
+  }
+#if DABHIP_VIT_TIMES
+  if (stamp) g_vit_times[4 * g + 2] = wall_clock64();
+#endif
 }
+
+#if DABHIP_VIT_TIMES
+}  // namespace
+}  // namespace dabhip
+extern "C" int dabhip_debug_vit_times(unsigned long long* out, int ngroups)
+{
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(dabhip::g_vit_times), sizeof(unsigned long long) * 4 * static_cast<size_t>(ngroups)) == hipSuccess ? 0 : -1;
+}
+namespace dabhip {
+namespace {
+#endif
 
 // ---------------------------------------------------------------------------------------
 // batched device-to-device copy (session carry-over of slots and rows): grid (piece, slice)
@@ -806,6 +839,43 @@ __global__ __launch_bounds__(256) void eti_finish_kernel(const EtiFrameMeta* __r
 }
 
 }  // namespace
+
+// Segment upload by a kernel that READS page-locked host memory over PCIe (dabhip_stream_prefetch): one launch moves the segments of
+// all streams -- a few hundred copy commands of a few MB each cost the copy engines ~8 us apiece on top of the transfer.  A small
+// persistent grid (the link, not the CUs, is the limit; the decode of the previous segment runs beside it): workgroup w takes pieces
+// w, w + G, ... of 64 KB; 16-byte nontemporal loads and stores, byte tails by the piece's first lanes.
+__global__ __launch_bounds__(256) void host_gather_kernel(const CopyDesc* __restrict__ descs, int ndesc)
+{
+  constexpr uint32_t kPiece = 64u << 10;
+  uint32_t piece0 = 0;                                     // index of the first piece of descriptor i in the global piece order
+  for (int i = 0; i < ndesc; ++i) {
+    const CopyDesc d = descs[i];
+    const uint32_t npieces = (d.nbytes + kPiece - 1) / kPiece;
+    // pieces of this descriptor that belong to this workgroup: global index = piece0 + p, taken when (piece0 + p) % gridDim.x == blockIdx.x
+    uint32_t p = (blockIdx.x + gridDim.x - piece0 % gridDim.x) % gridDim.x;
+    for (; p < npieces; p += gridDim.x) {
+      const uint32_t off = p * kPiece, n = min(kPiece, d.nbytes - off);
+      const uint8_t* s = d.src + off;
+      uint8_t* t = d.dst + off;
+      if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(t)) & 15u) == 0) {
+        const uint32_t nv = n >> 4;
+        for (uint32_t v = threadIdx.x; v < nv; v += 256u)
+          __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const vuint4*>(s) + v), reinterpret_cast<vuint4*>(t) + v);
+        for (uint32_t b = (nv << 4) + threadIdx.x; b < n; b += 256u) t[b] = s[b];
+      } else {
+        for (uint32_t b = threadIdx.x; b < n; b += 256u) t[b] = s[b];
+      }
+    }
+    piece0 += npieces;
+  }
+}
+
+hipError_t launch_host_gather(const CopyDesc* descs, int n, int workgroups, hipStream_t stream)
+{
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(host_gather_kernel, dim3(workgroups), dim3(256), 0, stream, descs, n);
+  return hipGetLastError();
+}
 
 hipError_t launch_batched_copy(const CopyDesc* descs, int n, hipStream_t stream)
 {

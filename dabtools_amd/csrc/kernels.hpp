@@ -72,9 +72,16 @@ hipError_t launch_symbol_delta(const uint8_t* const* iq, const CallDesc* descs, 
 hipError_t launch_exact_decide(const uint2* list, const unsigned* counter, unsigned cap, const uint8_t* const* iq, const CallDesc* descs,
                                int max_calls, const int2* frames, const double2* tw2048, const uint16_t* qpsk_of_carrier, const uint16_t* carrier_of_qpsk,
                                const int* frame_slot, const int* frame_cif_row, bool planar, uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream);
+// list overflow of a guarded launch: its frames' symbols [sym_a, sym_b) decided again in full from fp64 transforms (returns at once otherwise)
+hipError_t launch_exact_decide_all(const unsigned* counter, unsigned cap, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames,
+                                   int first, int nframes, int sym_a, int sym_b, const double2* tw2048, const uint16_t* qpsk_of_carrier,
+                                   const int* frame_slot, const int* frame_cif_row, bool planar, bool skip_fic, uint32_t* fic_bits, uint32_t* msc_bits,
+                                   hipStream_t stream);
 hipError_t launch_decision_audit(const uint8_t* frames_iq, int nframes, const float2* spectra, const uint32_t* fic_bits, const uint32_t* msc_bits,
                                  const double2* tw2048, const uint16_t* qpsk_of_carrier, void* out, hipStream_t stream);
 hipError_t launch_batched_copy(const CopyDesc* descs, int n, hipStream_t stream);
+// the descriptors' sources may be page-locked HOST memory (read over PCIe by a small persistent grid); nbytes < 4 GiB each
+hipError_t launch_host_gather(const CopyDesc* descs, int n, int workgroups, hipStream_t stream);
 hipError_t launch_fib_crc(const uint8_t* fibs, int nfib, const uint16_t* crc_tab, uint8_t* ok, hipStream_t stream);
 
 // K5: ETI header/FIB copy, EOF CRC, trailer

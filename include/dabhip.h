@@ -128,6 +128,12 @@ int dabhip_engine_set_soft(dabhip_engine *e, int enable);
 int dabhip_engine_set_parity_guard(dabhip_engine *e, int enable);
 /* Decisions the guard re-decided in the last decode, and hard decisions taken in all. */
 int dabhip_engine_guard_stats(const dabhip_engine *e, int64_t *flagged, int64_t *decisions);
+/* The guard lists the decisions to re-decide per kernel launch (64 entries per TF, at least 262,144).  A launch with more of them
+ * -- input that synchronises but has many near-zero products: strongly notched, narrowband or near-DC frames -- does not fail: its
+ * frames are decided again in full from fp64 transforms (slow, still the bits of exact arithmetic).  Number of such launches in the
+ * last decode; and the list capacity as a test knob (0 = automatic). */
+int dabhip_engine_guard_overflows(const dabhip_engine *e);
+int dabhip_engine_set_guard_list_cap(dabhip_engine *e, uint32_t cap);
 
 /* Sub-channel filter (the reference's TODO.md:28-31, "save CPU time by not decoding data which will later be discarded"):
  * only the listed SubChIds (0..63) are decoded and carried; the ETI frames then list exactly those in their STC (NST, FL,

@@ -1,6 +1,8 @@
 """GPU tests of the host-fed paths: the reference's input arrives in host buffers (dab2eti.c:117-130,238), so the batch entry
 and the streaming sessions take host memory -- page-locked (plain asynchronous DMA) or pageable (through the engine's staging
 ring) -- and must produce the ETI bytes of the device-resident decode."""
+import os
+
 import numpy as np
 import pytest
 
@@ -100,6 +102,21 @@ def test_stream_session_with_prefetched_segments_equals_one_shot_decode():
     for b, w in enumerate(want):
         assert np.array_equal(np.concatenate(got[b]), w), b
     st.close()
+    # the same through the copy engine instead of the gather kernel (a fresh process: the choice is read once)
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import dabtools_amd as dab\n"
+            "cfg = dab.synth_preset(1, seed=4100); iq = dab.synth_generate(cfg, 19); e = dab.Engine(0); e.decode([iq]); want = e.eti(0); e.close()\n"
+            "hb = dab.HostBuffer(iq.size); hb.array[:] = iq; st = dab.Stream(1); got = []\n"
+            "cuts = [0, 2500000, 5000001, iq.size]\n"
+            "segs = [([hb.ptr + a], [z - a]) for a, z in zip(cuts, cuts[1:])]\n"
+            "st.prefetch_ptrs(*segs[0])\n"
+            "for k in range(3):\n"
+            "    if k < 2: st.prefetch_ptrs(*segs[k + 1])\n"
+            "    st.feed_ptrs(*segs[k]); got.append(st.eti(0))\n"
+            "assert np.array_equal(np.concatenate(got), want) and len(want) > 8; print('copy-engine prefetch ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(dab.__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DABHIP_PREFETCH_KERNEL="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and "copy-engine prefetch ok" in r.stdout, r.stderr[-2000:]
     # misuse: feeding something else than the segment handed over first; three segments waiting
     st = dab.Stream(len(caps))
     st.prefetch_ptrs(*segs[0][:2])
