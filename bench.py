@@ -476,7 +476,7 @@ def run_rank(args, coord):
                 stage[k] = stage.get(k, 0.0) + v
         barrier()
         elapsed = time.perf_counter() - t0
-        stage = {k: v / args.steps for k, v in stage.items() if not k.startswith("h2d")}
+        stage = {k: v / args.steps for k, v in stage.items() if not k.startswith("h2d")}   # (sync_fp64_calls: a count per step, not ms)
         ntf_rank = eng.guard_stats()[1] // 230400 if not (args.soft or args.no_parity_guard) else 0
 
         fft = None

@@ -181,9 +181,9 @@ int dabhip_engine_trace(const dabhip_engine* e, int stream, int32_t* ints6, doub
 int dabhip_engine_stage_ms(const dabhip_engine* e, const char** names, float* ms, int cap)
 {
   if (!e) return -1;
-  constexpr int kN = 15;
+  constexpr int kN = 16;
   static const char* kNames[kN] = {"sync", "fft", "demap", "fic", "control", "gather", "viterbi", "eti", "host_setup", "host_frames", "host_worklist", "wall",
-                                   "h2d", "h2d_mbytes", "h2d_pinned_mbytes"};
+                                   "h2d", "h2d_mbytes", "h2d_pinned_mbytes", "sync_fp64_calls"};
   float v[kN] = {0};
   for (size_t l = 0; l < e->lanes.size(); ++l) {
     if (e->lane_frames.empty() || (l > 0 && e->lane_frames[l] == 0 && e->lane_of.size() < 64)) continue;
@@ -193,6 +193,7 @@ int dabhip_engine_stage_ms(const dabhip_engine* e, const char** names, float* ms
     v[12] += t.h2d;
     v[13] += static_cast<float>(t.h2d_bytes * 1e-6);
     v[14] += static_cast<float>(t.h2d_pinned_bytes * 1e-6);
+    v[15] += t.sync_fp64_calls;
   }
   v[11] = e->wall_ms;
   int n = 0;

@@ -614,10 +614,13 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
     // the OFDM stage, and -- after the LDS bank conflicts were gone -- the chain in 2..16 chunks of calls with each chunk's
     // verification beside the next chunk: 1.28 -> 1.30..1.40 ms.  A chain workgroup holds half of a CU's LDS, so the verification
     // beside it runs at half its rate and slows the chain.)
-    if (!h_viol_.resize(nstreams) || !d_viol_.reserve(nstreams) || !d_states_prev_.reserve(nstreams) ||
+    // d_viol_[0 .. nstreams): first call of a stream that broke the chain's assumption; [nstreams]: calls the fp32 pass of the
+    // verification left to the fp64 pass
+    if (!h_viol_.resize(nstreams + 1) || !d_viol_.reserve(nstreams + 1) || !d_states_prev_.reserve(nstreams) ||
         !d_calls_before_.upload(calls_done_.data(), nstreams, stream_) ||
         !check(hipMemcpyAsync(d_states_prev_.get(), d_states_.get(), nstreams * sizeof(StreamState), hipMemcpyDeviceToDevice, stream_), "state backup") ||
         !check(hipMemsetAsync(d_viol_.get(), 0x7f, nstreams * sizeof(int), stream_), "violation memset") ||
+        !check(hipMemsetAsync(d_viol_.get() + nstreams, 0, sizeof(int), stream_), "violation memset") ||
         !check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), nstreams, max_calls_, -1, -1,
                                 d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), 0, stream_, true),
                "sync chain launch") ||
@@ -633,7 +636,7 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
         !check(launch_sync_verify(d_iq_ptrs_.get(), d_nbytes_.get(), d_calls_before_.get(), d_states_.get(), d_descs_.get(), nstreams, max_calls_,
                                   d_tw2048_.get(), d_prs_.get(), d_viol_.get(), true, stream_),
                "sync carry launch") ||
-        !check(hipMemcpyAsync(h_viol_.data(), d_viol_.get(), nstreams * sizeof(int), hipMemcpyDeviceToHost, stream_), "violation download"))
+        !check(hipMemcpyAsync(h_viol_.data(), d_viol_.get(), (nstreams + 1) * sizeof(int), hipMemcpyDeviceToHost, stream_), "violation download"))
       return false;
     split_scan = true;
   }
@@ -656,6 +659,7 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
     for (int b = 0; b < nstreams; ++b)
       if (h_viol_[b] != 0x7f7f7f7f) redo.push_back(b);
     sync_rescanned_ = static_cast<int>(redo.size());
+    times_.sync_fp64_calls = static_cast<float>(h_viol_[nstreams]);
     if (!redo.empty()) {                                   // rare: those streams again, in the reference's order, from their incoming state
       if (!d_redo_.upload(redo, stream_) ||
           !check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), static_cast<int>(redo.size()), max_calls_,

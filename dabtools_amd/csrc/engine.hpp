@@ -130,6 +130,7 @@ class PinnedBuffer {
 struct StageTimes {
   float sync = 0, fft = 0, demap = 0, fic = 0, control = 0, gather = 0, viterbi = 0, eti = 0;
   float setup = 0, frames = 0, worklist = 0, wall = 0;   // host-side phases (wall clock)
+  float sync_fp64_calls = 0;                             // K1 verification: calls whose fp32 arg-max was not clear-cut (decided in fp64)
   float h2d = 0;                                         // host-fed decode: upload of the IQ (HIP events; 0 when the IQ was resident)
   double h2d_bytes = 0, h2d_pinned_bytes = 0;            // bytes uploaded, and how many of them came from page-locked memory
 };

@@ -24,10 +24,20 @@ __device__ __forceinline__ int lds_at(int i) { return i ^ ((i >> 3) & 7) ^ ((i >
 // The scan is a chain of dependent LDS round trips with only 2 waves per SIMD to hide them, so L consecutive
 // radix-2 levels are fused: a thread holds the 2^L points it needs in registers, runs the L levels on them (the same
 // butterflies, in the same order of operations as level-by-level radix 2) and meets the others at ONE barrier.
-template <int LOGN, int L>
-__device__ __forceinline__ void dif_levels(double2* buf, int nbatch, int s, double sign, const double2* tw2048)
+// V = double2 (the reference's arithmetic) or float2 (sync_verify_kernel's first pass, whose arg-max is re-done in double when it is
+// not clear-cut): the same butterflies in the same order.
+template <class V>
+struct ScalarOf;
+template <>
+struct ScalarOf<double2> { using type = double; };
+template <>
+struct ScalarOf<float2> { using type = float; };
+
+template <int LOGN, int L, class V>
+__device__ __forceinline__ void dif_levels(V* buf, int nbatch, int s, typename ScalarOf<V>::type sign, const V* tw2048)
 {
-  constexpr int N = 1 << LOGN, R = 1 << L;
+  using R = typename ScalarOf<V>::type;
+  constexpr int N = 1 << LOGN, RADIX = 1 << L;
   const int ms = N >> s;                         // size of the sub-transforms at level s
   const int q = ms >> L;                         // distance between the points one thread holds
   constexpr int per_batch = N >> L;
@@ -35,34 +45,36 @@ __device__ __forceinline__ void dif_levels(double2* buf, int nbatch, int s, doub
     const int batch = idx / per_batch, w = idx % per_batch;
     const int blk = w / q, k = w % q;
     const int e0 = batch * N + blk * ms + k;
-    double2 r[R];
+    V r[RADIX];
 #pragma unroll
-    for (int j = 0; j < R; ++j) r[j] = buf[lds_at(e0 + j * q)];
+    for (int j = 0; j < RADIX; ++j) r[j] = buf[lds_at(e0 + j * q)];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-      const int span = R >> (l + 1);             // partner distance in units of q
+      const int span = RADIX >> (l + 1);         // partner distance in units of q
       const int half = ms >> (l + 1);
       const int twstep = 1024 / half;
 #pragma unroll
-      for (int j = 0; j < R; ++j) {
+      for (int j = 0; j < RADIX; ++j) {
         if (j & span) continue;
         const int pos = k + (j & (span - 1)) * q;          // index of the butterfly inside its sub-transform
-        const double2 A = r[j], B = r[j + span];
-        double2 tw = tw2048[lds_at(pos * twstep)];
+        const V A = r[j], B = r[j + span];
+        V tw = tw2048[lds_at(pos * twstep)];
         tw.y *= sign;
-        const double dr = A.x - B.x, di = A.y - B.y;
-        r[j] = make_double2(A.x + B.x, A.y + B.y);
-        r[j + span] = make_double2(dr * tw.x - di * tw.y, dr * tw.y + di * tw.x);
+        const R dr = A.x - B.x, di = A.y - B.y;
+        r[j].x = A.x + B.x;
+        r[j].y = A.y + B.y;
+        r[j + span].x = dr * tw.x - di * tw.y;
+        r[j + span].y = dr * tw.y + di * tw.x;
       }
     }
 #pragma unroll
-    for (int j = 0; j < R; ++j) buf[lds_at(e0 + j * q)] = r[j];
+    for (int j = 0; j < RADIX; ++j) buf[lds_at(e0 + j * q)] = r[j];
   }
   __syncthreads();
 }
 
-template <int LOGN, int... Ls>
-__device__ __forceinline__ void dft_dif(double2* buf, int nbatch, double sign, const double2* tw2048)
+template <int LOGN, int... Ls, class V>
+__device__ __forceinline__ void dft_dif(V* buf, int nbatch, typename ScalarOf<V>::type sign, const V* tw2048)
 {
   int s = 0;
   ((dif_levels<LOGN, Ls>(buf, nbatch, s, sign, tw2048), s += Ls), ...);

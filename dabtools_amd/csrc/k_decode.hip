@@ -470,7 +470,11 @@ __device__ __forceinline__ void chain_back8(const uint4* my_rec, int nsteps, con
   // Only the word of a record that holds the current state's byte is fetched (its 16-byte part = state bits 5 and 3): a chain of
   // dependent loads, one memory round trip per 8 steps, but 45 % of the records' sectors instead of all of them -- the stage is
   // bound by the record traffic, and a wave that waits here leaves the SIMD to the forward passes of the others (5.42 -> 5.06 ms;
-  // fetching whole records 2 .. 8 blocks ahead, which hides the latency instead, made no difference at all).
+  // fetching whole records 2 .. 8 blocks ahead, which hides the latency instead, made no difference at all).  Round 3, from per-wave time
+  // stamps (profiles/r03_viterbi_tail.json): a 4614-step wave spends 1.07 ms here (577 dependent loads at HBM latency under load), a
+  // quarter of all resident wave-time is chain-back -- yet with the records kept in L2 the whole launch gains only 0.3 ms, without any
+  // chain-back 0.45.  A lane's record in ONE 64-byte line ([block][lane][part], read back whole, 2 or 4 blocks ahead) was 2.8 x slower
+  // (14 ms): 16-byte stores at a 64-byte stride.
   // A whole block per step: its decisions d_k = !tag_k (k = 0 .. 7, step 8 b + k), bit-reversed: r8 = d_0 .. d_7 from the top.  Walking
   // back from step 8 b + 7 to 8 b leaves state (d_0 .. d_5) = r8 >> 2; data bit i = step - 6 goes MSB-first into byte i >> 3: d_6, d_7
   // are the top two bits of byte b, d_0 .. d_5 the low six bits of byte b - 1 -- the new state itself.

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "dab_tables.hpp"
@@ -317,6 +318,79 @@ __device__ int coarse_freq_sync(const uint8_t* stream, const FrameView& view, in
   return hi - 14;
 }
 
+// ---- the same search in single precision: sync_verify_kernel's first pass ---------------------------------------------------
+// The reference's result is the OFFSET (0 .. 28) that holds the largest of the 29 x 128 magnitudes (float compare of double values,
+// first maximum wins).  In fp32 the same offset comes out whenever that maximum stands clear of every OTHER offset's maximum by far
+// more than the rounding of the transforms (1e-6 of the values' scale): the pass below demands 1 % and otherwise leaves the call to
+// the fp64 pass (a locked signal's true offset correlates ~100 x higher than the others; noise-only frames are not clear-cut and
+// simply take the fp64 path).  Half the LDS bytes and twice the instruction rate of the fp64 transforms.
+constexpr int kVerifyAgain = 0x7fff0000;                   // coarse_freq_shift marker: "decide this call in double"
+__device__ __forceinline__ float2 mul_conj_prs32(float2 x, int q)
+{
+  switch (q & 3) {
+    case 0: return x;
+    case 1: return make_float2(x.y, -x.x);
+    case 2: return make_float2(-x.x, -x.y);
+    default: return make_float2(-x.y, x.x);
+  }
+}
+__device__ int coarse_freq_sync32(const uint8_t* stream, const FrameView& view, int fine, float2* A, float2* spec, const float2* tw,
+                                  const uint8_t* __restrict__ prs_q, Red& red, bool* clear)
+{
+  const int tid = threadIdx.x;
+  {
+    const int p0 = 2 * (kNullSamples + kCpSamples + 1 + fine);
+    if (const uint8_t* win = contiguous_window(stream, view, p0, p0 + 2 * 2048)) {
+      const uint16_t* src = reinterpret_cast<const uint16_t*>(win);
+      unsigned w[2048 / kThreads];
+#pragma unroll
+      for (int i = 0; i < 2048 / kThreads; ++i) w[i] = src[tid + i * kThreads];
+#pragma unroll
+      for (int i = 0; i < 2048 / kThreads; ++i) {
+        const double2 x = sample_of(w[i]);
+        A[lds_at(tid + i * kThreads)] = make_float2(static_cast<float>(x.x), static_cast<float>(x.y));
+      }
+    } else {
+      for (int n = tid; n < 2048; n += kThreads) {
+        const double2 x = view_sample(stream, view, p0 + 2 * n, 0);
+        A[lds_at(n)] = make_float2(static_cast<float>(x.x), static_cast<float>(x.y));
+      }
+    }
+  }
+  __syncthreads();
+  dft_dif<11, 3, 3, 3, 2>(A, 1, -1.0f, tw);
+  for (int j = tid; j < kSpecBins; j += kThreads) spec[j] = A[lds_at(brev((256 + j + 1024) & 2047, 11))];
+  __syncthreads();
+  float2* W = A;                                           // 29 x 128 points
+  for (int idx = tid; idx < 29 * 128; idx += kThreads) {
+    const int o = idx / 128, s = idx % 128;
+    W[lds_at(idx)] = mul_conj_prs32(spec[o + s], prs_q[14 + s]);
+  }
+  __syncthreads();
+  dft_dif<7, 3, 2, 2>(W, 29, +1.0f, tw);
+  float cv = -99999.0f;
+  int ci = 0x7fffffff;
+  for (int idx = tid; idx < 29 * 128; idx += kThreads) {
+    const float2 x = W[lds_at(idx)];
+    const float mag = sqrtf(x.x * x.x + x.y * x.y);
+    if (mag > cv) { cv = mag; ci = idx / 128; }
+  }
+  float hv;
+  int hi;
+  block_argmax(red, cv, ci, &hv, &hi);
+  float ov = 0.0f;                                         // the largest magnitude of any OTHER offset
+  for (int idx = tid; idx < 29 * 128; idx += kThreads) {
+    if (idx / 128 == hi) continue;
+    const float2 x = W[lds_at(idx)];
+    ov = fmaxf(ov, sqrtf(x.x * x.x + x.y * x.y));
+  }
+  float rv;
+  int ri;
+  block_argmax(red, ov, tid, &rv, &ri);
+  *clear = hv > 0.0f && (hv - rv) > 0.01f * hv;
+  return hi - 14;
+}
+
 // dab_fine_freq_corr (sdr_sync.c:259-302): estimate only, in Hz
 __device__ double fine_freq_corr(const uint8_t* stream, const FrameView& view, int nco, Red& red)
 {
@@ -468,19 +542,21 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
 // The estimators the chain-only scan left out, for every call it assumed demodulated: grid (max_calls, nstreams).
 // Fills coarse_freq_shift and fine_freq_shift of the call's descriptor; an offset beyond +-1 carrier breaks the assumption:
 // the first such call of a stream is recorded in violation[stream].
+// only_marked: the second pass behind sync_verify32_kernel -- only the calls that one left undecided (kVerifyAgain).
 __global__ __launch_bounds__(kThreads) void sync_verify_kernel(const uint8_t* const* __restrict__ iq, CallDesc* __restrict__ descs, int max_calls,
                                                                int nstreams, const double2* __restrict__ tw2048, const uint8_t* __restrict__ prs_q,
-                                                               int* __restrict__ violation)
+                                                               int* __restrict__ violation, int only_marked)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int total = max_calls * nstreams;
-  if (static_cast<int>(gridDim.x) == total && descs[blockIdx.x].status != 2) return;   // nothing to do: skip the table fill as well
+  if (static_cast<int>(gridDim.x) == total && (descs[blockIdx.x].status != 2 || (only_marked && descs[blockIdx.x].coarse_freq_shift != kVerifyAgain)))
+    return;                                                // nothing to do: skip the table fill as well
   const SyncLds lds = sync_lds(smem, tw2048);
   Shared& sh = *lds.sh;
   for (int w = blockIdx.x; w < total; w += gridDim.x) {
     const int b = w / max_calls;
     CallDesc& d = descs[w];
-    if (d.status != 2) continue;                           // the same for every thread of the workgroup
+    if (d.status != 2 || (only_marked && d.coarse_freq_shift != kVerifyAgain)) continue;   // the same for every thread of the workgroup
     __syncthreads();                                       // the previous call's readers of sh.st.view are done
     {
       const uint32_t* src = reinterpret_cast<const uint32_t*>(&d.view);
@@ -498,6 +574,48 @@ __global__ __launch_bounds__(kThreads) void sync_verify_kernel(const uint8_t* co
     const double ffs = fine_freq_corr(stream, sh.st.view, 0, sh.red);
     if (threadIdx.x == 0) { d.coarse_freq_shift = cfs; d.fine_freq_shift = ffs; }
   }
+}
+
+// First pass of the verification in single precision (see coarse_freq_sync32): one workgroup per call.  LDS: 3712 + 1024 + 156 float2
+// and the small shared block = 39.5 KB, three workgroups per CU.  Calls whose arg-max is not clear-cut get the marker and are left to
+// sync_verify_kernel(only_marked); the fine frequency estimate is the fp64 routine as before.
+constexpr int kVerify32Points = 29 * 128;
+__global__ __launch_bounds__(kThreads, 6) void sync_verify32_kernel(const uint8_t* const* __restrict__ iq, CallDesc* __restrict__ descs, int max_calls,
+                                                                    int nstreams, const double2* __restrict__ tw2048, const uint8_t* __restrict__ prs_q,
+                                                                    int* __restrict__ violation, int distrust)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int w = blockIdx.x;
+  CallDesc& d = descs[w];
+  if (d.status != 2) return;
+  float2* A = reinterpret_cast<float2*>(smem);
+  float2* tw = A + kVerify32Points;
+  float2* spec = tw + 1024;
+  Shared& sh = *reinterpret_cast<Shared*>(spec + kSpecBins + (kSpecBins & 1));
+  for (int i = threadIdx.x; i < 1024; i += kThreads) {
+    const double2 t = tw2048[i];
+    tw[lds_at(i)] = make_float2(static_cast<float>(t.x), static_cast<float>(t.y));
+  }
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&d.view);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&sh.st.view);
+    if (threadIdx.x < sizeof(FrameView) / 4) dst[threadIdx.x] = src[threadIdx.x];
+  }
+  const int b = w / max_calls, fine = d.fine_timeshift;
+  __syncthreads();
+  const uint8_t* stream = iq[b];
+  bool clear;
+  const int cfs = coarse_freq_sync32(stream, sh.st.view, fine, A, spec, tw, prs_q, sh.red, &clear);
+  if (!clear || distrust) {                                // distrust: test mode, every call goes on to the fp64 pass
+    if (threadIdx.x == 0) { d.coarse_freq_shift = kVerifyAgain; atomicAdd(violation + nstreams, 1); }   // the counter behind the per-stream entries
+    return;
+  }
+  if (abs(cfs) > 1) {
+    if (threadIdx.x == 0) { d.coarse_freq_shift = cfs; atomicMin(violation + b, w % max_calls); }
+    return;
+  }
+  const double ffs = fine_freq_corr(stream, sh.st.view, 0, sh.red);
+  if (threadIdx.x == 0) { d.coarse_freq_shift = cfs; d.fine_freq_shift = ffs; }
 }
 
 // fine_freq_shift is only recomputed by calls that demodulate (input_sdr.c:112); every other call still shows the last value
@@ -520,6 +638,7 @@ __global__ void sync_carry_kernel(CallDesc* __restrict__ descs, int max_calls, c
 }  // namespace
 
 size_t sync_scan_lds_bytes() { return sizeof(double2) * (2048 + kBatchPoints + 1024 + kSpecBins) + sizeof(Shared); }
+static size_t sync_verify32_lds_bytes() { return sizeof(float2) * (kVerify32Points + 1024 + kSpecBins + (kSpecBins & 1)) + sizeof(Shared); }
 
 static hipError_t sync_attr()
 {
@@ -529,6 +648,7 @@ static hipError_t sync_attr()
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_scan_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_scan_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_verify_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_verify32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sync_verify32_lds_bytes()));
   if (e == hipSuccess) attr_set = true;
   return e;
 }
@@ -560,7 +680,15 @@ hipError_t launch_sync_verify(const uint8_t* const* iq, const int64_t* nbytes, c
   if (e != hipSuccess) return e;
   if (!carry_only) {
     const int blocks = max_calls * nstreams;                // one call per workgroup measured better than persistent ones (0.59 vs 0.63 ms)
-    hipLaunchKernelGGL(sync_verify_kernel, dim3(blocks), dim3(kThreads), sync_scan_lds_bytes(), stream, iq, descs, max_calls, nstreams, tw2048, prs_q, violation);
+    // fp32 first, fp64 for what that pass left undecided (DABHIP_VERIFY_FP32=0: everything in fp64, as before round 3)
+    // (= 2: test mode, the fp32 pass runs but hands every call on)
+    static const int mode = std::getenv("DABHIP_VERIFY_FP32") ? std::atoi(std::getenv("DABHIP_VERIFY_FP32")) : 1;
+    const bool fp32_first = mode != 0;
+    if (fp32_first)
+      hipLaunchKernelGGL(sync_verify32_kernel, dim3(blocks), dim3(kThreads), sync_verify32_lds_bytes(), stream, iq, descs, max_calls, nstreams, tw2048, prs_q, violation,
+                         mode == 2 ? 1 : 0);
+    hipLaunchKernelGGL(sync_verify_kernel, dim3(blocks), dim3(kThreads), sync_scan_lds_bytes(), stream, iq, descs, max_calls, nstreams, tw2048, prs_q, violation,
+                       fp32_first ? 1 : 0);
   } else {
     hipLaunchKernelGGL(sync_carry_kernel, dim3((nstreams + 63) / 64), dim3(64), 0, stream, descs, max_calls, nbytes, calls_before, states, violation, nstreams);
   }

@@ -226,7 +226,9 @@ int dabhip_engine_trace(const dabhip_engine *e, int stream, int32_t *ints6, doub
  * names: "sync", "fft", "demap", "fic", "control", "gather", "viterbi", "eti", then host wall-clock
  * phases "host_setup", "host_frames", "host_worklist" and the total "wall"; then, for a host-fed decode (on_device == 0),
  * "h2d" (ms of the IQ upload, HIP events), "h2d_mbytes" (10^6 bytes uploaded) and "h2d_pinned_mbytes" (how much of that came
- * straight from page-locked memory; the rest went through the engine's staging ring).  Returns number of entries written. */
+ * straight from page-locked memory; the rest went through the engine's staging ring); and "sync_fp64_calls": calls whose coarse
+ * frequency arg-max the single-precision first pass of K1's verification left to the fp64 pass (a count, not a time).
+ * Returns number of entries written. */
 int dabhip_engine_stage_ms(const dabhip_engine *e, const char **names, float *ms, int cap);
 /* Per-launch statistics of the OFDM FFT kernel in the last decode: number of launches,
  * transmission frames transformed, total kernel milliseconds (HIP events). */

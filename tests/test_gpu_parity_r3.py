@@ -89,3 +89,38 @@ def test_parity_guard_list_overflow_degrades_to_a_full_fp64_decision():
     eng.decode(caps)
     assert eng.guard_overflows() == 0
     eng.close()
+
+
+def test_sync_verification_fp32_first_pass_and_its_fp64_fallback():
+    """K1's verification runs the coarse frequency search in single precision first and leaves a call to the fp64 pass when its arg-max is
+    not clear-cut (never on a present signal: sync_fp64_calls == 0 on the captures below).  Three ways, one result: the default, fp64 only
+    (DABHIP_VERIFY_FP32=0, the round-2 behaviour) and the test mode that hands EVERY call on to the fp64 pass (=2) -- ETI bytes and the
+    per-call traces (coarse_freq_shift, fine_freq_shift ...) equal the oracle's, on off-tune captures that walk through k = +-1, 2, -6, 14."""
+    import subprocess
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import dabtools_amd as dab, oracle_lib as ol
+caps = [dab.synth_generate(dab.synth_preset(1, seed=1900 + i, cfo_hz=cfo, snr_db=snr, skip_samples=sk), 22)
+        for i, (cfo, snr, sk) in enumerate(((1000.0, 25.0, 0), (2300.0, 25.0, 40000), (-6000.0, 20.0, 0), (13700.0, 25.0, 0), (0.0, 6.0, 0), (150.0, 1000.0, 99)))]
+eng = dab.Engine(0)
+eng.decode(caps)
+fp64_calls = eng.stage_ms()["sync_fp64_calls"]
+seen = set()
+for b, iq in enumerate(caps):
+    want, trace = ol.or_replay(iq)
+    assert np.array_equal(eng.eti(b), want), b
+    ints, ffs = eng.trace(b, len(trace))
+    for k, t in enumerate(trace):
+        assert tuple(ints[k]) == (t.ok, t.read_frame, t.coarse_timeshift, t.fine_timeshift, t.coarse_freq_shift, t.fifo_count), (b, k)
+        assert abs(ffs[k] - t.fine_freq_shift) < 1e-9, (b, k)
+        seen.add(t.coarse_freq_shift)
+assert {1, 2, -6, 14} <= seen, seen
+print("ok fp64_calls=%%d" %% fp64_calls)
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    out = {}
+    for mode in ("1", "0", "2"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DABHIP_VERIFY_FP32=mode), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0 and "ok fp64_calls=" in r.stdout, (mode, r.stdout[-500:], r.stderr[-2000:])
+        out[mode] = int(r.stdout.strip().rsplit("=", 1)[1])
+    assert out["1"] == 0 and out["0"] == 0 and out["2"] > 50, out
