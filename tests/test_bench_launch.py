@@ -78,3 +78,38 @@ def test_cpu_baseline_tool_small_sample(tmp_path):
         for key in ("reference_backend_scalar", "reference_backend_sse"):
             assert res[key]["kind"] == "reference" and res[key]["value"] > 0 and res[key]["all_cores"]["cores"] == 2
         assert res["reference_backend_sse"]["value"] > res["reference_backend_scalar"]["value"]
+
+
+def test_roofline_objects_are_computable_from_the_tracked_profile():
+    """bench.py takes every roofline input it cannot measure live (VALU instructions per trellis step, effective clocks, HBM bytes from the PMC
+    passes, LDS conflict rate) from the tracked profile of the round -- and fails loudly without it.  The file is there, every cell the
+    rooflines read exists, and each `frac` follows from the named cells."""
+    import argparse
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert os.path.exists(bench.PROFILE_PMC), "profiles/rNN_pmc_summary.csv is not tracked: run tools/refresh_profiles.sh on a GPU box"
+    prof = bench.load_profile()
+    args = argparse.Namespace(streams=256, tfs=64, subchannels="", soft=False, two_kernel_ofdm=False, no_parity_guard=False)
+    frames, ntf = 256 * 196, 256 * 62
+    stage = {"viterbi": 5.0, "fft": 4.4}
+    out = bench.rooflines(prof, args, 1, frames, ntf, stage, (30, 30 * 3968, 35.0), {"fill": 6000.0, "copy": 5200.0, "k2_mix": 5500.0})
+    assert set(out) == {"roofline", "roofline_viterbi", "roofline_ofdm_fused"}
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12 and 0.95 < r["traffic"] / (1556480 * 3968) < 1.1
+    v = out["roofline_viterbi"]
+    insts = prof.cell("clk", "viterbi_fused_kernel<1>", "SQ_INSTS_VALU") / (prof.meta("full_decodes") * prof.meta("viterbi_wave_steps_per_decode")
+                                                                               + prof.meta("viterbi_wave_steps_setup"))
+    clock = prof.cell("clk", "viterbi_fused_kernel<1>", "GRBM_GUI_ACTIVE") / 8 / prof.cell("clk", "viterbi_fused_kernel<1>", "DURATION_NS")
+    assert 100 < insts < 140 and 1.5 < clock < 2.5
+    cycles = 2 * 64 + 4 * (insts - 64)
+    assert abs(v["frac"] - cycles * bench.wave_steps(frames, 0) / 5.0e-3 / (1024 * clock * 1e9)) < 1e-9
+    assert v["survivor_traffic"]["x_stage_io"] > 10
+    f = out["roofline_ofdm_fused"]
+    assert f["bound"] == "valu issue / lds" and 5 < f["lds"]["bank_conflict_pct"] < 40 and f["hbm"]["frac"] < 0.3
+    assert f["valu_issue"]["frac_if_all_2_cycle"] < f["valu_issue"]["frac_if_all_4_cycle"] < 1.2
+    # a missing profile, or a missing cell, is an error that says what to do
+    import pytest
+    with pytest.raises(SystemExit, match="refresh_profiles"):
+        prof.cell("clk", "no_such_kernel", "SQ_INSTS_VALU")

@@ -44,6 +44,10 @@ def test_no_cpu_fallback():
         dab.Sdr(0)
     with pytest.raises(dab.DabhipError):
         dab.Dab(0)
+    with pytest.raises(dab.DabhipError, match="no HIP device"):
+        dab.Multi([0, 0])
+    with pytest.raises(dab.DabhipError):
+        dab.Stream(2)
 
 
 def test_product_does_not_link_the_oracle():

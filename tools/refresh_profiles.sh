@@ -36,7 +36,7 @@ mkdir -p "$R/profiles"
 [ -f "$R/profiles/${ROUND}_pmc_summary.csv" ] && cp "$R/profiles/${ROUND}_pmc_summary.csv" "$O/pmc_summary_previous.csv"
 cp "$O/pmc_summary.csv" "$R/profiles/${ROUND}_pmc_summary.csv"
 python3 "$B" --steps 20 > "$O/bench.json" 2>> "$O/bench.err"
-python3 "$B" --steps 10 --snr 5 --soft --no-cpu-baseline > "$O/bench_soft5db.json" 2>> "$O/bench.err"
+python3 "$B" --steps 10 --snr 5 --soft > "$O/bench_soft5db.json" 2>> "$O/bench.err"
 python3 "$B" --steps 10 --snr 5 --no-cpu-baseline > "$O/bench_hard5db.json" 2>> "$O/bench.err"
 python3 "$B" --steps 10 --snr 7 --soft --no-cpu-baseline > "$O/bench_soft7db.json" 2>> "$O/bench.err"
 python3 "$B" --steps 10 --snr 7 --no-cpu-baseline > "$O/bench_hard7db.json" 2>> "$O/bench.err"
