@@ -601,6 +601,55 @@ def run_rank(args, coord):
     coord.close()
 
 
+def run_in_process(args):
+    """`--in-process`: the N GPUs of the node driven from THIS process through dabhip_multi (one engine + one host thread per device, streams
+    dealt in contiguous slices, no exchange) instead of one rank process per GPU.  Same workload, same timing rule; one JSON line."""
+    import torch
+    import dabtools_amd as dab
+    from dabtools_amd import payload
+    n = args.gpus
+    one_device = os.environ.get("DABHIP_BENCH_ONE_DEVICE") == "1"
+    devices = [0 if one_device else i for i in range(n)]
+    tensors = []
+    for sl, d in enumerate(devices):
+        torch.cuda.set_device(d)
+        cfgs = [payload.bench_cfg(dab, sl * args.streams + i, args.snr) for i in range(args.streams)]
+        ts = [torch.empty(dab.synth_bytes(c, args.tfs), dtype=torch.uint8, device=torch.device("cuda", d)) for c in cfgs]
+        dab.synth_generate_device(cfgs, args.tfs, [t.data_ptr() for t in ts], d)
+        tensors += ts
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    multi = dab.Multi(devices)
+    if args.soft:
+        multi.set_soft(True)
+    ptrs, sizes = [t.data_ptr() for t in tensors], [t.numel() for t in tensors]
+    frames = 0
+    for _ in range(args.warmup):
+        frames = multi.decode_device(ptrs, sizes)
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frames = multi.decode_device(ptrs, sizes)
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    elapsed = time.perf_counter() - t0
+    value = frames * args.steps / elapsed
+    per_slice = []
+    for i in range(n):
+        st = multi.engine(i).stage_ms()
+        per_slice.append({"slice": i, "device": devices[i], "wall_ms": round(multi.wall_ms(i), 3), "control_ms": round(st["control"], 3),
+                          "host_worklist_ms": round(st["host_worklist"], 3), "eti_frames": sum(multi.eti_count(b) for b in range(i * args.streams, (i + 1) * args.streams))})
+    print(json.dumps({
+        "metric": "ETI frames/s (24 ms each), Mode-I batch, synthetic IQ resident in HBM", "value": value, "unit": "ETI frames/s", "x_realtime": value / REALTIME_FPS,
+        "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64 sync / f32 OFDM / u16 ACS / u8 ETI", "data": "synthetic (%d distinct ensembles per slice, device-side modulator)" % args.streams,
+        "config": {"workload": workload_text(args), "streams_per_gpu": args.streams, "tf_per_stream": args.tfs, "eti_frames_per_step": frames,
+                   "launch": "in-process: dabhip_multi over devices %s (one engine + host thread per entry)" % devices,
+                   "sharding": "independent ensembles, %d per slice, stream s on slice s // %d, no collective" % (args.streams, args.streams)},
+        "slices": per_slice}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -622,8 +671,12 @@ def main():
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-fed measurement (h2d_inclusive: 6.4 GB of page-locked host memory at the default size)")
     ap.add_argument("--h2d-segment-tfs", type=int, default=8, help="segment length of the host-fed streaming session, in transmission frames")
     ap.add_argument("--profile-pass", action="store_true", help="run under tools/refresh_profiles.sh: no profile-derived objects (they are being produced), emit profile_meta")
+    ap.add_argument("--in-process", action="store_true", help="drive the --gpus N devices from this one process through dabhip_multi instead of N rank processes")
     args = ap.parse_args()
 
+    if args.in_process:
+        run_in_process(args)
+        return
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world_env == 1:
         sys.exit(launch_ranks(args, sys.argv[1:]))          # before any torch / HIP call in this process

@@ -89,6 +89,9 @@ __device__ __forceinline__ void fft2048_rest(float2 (&v)[8], float2* bufP, float
 // in a cold block; the guard flag as a template parameter; stage-2 twiddles from LDS to free registers.  What did pay (6.5 ->
 // 4.9 ms): one decision layout for FIC and MSC symbols (no per-symbol address selects), the flag instead of a per-bin mask, the
 // symbol energy summed with DPP adds instead of __shfl_xor steps (1 ms by itself), cmul in two packed instructions, four waves.
+// Round 3, at four waves per SIMD: the per-thread threshold again (one threshold from the largest |bin|_1 of the thread's eight bins and of
+// the previous symbol's, 22 instructions fewer per symbol and thread, exact test cold): 4.43 .. 4.48 ms against 4.40 .. 4.47 -- the kernel
+// is not bound by its instruction count (57 % of the SIMDs' issue time; barriers and LDS round trips are the rest).
 struct FusedGuard {
   GuardArgs g;
   unsigned frame;        // index of this TF in the frame list
