@@ -527,11 +527,18 @@ class Engine:
 
     def decode_device(self, ptrs, sizes):
         """ptrs: device addresses (ints, e.g. torch tensor.data_ptr()), sizes: byte counts."""
-        p = (C.c_void_p * len(ptrs))(*ptrs)
-        s = (C.c_size_t * len(sizes))(*sizes)
-        n = lib().dabhip_engine_decode(self._h, p, s, len(ptrs), 1)
+        return self.decode_marshalled(self.marshal(ptrs, sizes), on_device=True)
+
+    @staticmethod
+    def marshal(ptrs, sizes):
+        """The C argument arrays of a decode, built once for callers that decode the same buffers again and again."""
+        return (C.c_void_p * len(ptrs))(*ptrs), (C.c_size_t * len(sizes))(*sizes), len(ptrs)
+
+    def decode_marshalled(self, args, on_device=True):
+        p, s, n_streams = args
+        n = lib().dabhip_engine_decode(self._h, p, s, n_streams, 1 if on_device else 0)
         _need(n >= 0, "engine_decode")
-        self.nstreams = len(ptrs)
+        self.nstreams = n_streams
         return n
 
     def eti(self, stream):
