@@ -521,14 +521,17 @@ bool Engine::upload_iq(const uint8_t* const* iq, const size_t* nbytes, int nstre
     uint8_t* const dst = d_iq_own_.get() + off;
     ptrs[b] = dst;
     const size_t n = nbytes[b], padded = (n + 15) & ~size_t(15);
+    // memory the runtime knows (page-locked / registered host memory; also device or managed memory handed in by mistake as "host") is copied
+    // by the copy engine directly; everything else is ordinary pageable memory
     hipPointerAttribute_t attr;
-    const bool pinned = n && hipPointerGetAttributes(&attr, iq[b]) == hipSuccess && attr.type == hipMemoryTypeHost;
+    const bool pinned = n && hipPointerGetAttributes(&attr, iq[b]) == hipSuccess &&
+                        (attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged);
     if (!pinned) (void)hipGetLastError();      // an unregistered pointer is reported as an error: that is the answer, not a failure
     times_.h2d_bytes += static_cast<double>(n);
     if (pinned) {
       if (!flush()) return false;              // keeps the copies in stream order (cheap: at most one partly filled buffer)
       times_.h2d_pinned_bytes += static_cast<double>(n);
-      if (!check(hipMemcpyAsync(dst, iq[b], n, hipMemcpyHostToDevice, stream_), "IQ upload")) return false;
+      if (!check(hipMemcpyAsync(dst, iq[b], n, hipMemcpyDefault, stream_), "IQ upload")) return false;
     } else {
       // staged: a stream's bytes continue in the buffer where the previous stream's ended only when they are adjacent on the device
       // (they are, up to the 16-byte padding: a buffer is flushed at a stream boundary when the padding is not zero)

@@ -58,6 +58,11 @@ def test_host_fed_decode_pinned_pageable_and_mixed_equal_resident_decode():
     assert 0 < st["h2d_pinned_mbytes"] < st["h2d_mbytes"]
     for b, w in enumerate(want):
         assert np.array_equal(eng.eti(b), w), b
+    # device memory handed in through the HOST form of the call (a caller's mistake the library absorbs: the copy engine knows the pointer)
+    devs = [b.ptr if c.size else pinned[i].ptr for i, (b, c) in enumerate(zip(bufs, caps))]
+    assert eng.decode_host_ptrs(devs, [c.size for c in caps]) == total
+    for b, w in enumerate(want):
+        assert np.array_equal(eng.eti(b), w), b
     for x in bufs + pinned:
         x.free()
     eng.close()
