@@ -68,7 +68,15 @@ Engine::Engine(int device, int host_threads) : device_(device)
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device: libdabhip has no CPU fallback"); return; }
   if (device < 0 || device >= ndev) { set_error("device index out of range"); return; }
   if (!check(hipSetDevice(device), "hipSetDevice")) return;
-  if (!check(hipStreamCreate(&stream_), "hipStreamCreate") || !check(hipStreamCreate(&copy_stream_), "hipStreamCreate")) return;
+  // The side stream carries the FIC decode (1008 short waves beside the OFDM stage's 16 k workgroups) and the small copies the host waits for:
+  // it gets the highest priority, so that the FIBs -- and with them the host control plane -- are not queued behind the bulk of the OFDM stage
+  // (DABHIP_SIDE_PRIORITY=0: equal priorities, as before round 3).
+  int prio_low = 0, prio_high = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+  static const bool side_prio = !(std::getenv("DABHIP_SIDE_PRIORITY") && std::atoi(std::getenv("DABHIP_SIDE_PRIORITY")) == 0);
+  if (!check(hipStreamCreate(&stream_), "hipStreamCreate") ||
+      !check(side_prio ? hipStreamCreateWithPriority(&copy_stream_, hipStreamDefault, prio_high) : hipStreamCreate(&copy_stream_), "hipStreamCreate"))
+    return;
   for (auto& e : ev_)
     if (!check(hipEventCreate(&e), "hipEventCreate")) return;
   if (!check(hipEventCreate(&ev_upload_), "hipEventCreate") || !check(hipEventCreate(&ev_fic_), "hipEventCreate") || !check(hipEventCreate(&ev_fic_done_), "hipEventCreate") ||
