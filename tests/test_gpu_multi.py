@@ -119,3 +119,23 @@ def test_eti_consumer_pipe_against_the_reference_eti2mpa(tmp_path):
         sent = b"".join(dab.synth_payload(cfg, fib_index[f[12 + 4 * (f[5] & 0x7f):][:96].tobytes()], slot).tobytes() for f in frames)
         # STL counts 64-bit words: the 8 kbit/s sub-channel's 24 payload bytes sit in 3 words exactly, the others likewise
         assert ref.stdout == sent, scid
+
+
+def test_bench_in_process_mode_and_config3_tool_at_reduced_size():
+    """`bench.py --gpus N --in-process` (dabhip_multi over the node's devices from one process) and tools/config3_one_gpu.py, both with all
+    slices on GPU 0 and a small batch: one JSON line each, every slice its frames, sampled streams equal to the oracle."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(dab.LIB_PATH))
+    env = dict(os.environ, DABHIP_BENCH_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--in-process", "--streams", "8", "--tfs", "20", "--steps", "2", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 3 and d["config"]["eti_frames_per_step"] == 3 * 8 * 4 * (20 - 15)
+    assert [s["eti_frames"] for s in d["slices"]] == [8 * 20] * 3 and d["value"] > 0
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "config3_one_gpu.py"), "--slices", "4", "--streams-per-slice", "6", "--tfs", "19", "--steps", "1",
+                        "--oracle-streams", "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["eti_frames"] == 24 * 16 and d["all_streams_full_count"] and d["oracle_byte_equal"].startswith("3 of 3") and d["sharding_rule_ok"]
