@@ -193,6 +193,66 @@ __device__ __forceinline__ void acs_step_soft(unsigned nib16, const pk16 (&p)[32
   all_pairs<kTau>(p, n, bl, bh, std::make_integer_sequence<int, 16>{});
 }
 
+// Soft decisions, branch metrics from two LDS tables (viterbi_fused_kernel<4>; DABHIP_SOFT_LUT=0 keeps the dot-product form above).  The
+// metric of code c, (28 + sg0 (s0 + s3) + sg1 s1 + s2) << 4 with sg0 = -1 for odd c, sg1 = -1 for c & 2, is the sum of a part of (s0, s3)
+// and a part of (s1, s2), each made non-negative by its share of the 28: A_c = (14 + sg0 (s0 + s3)) << 4, B_c = (14 + sg1 s1 + s2) << 4;
+// the complementary code's metric (56 << 4) - (A_c + B_c) splits the same way, (28 << 4) - A_c and (28 << 4) - B_c.  A table row holds the
+// four packed words of codes 0..3 for one layout tau (low half: code c, high half: code c ^ gamma(tau)), indexed by the two raw nibbles:
+// one 16-byte read per table and step, then 4 adds, instead of a byte permute, four dot products and a dozen shifts, ors and subtracts.
+#ifndef DABHIP_SOFT_LUT
+#define DABHIP_SOFT_LUT 1
+#endif
+struct SoftLut {
+  uint4 a[4][256];       // [tau][s0 | s3 << 4]
+  uint4 b[4][256];       // [tau][s1 | s2 << 4]
+};
+__device__ __forceinline__ void build_soft_lut(SoftLut* lut)
+{
+  for (int e = threadIdx.x; e < 2 * 4 * 256; e += blockDim.x) {
+    const int which = e >> 10, tau = (e >> 8) & 3, idx = e & 255;
+    // the two signed 4-bit values of this row (the demapper clamps to +-7; a -8 that could only come from corrupted input counts as -7, so that every share stays >= 0)
+    const int v0 = max(((idx & 15) ^ 8) - 8, -7), v1 = max(((idx >> 4) ^ 8) - 8, -7);
+    const unsigned gamma = tau == 0 ? branch_code3(2u) : tau == 1 ? branch_code3(4u) : tau == 2 ? branch_code3(8u) : branch_code3(16u);
+    uint32_t w[4];
+#pragma unroll
+    for (unsigned c = 0; c < 4; ++c) {
+      auto part = [&](unsigned code) -> uint32_t {          // this table's share of the metric of `code` (0..7)
+        const unsigned q = code < 4 ? code : code ^ 7;      // complementary codes: the share's mirror image
+        const int sg0 = (q & 1) ? -1 : 1, sg1 = (q & 2) ? -1 : 1;
+        const int share = which == 0 ? 14 + sg0 * (v0 + v1) : 14 + sg1 * v0 + v1;     // table a: (s0, s3); table b: (s1, s2)
+        return static_cast<uint32_t>((code < 4 ? share : 28 - share) << kMetricShift);
+      };
+      w[c] = part(c) | (part(c ^ gamma) << 16);
+    }
+    (which == 0 ? lut->a[tau][idx] : lut->b[tau][idx]) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  __syncthreads();
+}
+template <int kTau>
+__device__ __forceinline__ void acs_step_soft_lut(unsigned nib16, const SoftLut* lut, const pk16 (&p)[32], pk16 (&n)[32])
+{
+  constexpr uint32_t tag = 0x00010001u << kTau;
+  constexpr uint32_t kAll = static_cast<uint32_t>(56 << kMetricShift) * 0x00010001u;
+  const uint4 ta = lut->a[kTau][(nib16 & 15u) | ((nib16 >> 8) & 0xf0u)], tb = lut->b[kTau][(nib16 >> 4) & 0xffu];
+  const uint32_t w[4] = {ta.x + tb.x, ta.y + tb.y, ta.z + tb.z, ta.w + tb.w};
+  pk16 bl[8], bh[8];
+#pragma unroll
+  for (unsigned c = 0; c < 4; ++c) {
+    const uint32_t wc = kAll - w[c];
+    bh[c] = as_pk(w[c]);
+    bl[c] = as_pk(w[c] + tag);
+    bh[c ^ 7] = as_pk(wc);
+    bl[c ^ 7] = as_pk(wc + tag);
+  }
+  all_pairs<kTau>(p, n, bl, bh, std::make_integer_sequence<int, 16>{});
+}
+template <int kTau>
+__device__ __forceinline__ void acs_step_soft_any(unsigned nib16, const SoftLut* lut, const pk16 (&p)[32], pk16 (&n)[32])
+{
+  if (DABHIP_SOFT_LUT) acs_step_soft_lut<kTau>(nib16, lut, p, n);
+  else acs_step_soft<kTau>(nib16, p, n);
+}
+
 // Hard decisions with the de-puncturing fused in (viterbi_fused_kernel<1>): a step receives the first n = 0..4 bits of its group of
 // four (wave-uniform n), so only 16 + 8 + 4 + 2 + 1 = 31 (mask, value) pairs occur.  Their eight packed branch-metric words
 // per step type sit in an LDS table (8 tag bits x 4 parts x 32 rows x 16 B = 16 KB, shared by the 4 waves of a workgroup); a step
@@ -379,12 +439,12 @@ __device__ __forceinline__ void acs4(uint32_t ww, pk16 (&pm)[32], pk16 (&pn)[32]
   repair_layout(pl4, pm);
 }
 
-__device__ __forceinline__ void acs4_soft(uint64_t nibs, pk16 (&pm)[32], pk16 (&pn)[32], pk16 (&pl4)[32], uint4* rec)
+__device__ __forceinline__ void acs4_soft(uint64_t nibs, const SoftLut* lut, pk16 (&pm)[32], pk16 (&pn)[32], pk16 (&pl4)[32], uint4* rec)
 {
-  acs_step_soft<0>(static_cast<unsigned>(nibs) & 0xffffu, pm, pn);
-  acs_step_soft<1>(static_cast<unsigned>(nibs >> 16) & 0xffffu, pn, pm);
-  acs_step_soft<2>(static_cast<unsigned>(nibs >> 32) & 0xffffu, pm, pn);
-  acs_step_soft<3>(static_cast<unsigned>(nibs >> 48), pn, pl4);
+  acs_step_soft_any<0>(static_cast<unsigned>(nibs) & 0xffffu, lut, pm, pn);
+  acs_step_soft_any<1>(static_cast<unsigned>(nibs >> 16) & 0xffffu, lut, pn, pm);
+  acs_step_soft_any<2>(static_cast<unsigned>(nibs >> 32) & 0xffffu, lut, pm, pn);
+  acs_step_soft_any<3>(static_cast<unsigned>(nibs >> 48), lut, pn, pl4);
   survivor_record(pl4, rec);
   repair_layout(pl4, pm);
 }
@@ -400,13 +460,13 @@ __device__ __forceinline__ void acs_tail(uint32_t ww, int r, pk16 (&pm)[32], pk1
   acs_step<2>((ww >> 16) & 0xff, pm, pn);
   survivor_record(pn, rec);
 }
-__device__ __forceinline__ void acs_tail_soft(uint64_t nibs, int r, pk16 (&pm)[32], pk16 (&pn)[32], uint4* rec)
+__device__ __forceinline__ void acs_tail_soft(uint64_t nibs, int r, const SoftLut* lut, pk16 (&pm)[32], pk16 (&pn)[32], uint4* rec)
 {
-  acs_step_soft<0>(static_cast<unsigned>(nibs) & 0xffffu, pm, pn);
+  acs_step_soft_any<0>(static_cast<unsigned>(nibs) & 0xffffu, lut, pm, pn);
   if (r == 1) { survivor_record(pn, rec); return; }
-  acs_step_soft<1>(static_cast<unsigned>(nibs >> 16) & 0xffffu, pn, pm);
+  acs_step_soft_any<1>(static_cast<unsigned>(nibs >> 16) & 0xffffu, lut, pn, pm);
   if (r == 2) { survivor_record(pm, rec); return; }
-  acs_step_soft<2>(static_cast<unsigned>(nibs >> 32) & 0xffffu, pm, pn);
+  acs_step_soft_any<2>(static_cast<unsigned>(nibs >> 32) & 0xffffu, lut, pm, pn);
   survivor_record(pn, rec);
 }
 
@@ -656,8 +716,12 @@ __global__ __launch_bounds__(256, DABHIP_VIT_WAVES) void viterbi_fused_kernel(co
 {
   // four independent waves per workgroup (one wave-group of code words each); they only share the branch-metric table
   // (two per workgroup -- finer dispatch granularity for the launch's tail -- measured the same, 5.01 .. 5.05 against 5.02 .. 5.07 ms; one: 5.8)
-  __shared__ MetricLut lut[kBits == 1 ? 8 : 1];
+  constexpr size_t kLutBytes = kBits == 1 ? 8 * sizeof(MetricLut) : (DABHIP_SOFT_LUT ? sizeof(SoftLut) : 16);
+  __shared__ __attribute__((aligned(16))) unsigned char lut_raw[kLutBytes];
+  MetricLut* lut = reinterpret_cast<MetricLut*>(lut_raw);
+  SoftLut* soft_lut = reinterpret_cast<SoftLut*>(lut_raw);
   if (kBits == 1) build_metric_lut(lut);
+  else if (DABHIP_SOFT_LUT) build_soft_lut(soft_lut);
   const int lane = threadIdx.x & 63, g = 4 * blockIdx.x + (threadIdx.x >> 6);
   if (g >= ngroups) return;
   const WaveGroup grp = groups[g];
@@ -733,9 +797,9 @@ __global__ __launch_bounds__(256, DABHIP_VIT_WAVES) void viterbi_fused_kernel(co
             nibs[h] |= v << (16 * g);
           }
         }
-        if (t + 4 <= nsteps) acs4_soft(nibs[0], pm, pn, pl4, my_rec + static_cast<size_t>(t >> 2) * 128);
-        if (t + 8 <= nsteps) acs4_soft(nibs[1], pm, pn, pl4, my_rec + static_cast<size_t>((t >> 2) + 1) * 128);
-        else if (t + 4 < nsteps) acs_tail_soft(nibs[1], nsteps - t - 4, pm, pn, my_rec + static_cast<size_t>((t >> 2) + 1) * 128);
+        if (t + 4 <= nsteps) acs4_soft(nibs[0], soft_lut, pm, pn, pl4, my_rec + static_cast<size_t>(t >> 2) * 128);
+        if (t + 8 <= nsteps) acs4_soft(nibs[1], soft_lut, pm, pn, pl4, my_rec + static_cast<size_t>((t >> 2) + 1) * 128);
+        else if (t + 4 < nsteps) acs_tail_soft(nibs[1], nsteps - t - 4, soft_lut, pm, pn, my_rec + static_cast<size_t>((t >> 2) + 1) * 128);
       }
       t += 8;
       if ((t & (MetricScale<kScale>::kRebaseSteps - 1)) == 0 && t < nsteps) rebase_metrics<kScale>(pm);
