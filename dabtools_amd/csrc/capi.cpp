@@ -609,7 +609,14 @@ extern "C" int dabhip_synth_generate_device(const dabhip_synth_cfg* cfgs, int ns
 // fed.  Three windows so that the NEXT segment (k + 1) can be uploading into its window -- which holds segment k - 2, dead since
 // feed(k - 1) -- on a stream of its own while segment k decodes (dabhip_stream_prefetch).
 namespace {
-constexpr size_t kWindowReserve = size_t(8) << 20;    // > FIFO capacity (1.5 MiB) + 12 nested stale tails of one TF each
+// room in front of every segment for the bytes of earlier segments K1 may still read: > FIFO capacity (1.5 MiB) + 12 nested stale tails of
+// one TF each.  (DABHIP_WINDOW_RESERVE=bytes: test knob -- a small reserve sends every feed through the "more history than the reserve
+// holds" path.)
+const size_t kWindowReserve = [] {
+  const char* env = std::getenv("DABHIP_WINDOW_RESERVE");
+  const size_t v = env ? static_cast<size_t>(std::strtoull(env, nullptr, 10)) & ~size_t(255) : 0;
+  return v ? v : size_t(8) << 20;
+}();
 }
 struct dabhip_stream {
   Engine eng;

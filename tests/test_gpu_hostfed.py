@@ -122,6 +122,32 @@ def test_stream_session_with_prefetched_segments_equals_one_shot_decode():
             "assert np.array_equal(np.concatenate(got), want) and len(want) > 8; print('copy-engine prefetch ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(dab.__file__)))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DABHIP_PREFETCH_KERNEL="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0 and "copy-engine prefetch ok" in r.stdout, r.stderr[-2000:]
+    # ... and with a window reserve too small for the history K1 still needs (64 KB): every feed moves its segment into a larger window
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DABHIP_WINDOW_RESERVE="65536"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and "copy-engine prefetch ok" in r.stdout, r.stderr[-2000:]
+    # segments that are already on the device (on_device = 1) prefetch as device-to-device copies on the upload stream
+    st = dab.Stream(len(caps))
+    dsegs = []
+    for ptrs_k, sizes_k, hbs in segs:
+        bufs = [dab.DeviceBuffer(max(n, 16)) for n in sizes_k]
+        for buf, hb, n in zip(bufs, hbs, sizes_k):
+            if n:
+                buf.upload(hb.array[:n])
+        dsegs.append(([b.ptr for b in bufs], sizes_k, bufs))
+    got = [[] for _ in caps]
+    st.prefetch_ptrs(dsegs[0][0], dsegs[0][1], on_device=True)
+    for k in range(len(dsegs)):
+        if k + 1 < len(dsegs):
+            st.prefetch_ptrs(dsegs[k + 1][0], dsegs[k + 1][1], on_device=True)
+        st.feed_ptrs(dsegs[k][0], dsegs[k][1], on_device=True)
+        for b in range(len(caps)):
+            got[b].append(st.eti(b))
+    for b, w in enumerate(want):
+        assert np.array_equal(np.concatenate(got[b]), w), b
+    st.close()
+    for _, _, bufs in dsegs:
+        for buf in bufs:
+            buf.free()
     # misuse: feeding something else than the segment handed over first; three segments waiting
     st = dab.Stream(len(caps))
     st.prefetch_ptrs(*segs[0][:2])
