@@ -464,13 +464,13 @@ int dabhip_dab_process_frame(dabhip_dab* d)
   }
   if (!d->eng.store_tf_bytes(d->slot, d->fic.data(), d->msc.data())) return -1;
   if (!d->eng.fic_decode_slots(d->slot, 1, d->fibs.data(), d->ok.data())) return -1;
-  std::vector<EtiJob> jobs;
+  JobList jobs;
   d->plane.on_tf(d->slot, d->fibs.data(), d->ok.data(), jobs);
   ++d->slot;
   if (jobs.empty()) return 0;
   std::vector<int> row_base = {15}, fib_base = {0};   // single stream: CIF 0 at logical row 15 (Engine::store_tf_bytes)
   std::vector<const ControlPlane*> planes = {&d->plane};
-  std::vector<const std::vector<EtiJob>*> job_lists = {&jobs};
+  std::vector<const JobList*> job_lists = {&jobs};
   if (!d->eng.msc_decode(job_lists, planes, row_base, fib_base)) return -1;
   if (!d->eng.read_eti(0, static_cast<int64_t>(jobs.size()), d->eti.data())) return -1;
   if (d->cb)
@@ -514,6 +514,7 @@ int dabhip_host_eti_header(const int32_t* hdr3, const int32_t* sub, uint8_t* out
     s.id = r[0]; s.slform = r[1]; s.uep_index = r[2]; s.start_cu = r[3];
     s.size_cu = r[4]; s.bitrate = r[5]; s.protlev = r[6]; s.ascty = r[7];
   }
+  info.rescan();
   return build_eti_header(out, info);
 }
 
@@ -522,13 +523,14 @@ int dabhip_host_control_replay(const uint8_t* fibs, const uint8_t* crc_ok, int n
 {
   if (!fibs || !crc_ok || !first_cif || !headers || !header_len) { set_error("host_control_replay: null argument"); return -1; }
   ControlPlane plane;
-  std::vector<EtiJob> jobs;
+  JobList jobs;
   for (int t = 0; t < ntf; ++t) plane.on_tf(t, fibs + static_cast<size_t>(t) * 384, crc_ok + static_cast<size_t>(t) * 12, jobs);
   const int n = static_cast<int>(jobs.size());
   for (int i = 0; i < n && i < cap_frames; ++i) {
     first_cif[i] = jobs[i].first_cif;
     header_len[i] = jobs[i].header_len;
-    std::memcpy(headers + static_cast<size_t>(i) * kEtiHeaderMax, jobs[i].header, kEtiHeaderMax);
+    std::memset(headers + static_cast<size_t>(i) * kEtiHeaderMax, 0, kEtiHeaderMax);
+    std::memcpy(headers + static_cast<size_t>(i) * kEtiHeaderMax, jobs.header(jobs[i]), static_cast<size_t>(jobs[i].header_len));
   }
   return n;
 }

@@ -25,7 +25,26 @@ struct EnsembleInfo {
   uint16_t eid = 0;
   uint8_t cif_hi = 0, cif_lo = 0;
   SubChannel sub[64];
+  // bookkeeping for speed only (the per-TF pass used to clear and walk all 64 slots, 2 KB, for ensembles that carry a dozen sub-channels):
+  // present = slots whose id is set (slot i holds id i), touched = slots written at all (FIG 0/2 may set ascty of a slot without an id)
+  uint64_t present = 0, touched = 0;
+  // after filling sub[] by hand (dabhip_host_eti_header): derive the masks from the slots
+  void rescan()
+  {
+    present = touched = 0;
+    for (int i = 0; i < 64; ++i)
+      if (sub[i].id >= 0) { present |= 1ull << i; touched |= 1ull << i; }
+  }
 };
+template <class F>
+inline void for_each_slot(uint64_t mask, F&& fn)     // ascending slot order, like the reference's loops over 64 slots
+{
+  while (mask) {
+    const int i = __builtin_ctzll(mask);
+    mask &= mask - 1;
+    fn(i);
+  }
+}
 
 // Parse the FIGs of one FIB into `info`.  `limit` bounds reads for FIGs whose length field
 // runs past the FIB: the reference reads on into the following FIBs / CRC flags of
@@ -49,6 +68,8 @@ inline void parse_fib(EnsembleInfo& info, const uint8_t* fib, const uint8_t* lim
           const int id = at(j) >> 2;
           SubChannel& sc = info.sub[id];
           sc.id = id;
+          info.present |= 1ull << id;
+          info.touched |= 1ull << id;
           sc.start_cu = ((at(j) & 3) << 8) | at(j + 1);
           sc.slform = at(j + 2) >> 7;
           if (!sc.slform) {
@@ -72,7 +93,10 @@ inline void parse_fib(EnsembleInfo& info, const uint8_t* fib, const uint8_t* lim
           const int ncomp = at(j) & 0x0f;
           ++j;
           for (int k = 0; k < ncomp; ++k) {
-            if ((at(j) >> 6) == 0) info.sub[at(j + 1) >> 2].ascty = at(j) & 0x3f;
+            if ((at(j) >> 6) == 0) {
+              info.sub[at(j + 1) >> 2].ascty = at(j) & 0x3f;
+              info.touched |= 1ull << (at(j + 1) >> 2);
+            }
             j += 2;
           }
         }
@@ -87,7 +111,10 @@ inline void decode_fibs(EnsembleInfo& info, const uint8_t* fibs /*12 x 32*/, con
   uint8_t image[12 * 32 + 12];
   std::memcpy(image, fibs, 12 * 32);
   std::memcpy(image + 12 * 32, crc_ok, 12);
-  info = EnsembleInfo{};
+  for_each_slot(info.touched, [&](int i) { info.sub[i] = SubChannel{}; });     // = info = EnsembleInfo{}: untouched slots are pristine
+  info.present = info.touched = 0;
+  info.eid = 0;
+  info.cif_hi = info.cif_lo = 0;
   for (int f = 0; f < 12; ++f)
     if (crc_ok[f]) parse_fib(info, image + 32 * f, image + sizeof image);
 }
@@ -103,22 +130,21 @@ inline int build_eti_header(uint8_t* eti, const EnsembleInfo& info, uint64_t kee
   eti[n++] = odd ? 0xc5 : 0x3a;
   eti[n++] = odd ? 0x49 : 0xb6;
   eti[n++] = info.cif_lo;                                       // FCT
-  for (const SubChannel& sc : info.sub)
-    if (sc.id >= 0 && ((keep >> sc.id) & 1)) { ++nst; fl += sc.bitrate * 3 / 4; }
+  for_each_slot(info.present & keep, [&](int i) { ++nst; fl += info.sub[i].bitrate * 3 / 4; });
   fl += nst + 1 + 24;                                           // STC + EOH + FIC (Mode I) in words
   eti[n++] = static_cast<uint8_t>(0x80 | nst);                  // FICF | NST
   const int fp = (info.cif_hi * 250 + info.cif_lo) % 8;
   eti[n++] = static_cast<uint8_t>((fp << 5) | (1 << 3) | ((fl & 0x700) >> 8));   // FP, MID = 1, FL
   eti[n++] = static_cast<uint8_t>(fl & 0xff);
-  for (const SubChannel& sc : info.sub) {
-    if (sc.id < 0 || !((keep >> sc.id) & 1)) continue;
+  for_each_slot(info.present & keep, [&](int i) {
+    const SubChannel& sc = info.sub[i];
     const int tpl = sc.slform ? (0x20 | sc.protlev) : (0x10 | (sc.protlev - 1));
     const int stl = sc.bitrate * 3 / 8;
     eti[n++] = static_cast<uint8_t>((sc.id << 2) | ((sc.start_cu & 0x300) >> 8));
     eti[n++] = static_cast<uint8_t>(sc.start_cu & 0xff);
     eti[n++] = static_cast<uint8_t>((tpl << 2) | ((stl & 0x300) >> 8));
     eti[n++] = static_cast<uint8_t>(stl & 0xff);
-  }
+  });
   eti[n++] = 0xff;                                              // MNSC
   eti[n++] = 0xff;
   const uint16_t hcrc = static_cast<uint16_t>(~crc16_ccitt(eti + 4, static_cast<size_t>(n - 4)));
@@ -134,7 +160,34 @@ struct EtiJob {
   int32_t first_cif;
   int32_t layout;                  // index into ControlPlane::layouts()
   int32_t header_len;
-  uint8_t header[kEtiHeaderMax];
+  int32_t header_off;              // the header's bytes: JobList::header(job)
+};
+// The jobs of one stream and their header bytes, back to back.  (A fixed 272-byte header inside every record -- room for 64 sub-channels --
+// made the control-plane pass write 18 MB per benchmark step for headers of 60 bytes: its time was that memory traffic.)
+class JobList {
+ public:
+  size_t size() const { return jobs_.size(); }
+  bool empty() const { return jobs_.empty(); }
+  void clear() { jobs_.clear(); bytes_.clear(); }
+  void reserve(size_t n) { jobs_.reserve(n); bytes_.reserve(n * 64); }
+  std::vector<EtiJob>::const_iterator begin() const { return jobs_.begin(); }
+  std::vector<EtiJob>::const_iterator end() const { return jobs_.end(); }
+  const EtiJob& operator[](size_t i) const { return jobs_[i]; }
+  const uint8_t* header(const EtiJob& j) const { return bytes_.data() + j.header_off; }
+  // appends a job; build(dst) writes its header (at most kEtiHeaderMax bytes) and returns the length
+  template <class F>
+  void emplace(int32_t first_cif, int32_t layout, F&& build)
+  {
+    const size_t off = bytes_.size();
+    bytes_.resize(off + kEtiHeaderMax);
+    const int len = build(bytes_.data() + off);
+    bytes_.resize(off + static_cast<size_t>(len));
+    jobs_.push_back(EtiJob{first_cif, layout, len, static_cast<int32_t>(off)});
+  }
+
+ private:
+  std::vector<EtiJob> jobs_;
+  std::vector<uint8_t> bytes_;
 };
 
 class ControlPlane {
@@ -147,7 +200,7 @@ class ControlPlane {
 
   // Feed the decoded FIBs of the next demodulated TF (ordinal = its index among the
   // stream's demodulated TFs).  Appends 0 or 4 jobs.  Mirrors dab_process_frame.
-  int on_tf(int ordinal, const uint8_t* fibs, const uint8_t* crc_ok, std::vector<EtiJob>& jobs)
+  int on_tf(int ordinal, const uint8_t* fibs, const uint8_t* crc_ok, JobList& jobs)
   {
     int ok_count = 0;
     for (int f = 0; f < 12; ++f) ok_count += crc_ok[f] ? 1 : 0;
@@ -166,21 +219,21 @@ class ControlPlane {
     if (!locked_) return 0;
 
     bool layout_changed = layouts_.empty();
-    for (int i = 0; i < 64; ++i) {
+    for_each_slot(tf_info_.present, [&](int i) {
       const SubChannel& s = tf_info_.sub[i];
-      if (s.id < 0) continue;
       SubChannel& d = ens_.sub[i];
       if (d.id != s.id || d.slform != s.slform || d.uep_index != s.uep_index || d.start_cu != s.start_cu ||
           d.size_cu != s.size_cu || d.bitrate != s.bitrate || d.protlev != s.protlev)
         layout_changed = true;
       d = s;
-    }
+    });
+    ens_.present |= tf_info_.present;
+    ens_.touched |= tf_info_.present;
     ens_.eid = tf_info_.eid;
     if (ens_.cif_hi == 0xff) { ens_.cif_hi = tf_info_.cif_hi; ens_.cif_lo = tf_info_.cif_lo; }
     if (layout_changed) {
       std::vector<SubChannel> active;
-      for (const SubChannel& sc : ens_.sub)
-        if (sc.id >= 0 && ((keep_ >> sc.id) & 1)) active.push_back(sc);
+      for_each_slot(ens_.present & keep_, [&](int i) { active.push_back(ens_.sub[i]); });
       layouts_.push_back(std::move(active));
     }
 
@@ -190,11 +243,7 @@ class ControlPlane {
       return 0;
     }
     for (int i = 0; i < 4; ++i) {    // emit the oldest CIF, then slide (dab.c:85-95)
-      jobs.emplace_back();           // built in place: the record is 284 bytes, 50 k of them per benchmark step
-      EtiJob& job = jobs.back();
-      job.first_cif = ring_first_++;
-      job.layout = static_cast<int32_t>(layouts_.size()) - 1;
-      job.header_len = build_eti_header(job.header, ens_, keep_);
+      jobs.emplace(ring_first_++, static_cast<int32_t>(layouts_.size()) - 1, [&](uint8_t* dst) { return build_eti_header(dst, ens_, keep_); });
       if (++ens_.cif_lo == 250) {
         ens_.cif_lo = 0;
         if (++ens_.cif_hi == 20) ens_.cif_hi = 0;

@@ -311,7 +311,7 @@ bool Engine::fic_decode_slots_async(int first, int n, uint8_t* fibs_host, uint8_
          check(hipEventRecord(ev_fibs_, copy), "fib download event");
 }
 
-bool Engine::msc_prepare(const std::vector<const std::vector<EtiJob>*>& stream_jobs, const std::vector<const ControlPlane*>& planes,
+bool Engine::msc_prepare(const std::vector<const JobList*>& stream_jobs, const std::vector<const ControlPlane*>& planes,
                          const std::vector<int>& stream_row_base, const std::vector<int>& stream_fib_base, MscWork& out)
 {
   static const bool trace_host = std::getenv("DABHIP_TRACE_HOST") != nullptr;
@@ -875,7 +875,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   // control plane + work lists on a host thread, hidden behind the MSC symbols' part of the OFDM stage
   std::vector<ControlPlane>& planes = planes_;
   // host work lists live in the engine: ~35 MB per step at the benchmark size, reused instead of re-allocated
-  std::vector<std::vector<EtiJob>>& stream_jobs = stream_jobs_;
+  std::vector<JobList>& stream_jobs = stream_jobs_;
   stream_jobs.resize(nstreams);
   for (auto& v : stream_jobs) v.clear();
   MscWork& work = work_;
@@ -898,7 +898,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
         planes[b].on_tf(s - tf_base[b], fibs + static_cast<size_t>(s) * 384, ok + static_cast<size_t>(s) * 12, stream_jobs[b]);
     });
     std::vector<const ControlPlane*> plane_ptrs(nstreams);
-    std::vector<const std::vector<EtiJob>*> job_ptrs(nstreams);
+    std::vector<const JobList*> job_ptrs(nstreams);
     total_eti_ = 0;
     for (int b = 0; b < nstreams; ++b) {
       plane_ptrs[b] = &planes[b];

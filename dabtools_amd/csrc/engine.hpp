@@ -204,13 +204,13 @@ class Engine {
   bool fic_decode_slots_async(int first, int n, uint8_t* fibs_host, uint8_t* ok_host, hipStream_t copy);   // completion: ev_fibs_
   // decode the ETI frames described by the per-stream job lists into the ETI buffer (stream-major order)
   // stream_row_base[b]: logical CIF row of stream b's CIF 0; stream_fib_base[b]: FIB block (4 per TF slot) of its CIF 0
-  bool msc_decode(const std::vector<const std::vector<EtiJob>*>& stream_jobs, const std::vector<const ControlPlane*>& planes,
+  bool msc_decode(const std::vector<const JobList*>& stream_jobs, const std::vector<const ControlPlane*>& planes,
                   const std::vector<int>& stream_row_base, const std::vector<int>& stream_fib_base)
   {
     return msc_prepare(stream_jobs, planes, stream_row_base, stream_fib_base, work_s3_) && msc_run(work_s3_);   // reused: its lists are page-locked
   }
   // host half (work lists, headers, plans) and GPU half (regroup, Viterbi, ETI finish) of msc_decode
-  bool msc_prepare(const std::vector<const std::vector<EtiJob>*>& stream_jobs, const std::vector<const ControlPlane*>& planes,
+  bool msc_prepare(const std::vector<const JobList*>& stream_jobs, const std::vector<const ControlPlane*>& planes,
                    const std::vector<int>& stream_row_base, const std::vector<int>& stream_fib_base, MscWork& out);
   bool msc_run(MscWork& w);
   bool msc_upload(const MscWork& w, hipStream_t s);
@@ -302,7 +302,7 @@ class Engine {
   DeviceBuffer<uint8_t> d_headers_, d_eti_, d_bytes_;
   int tf_slots_ = 0, msc_rows_ = 0;
 
-  std::vector<std::vector<EtiJob>> stream_jobs_;
+  std::vector<JobList> stream_jobs_;
   MscWork work_, work_s3_;
   // session state (decode() resets it, feed() continues it)
   std::vector<ControlPlane> planes_;

@@ -139,7 +139,7 @@ void plan_decode_batch(DecodeBatchT<Alloc>& b, int64_t max_rows)
 // stream_row_base[b]: logical CIF row of stream b's CIF 0; stream_fib_base[b]: FIB block (4 per TF slot) of its CIF 0.
 // Returns false (with *error set) when a multiplex does not fit an ETI frame.
 template <template <class> class Alloc>
-bool prepare_msc_work(PlanTable& plans, ThreadPool& pool, const std::vector<const std::vector<EtiJob>*>& stream_jobs,
+bool prepare_msc_work(PlanTable& plans, ThreadPool& pool, const std::vector<const JobList*>& stream_jobs,
                       const std::vector<const ControlPlane*>& planes, const std::vector<int>& stream_row_base,
                       const std::vector<int>& stream_fib_base, int64_t max_rows, MscWorkT<Alloc>& out, std::string* error,
                       const std::function<void(const char*)>& mark = nullptr)
@@ -240,7 +240,7 @@ bool prepare_msc_work(PlanTable& plans, ThreadPool& pool, const std::vector<cons
       runs[b].back().second.second = static_cast<int>(f) + 1;
       jobs[f] = DecodeJob{static_cast<int32_t>(b), job.first_cif};
       meta[f] = EtiFrameMeta{job.header_len, layouts[gid].mst_bytes, stream_fib_base[b] + job.first_cif, 0};
-      std::memcpy(headers.data() + f * header_stride, job.header, static_cast<size_t>(job.header_len));
+      std::memcpy(headers.data() + f * header_stride, stream_jobs[b]->header(job), static_cast<size_t>(job.header_len));
       ++f;
     }
   });

@@ -98,7 +98,7 @@ static void control_and_worklist(int nstreams, int ntf, int64_t max_rows, unsign
       ok[static_cast<size_t>(b)][static_cast<size_t>(12 * (ntf - 4) + 4)] = 0;
   }
   std::vector<ControlPlane> planes(static_cast<size_t>(nstreams));
-  std::vector<std::vector<EtiJob>> jobs(static_cast<size_t>(nstreams));
+  std::vector<JobList> jobs(static_cast<size_t>(nstreams));
   pool.parallel_for(nstreams, [&](int b) {
     const size_t sb = static_cast<size_t>(b);
     planes[sb] = ControlPlane();
@@ -106,7 +106,7 @@ static void control_and_worklist(int nstreams, int ntf, int64_t max_rows, unsign
     for (int t = 0; t < ntf; ++t) planes[sb].on_tf(t, fibs[sb].data() + static_cast<size_t>(t) * 384, ok[sb].data() + static_cast<size_t>(t) * 12, jobs[sb]);
   });
   std::vector<const ControlPlane*> plane_ptrs;
-  std::vector<const std::vector<EtiJob>*> job_ptrs;
+  std::vector<const JobList*> job_ptrs;
   std::vector<int> row_base, fib_base;
   size_t nf = 0;
   for (int b = 0; b < nstreams; ++b) {
@@ -131,7 +131,7 @@ static void control_and_worklist(int nstreams, int ntf, int64_t max_rows, unsign
     for (const EtiJob& j : jobs[static_cast<size_t>(b)]) {
       CHECK(work.jobs[f].stream == b && work.jobs[f].cif == j.first_cif);
       CHECK(work.meta[f].header_len == j.header_len && work.meta[f].fib_block == fib_base[static_cast<size_t>(b)] + j.first_cif);
-      CHECK(std::memcmp(work.headers.data() + f * static_cast<size_t>(work.header_stride), j.header, static_cast<size_t>(j.header_len)) == 0);
+      CHECK(std::memcmp(work.headers.data() + f * static_cast<size_t>(work.header_stride), jobs[static_cast<size_t>(b)].header(j), static_cast<size_t>(j.header_len)) == 0);
       CHECK(12 + 96 + work.meta[f].mst_bytes + 8 <= 6144 + 12);
       ++f;
     }
