@@ -232,6 +232,7 @@ class ControlPlane {
     ens_.eid = tf_info_.eid;
     if (ens_.cif_hi == 0xff) { ens_.cif_hi = tf_info_.cif_hi; ens_.cif_lo = tf_info_.cif_lo; }
     if (layout_changed) {
+      hdr_valid_ = false;
       std::vector<SubChannel> active;
       for_each_slot(ens_.present & keep_, [&](int i) { active.push_back(ens_.sub[i]); });
       layouts_.push_back(std::move(active));
@@ -243,7 +244,7 @@ class ControlPlane {
       return 0;
     }
     for (int i = 0; i < 4; ++i) {    // emit the oldest CIF, then slide (dab.c:85-95)
-      jobs.emplace(ring_first_++, static_cast<int32_t>(layouts_.size()) - 1, [&](uint8_t* dst) { return build_eti_header(dst, ens_, keep_); });
+      jobs.emplace(ring_first_++, static_cast<int32_t>(layouts_.size()) - 1, [&](uint8_t* dst) { return frame_header(dst); });
       if (++ens_.cif_lo == 250) {
         ens_.cif_lo = 0;
         if (++ens_.cif_hi == 20) ens_.cif_hi = 0;
@@ -257,7 +258,54 @@ class ControlPlane {
   // streaming use: CIF indices are rebased when old TF slots are dropped
   void rebase(int cif_shift) { ring_first_ -= cif_shift; }
   // sub-channel filter: only these SubChIds are listed in the STC, decoded and carried (set before the first frame)
-  void set_filter(uint64_t keep) { keep_ = keep; }
+  void set_filter(uint64_t keep) { keep_ = keep; hdr_valid_ = false; }
+  // The ETI header of the frame with the current CIF counter (= build_eti_header(dst, ens_, keep_), byte for byte).  Between two changes of the
+  // multiplex only FSYNC, FCT and FP move from frame to frame; the rest -- and the header CRC up to the contribution of those two bytes, the
+  // CRC being linear over GF(2) -- is kept per layout: a copy, three patches and two table look-ups instead of two walks over the sub-channels and
+  // a 56-byte CRC chain per frame (four frames per TF: it was four fifths of the control-plane pass).
+  int frame_header(uint8_t* dst)
+  {
+    if (!hdr_valid_) {
+      const uint8_t hi = ens_.cif_hi, lo = ens_.cif_lo;
+      ens_.cif_hi = ens_.cif_lo = 0;                       // base: FCT 0, FP 0, even FSYNC
+      hdr_len_ = build_eti_header(hdr_base_, ens_, keep_);
+      ens_.cif_hi = hi;
+      ens_.cif_lo = lo;
+      const size_t span = static_cast<size_t>(hdr_len_) - 6;      // the CRC covers bytes 4 .. len - 3
+      base_crc_ = crc16_ccitt(hdr_base_ + 4, span);
+      // contributions of the 8 FCT bits (CRC byte 0) and the 3 FP bits (CRC byte 2, bits 7..5): 11 chains, the tables are their XOR combinations
+      uint8_t delta[kEtiHeaderMax] = {0};
+      uint16_t bit_fct[8], bit_fp[3];
+      for (int b = 0; b < 8; ++b) {
+        delta[0] = static_cast<uint8_t>(1 << b);
+        bit_fct[b] = crc16_ccitt(delta, span, 0);
+      }
+      delta[0] = 0;
+      for (int b = 0; b < 3; ++b) {
+        delta[2] = static_cast<uint8_t>(0x20 << b);
+        bit_fp[b] = crc16_ccitt(delta, span, 0);
+      }
+      t_fct_[0] = t_fp_[0] = 0;
+      for (int v = 1; v < 256; ++v) t_fct_[v] = t_fct_[v & (v - 1)] ^ bit_fct[__builtin_ctz(v)];
+      for (int f = 1; f < 8; ++f) t_fp_[f] = t_fp_[f & (f - 1)] ^ bit_fp[__builtin_ctz(f)];
+      hdr_valid_ = true;
+    }
+    std::memcpy(dst, hdr_base_, static_cast<size_t>(hdr_len_));
+    const bool odd = ens_.cif_lo & 1;
+    dst[1] = odd ? 0xf8 : 0x07;
+    dst[2] = odd ? 0xc5 : 0x3a;
+    dst[3] = odd ? 0x49 : 0xb6;
+    dst[4] = ens_.cif_lo;
+    const int fp = (ens_.cif_hi * 250 + ens_.cif_lo) % 8;
+    dst[6] = static_cast<uint8_t>(hdr_base_[6] | (fp << 5));
+    const uint16_t hcrc = static_cast<uint16_t>(~(base_crc_ ^ t_fct_[ens_.cif_lo] ^ t_fp_[fp]));
+    dst[hdr_len_ - 2] = static_cast<uint8_t>(hcrc >> 8);
+    dst[hdr_len_ - 1] = static_cast<uint8_t>(hcrc & 0xff);
+    return hdr_len_;
+  }
+  // (tests) the current ensemble, to hold frame_header() against build_eti_header()
+  const EnsembleInfo& ensemble() const { return ens_; }
+  uint64_t filter() const { return keep_; }
 
  private:
   EnsembleInfo tf_info_, ens_;
@@ -265,6 +313,10 @@ class ControlPlane {
   uint64_t keep_ = ~0ull;
   int okcount_ = 0, ncifs_ = 0, ring_first_ = 0;
   std::vector<std::vector<SubChannel>> layouts_;
+  bool hdr_valid_ = false;
+  int hdr_len_ = 0;
+  uint16_t base_crc_ = 0, t_fct_[256], t_fp_[8];
+  uint8_t hdr_base_[kEtiHeaderMax];
 };
 
 }  // namespace dabhip

@@ -103,7 +103,14 @@ static void control_and_worklist(int nstreams, int ntf, int64_t max_rows, unsign
     const size_t sb = static_cast<size_t>(b);
     planes[sb] = ControlPlane();
     if (b % 7 == 6) planes[sb].set_filter(0x6ull);                 // sub-channel filter: SubChIds 1 and 2 only
-    for (int t = 0; t < ntf; ++t) planes[sb].on_tf(t, fibs[sb].data() + static_cast<size_t>(t) * 384, ok[sb].data() + static_cast<size_t>(t) * 12, jobs[sb]);
+    for (int t = 0; t < ntf; ++t) {
+      planes[sb].on_tf(t, fibs[sb].data() + static_cast<size_t>(t) * 384, ok[sb].data() + static_cast<size_t>(t) * 12, jobs[sb]);
+      if (planes[sb].locked() && t >= 10) {                // the cached header against the straightforward builder, at this TF's CIF counter
+        uint8_t fast[kEtiHeaderMax], slow[kEtiHeaderMax];
+        const int n1 = planes[sb].frame_header(fast), n2 = build_eti_header(slow, planes[sb].ensemble(), planes[sb].filter());
+        CHECK(n1 == n2 && std::memcmp(fast, slow, static_cast<size_t>(n1)) == 0);
+      }
+    }
   });
   std::vector<const ControlPlane*> plane_ptrs;
   std::vector<const JobList*> job_ptrs;
