@@ -82,7 +82,7 @@ def main():
            "oracle_byte_equal": "%d of %d sampled streams" % (oracle_equal, len(sample)), "sharding_rule_ok": sharding_ok,
            "wall_ms_per_decode": [round(w, 2) for w in walls], "value_one_gpu_time_sliced": total / (best * 1e-3), "unit": "ETI frames/s (ONE GPU)",
            "slice_wall_ms_last": [round(w, 2) for w in slice_walls[-1]], "per_slice_last": host,
-           "single_engine_reference": "one engine alone at 256 streams: about 11.4 ms per decode, control 1.0-1.2 ms, work lists 0.45-0.6 ms (profiles/r03_bench.json)"}
+           "single_engine_reference": "one engine alone at 256 streams: about 11.4 ms per decode, control 0.52-0.55 ms, work lists 0.4-0.76 ms (profiles/r03_bench.json)"}
     print(json.dumps(out))
     ok = out["all_streams_full_count"] and oracle_equal == len(sample) and total == n * want_per_stream and sharding_ok
     sys.exit(0 if ok else 1)
