@@ -25,8 +25,24 @@
 namespace dabhip {
 namespace {
 
-// the transform of k_fft.hip's fft2048_store with the bins left in registers:
-// x[k3] = bin 2 tid + 512 k3, y[k3] = bin 2 tid + 1 + 512 k3
+// The transform of k_fft.hip's fft2048_store (same butterflies, same factors, same roundings) with the bins left in registers and only TWO
+// trips through LDS and two workgroup barriers per symbol.  Index digits: n = 256 a + 32 b + 4 c + d, bin k = a' + 8 b' + 64 c' + 512 d'.
+//   stage A (thread = (b, c, d) = tid):                              DFT-8 over a, factors W_2048^(a' tid)      -> P[a'][tid]        barrier
+//   stage B (thread = (a' = tid >> 5, (c, d) = tid & 31)):           DFT-8 over b, factors W_256^(b' (4c + d))   -> Q (below)         barrier
+//   stage C (lane = a' | b'_0 << 3 | d << 4, wave = b' >> 1):         DFT-8 over c, factors W_32^(c' d)
+//   stage D: DFT-4 over d.  Its four inputs sit in four lanes of the SAME wave that differ in lane bits 4 and 5 only, so the last exchange is
+//   a transposition of (lane bits 4, 5) with (register bits 0, 1): eight v_permlane16_swap + eight v_permlane32_swap (gfx950), no LDS, no barrier.
+// Afterwards the thread holds x[k3] = bin a' + 8 b' + 64 c' + 512 k3 with c' = (tid >> 4 & 3), y[k3] = the same with c' + 4 (fused_bin below).
+// Any bin-to-thread assignment serves this kernel: the decisions go wherever the de-interleaver table says (ak[] in the kernel's prologue).
+// With no third trip the two exchange arrays keep their roles for every symbol: P is rewritten by the next symbol's stage A after this symbol's
+// second barrier (its last readers, stage B, came before it), Q by the next stage B after the next first barrier (its readers, stage C, before it).
+// Round 3: 3 barriers + 3 trips -> 2 + 2.
+constexpr int kQStride = 260;                           // [a'] stride of Q in float2: 8 x 32 + 4, so that the 32 lanes (a', b'_0, d_0) of a stage-C read cover 32 bank pairs
+constexpr int kPSize = 8 * 256, kQSize = 8 * kQStride;  // float2 each
+__device__ __forceinline__ int fused_bin(int tid, int m)   // raw bin of x[m >> 1] (m even) / y[m >> 1] (m odd) of thread tid
+{
+  return (tid & 7) + 8 * (((tid >> 3) & 1) | ((tid >> 6) << 1)) + 64 * (((tid >> 4) & 3) + 4 * (m & 1)) + 512 * (m >> 1);
+}
 __device__ __forceinline__ void fft2048_first(float2 (&v)[8], float2* bufP, const Twiddles& tw)
 {
   const int tid = threadIdx.x;
@@ -37,7 +53,25 @@ __device__ __forceinline__ void fft2048_first(float2 (&v)[8], float2* bufP, cons
   for (int q = 0; q < 8; ++q) bufP[q * 256 + tid] = v[q];
   __syncthreads();
 }
-__device__ __forceinline__ void fft2048_rest(float2 (&v)[8], float2* bufP, float2* bufQ, const Twiddles& tw, float2 (&x)[4], float2 (&y)[4])
+// The transposition of stage D (see above) on the eight complex registers of a thread: (lane bit 4 <-> register bit 0) by v_permlane16_swap (rows 1, 3
+// of the first operand <-> rows 0, 2 of the second), then (lane bit 5 <-> register bit 1) by v_permlane32_swap (upper half of the first <-> lower half of
+// the second); tools/ubench/lane_swap_check.hip prints what the two do, valu_rates.hip their rate (8.3 clocks each, a pair of moves' worth).  One asm
+// block: the s_nop covers the two wait states a swap needs after a VALU write of its operands (the compiler cannot see inside); every later swap
+// reads registers written at least three instructions earlier.  (The builtins of ROCm 7.2 miscompile this pattern: chained swaps of the same
+// registers came out with results folded together -- hence the asm.)
+__device__ __forceinline__ void transpose_lanes45(float2 (&v)[8])
+{
+  asm volatile(
+      "s_nop 1\n"
+      "v_permlane16_swap_b32 %0, %2\n v_permlane16_swap_b32 %1, %3\n v_permlane16_swap_b32 %4, %6\n v_permlane16_swap_b32 %5, %7\n"
+      "v_permlane16_swap_b32 %8, %10\n v_permlane16_swap_b32 %9, %11\n v_permlane16_swap_b32 %12, %14\n v_permlane16_swap_b32 %13, %15\n"
+      "v_permlane32_swap_b32 %0, %4\n v_permlane32_swap_b32 %1, %5\n v_permlane32_swap_b32 %2, %6\n v_permlane32_swap_b32 %3, %7\n"
+      "v_permlane32_swap_b32 %8, %12\n v_permlane32_swap_b32 %9, %13\n v_permlane32_swap_b32 %10, %14\n v_permlane32_swap_b32 %11, %15\n"
+      "s_nop 1"
+      : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[3].x), "+v"(v[3].y),
+        "+v"(v[4].x), "+v"(v[4].y), "+v"(v[5].x), "+v"(v[5].y), "+v"(v[6].x), "+v"(v[6].y), "+v"(v[7].x), "+v"(v[7].y));
+}
+__device__ __forceinline__ void fft2048_rest(float2 (&v)[8], const float2* bufP, float2* bufQ, const Twiddles& tw, float2 (&x)[4], float2 (&y)[4])
 {
   const int tid = threadIdx.x;
   {
@@ -47,25 +81,24 @@ __device__ __forceinline__ void fft2048_rest(float2 (&v)[8], float2* bufP, float
     dft8(v);
 #pragma unroll
     for (int q2 = 1; q2 < 8; ++q2) v[q2] = cmul(v[q2], tw.s2[q2 - 1]);
+    // Q[a'][b' >> 1][(c, d)][b' & 1]: the pair b' = 2 p, 2 p + 1 of one (c, d) leaves as one 16-byte store
+    float4* dst = reinterpret_cast<float4*>(bufQ) + q * (kQStride / 2) + t1;
 #pragma unroll
-    for (int q2 = 0; q2 < 8; ++q2) bufQ[q * kEx2Stride + q2 * 32 + t1] = v[q2];
+    for (int p = 0; p < 4; ++p) dst[32 * p] = make_float4(v[2 * p].x, v[2 * p].y, v[2 * p + 1].x, v[2 * p + 1].y);
   }
   __syncthreads();
   {
-    const int q = tid & 7, t2 = (tid >> 3) & 3, q2 = tid >> 5;
+    const int q = tid & 7, q2 = ((tid >> 3) & 1) | ((tid >> 6) << 1), t2 = (tid >> 4) & 3;
+    const float2* src = bufQ + q * kQStride + 64 * (q2 >> 1) + 2 * t2 + (q2 & 1);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = bufQ[q * kEx2Stride + q2 * 32 + t2 + 4 * r];
+    for (int r = 0; r < 8; ++r) v[r] = src[8 * r];
     dft8(v);
 #pragma unroll
     for (int q3 = 1; q3 < 8; ++q3) v[q3] = cmul(v[q3], tw.s3[q3]);
-#pragma unroll
-    for (int q3 = 0; q3 < 8; ++q3) bufP[t2 * kEx3Stride + q + 8 * q2 + 64 * q3] = v[q3];
   }
-  __syncthreads();
-  const float4* src = reinterpret_cast<const float4*>(bufP);
-  const float4 a0 = src[tid], a1 = src[kEx3Stride / 2 + tid], a2 = src[kEx3Stride + tid], a3 = src[3 * kEx3Stride / 2 + tid];
-  x[0] = make_float2(a0.x, a0.y); x[1] = make_float2(a1.x, a1.y); x[2] = make_float2(a2.x, a2.y); x[3] = make_float2(a3.x, a3.y);
-  y[0] = make_float2(a0.z, a0.w); y[1] = make_float2(a1.z, a1.w); y[2] = make_float2(a2.z, a2.w); y[3] = make_float2(a3.z, a3.w);
+  transpose_lanes45(v);                                // register r now holds d = r & 3 of c' = (lane bits 4, 5) + (r & 4)
+#pragma unroll
+  for (int k3 = 0; k3 < 4; ++k3) { x[k3] = v[k3]; y[k3] = v[4 + k3]; }
   dft4(x[0], x[1], x[2], x[3]);
   dft4(y[0], y[1], y[2], y[3]);
 }
@@ -127,7 +160,7 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
     }
   }
 #if DABHIP_FUSED_GUARD
-  if (any && guard.g.delta != nullptr) {                  // rare: which bins?  bin m of thread t is raw bin 2 t + 512 (m >> 1) + (m & 1)
+  if (any && guard.g.delta != nullptr) {                  // rare: which bins?  bin m of thread t is raw bin fused_bin(t, m)
     unsigned hits = 0;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -139,7 +172,7 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
       const unsigned m = __ffs(hits) - 1;
       hits &= hits - 1;
       const unsigned at = atomicAdd(guard.g.counter, 1u);
-      const unsigned k = 2u * threadIdx.x + 512u * (m >> 1) + (m & 1u);
+      const unsigned k = static_cast<unsigned>(fused_bin(threadIdx.x, static_cast<int>(m)));
       if (at < guard.g.cap) guard.g.list[at] = make_uint2(guard.frame, (static_cast<unsigned>(sym) << 16) | k);
     }
   }
@@ -309,7 +342,7 @@ __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t*
   unsigned raw[8];
   if (kFast) load_symbol<true>(fast_src, stream, view, sym_begin, raw);
   else load_symbol_view(stream, view, sym_begin, decA, raw);
-  // two symbols per trip: the LDS buffers swap roles every symbol, so the trip body sees them at fixed places
+  // two symbols per trip: the decision arrays swap roles every symbol, so the trip body sees them at fixed places
   for (int sym = sym_begin; sym < sym_end; sym += 2) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -326,7 +359,7 @@ __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t*
 #ifndef DABHIP_PROBE_NOENERGY
         if (guarded) symbol_energy_part(v, esum + 4 * h);
 #endif
-        fft2048_first(v, h ? exB : exA, tw);
+        fft2048_first(v, exA, tw);
 #ifndef DABHIP_PROBE_NOENERGY
         const float dcur = guarded ? symbol_bound(esum + 4 * h) : 0.0f;
 #else
@@ -335,8 +368,7 @@ __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t*
         // the barrier just passed also orders the previous symbol's decisions: they leave now, one symbol late, so that
         // the wait for the NEXT prefetch (issued above) never has to drain a store issued right before it
         if (have_out) flush_symbol(h ? decA : decB, s - 1, out);
-        if (h) fft2048_rest(v, exB, exA, tw, x, y);
-        else fft2048_rest(v, exA, exB, tw, x, y);
+        fft2048_rest(v, exA, exB, tw, x, y);
 #if DABHIP_FUSED_SOFT
         if (have_prev) decide(x, y, px, py, qk, h ? decB : decA, soft_scale(dcur, dprev));
 #else
@@ -373,8 +405,8 @@ __global__ __launch_bounds__(kThreads, DABHIP_FUSED_WG_PER_CU) void ofdm_demap_k
                                                                  uint32_t* __restrict__ fic_bits, uint32_t* __restrict__ msc_bits, const GuardArgs gargs,
                                                                  int sym_a, int sym_b, int nparts)
 {
-  __shared__ __attribute__((aligned(16))) float2 exA[kExSize];
-  __shared__ __attribute__((aligned(16))) float2 exB[kExSize];
+  __shared__ __attribute__((aligned(16))) float2 exA[kPSize];        // P: stage A -> B
+  __shared__ __attribute__((aligned(16))) float2 exB[kQSize];        // Q: stage B -> C
   __shared__ __attribute__((aligned(16))) uint8_t decA[kBitsPerSym], decB[kBitsPerSym];   // 3072 B each
   __shared__ FrameView view;
   __shared__ float2 tw3[4 * 8];
@@ -388,7 +420,7 @@ __global__ __launch_bounds__(kThreads, DABHIP_FUSED_WG_PER_CU) void ofdm_demap_k
   if (tid < 32) tw3[tid] = tw_global[64 * (tid >> 3) * (tid & 7)];
   Twiddles tw;
   {
-    const int t1 = tid & 31, t2 = (tid >> 3) & 3;
+    const int t1 = tid & 31, t2 = (tid >> 4) & 3;      // t2 = d of this thread in stage C (fft2048_rest)
 #pragma unroll
     for (int q = 1; q < 8; ++q) {
       tw.s1[q - 1] = tw_global[tid * q];
@@ -401,7 +433,7 @@ __global__ __launch_bounds__(kThreads, DABHIP_FUSED_WG_PER_CU) void ofdm_demap_k
   int qk[8];
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
-    const int k = 2 * tid + 512 * (m >> 1) + (m & 1);
+    const int k = fused_bin(tid, m);
     const int c = (k >= 1 && k <= 768) ? k + 767 : (k >= 1280 ? k - 1280 : -1);
     qk[m] = c >= 0 ? qpsk_of_carrier[c] : -1;
 #if DABHIP_FUSED_SOFT

@@ -1,0 +1,5 @@
+#!/bin/bash
+# bench lines of the library variants named in $VARIANTS (tools/build_variant.sh), no CPU baseline / host-fed leg
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out/variants
+BENCH_EXTRA="--no-h2d" bash tools/bench_variants.sh ${VARIANTS:-base} | tee gpurun_out/variants/lines.txt

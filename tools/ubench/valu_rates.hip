@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, int iters)
   for (int i = 0; i < 8; ++i) { a[i] = v2f{threadIdx.x * 1.0f + i, 0.5f * i}; u[i] = threadIdx.x * 7u + i; }
   const v2f m = v2f{1.0001f, 0.9999f}, c = v2f{0.001f, -0.001f};
   const unsigned k = 0x00030001u;
-  if (kOp == 36 || kOp == 37 || kOp == 44 || kOp == 45) asm volatile("s_mov_b64 vcc, 0x5555" : : : "vcc");
+  if (kOp == 36 || kOp == 37 || kOp == 44 || kOp == 45 || kOp == 53) asm volatile("s_mov_b64 vcc, 0x5555" : : : "vcc");
   if (kOp == 49) asm volatile("s_mov_b64 vcc, exec" : : : "vcc");
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -72,7 +72,12 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, int iters)
   if (kOp == 46) asm volatile("v_cndmask_b32_e64 %0, 0, 1, s[2:3]" : "=v"(u[i]));                                  \
   if (kOp == 47) asm volatile("v_cmp_lt_f32 vcc, %1, %2\n v_cndmask_b32 %0, %0, %3, vcc" : "+v"(u[i]) : "v"(a[i].x), "v"(c.x), "v"(k) : "vcc"); \
   if (kOp == 48) asm volatile("v_cmp_lt_f32_e64 s[4:5], %1, %2\n v_cndmask_b32_e64 %0, %0, %3, s[4:5]" : "+v"(u[i]) : "v"(a[i].x), "v"(c.x), "v"(k) : "s4", "s5"); \
-  if (kOp == 49) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(k));
+  if (kOp == 49) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(k));                              \
+  if (kOp == 50) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(u[i]), "+v"(u[(i + 1) & 7]));                  \
+  if (kOp == 51) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(u[i]), "+v"(u[(i + 1) & 7]));                  \
+  if (kOp == 52) asm volatile("v_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(u[i]) : "v"(u[(i + 1) & 7])); \
+  if (kOp == 53) asm volatile("v_cndmask_b32_dpp %0, %1, %2, vcc row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(k)); \
+  if (kOp == 54) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(u[i]), "+v"(u[i ^ 1]));
       REP8(OP)
 #undef OP
     }
@@ -102,10 +107,19 @@ double run(const char* name, float* out)
   return ms;
 }
 
-int main()
+int main(int argc, char** argv)
 {
   float* out;
   hipMalloc(&out, 256 * 8 * 256 * sizeof(float));
+  if (argc > 1) {                                    // "lanes": only the cross-lane moves (round 3)
+    run<26>("v_mov_b32", out);
+    run<50>("permlane32_swap", out);
+    run<51>("permlane16_swap", out);
+    run<54>("permlane32_swap pair", out);
+    run<52>("mov_dpp row_ror:8", out);
+    run<53>("cndmask_dpp ror:8", out);
+    return 0;
+  }
   run<0>("v_fma_f32", out);
   run<1>("v_pk_fma_f32", out);
   run<2>("v_pk_add_f32", out);
