@@ -138,46 +138,85 @@ __device__ __forceinline__ float l1norm(const float2 v)
 }
 #endif
 #if !DABHIP_FUSED_SOFT
-__device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4], const float2 (&px)[4], const float2 (&py)[4],
-                                       const int (&ak)[8], uint8_t* dec, const FusedGuard& guard, int sym, float dc, float dp)
-{
+// Which of the thread's eight bins carry a carrier is known at compile time for all but two: x[2] (bins 1024 + 0..255) never does, y[1] (bins
+// 768 + 0..255) only in thread 0 (bin 768, the last carrier of the upper half), and x[0] of thread 0 is the DC bin -- ak[] says so at run time.
+__device__ __forceinline__ bool bin_in_use(int m) { return m != 4; }
 #if DABHIP_FUSED_GUARD
-  bool any = false;
-#endif
+// Guarded build.  The decision bytes are the SIGN bits of re and im (one shift each; the flush inverts the words of the second bits): that equals the
+// reference's comparisons (input_sdr.c:157-158) for every value except an exact zero -- and a decision with a zero in it is always listed and re-decided in
+// fp64 (the test below), as is every decision inside the error band.  The in-loop test is one threshold per thread, made of the largest |bin|_1 among the
+// thread's bins of this symbol (maxc) and of the previous one (maxp; guard_threshold grows with both), against the smallest |re|, |im| of the thread: three
+// instructions per bin (|bin|_1, max, min3) instead of seven.  Only a thread that trips it repeats the exact per-bin test (rare), so the LIST is the one
+// the per-bin rule makes, plus the zeros.
+__device__ __forceinline__ float bins_l1max(const float2 (&x)[4], const float2 (&y)[4])
+{
+  float mx = 0.0f;
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+    if (bin_in_use(m)) mx = fmaxf(mx, l1norm((m & 1) ? y[m >> 1] : x[m >> 1]));
+  return mx;
+}
+__device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4], const float2 (&px)[4], const float2 (&py)[4],
+                                       const int (&ak)[8], uint8_t* dec, const FusedGuard& guard, int sym, float dc, float dp, float& maxp)
+{
+  float lo = __builtin_inff(), maxc = 0.0f;
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
+    if (!bin_in_use(m)) continue;
+    if (m == 3 && threadIdx.x != 0) continue;               // y[1]: thread 0 only (wave-uniform everywhere else)
+    const float2 cur = (m & 1) ? y[m >> 1] : x[m >> 1], prev = (m & 1) ? py[m >> 1] : px[m >> 1];
+    const float re = cur.x * prev.x + cur.y * prev.y;     // Re(cur conj(prev))
+    const float im = cur.x * prev.y - cur.y * prev.x;     // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
+    if (m == 0 && ak[0] < 0) continue;                      // the DC bin (thread 0)
+    dec[ak[m]] = static_cast<uint8_t>(__builtin_bit_cast(unsigned, re) >> 31);        // 1 = "not re > 0" (input_sdr.c:157), zeros aside
+    dec[ak[m] + 96] = static_cast<uint8_t>(__builtin_bit_cast(unsigned, im) >> 31);   // 0 = "im > 0" (input_sdr.c:158): inverted by the flush
+    asm("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(lo) : "v"(re), "v"(im));
+    maxc = fmaxf(maxc, l1norm(cur));
+  }
+#ifndef DABHIP_PROBE_NOTEST
+  const bool any = !(lo > guard_threshold(maxc, maxp, dc, dp));
+#else
+  const bool any = false;
+#endif
+  maxp = maxc;
+  if (any) {                                              // rare: which bins?  bin m of thread t is raw bin fused_bin(t, m)
+    unsigned hits = 0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      if (!bin_in_use(m)) continue;
+      const float2 cur = (m & 1) ? y[m >> 1] : x[m >> 1], prev = (m & 1) ? py[m >> 1] : px[m >> 1];
+      const float re = cur.x * prev.x + cur.y * prev.y, im = cur.x * prev.y - cur.y * prev.x;
+      const float least = fminf(fabsf(re), fabsf(im));
+      hits |= (ak[m] >= 0 && (least < guard_threshold(l1norm(cur), l1norm(prev), dc, dp) || !(least > 0.0f)) ? 1u : 0u) << m;
+    }
+    while (hits) {
+      const unsigned m = __ffs(hits) - 1;
+      hits &= hits - 1;
+      if (guard.g.delta == nullptr) continue;             // (never in this build: the engine runs the plain kernel when the guard is off)
+      const unsigned at = atomicAdd(guard.g.counter, 1u);
+      const unsigned k = static_cast<unsigned>(fused_bin(threadIdx.x, static_cast<int>(m)));
+      if (at < guard.g.cap) guard.g.list[at] = make_uint2(guard.frame, (static_cast<unsigned>(sym) << 16) | k);
+    }
+  }
+}
+#else
+// Plain build (no guard, also the software-AFC variant): the reference's comparisons as they stand.
+__device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4], const float2 (&px)[4], const float2 (&py)[4],
+                                       const int (&ak)[8], uint8_t* dec, const FusedGuard&, int, float, float, float&)
+{
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    if (!bin_in_use(m)) continue;
     const float2 cur = (m & 1) ? y[m >> 1] : x[m >> 1], prev = (m & 1) ? py[m >> 1] : px[m >> 1];
     const float re = cur.x * prev.x + cur.y * prev.y;     // Re(cur conj(prev))
     const float im = cur.x * prev.y - cur.y * prev.x;     // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
     if (ak[m] >= 0) {                                     // bins without a carrier (DC, guard bands) decide nothing
       dec[ak[m]] = (re > 0.0f) ? 0 : 1;                   // input_sdr.c:157
       dec[ak[m] + 96] = (im > 0.0f) ? 1 : 0;              // input_sdr.c:158
-#if DABHIP_FUSED_GUARD
-#ifndef DABHIP_PROBE_NOTEST
-      any |= fminf(fabsf(re), fabsf(im)) < guard_threshold(l1norm(cur), l1norm(prev), dc, dp);
-#endif
-#endif
     }
   }
-#if DABHIP_FUSED_GUARD
-  if (any && guard.g.delta != nullptr) {                  // rare: which bins?  bin m of thread t is raw bin fused_bin(t, m)
-    unsigned hits = 0;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const float2 cur = (m & 1) ? y[m >> 1] : x[m >> 1], prev = (m & 1) ? py[m >> 1] : px[m >> 1];
-      const float re = cur.x * prev.x + cur.y * prev.y, im = cur.x * prev.y - cur.y * prev.x;
-      hits |= (ak[m] >= 0 && fminf(fabsf(re), fabsf(im)) < guard_threshold(l1norm(cur), l1norm(prev), dc, dp) ? 1u : 0u) << m;
-    }
-    while (hits) {
-      const unsigned m = __ffs(hits) - 1;
-      hits &= hits - 1;
-      const unsigned at = atomicAdd(guard.g.counter, 1u);
-      const unsigned k = static_cast<unsigned>(fused_bin(threadIdx.x, static_cast<int>(m)));
-      if (at < guard.g.cap) guard.g.list[at] = make_uint2(guard.frame, (static_cast<unsigned>(sym) << 16) | k);
-    }
-  }
-#endif
 }
+#endif
 #else
 // 4-bit soft values (extension): round(scale x) clamped to +-7, positive = "bit 0"; x = Re for the first
 // bit and Im(cur conj(prev)) = -im for the second; scale = soft_scale(dc, dp) (device_types.hpp).  One byte per value, placed
@@ -231,7 +270,8 @@ __device__ __forceinline__ float symbol_bound(const int* esum)
 }
 
 #if !DABHIP_FUSED_SOFT
-// 32 decision bytes -> one output word, by thread t < 96
+// 32 decision bytes (0 / 1) -> one output word, by thread t < 96: v_dot4_u32_u8 with the weights 1, 2, 4, 8 / 16, 32, 64, 128 gathers eight of them
+// into a byte (the multiply-and-shift this replaces cost four times as much: v_mul_lo_u32 is a quarter-rate instruction).
 __device__ __forceinline__ uint32_t pack_word(const uint8_t* dec, int t)
 {
   const uint4* p = reinterpret_cast<const uint4*>(dec + 32 * t);
@@ -239,7 +279,10 @@ __device__ __forceinline__ uint32_t pack_word(const uint8_t* dec, int t)
   const uint32_t d[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
   uint32_t w = 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) w |= ((d[k] * 0x01020408u) >> 24 & 15u) << (4 * k);   // bytes b0..b3 (0/1) -> b0 | b1<<1 | b2<<2 | b3<<3
+  for (int k = 3; k >= 0; --k) {
+    const uint32_t byte = __builtin_amdgcn_udot4(d[2 * k], 0x08040201u, __builtin_amdgcn_udot4(d[2 * k + 1], 0x80402010u, 0u, false), false);
+    w = (w << 8) | byte;
+  }
   return w;
 }
 #endif
@@ -312,11 +355,17 @@ __device__ __forceinline__ void flush_symbol(const uint8_t* dec, int sym, const 
       const uint32_t u = *reinterpret_cast<const uint16_t*>(src + 192 * j);
       bits |= ((u & 1u) << j) | ((u >> 8) << (16 + j));
     }
+#if DABHIP_FUSED_GUARD
+    if (tid >= 48) bits = ~bits;                          // second bits of the carriers: the bytes hold the sign of im (decide)
+#endif
     o.fic_row[(sym - 1) * 96 + tid] = bits;
   } else {
-    const uint32_t bits = pack_word(dec, tid);
+    uint32_t bits = pack_word(dec, tid);
     const int q = (sym - 4) / 18, sidx = (sym - 4) % 18;
     const int r = tid / 6, wq = tid % 6;
+#if DABHIP_FUSED_GUARD
+    if (wq >= 3) bits = ~bits;                            // words 3..5 of a plane: the second bits (sign of im, see decide)
+#endif
     const int delay = static_cast<int>(__brev(static_cast<unsigned>(r)) >> 28);   // map[r], misc.c:32
     o.msc[static_cast<size_t>(o.cif_row + q - delay) * 1728 + r * 108 + sidx * 6 + wq] = bits;
   }
@@ -328,7 +377,7 @@ template <bool kFast, bool kNco>
 __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t* stream, const FrameView& view, int sym_begin, int sym_end,
                                               bool have_prev, float2 (&px)[4], float2 (&py)[4], float2* exA, float2* exB, uint8_t* decA,
                                               uint8_t* decB, const Twiddles& tw, const int (&qk)[8], uint32_t nco_inc, const FusedOut& out,
-                                              const FusedGuard& guard, int* esum, float& dprev)
+                                              const FusedGuard& guard, int* esum, float& dprev, float& maxp)
 {
   if (sym_begin >= sym_end) return;
 #if DABHIP_FUSED_SOFT
@@ -372,7 +421,10 @@ __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t*
 #if DABHIP_FUSED_SOFT
         if (have_prev) decide(x, y, px, py, qk, h ? decB : decA, soft_scale(dcur, dprev));
 #else
-        if (have_prev) decide(x, y, px, py, qk, h ? decB : decA, guard, s, dcur, dprev);
+        if (have_prev) decide(x, y, px, py, qk, h ? decB : decA, guard, s, dcur, dprev, maxp);
+#if DABHIP_FUSED_GUARD
+        else maxp = bins_l1max(x, y);                     // the run's reference symbol
+#endif
 #endif
         dprev = dcur;
         have_out = have_prev;
@@ -466,8 +518,9 @@ __global__ __launch_bounds__(kThreads, DABHIP_FUSED_WG_PER_CU) void ofdm_demap_k
   FusedGuard guard{gargs, static_cast<unsigned>(first + j)};
   if (nco_inc) guard.g.delta = nullptr;
   float dprev = 0.0f;                                   // error bound of the previous symbol's bins
-  fused_symbols<true, kNco>(src, stream, view, sym_begin, fast_end, false, px, py, exA, exB, decA, decB, tw, qk, nco_inc, out, guard, esum, dprev);
-  fused_symbols<false, kNco>(src, stream, view, fast_end, sym_end, fast_end > sym_begin, px, py, exA, exB, decA, decB, tw, qk, nco_inc, out, guard, esum, dprev);
+  float maxp = 0.0f;                                    // largest |bin|_1 of the previous symbol among this thread's bins (guarded build)
+  fused_symbols<true, kNco>(src, stream, view, sym_begin, fast_end, false, px, py, exA, exB, decA, decB, tw, qk, nco_inc, out, guard, esum, dprev, maxp);
+  fused_symbols<false, kNco>(src, stream, view, fast_end, sym_end, fast_end > sym_begin, px, py, exA, exB, decA, decB, tw, qk, nco_inc, out, guard, esum, dprev, maxp);
 }
 
 }  // namespace
