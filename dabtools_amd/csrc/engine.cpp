@@ -420,39 +420,52 @@ bool Engine::carry_and_reserve(const std::vector<int>& tf_base, const std::vecto
 }
 
 // ---------------------------------------------------------------------------------------------
-// Parity guard around one demapping launch: guard_begin() clears the counter and hands the kernel its list; guard_finish()
-// queues the fp64 re-decision of what was listed and the copy of the entry count to the host; guard_check() (after the
-// stream has been awaited) adds the counts up and refuses a result whose list overflowed.
+// Parity guard around one demapping launch: guard_begin() hands the kernel its list and its counter (all counters of a decode are cleared
+// before the first launch); guard_finish() queues the fp64 re-decision of what was listed; guard_download() (once, behind the last launch)
+// copies the entry counts to the host; guard_check() (after the stream has been awaited) adds them up and counts the launches whose
+// list overflowed (those were decided again in full).
 constexpr int kGuardMinLaunches = 64;
+constexpr int kGuardSlotWords = 4;                       // a launch's counter and three spare words
 bool Engine::guard_begin(int ntf_in_launch, GuardArgs* out)
 {
   // the list: flag rates measured on noisy input are a few decisions per TF (7e-6 of 230,400 at 5 dB); 64 entries per TF, at least
   // 256 K, and a launch that overflows it is decided again in full (exact_decide_all_kernel) instead of failing
   uint32_t cap = static_cast<uint32_t>(std::max<int64_t>(int64_t(1) << 18, static_cast<int64_t>(ntf_in_launch) * 64));
   if (guard_cap_override_) cap = guard_cap_override_;
-  if (!d_guard_list_.reserve(cap) || !d_guard_counter_.reserve(4)) return false;
-  if (guard_launches_ == 0 && h_guard_counts_.size() < static_cast<size_t>(kGuardMinLaunches) && !h_guard_counts_.resize(kGuardMinLaunches)) return false;
+  if (guard_launches_ == 0 && h_guard_counts_.size() < static_cast<size_t>(kGuardMinLaunches) * kGuardSlotWords && !h_guard_counts_.resize(static_cast<size_t>(kGuardMinLaunches) * kGuardSlotWords)) return false;
+  if (static_cast<size_t>(guard_launches_ + 1) * kGuardSlotWords > h_guard_counts_.size()) { set_error("parity guard: more guarded launches than planned for in one decode"); return false; }
+  if (!d_guard_list_.reserve(cap) || !d_guard_counter_.reserve(h_guard_counts_.size())) return false;
   guard_cap_ = guard_cap_override_ ? guard_cap_override_ : static_cast<uint32_t>(std::min<size_t>(d_guard_list_.capacity(), 0xffffffffu));
-  if (!check(hipMemsetAsync(d_guard_counter_.get(), 0, 4 * sizeof(uint32_t), stream_), "guard counter")) return false;
-  *out = GuardArgs{d_delta_.get(), kSymbolsPerTf, guard_cap_, d_guard_list_.get(), d_guard_counter_.get()};
+  // every launch of a decode has its own counter: ONE clear before the first and ONE download behind the last (guard_download) instead of a
+  // clear and a download per launch (small copy-engine operations cost 20 .. 35 us of idle GPU each between two kernels)
+  if (guard_launches_ == 0 && !check(hipMemsetAsync(d_guard_counter_.get(), 0, h_guard_counts_.size() * sizeof(uint32_t), stream_), "guard counters")) return false;
+  *out = GuardArgs{d_delta_.get(), kSymbolsPerTf, guard_cap_, d_guard_list_.get(), d_guard_counter_.get() + static_cast<size_t>(guard_launches_) * kGuardSlotWords};
   return true;
 }
 bool Engine::guard_finish(bool planar, int first, int n, int sym_a, int sym_b, bool skip_fic)
 {
-  if (static_cast<size_t>(guard_launches_) >= h_guard_counts_.size()) { set_error("parity guard: more guarded launches than planned for in one decode"); return false; }
-  return check(launch_exact_decide(d_guard_list_.get(), d_guard_counter_.get(), guard_cap_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(),
+  uint32_t* const counter = d_guard_counter_.get() + static_cast<size_t>(guard_launches_) * kGuardSlotWords;    // guard_begin's
+  ++guard_launches_;
+  return check(launch_exact_decide(d_guard_list_.get(), counter, guard_cap_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(),
                                    d_tw2048_.get(), d_qpsk_.get(), d_qpsk_inv_.get(), d_frame_slot_.get(), d_frame_cif_row_.get(), planar, d_fic_bits_.get(), d_msc_bits_.get(), stream_),
                "exact decide launch") &&
-         check(launch_exact_decide_all(d_guard_counter_.get(), guard_cap_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, sym_a, sym_b,
+         check(launch_exact_decide_all(counter, guard_cap_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, sym_a, sym_b,
                                        d_tw2048_.get(), d_qpsk_.get(), d_frame_slot_.get(), d_frame_cif_row_.get(), planar, skip_fic, d_fic_bits_.get(), d_msc_bits_.get(), stream_),
-               "exact decide (overflow) launch") &&
-         check(hipMemcpyAsync(h_guard_counts_.data() + guard_launches_++, d_guard_counter_.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, stream_), "guard count download");
+               "exact decide (overflow) launch");
+}
+// behind the last guarded launch of a decode, before the stream is awaited
+bool Engine::guard_download()
+{
+  return guard_launches_ == 0 ||
+         check(hipMemcpyAsync(h_guard_counts_.data(), d_guard_counter_.get(), static_cast<size_t>(guard_launches_) * kGuardSlotWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_),
+               "guard count download");
 }
 bool Engine::guard_check()
 {
   for (int i = 0; i < guard_launches_; ++i) {
-    if (h_guard_counts_[i] > guard_cap_) ++guard_overflows_;       // that launch was decided again in full: still exact, only slow
-    guard_flagged_ += h_guard_counts_[i];
+    const uint32_t count = h_guard_counts_[static_cast<size_t>(i) * kGuardSlotWords];
+    if (count > guard_cap_) ++guard_overflows_;       // that launch was decided again in full: still exact, only slow
+    guard_flagged_ += count;
   }
   guard_launches_ = 0;
   return true;
@@ -595,14 +608,38 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
   if (!h_states_.resize(nstreams)) return false;
   StreamState* const states = h_states_.data();
   const size_t ndesc = static_cast<size_t>(nstreams) * max_calls_;
-  if (!cont) {
-    std::fill(states, states + nstreams, initial_state());
-    if (!d_states_.upload(states, nstreams, stream_)) return false;
+  const bool split_wanted = !(afc_ || full_scan);
+  if (!cont) std::fill(states, states + nstreams, initial_state());
+  static_assert(sizeof(CallDesc) % 16 == 0, "cleared in 16-byte pieces");
+  if (!d_states_.reserve(nstreams) || !d_iq_ptrs_.reserve(nstreams) || !d_nbytes_.reserve(nstreams) || !d_descs_.reserve(ndesc) || !d_info_.reserve(ndesc + 1)) return false;
+  if (split_wanted) {
+    // d_viol_[0 .. nstreams): first call of a stream that broke the chain's assumption; [nstreams]: calls the fp32 pass of the
+    // verification left to the fp64 pass
+    if (!h_viol_.resize(nstreams + 1) || !d_viol_.reserve(nstreams + 1) || !d_states_prev_.reserve(nstreams) || !d_calls_before_.reserve(nstreams) ||
+        !h_calls_before_.resize(nstreams))
+      return false;
+    std::copy(calls_done_.begin(), calls_done_.begin() + nstreams, h_calls_before_.data());
   }
-  if (!d_iq_ptrs_.upload(ptrs, nstreams, stream_) || !d_nbytes_.upload(nb, nstreams, stream_) || !d_descs_.reserve(ndesc) || !d_info_.reserve(ndesc)) return false;
-  if (!check(hipMemsetAsync(d_descs_.get(), 0, ndesc * sizeof(CallDesc), stream_), "desc memset") ||
-      !check(hipMemsetAsync(d_info_.get(), 0, ndesc * sizeof(int2), stream_), "info memset"))
-    return false;
+  {
+    // one launch instead of nine copies and fills (launch_scan_setup): the kernel reads the page-locked host arrays itself
+    ScanSetupArgs a{};
+    a.h_states = cont ? nullptr : states;
+    a.h_ptrs = ptrs;
+    a.h_nbytes = nb;
+    a.h_calls_before = split_wanted ? h_calls_before_.data() : nullptr;
+    a.states = d_states_.get();
+    a.states_prev = split_wanted ? d_states_prev_.get() : nullptr;
+    a.iq_ptrs = d_iq_ptrs_.get();
+    a.nbytes = d_nbytes_.get();
+    a.calls_before = split_wanted ? d_calls_before_.get() : nullptr;
+    a.viol = split_wanted ? d_viol_.get() : nullptr;
+    a.descs = reinterpret_cast<uint4*>(d_descs_.get());
+    a.desc_vec = ndesc * (sizeof(CallDesc) / 16);
+    a.info = reinterpret_cast<uint4*>(d_info_.get());
+    a.info_vec = (ndesc + 1) / 2;
+    a.nstreams = nstreams;
+    if (!check(launch_scan_setup(a, stream_), "scan setup launch")) return false;
+  }
   scan_setup_ms_ = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
 
   if (!h_descs_.resize(ndesc) || !h_info_.resize(ndesc)) return false;
@@ -625,14 +662,7 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
     // the OFDM stage, and -- after the LDS bank conflicts were gone -- the chain in 2..16 chunks of calls with each chunk's
     // verification beside the next chunk: 1.28 -> 1.30..1.40 ms.  A chain workgroup holds half of a CU's LDS, so the verification
     // beside it runs at half its rate and slows the chain.)
-    // d_viol_[0 .. nstreams): first call of a stream that broke the chain's assumption; [nstreams]: calls the fp32 pass of the
-    // verification left to the fp64 pass
-    if (!h_viol_.resize(nstreams + 1) || !d_viol_.reserve(nstreams + 1) || !d_states_prev_.reserve(nstreams) ||
-        !d_calls_before_.upload(calls_done_.data(), nstreams, stream_) ||
-        !check(hipMemcpyAsync(d_states_prev_.get(), d_states_.get(), nstreams * sizeof(StreamState), hipMemcpyDeviceToDevice, stream_), "state backup") ||
-        !check(hipMemsetAsync(d_viol_.get(), 0x7f, nstreams * sizeof(int), stream_), "violation memset") ||
-        !check(hipMemsetAsync(d_viol_.get() + nstreams, 0, sizeof(int), stream_), "violation memset") ||
-        !check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), nstreams, max_calls_, -1, -1,
+    if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), nstreams, max_calls_, -1, -1,
                                 d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), 0, stream_, true),
                "sync chain launch") ||
         // {status, ordinal} of every call are final once the chain is through (a stream that breaks its assumption is scanned again
@@ -794,7 +824,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     ok = h_fib_ok_.data();
     (void)hipEventRecord(ev_[3], stream_);
     if (energies && !d_delta_.reserve(static_cast<size_t>(ntf) * kSymbolsPerTf)) return false;
-    if (guard && guard_launches_ == 0 && !h_guard_counts_.resize(static_cast<size_t>(kGuardMinLaunches) + 2 * static_cast<size_t>(ntf / kFftChunkTfs + 1))) return false;
+    if (guard && guard_launches_ == 0 && !h_guard_counts_.resize((static_cast<size_t>(kGuardMinLaunches) + 2 * static_cast<size_t>(ntf / kFftChunkTfs + 1)) * kGuardSlotWords)) return false;
     soft_args.delta = d_delta_.get();
     soft_args.delta_stride = kSymbolsPerTf;
     if (one_kernel) {
@@ -925,6 +955,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   host_lane_->wait();
   if (gpu_ok && host_ok)
     gpu_ok = check(hipStreamWaitEvent(stream_, ev_upload_, 0), "work list wait") && msc_launch_async(work);
+  if (guard && gpu_ok) gpu_ok = guard_download();        // the entry counts of all guarded launches, behind everything else
   mark("all queued");
   const bool drained = check(hipStreamSynchronize(stream_), "decode");      // also on the error paths: nothing may stay in flight
   mark("stream drained");
@@ -1146,7 +1177,7 @@ int Engine::stage_decision_audit(const uint8_t* frames, int nframes, bool on_dev
         !check(launch_demap(false, 0, d_spectra_.get(), 0, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_), "demap launch") ||
         (guard_on && !guard_finish(false, 0, n, 1, kSymbolsPerTf, false)) ||
         !check(launch_decision_audit(d_in + static_cast<size_t>(first) * kTfBytes, n, d_spectra_.get(), d_fic_bits_.get(), d_msc_bits_.get(), d_tw2048_.get(), d_qpsk_.get(), d_out.get(), stream_), "audit launch") ||
-        !check(hipStreamSynchronize(stream_), "audit") || (guard_on && !guard_check()))
+        (guard_on && !guard_download()) || !check(hipStreamSynchronize(stream_), "audit") || (guard_on && !guard_check()))
       return -1;
     listed += static_cast<uint64_t>(guard_flagged_);
   }
@@ -1242,7 +1273,7 @@ bool Engine::demod_one_frame(const uint8_t* iq_virtual_base, const CallDesc& des
     return false;
   if (!check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), 1, d_frames_.get(), 0, 1, d_spectra_.get(), d_twf_.get(), stream_), "fft launch") ||
       !check(launch_demap(false, 0, d_spectra_.get(), 0, 1, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_), "demap launch") ||
-      (guard && !guard_finish(false, 0, 1, 1, kSymbolsPerTf, false)) ||
+      (guard && !guard_finish(false, 0, 1, 1, kSymbolsPerTf, false)) || (guard && !guard_download()) ||
       !check(hipStreamSynchronize(stream_), "demod") || (guard && !guard_check()))
     return false;
   return unpack_tf_slot(0, fic_bytes, msc_bytes);

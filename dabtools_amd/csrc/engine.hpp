@@ -246,6 +246,7 @@ class Engine {
   bool guard_begin(int ntf_in_launch, GuardArgs* out);
   // the launch just queued covered frames [first, first + n) of the frame list, data symbols [sym_a, sym_b); skip_fic: another launch owns symbols 1..3
   bool guard_finish(bool planar, int first, int n, int sym_a, int sym_b, bool skip_fic);
+  bool guard_download();
   bool guard_check();
 
   bool ok_ = false;
@@ -282,7 +283,7 @@ class Engine {
   DeviceBuffer<int64_t> d_nbytes_;
   DeviceBuffer<StreamState> d_states_, d_states_prev_;
   DeviceBuffer<int> d_viol_, d_redo_, d_calls_before_;
-  PinnedBuffer<int> h_viol_;
+  PinnedBuffer<int> h_viol_, h_calls_before_;
   int sync_rescanned_ = 0;            // streams the split scan had to scan again in full (last decode)
   DeviceBuffer<CallDesc> d_descs_;
   DeviceBuffer<int2> d_info_;

@@ -368,22 +368,29 @@ __device__ int coarse_freq_sync32(const uint8_t* stream, const FrameView& view, 
   }
   __syncthreads();
   dft_dif<7, 3, 2, 2>(W, 29, +1.0f, tw);
+  // a thread's points idx = tid + 512 k lie in offsets tid / 128 + 4 k: eight different ones, their magnitudes kept for the second question
+  constexpr int kPer = (29 * 128 + kThreads - 1) / kThreads;
+  static_assert(kThreads % 128 == 0, "one offset per point of a thread");
+  float mags[kPer];
   float cv = -99999.0f;
   int ci = 0x7fffffff;
-  for (int idx = tid; idx < 29 * 128; idx += kThreads) {
-    const float2 x = W[lds_at(idx)];
-    const float mag = sqrtf(x.x * x.x + x.y * x.y);
-    if (mag > cv) { cv = mag; ci = idx / 128; }
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int idx = tid + k * kThreads;
+    mags[k] = -1.0f;
+    if (idx < 29 * 128) {
+      const float2 x = W[lds_at(idx)];
+      mags[k] = sqrtf(x.x * x.x + x.y * x.y);
+      if (mags[k] > cv) { cv = mags[k]; ci = idx / 128; }  // idx ascending per thread
+    }
   }
   float hv;
   int hi;
   block_argmax(red, cv, ci, &hv, &hi);
   float ov = 0.0f;                                         // the largest magnitude of any OTHER offset
-  for (int idx = tid; idx < 29 * 128; idx += kThreads) {
-    if (idx / 128 == hi) continue;
-    const float2 x = W[lds_at(idx)];
-    ov = fmaxf(ov, sqrtf(x.x * x.x + x.y * x.y));
-  }
+#pragma unroll
+  for (int k = 0; k < kPer; ++k)
+    if ((tid + k * kThreads) / 128 != hi) ov = fmaxf(ov, mags[k]);
   float rv;
   int ri;
   block_argmax(red, ov, tid, &rv, &ri);
@@ -549,6 +556,7 @@ __global__ __launch_bounds__(kThreads) void sync_verify_kernel(const uint8_t* co
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int total = max_calls * nstreams;
+  if (only_marked && violation[nstreams] == 0) return;     // the fp32 pass left nothing (its count of marked calls sits behind the per-stream entries)
   if (static_cast<int>(gridDim.x) == total && (descs[blockIdx.x].status != 2 || (only_marked && descs[blockIdx.x].coarse_freq_shift != kVerifyAgain)))
     return;                                                // nothing to do: skip the table fill as well
   const SyncLds lds = sync_lds(smem, tw2048);
@@ -667,6 +675,42 @@ static hipError_t sync_attr()
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_verify32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sync_verify32_lds_bytes()));
   if (e == hipSuccess) attr_set = true;
   return e;
+}
+
+// Everything a scan needs on the device before its first kernel, in ONE launch: the per-stream arrays straight out of the caller's page-locked
+// host arrays (a few KB over the link), the descriptors and call infos cleared, the violation marks set, the incoming states kept for a rescan.
+// (Nine small copy-engine operations before: each costs 5 .. 10 us of idle GPU between two of them.)
+namespace {
+__global__ __launch_bounds__(256) void scan_setup_kernel(ScanSetupArgs a)
+{
+  const size_t tid = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x, step = static_cast<size_t>(gridDim.x) * blockDim.x;
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+  for (size_t i = tid; i < a.desc_vec; i += step) a.descs[i] = zero;
+  for (size_t i = tid; i < a.info_vec; i += step) a.info[i] = zero;
+  constexpr size_t kStateWords = sizeof(StreamState) / 4;
+  const size_t nstate_words = static_cast<size_t>(a.nstreams) * kStateWords;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(a.h_states ? a.h_states : a.states);      // host array (fresh decode) or what the device holds (session)
+  for (size_t i = tid; i < nstate_words; i += step) {
+    const uint32_t w = src[i];
+    if (a.h_states) reinterpret_cast<uint32_t*>(a.states)[i] = w;
+    if (a.states_prev) reinterpret_cast<uint32_t*>(a.states_prev)[i] = w;
+  }
+  for (size_t b = tid; b < static_cast<size_t>(a.nstreams); b += step) {
+    a.iq_ptrs[b] = a.h_ptrs[b];
+    a.nbytes[b] = a.h_nbytes[b];
+    if (a.calls_before) a.calls_before[b] = a.h_calls_before[b];
+    if (a.viol) a.viol[b] = 0x7f7f7f7f;
+  }
+  if (tid == 0 && a.viol) a.viol[a.nstreams] = 0;
+}
+}  // namespace
+hipError_t launch_scan_setup(const ScanSetupArgs& a, hipStream_t stream)
+{
+  static_assert(sizeof(StreamState) % 4 == 0, "copied word by word");
+  const size_t most = a.desc_vec > a.info_vec ? a.desc_vec : a.info_vec;
+  const int blocks = static_cast<int>(most / 256 / 4 < 64 ? 64 : (most / 256 / 4 > 2048 ? 2048 : most / 256 / 4));
+  hipLaunchKernelGGL(scan_setup_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, StreamState* states, CallDesc* descs, int2* info,

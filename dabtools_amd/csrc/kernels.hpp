@@ -10,6 +10,25 @@
 
 namespace dabhip {
 
+// the scan's device-side preparation in one launch (k_sync.hip): h_* are page-locked host arrays the kernel reads directly
+struct ScanSetupArgs {
+  const StreamState* h_states;        // null: the device's states stay (a session's further segment)
+  const uint8_t* const* h_ptrs;
+  const int64_t* h_nbytes;
+  const int* h_calls_before;
+  StreamState* states;
+  StreamState* states_prev;           // null unless the split scan runs (with calls_before and viol)
+  const uint8_t** iq_ptrs;
+  int64_t* nbytes;
+  int* calls_before;
+  int* viol;                          // nstreams + 1 entries
+  uint4* descs;                       // cleared: desc_vec 16-byte pieces
+  size_t desc_vec;
+  uint4* info;
+  size_t info_vec;
+  int nstreams;
+};
+hipError_t launch_scan_setup(const ScanSetupArgs& a, hipStream_t stream);
 // K1: synchronisation scan, one workgroup per stream, calls [call_begin, call_end) (call_end < 0: all).
 // chain_only: FIFO bookkeeping, coarse and fine time only, assuming every frame's coarse frequency offset stays within +-1
 // carrier; launch_sync_verify then computes both frequency estimates for all frames in parallel and records the first call
