@@ -37,7 +37,7 @@ namespace {
 // With no third trip the two exchange arrays keep their roles for every symbol: P is rewritten by the next symbol's stage A after this symbol's
 // second barrier (its last readers, stage B, came before it), Q by the next stage B after the next first barrier (its readers, stage C, before it).
 // Round 3: 3 barriers + 3 trips -> 2 + 2.
-constexpr int kQStride = 260;                           // [a'] stride of Q in float2: 8 x 32 + 4, so that the 32 lanes (a', b'_0, d_0) of a stage-C read cover 32 bank pairs
+constexpr int kQStride = 258;                           // [a'] stride of Q in float2: 8 x 32 + 2 (bank arithmetic in fft2048_rest)
 constexpr int kPSize = 8 * 256, kQSize = 8 * kQStride;  // float2 each
 __device__ __forceinline__ int fused_bin(int tid, int m)   // raw bin of x[m >> 1] (m even) / y[m >> 1] (m odd) of thread tid
 {
@@ -75,23 +75,26 @@ __device__ __forceinline__ void fft2048_rest(float2 (&v)[8], const float2* bufP,
 {
   const int tid = threadIdx.x;
   {
-    const int q = tid >> 5, t1 = tid & 31;
+    // lane l of a half-wave takes (c, d) = (l & 7, l >> 3): its P reads are a permutation of 32 consecutive places, and its Q stores come out in lane order
+    const int q = tid >> 5, l = tid & 31, t1 = 4 * (l & 7) + (l >> 3);
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = bufP[q * 256 + t1 + 32 * r];
     dft8(v);
 #pragma unroll
     for (int q2 = 1; q2 < 8; ++q2) v[q2] = cmul(v[q2], tw.s2[q2 - 1]);
-    // Q[a'][b' >> 1][(c, d)][b' & 1]: the pair b' = 2 p, 2 p + 1 of one (c, d) leaves as one 16-byte store
-    float4* dst = reinterpret_cast<float4*>(bufQ) + q * (kQStride / 2) + t1;
+    // Q[a'][b' >> 1][d][c][b' & 1]: the pair b' = 2 p, 2 p + 1 of one (c, d) leaves as one 16-byte store, eight consecutive lanes fill a 128-byte row
+    float4* dst = reinterpret_cast<float4*>(bufQ) + q * (kQStride / 2) + l;
 #pragma unroll
     for (int p = 0; p < 4; ++p) dst[32 * p] = make_float4(v[2 * p].x, v[2 * p].y, v[2 * p + 1].x, v[2 * p + 1].y);
   }
   __syncthreads();
   {
+    // place of (a', b', c, d) in float2: 258 a' + 64 (b' >> 1) + 16 d + 2 c + (b' & 1).  A read (fixed c) of the 32 lanes (a', b'_0, d_0) covers the 32 bank
+    // pairs 2 a' + b'_0 + 16 d_0, and its 16-lane groups (a', b'_0) 16 different ones modulo 16: free of conflicts as ds_read_b64 and as ds_read2_b64
     const int q = tid & 7, q2 = ((tid >> 3) & 1) | ((tid >> 6) << 1), t2 = (tid >> 4) & 3;
-    const float2* src = bufQ + q * kQStride + 64 * (q2 >> 1) + 2 * t2 + (q2 & 1);
+    const float2* src = bufQ + q * kQStride + 64 * (q2 >> 1) + 16 * t2 + (q2 & 1);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = src[8 * r];
+    for (int r = 0; r < 8; ++r) v[r] = src[2 * r];
     dft8(v);
 #pragma unroll
     for (int q3 = 1; q3 < 8; ++q3) v[q3] = cmul(v[q3], tw.s3[q3]);
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(kThreads, DABHIP_FUSED_WG_PER_CU) void ofdm_demap_k
   if (tid < 32) tw3[tid] = tw_global[64 * (tid >> 3) * (tid & 7)];
   Twiddles tw;
   {
-    const int t1 = tid & 31, t2 = (tid >> 4) & 3;      // t2 = d of this thread in stage C (fft2048_rest)
+    const int t1 = 4 * (tid & 7) + ((tid >> 3) & 3), t2 = (tid >> 4) & 3;   // (c, d) of this thread in stage B, d in stage C (fft2048_rest)
 #pragma unroll
     for (int q = 1; q < 8; ++q) {
       tw.s1[q - 1] = tw_global[tid * q];
