@@ -722,7 +722,10 @@ __global__ __launch_bounds__(256, DABHIP_VIT_WAVES) void viterbi_fused_kernel(co
   SoftLut* soft_lut = reinterpret_cast<SoftLut*>(lut_raw);
   if (kBits == 1) build_metric_lut(lut);
   else if (DABHIP_SOFT_LUT) build_soft_lut(soft_lut);
-  const int lane = threadIdx.x & 63, g = 4 * blockIdx.x + (threadIdx.x >> 6);
+  // the wave's index as a SCALAR (readfirstlane): its group and plan then come through scalar loads, and everything the loop derives from them -- step
+  // counts, puncturing masks, bit counts, the fifo's fill and the word index -- lives in SGPRs with SALU arithmetic and scalar branches (as vector values
+  // they cost two dozen VGPRs, spills with scratch reloads at every refill, and exec-mask branches around wave-uniform conditions)
+  const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(4 * blockIdx.x + (threadIdx.x >> 6));
   if (g >= ngroups) return;
   const WaveGroup grp = groups[g];
   const CodewordPlan pl = plans[grp.plan];

@@ -77,7 +77,12 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, int iters)
   if (kOp == 51) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(u[i]), "+v"(u[(i + 1) & 7]));                  \
   if (kOp == 52) asm volatile("v_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(u[i]) : "v"(u[(i + 1) & 7])); \
   if (kOp == 53) asm volatile("v_cndmask_b32_dpp %0, %1, %2, vcc row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(k)); \
-  if (kOp == 54) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(u[i]), "+v"(u[i ^ 1]));
+  if (kOp == 54) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(u[i]), "+v"(u[i ^ 1]));                          \
+  if (kOp == 55) asm volatile("v_lshrrev_b64 %0, %1, %0" : "+v"(*reinterpret_cast<unsigned long long*>(&a[i])) : "v"(k & 7u)); \
+  if (kOp == 56) asm volatile("v_dot4_u32_u8 %0, %0, %1, %0" : "+v"(u[i]) : "v"(k));                              \
+  if (kOp == 57) asm volatile("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(a[i].x) : "v"(c.x), "v"(m.x));               \
+  if (kOp == 58) asm volatile("v_lshl_or_b32 %0, %0, 8, %1" : "+v"(u[i]) : "v"(k));                               \
+  if (kOp == 59) asm volatile("v_add_lshl_u32 %0, %0, %1, 16" : "+v"(u[i]) : "v"(k));
       REP8(OP)
 #undef OP
     }
@@ -118,6 +123,11 @@ int main(int argc, char** argv)
     run<54>("permlane32_swap pair", out);
     run<52>("mov_dpp row_ror:8", out);
     run<53>("cndmask_dpp ror:8", out);
+    run<55>("v_lshrrev_b64", out);
+    run<56>("v_dot4_u32_u8", out);
+    run<57>("v_min3_f32 abs", out);
+    run<58>("v_lshl_or_b32", out);
+    run<59>("v_add_lshl_u32", out);
     return 0;
   }
   run<0>("v_fma_f32", out);
