@@ -883,7 +883,9 @@ __device__ __forceinline__ uint16_t crc_shift(uint16_t crc, int nbytes, const ui
 // slice of the CRC range; the partial CRCs are combined with crc_shift.  The 0x55 padding behind the trailer is written here too.
 // The CRC runs four bytes at a time ("slicing by 4": tab[k][x] = CRC of byte x followed by k zero bytes, so that one 32-bit word
 // costs four INDEPENDENT look-ups instead of a chain of four); the range is a multiple of 8 bytes (96 + 8-byte sub-channel units)
-// and starts 4-byte aligned, so a lane's slice is whole words.
+// and starts 4-byte aligned, so a lane's slice is whole words.  (Round 3: the words dealt to the lanes one by one instead -- every load of the wave one
+// 256-byte run, a lane's part folded by Horner's rule in 256-byte steps with two more look-ups per word -- was SLOWER, 0.25 against 0.22 ms: the kernel
+// is bound by its random 2-byte LDS look-ups, not by the lane-strided loads.)
 __global__ __launch_bounds__(256) void eti_finish_kernel(const EtiFrameMeta* __restrict__ meta, int nframes,
                                                          const uint8_t* __restrict__ headers, int header_stride,
                                                          const uint8_t* __restrict__ fibs, const uint16_t* __restrict__ crc_tab,
