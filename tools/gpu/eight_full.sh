@@ -2,7 +2,7 @@
 # The 8-rank rehearsal at FULL size on one GPU: 8 bench.py rank processes x 256 streams x 64 TF sharing GPU 0 (profiles/r03_eight_ranks_full_size_one_gpu.json),
 # twice, then one rank alone with the same flags.
 set -euo pipefail
-cd "$GRAFT_REPO_ROOT"
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}; export GRAFT_REPO_ROOT; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/eight_full; mkdir -p $O
 F="--streams 256 --steps 5 --warmup 2 --no-cpu-baseline --no-variants --no-h2d"
 for i in 1 2; do DABHIP_BENCH_ONE_DEVICE=1 timeout 900 python bench.py --gpus 8 $F > $O/eight_$i.json 2> $O/eight_$i.err || echo "run $i rc=$?"; done

@@ -1,7 +1,8 @@
 #!/bin/bash
+set -u
 # One GPU-box pass over everything the round is judged on: the GPU test-suite, the profile refresh (bench + rocprofv3 passes), the
 # 8-rank rehearsal, configs[3] on one GPU.  Results under gpurun_out/full/.
-cd "$GRAFT_REPO_ROOT"
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}; export GRAFT_REPO_ROOT; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/full; mkdir -p $O
 timeout 3000 python -m pytest tests -q -m gpu > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -n 6 $O/gpu_tests.log
 timeout 3000 bash tools/refresh_profiles.sh > $O/refresh.log 2>&1; echo "refresh rc=$?"

@@ -1,6 +1,7 @@
 #!/bin/bash
+set -u
 # GPU test-suite + two short bench lines (no CPU baseline, no host-fed leg); optional: the cross-lane microbenchmarks.
-cd "$GRAFT_REPO_ROOT"
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}; export GRAFT_REPO_ROOT; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/quick; mkdir -p $O
 timeout 1500 python -m pytest tests -q -x -m gpu > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -n 5 $O/gpu_tests.log
 for i in 1 2; do
