@@ -864,7 +864,7 @@ __global__ void fib_crc_kernel(const uint8_t* __restrict__ fibs, int nfib, const
 
 // CRC-16/CCITT is linear over GF(2): crc(A || B) = shift(crc(A), |B|) xor crc_0(B), where shift multiplies by
 // x^(8 |B|) modulo the polynomial.  shift_cols[i][b] = image of bit b under a shift by 2^i bytes.
-__device__ __forceinline__ uint16_t crc_shift(uint16_t crc, int nbytes, const uint16_t* __restrict__ shift_cols)
+__device__ __forceinline__ uint16_t crc_shift(uint16_t crc, int nbytes, const uint16_t* shift_cols)
 {
   for (int i = 0; nbytes; ++i, nbytes >>= 1) {
     if (nbytes & 1) {
@@ -886,17 +886,19 @@ __device__ __forceinline__ uint16_t crc_shift(uint16_t crc, int nbytes, const ui
 // and starts 4-byte aligned, so a lane's slice is whole words.  (Round 3: the words dealt to the lanes one by one instead -- every load of the wave one
 // 256-byte run, a lane's part folded by Horner's rule in 256-byte steps with two more look-ups per word -- was SLOWER, 0.25 against 0.22 ms: the kernel
 // is not bound by the lane-strided loads.  Nor by the bank conflicts of the random 2-byte look-ups: a copy of the tables per LDS bank (64 KB, 16 frames per
-// workgroup, every look-up conflict-free) also came out at 0.25 ms.  762 VALU instructions per wave, 0.13 GB read and 0.1 GB written per launch: what is left is
-// the length of a wave's dependent chain -- descriptor, words, four look-ups per word, the log-step shift -- at eight waves per SIMD.)
+// workgroup, every look-up conflict-free) also came out at 0.25 ms.  What it was bound by: the log-step shift at the end, up to 13 DEPENDENT levels of
+// look-ups in a table that sat in global memory -- with the 448 bytes of shift matrices in LDS the kernel takes 0.14 ms.)
 __global__ __launch_bounds__(256) void eti_finish_kernel(const EtiFrameMeta* __restrict__ meta, int nframes,
                                                          const uint8_t* __restrict__ headers, int header_stride,
                                                          const uint8_t* __restrict__ fibs, const uint16_t* __restrict__ crc_tab,
                                                          const uint16_t* __restrict__ shift_cols, uint8_t* __restrict__ eti)
 {
   __shared__ uint16_t tab[4][256];
+  __shared__ uint16_t cols[14 * 16];                     // the shift matrices, next to the lanes (see crc_shift below: up to 13 dependent levels per lane)
   {
     uint16_t v = crc_tab[threadIdx.x];
     tab[0][threadIdx.x] = v;
+    if (threadIdx.x < 14 * 16) cols[threadIdx.x] = shift_cols[threadIdx.x];
     __syncthreads();
 #pragma unroll
     for (int k = 1; k < 4; ++k) {                          // one more zero byte: v <- step(v, 0)
@@ -932,7 +934,7 @@ __global__ __launch_bounds__(256) void eti_finish_kernel(const EtiFrameMeta* __r
       if (i0 + u < hi)
         crc = tab[3][((crc >> 8) ^ w[u]) & 0xff] ^ tab[2][(crc ^ (w[u] >> 8)) & 0xff] ^ tab[1][(w[u] >> 16) & 0xff] ^ tab[0][w[u] >> 24];
   }
-  unsigned acc = crc_shift(static_cast<uint16_t>(crc), n - 4 * hi, shift_cols);
+  unsigned acc = crc_shift(static_cast<uint16_t>(crc), n - 4 * hi, cols);
 #pragma unroll
   for (int s = 32; s > 0; s >>= 1) acc ^= __shfl_xor(acc, s);
   if (lane == 0) {
