@@ -574,7 +574,10 @@ __device__ __forceinline__ void chain_back8(const uint4* my_rec, int nsteps, con
   // stamps (profiles/r03_viterbi_tail.json): a 4614-step wave spends 1.07 ms here (577 dependent loads at HBM latency under load), a
   // quarter of all resident wave-time is chain-back -- yet with the records kept in L2 the whole launch gains only 0.3 ms, without any
   // chain-back 0.45.  A lane's record in ONE 64-byte line ([block][lane][part], read back whole, 2 or 4 blocks ahead) was 2.8 x slower
-  // (14 ms): 16-byte stores at a 64-byte stride.
+  // (14 ms): 16-byte stores at a 64-byte stride.  Also measured (round 3) and dropped: the launch as PERSISTENT waves that take groups off a counter and advance
+  // the chain-back of the group before by one record per eight steps of the next group's forward pass (the load issued at the end of a block, consumed a block
+  // later): 5.5 ms against 4.85.  The four words of chain state live across the forward pass's blocks, the kernel has no register to spare (12 spilled), and a
+  // scratch reload inside the block waits -- loads and stores retire in order on one counter -- for the record stores issued just before it.
   // A whole block per step: its decisions d_k = !tag_k (k = 0 .. 7, step 8 b + k), bit-reversed: r8 = d_0 .. d_7 from the top.  Walking
   // back from step 8 b + 7 to 8 b leaves state (d_0 .. d_5) = r8 >> 2; data bit i = step - 6 goes MSB-first into byte i >> 3: d_6, d_7
   // are the top two bits of byte b, d_0 .. d_5 the low six bits of byte b - 1 -- the new state itself.
