@@ -124,3 +124,26 @@ print("ok fp64_calls=%%d" %% fp64_calls)
         assert r.returncode == 0 and "ok fp64_calls=" in r.stdout, (mode, r.stdout[-500:], r.stderr[-2000:])
         out[mode] = int(r.stdout.strip().rsplit("=", 1)[1])
     assert out["1"] <= 5 and out["0"] == 0 and out["2"] > 50, out      # default: at most a handful of the ~120 calls are not clear-cut (off-tune by 14 carriers, 6 dB)
+
+
+def test_exact_zero_products_are_decided_as_the_reference_decides_them():
+    """Two whole OFDM symbols of a locked capture replaced by the byte 127 (sample value 0): the transform of the second one is exactly
+    zero, so every differential product of that symbol and of the next is an exact +-0 -- where the sign bit of the product (what the
+    guarded fused kernel writes, round 3) and the reference's comparisons `re > 0`, `im > 0` (input_sdr.c:157-158) part ways.  Such
+    decisions are always listed for the fp64 re-decision (also when the symbol's error bound is zero): ETI byte-equal to the oracle, with
+    the fused kernel and with the two-kernel stage."""
+    cfg = dab.synth_preset(1, seed=8801, cif_count0=40, snr_db=1000.0)
+    iq = dab.synth_generate(cfg, 24).copy()
+    for tf, sym in ((15, 40), (18, 4), (20, 74)):          # an MSC symbol pair in mid-frame, the first MSC symbols, the last two of a frame
+        a = 2 * (tf * 196608 + 2656 + sym * 2552)
+        iq[a: a + 2 * 2 * 2552] = 127
+    want, _ = ol.or_replay(iq)
+    assert len(want) >= 4 * (24 - 16)
+    eng = dab.Engine(0)
+    for fused in (True, False):
+        eng.set_fused(fused)
+        assert eng.decode([iq]) == len(want)
+        assert np.array_equal(eng.eti(0), want), fused
+        if fused:
+            assert eng.guard_stats()[0] >= 3 * 1536            # at least the carriers of three all-zero symbols were listed and re-decided
+    eng.close()
