@@ -181,10 +181,12 @@ bool Engine::upload_decode_batch(const DecodeBatch& b, const HostList<DecodeJob>
 bool Engine::launch_decode_batch(const DecodeBatch& b, const uint32_t* bits, const int* d_stream_cif_base, const uint32_t* prbs, uint8_t* out,
                                  int record_stride)
 {
-  (void)hipEventRecord(ev_msc_[0], stream_);
-  (void)hipEventRecord(ev_msc_[1], stream_);
-  (void)hipEventRecord(ev_msc_[2], stream_);
-  if (b.groups.empty()) return true;
+  if (b.groups.empty()) {                                 // nothing to decode: the three stamps still exist for msc_collect
+    (void)hipEventRecord(ev_msc_[0], stream_);
+    (void)hipEventRecord(ev_msc_[1], stream_);
+    (void)hipEventRecord(ev_msc_[2], stream_);
+    return true;
+  }
   const int* ids = d_job_ids_.get();
   const int row_words = kCifWords * (soft_bits_ ? 4 : 1);
   const int ntiles = static_cast<int>(b.job_ids.size() / 64);
@@ -437,10 +439,20 @@ bool Engine::guard_begin(int ntf_in_launch, GuardArgs* out)
   if (!d_guard_list_.reserve(cap) || !d_guard_counter_.reserve(h_guard_counts_.size())) return false;
   guard_cap_ = guard_cap_override_ ? guard_cap_override_ : static_cast<uint32_t>(std::min<size_t>(d_guard_list_.capacity(), 0xffffffffu));
   // every launch of a decode has its own counter: ONE clear before the first and ONE download behind the last (guard_download) instead of a
-  // clear and a download per launch (small copy-engine operations cost 20 .. 35 us of idle GPU each between two kernels)
-  if (guard_launches_ == 0 && !check(hipMemsetAsync(d_guard_counter_.get(), 0, h_guard_counts_.size() * sizeof(uint32_t), stream_), "guard counters")) return false;
+  // clear and a download per launch (small copy-engine operations cost 20 .. 35 us of idle GPU each between two kernels); a decode's layout
+  // kernel has normally cleared them already (guard_counters_clear_)
+  if (guard_launches_ == 0 && !guard_counters_clear_ &&
+      !check(hipMemsetAsync(d_guard_counter_.get(), 0, h_guard_counts_.size() * sizeof(uint32_t), stream_), "guard counters"))
+    return false;
+  guard_counters_clear_ = false;
   *out = GuardArgs{d_delta_.get(), kSymbolsPerTf, guard_cap_, d_guard_list_.get(), d_guard_counter_.get() + static_cast<size_t>(guard_launches_) * kGuardSlotWords};
   return true;
+}
+// the counters' host and device arrays for a decode of ntf frames (the layout kernel clears the device side)
+bool Engine::guard_reserve_counters(int ntf)
+{
+  const size_t words = (static_cast<size_t>(kGuardMinLaunches) + 2 * static_cast<size_t>(ntf / kFftChunkTfs + 1)) * kGuardSlotWords;
+  return (h_guard_counts_.size() >= words || h_guard_counts_.resize(words)) && d_guard_counter_.reserve(h_guard_counts_.size());
 }
 bool Engine::guard_finish(bool planar, int first, int n, int sym_a, int sym_b, bool skip_fic)
 {
@@ -702,7 +714,8 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
     sync_rescanned_ = static_cast<int>(redo.size());
     times_.sync_fp64_calls = static_cast<float>(h_viol_[nstreams]);
     if (!redo.empty()) {                                   // rare: those streams again, in the reference's order, from their incoming state
-      if (!d_redo_.upload(redo, stream_) ||
+      // (what the first layout queued -- its set-up kernel reads the page-locked frame lists when it RUNS -- is through before the lists are rewritten)
+      if (!check(hipStreamSynchronize(stream_), "before the rescan") || !d_redo_.upload(redo, stream_) ||
           !check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), static_cast<int>(redo.size()), max_calls_,
                                   -1, -1, d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), 0, stream_, false, d_states_prev_.get(), d_redo_.get()),
                  "sync rescan launch"))
@@ -730,6 +743,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   static const bool trace_host = std::getenv("DABHIP_TRACE_HOST") != nullptr;
   auto mark = [&](const char* what) { if (trace_host) std::fprintf(stderr, "[host] %-18s %8.3f ms\n", what, since(wall0)); };
   times_ = StageTimes{};
+  guard_counters_clear_ = false;
   fft_launches_ = fft_tfs_ = 0;
   fft_ms_ = 0;
   guard_flagged_ = guard_decisions_ = 0;
@@ -773,8 +787,28 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
       fib_base[b] = 4 * tf_base[b];
       next_row += kRowLead + 4 * (keep + nnew[b]);
     }
-    const bool up = ntf_new == 0 || (d_frames_.upload(h_frames_.data(), ntf_new, stream_) && d_frame_slot_.upload(h_frame_slot_.data(), ntf_new, stream_) &&
-                                     d_frame_cif_row_.upload(h_frame_cif_row_.data(), ntf_new, stream_));
+    // the three lists go up in ONE launch that reads the page-locked arrays itself (three copy-engine copies cost 45 us of idle GPU before the first
+    // OFDM launch); with the guard on it also clears the guard's counters, which guard_begin() then leaves alone
+    bool up = true;
+    if (ntf_new > 0) {
+      up = d_frames_.reserve(ntf_new) && d_frame_slot_.reserve(ntf_new) && d_frame_cif_row_.reserve(ntf_new);
+      HostWordsArgs hw{};
+      hw.src[0] = reinterpret_cast<const uint32_t*>(h_frames_.data());
+      hw.dst[0] = reinterpret_cast<uint32_t*>(d_frames_.get());
+      hw.nwords[0] = 2u * static_cast<uint32_t>(ntf_new);
+      hw.src[1] = reinterpret_cast<const uint32_t*>(h_frame_slot_.data());
+      hw.dst[1] = reinterpret_cast<uint32_t*>(d_frame_slot_.get());
+      hw.nwords[1] = static_cast<uint32_t>(ntf_new);
+      hw.src[2] = reinterpret_cast<const uint32_t*>(h_frame_cif_row_.data());
+      hw.dst[2] = reinterpret_cast<uint32_t*>(d_frame_cif_row_.get());
+      hw.nwords[2] = static_cast<uint32_t>(ntf_new);
+      if (up && guard_active() && guard_launches_ == 0 && guard_reserve_counters(ntf_new)) {
+        hw.zero = d_guard_counter_.get();
+        hw.nzero = static_cast<uint32_t>(h_guard_counts_.size());
+        guard_counters_clear_ = true;
+      }
+      up = up && check(launch_host_words(hw, stream_), "frame list upload");
+    }
     frames_ms += since(tfr);
     return up;
   };
@@ -824,7 +858,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     ok = h_fib_ok_.data();
     (void)hipEventRecord(ev_[3], stream_);
     if (energies && !d_delta_.reserve(static_cast<size_t>(ntf) * kSymbolsPerTf)) return false;
-    if (guard && guard_launches_ == 0 && !h_guard_counts_.resize((static_cast<size_t>(kGuardMinLaunches) + 2 * static_cast<size_t>(ntf / kFftChunkTfs + 1)) * kGuardSlotWords)) return false;
+    if (guard && guard_launches_ == 0 && !guard_counters_clear_ && !guard_reserve_counters(ntf)) return false;
     soft_args.delta = d_delta_.get();
     soft_args.delta_stride = kSymbolsPerTf;
     if (one_kernel) {

@@ -247,6 +247,7 @@ class Engine {
   // the launch just queued covered frames [first, first + n) of the frame list, data symbols [sym_a, sym_b); skip_fic: another launch owns symbols 1..3
   bool guard_finish(bool planar, int first, int n, int sym_a, int sym_b, bool skip_fic);
   bool guard_download();
+  bool guard_reserve_counters(int ntf);
   bool guard_check();
 
   bool ok_ = false;
@@ -319,6 +320,7 @@ class Engine {
   DeviceBuffer<uint32_t> d_guard_counter_;
   PinnedBuffer<uint32_t> h_guard_counts_;
   int guard_launches_ = 0;
+  bool guard_counters_clear_ = false;   // the layout kernel of this decode has cleared the device counters
   uint32_t guard_cap_ = 0, guard_cap_override_ = 0;
   int64_t guard_flagged_ = 0, guard_decisions_ = 0;
   int guard_overflows_ = 0;          // launches of the last decode whose list overflowed (decided again in full, fp64)

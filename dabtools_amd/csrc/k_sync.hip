@@ -704,6 +704,27 @@ __global__ __launch_bounds__(256) void scan_setup_kernel(ScanSetupArgs a)
   if (tid == 0 && a.viol) a.viol[a.nstreams] = 0;
 }
 }  // namespace
+// A few small page-locked host arrays to the device (and a small region cleared) in one launch: the frame lists behind the layout
+namespace {
+__global__ __launch_bounds__(256) void host_words_kernel(HostWordsArgs a)
+{
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    for (uint32_t i = tid; i < a.nwords[k]; i += step) a.dst[k][i] = a.src[k][i];
+  for (uint32_t i = tid; i < a.nzero; i += step) a.zero[i] = 0;
+}
+}  // namespace
+hipError_t launch_host_words(const HostWordsArgs& a, hipStream_t stream)
+{
+  uint32_t most = a.nzero;
+  for (int k = 0; k < 4; ++k) most = most > a.nwords[k] ? most : a.nwords[k];
+  if (most == 0) return hipSuccess;
+  const int blocks = static_cast<int>(most / 256 + 1 > 256 ? 256 : most / 256 + 1);
+  hipLaunchKernelGGL(host_words_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_scan_setup(const ScanSetupArgs& a, hipStream_t stream)
 {
   static_assert(sizeof(StreamState) % 4 == 0, "copied word by word");

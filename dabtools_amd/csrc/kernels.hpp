@@ -29,6 +29,15 @@ struct ScanSetupArgs {
   int nstreams;
 };
 hipError_t launch_scan_setup(const ScanSetupArgs& a, hipStream_t stream);
+// up to four small arrays of 32-bit words from page-locked host memory to the device, and nzero words cleared, in one launch
+struct HostWordsArgs {
+  const uint32_t* src[4];
+  uint32_t* dst[4];
+  uint32_t nwords[4];
+  uint32_t* zero;
+  uint32_t nzero;
+};
+hipError_t launch_host_words(const HostWordsArgs& a, hipStream_t stream);
 // K1: synchronisation scan, one workgroup per stream, calls [call_begin, call_end) (call_end < 0: all).
 // chain_only: FIFO bookkeeping, coarse and fine time only, assuming every frame's coarse frequency offset stays within +-1
 // carrier; launch_sync_verify then computes both frequency estimates for all frames in parallel and records the first call
