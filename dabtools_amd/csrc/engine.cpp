@@ -1203,6 +1203,7 @@ int Engine::stage_decision_audit(const uint8_t* frames, int nframes, bool on_dev
       return -1;
     GuardArgs ga{};
     guard_launches_ = 0;
+    guard_counters_clear_ = false;
     guard_flagged_ = 0;
     if (guard_on && (!d_delta_.reserve(static_cast<size_t>(n) * kSymbolsPerTf) || !guard_begin(n, &ga) ||
                      !check(launch_symbol_delta(d_iq_ptrs_.get(), d_descs_.get(), n, d_frames_.get(), 0, n, kSymbolsPerTf, d_delta_.get(), kSymbolsPerTf, stream_), "symbol delta launch")))
@@ -1302,6 +1303,7 @@ bool Engine::demod_one_frame(const uint8_t* iq_virtual_base, const CallDesc& des
   const bool guard = guard_active();
   GuardArgs ga{};
   guard_launches_ = 0;
+  guard_counters_clear_ = false;
   if (guard && (!d_delta_.reserve(kSymbolsPerTf) || !guard_begin(1, &ga) ||
                 !check(launch_symbol_delta(d_iq_ptrs_.get(), d_descs_.get(), 1, d_frames_.get(), 0, 1, kSymbolsPerTf, d_delta_.get(), kSymbolsPerTf, stream_), "symbol delta launch")))
     return false;
