@@ -27,6 +27,18 @@ namespace {
 
 constexpr int kThreads = kFft64Threads;   // 512; one workgroup per stream: more threads = shorter butterfly stages
 
+// measurement build only (tools/sync_times.py, -DDABHIP_SYNC_TIMES=1): time stamps of the chain's phases, stream 0, the first 96 calls
+#ifndef DABHIP_SYNC_TIMES
+#define DABHIP_SYNC_TIMES 0
+#endif
+#if DABHIP_SYNC_TIMES
+__device__ unsigned long long g_sync_times[96 * 16];
+__device__ int g_sync_call;
+#define SYNC_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_sync_call < 96) g_sync_times[g_sync_call * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define SYNC_STAMP(i) do {} while (0)
+#endif
+
 __device__ __forceinline__ int view_byte(const uint8_t* stream, const FrameView& v, int p)
 {
   int i = 0;
@@ -249,9 +261,30 @@ __device__ int coarse_time_sync(const uint8_t* stream, const FrameView& view, in
   return coarse;
 }
 
+// What a thread of the fine time search reads from tables at places that depend on its index only: the PRS quarter turns of its three carriers and the
+// radix-3 factors of its three correlation lags.  Fetched ONCE per kernel: inside the chain they were two rounds of global loads per call (0.9 of 8.6 us,
+// tools/sync_times.py).
+struct FineTimeTables {
+  int q[3];
+  double2 w1[3], w2[3];
+};
+__device__ __forceinline__ FineTimeTables fine_time_tables(const double2* __restrict__ tw1536, const uint8_t* __restrict__ prs_q)
+{
+  static_assert(kCarriers == 3 * kThreads, "three carriers per thread");
+  FineTimeTables t;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int i = threadIdx.x + j * kThreads;
+    t.q[j] = prs_q[i];
+    t.w1[j] = tw1536[i];
+    t.w2[j] = tw1536[(2 * i) % 1536];
+  }
+  return t;
+}
+
 // dab_fine_time_sync (sdr_sync.c:71-202) -> signed byte shift
 __device__ int fine_time_sync(const uint8_t* stream, const FrameView& view, int nco, double2* A, double2* Bf, const double2* tw,
-                              const double2* __restrict__ tw1536, const uint8_t* __restrict__ prs_q, Red& red, const Prefetched<2048>& pf)
+                              const FineTimeTables& tab, Red& red, const Prefetched<2048>& pf)
 {
   const int tid = threadIdx.x;
   if (pf.ok) {
@@ -261,20 +294,28 @@ __device__ int fine_time_sync(const uint8_t* stream, const FrameView& view, int 
     load_samples<2048>(stream, view, 2 * (kNullSamples + kCpSamples), nco, A);
   }
   __syncthreads();
+  SYNC_STAMP(3);
   dft_dif<11, 3, 3, 3, 2>(A, 1, -1.0, tw);
-  for (int i = tid; i < kCarriers; i += kThreads) {
+  SYNC_STAMP(4);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int i = tid + j * kThreads;
     const int bin = i < 768 ? i + 1280 : i - 765;
-    const double2 c = mul_conj_prs(A[lds_at(brev(bin, 11))], prs_q[i]);
+    const double2 c = mul_conj_prs(A[lds_at(brev(bin, 11))], tab.q[j]);
     Bf[lds_at((i % 3) * 512 + i / 3)] = c;       // decimate by 3 for the 3 x 512 inverse DFT
   }
   __syncthreads();
+  SYNC_STAMP(5);
   dft_dif<9, 3, 3, 3>(Bf, 3, +1.0, tw);
+  SYNC_STAMP(6);
   float fv = -99999.0f;
   int fi = 0x7fffffff;
-  for (int kk = tid; kk < kCarriers; kk += kThreads) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int kk = tid + j * kThreads;
     const int r = brev(kk & 511, 9);
     const double2 f0 = Bf[lds_at(r)], f1 = Bf[lds_at(512 + r)], f2 = Bf[lds_at(1024 + r)];
-    const double2 w1 = tw1536[kk], w2 = tw1536[(2 * kk) % 1536];
+    const double2 w1 = tab.w1[j], w2 = tab.w2[j];
     const double xr = f0.x + (f1.x * w1.x - f1.y * w1.y) + (f2.x * w2.x - f2.y * w2.y);
     const double xi = f0.y + (f1.x * w1.y + f1.y * w1.x) + (f2.x * w2.y + f2.y * w2.x);
     const float mag = static_cast<float>(sqrt(xr * xr + xi * xi));
@@ -282,7 +323,9 @@ __device__ int fine_time_sync(const uint8_t* stream, const FrameView& view, int 
   }
   float gv;
   int gi;
+  SYNC_STAMP(7);
   block_argmax(red, fv, fi, &gv, &gi);
+  SYNC_STAMP(8);
   return gi < 768 ? gi * 2 + 16 : (gi - 1536) * 2;
 }
 
@@ -440,6 +483,68 @@ __device__ __forceinline__ SyncLds sync_lds(unsigned char* smem, const double2* 
   return l;
 }
 
+// fifo_call (fifo_view.hpp) on the workgroup's shared state, by the first wave instead of one thread: lane i looks at segment i of the old view (12 at most), a
+// ballot says which survive the read and a prefix count where each goes; the scalar part is computed by every lane alike.  One thread walking the LDS-resident
+// state, building the new view through a dynamically indexed local copy, took well over a microsecond of every call of the chain (tools/sync_times.py).
+// Same results as fifo_call: the host replay of that function is what the CPU suite holds against the reference's sdr_fifo.c, and every GPU trace test
+// compares fifo_count and the views' effects call by call.
+__device__ __forceinline__ void fifo_call_wave(Shared& sh)
+{
+  const int lane = threadIdx.x;                          // caller: threadIdx.x < 64
+  StreamState& st = sh.st;
+  const int64_t fed = st.fed + kChunkBytes;
+  int64_t consumed = st.consumed, count = fed - consumed;
+  int status = 0, do_sync = 0;
+  int startup = st.startup_delay;
+  if (count >= 3 * kTfSamples) {
+    const int shift = st.coarse_timeshift + st.fine_timeshift;
+    const int64_t consumed0 = consumed;
+    int len, skipped = 0;
+    if (shift > 0) {
+      consumed += shift;
+      count -= shift;
+      len = count < kTfBytes ? static_cast<int>(count) : kTfBytes;
+      skipped = shift;
+    } else {
+      len = kTfBytes + shift;
+    }
+    const bool extra = skipped > len;                    // the skipped bytes beyond a short frame stay visible
+    const int n0 = extra ? 2 : 1, covered = extra ? skipped : len;
+    // old entries, one per lane (read before anything is written: one instruction stream)
+    const int old_n = st.view.nseg;
+    const int old_end = lane < kMaxSeg ? st.view.seg_end[lane] : 0;
+    const int64_t old_src = lane < kMaxSeg ? st.view.seg_src[lane] : -1;
+    const bool keep = lane < old_n && lane < kMaxSeg && old_end > covered;
+    const unsigned long long mask = __ballot(keep);
+    const int pos = n0 + __popcll(mask & ((1ull << lane) - 1ull));
+    const int total = n0 + __popcll(mask);
+    const int n = total < kMaxSeg ? total : kMaxSeg;
+    if (keep && pos < kMaxSeg) { st.view.seg_end[pos] = old_end; st.view.seg_src[pos] = old_src; }
+    if (lane >= n && lane < kMaxSeg) { st.view.seg_end[lane] = kTfBytes; st.view.seg_src[lane] = -1; }
+    if (lane == 0) {
+      st.view.seg_end[0] = len;
+      st.view.seg_src[0] = consumed;
+      if (extra) { st.view.seg_end[1] = skipped; st.view.seg_src[1] = consumed0; }   // buffer[p] = stream[consumed0 + p] for p < shift
+      st.view.nseg = n;
+      if (total > kMaxSeg) st.overflow = 1;
+    }
+    consumed += len;
+    count -= len;
+    status = 1;
+    if (startup <= 0) ++startup;
+    else do_sync = 1;
+  }
+  if (lane == 0) {
+    st.fed = fed;
+    st.consumed = consumed;
+    st.startup_delay = startup;
+    sh.status = status;
+    sh.do_sync = do_sync;
+    sh.fifo_count = static_cast<int>(count);
+    sh.coarse_fs = 0;
+  }
+}
+
 // kChainOnly = false: sdr_demod's synchronisation as the reference runs it, call after call.
 // kChainOnly = true : only what the NEXT call depends on -- FIFO bookkeeping, coarse time, fine time.  The coarse frequency
 //   offset is assumed to come out within +-1 carrier (so the frame is demodulated and no resync is forced) and left, with the
@@ -472,28 +577,29 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
   const int kfirst = call_begin >= 0 ? call_begin : static_cast<int>(states_in[b].fed / kChunkBytes);
   const int kdesc0 = call_begin >= 0 ? 0 : kfirst;
   if (tid == 0) { sh.st = states_in[b]; sh.fine_fs = sh.st.fine_freq_shift; }
+  const FineTimeTables fine_tab = fine_time_tables(tw1536, prs_q);
   __syncthreads();
 
   for (int k = kfirst; k < kend; ++k) {
+#if DABHIP_SYNC_TIMES
+    if (blockIdx.x == 0 && tid == 0) g_sync_call = k - kfirst;
+#endif
+    SYNC_STAMP(0);
     // ---- FIFO bookkeeping: input_sdr.c:36-55 over sdr_fifo.c:43-61 (fifo_view.hpp) -------
-    if (tid == 0) {
-      const FifoCall fc = fifo_call(sh.st);
-      sh.status = fc.status;
-      sh.do_sync = fc.do_sync;
-      sh.fifo_count = fc.fifo_count;
-      sh.coarse_fs = 0;
-    }
+    if (tid < 64) fifo_call_wave(sh);
     __syncthreads();
 
     const int nco = afc ? sh.st.tuner_hz : 0;
     if (sh.do_sync) {
       const FrameView& view = sh.st.view;
       const Prefetched<2048> pf = prefetch_samples<2048>(stream, view, 2 * (kNullSamples + kCpSamples), nco);   // for the fine time search
+      SYNC_STAMP(1);
       const int coarse = coarse_time_sync(stream, view, sh.st.force_timesync, sh.red, env);      // input_sdr.c:64-74
       if (tid == 0) { sh.st.coarse_timeshift = coarse; sh.st.force_timesync = 0; }
       __syncthreads();
+      SYNC_STAMP(2);
       if (coarse == 0) {
-        const int fine = fine_time_sync(stream, view, nco, A, Bf, tw, tw1536, prs_q, sh.red, pf);   // input_sdr.c:84
+        const int fine = fine_time_sync(stream, view, nco, A, Bf, tw, fine_tab, sh.red, pf);   // input_sdr.c:84
         if (tid == 0) sh.st.fine_timeshift = fine;
         if (kChainOnly) {
           if (tid == 0) sh.status = 2;                    // assumed; sync_verify_kernel checks it
@@ -513,6 +619,10 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
       }
     }
     __syncthreads();
+    if (tid >= 64 && tid < 64 + static_cast<int>(sizeof(FrameView) / 4)) {     // the view, word by word, by the second wave (one thread copying 152 bytes out of LDS was a microsecond)
+      CallDesc& d = descs[static_cast<size_t>(b) * max_calls + (k - kdesc0)];
+      reinterpret_cast<uint32_t*>(&d.view)[tid - 64] = reinterpret_cast<const uint32_t*>(&sh.st.view)[tid - 64];
+    }
     if (tid == 0) {
       CallDesc& d = descs[static_cast<size_t>(b) * max_calls + (k - kdesc0)];
       d.status = sh.status;
@@ -524,7 +634,6 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
       d.fifo_count = sh.fifo_count;
       d.fine_freq_shift = sh.fine_fs;
       d.nco_hz = nco;
-      d.view = sh.st.view;
       if (afc) {
         // the tuner feedback of demod_thread_fn (dab2eti.c:76-103), applied to the NCO instead of the tuner; it runs
         // after EVERY call, also those that produced no frame (coarse 0, fine estimate stale), exactly as there
@@ -542,6 +651,7 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
       }
     }
     __syncthreads();
+    SYNC_STAMP(9);
   }
   if (tid == 0) { sh.st.fine_freq_shift = sh.fine_fs; states[b] = sh.st; }
 }
@@ -777,4 +887,13 @@ hipError_t launch_sync_verify(const uint8_t* const* iq, const int64_t* nbytes, c
   return hipGetLastError();
 }
 
+
+#if DABHIP_SYNC_TIMES
+}  // namespace dabhip
+extern "C" int dabhip_debug_sync_times(unsigned long long* out)
+{
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(dabhip::g_sync_times), sizeof(unsigned long long) * 96 * 16) == hipSuccess ? 0 : -1;
+}
+namespace dabhip {
+#endif
 }  // namespace dabhip
