@@ -33,7 +33,7 @@ constexpr int kThreads = kFft64Threads;   // 512; one workgroup per stream: more
 #endif
 #if DABHIP_SYNC_TIMES
 __device__ unsigned long long g_sync_times[96 * 16];
-__device__ int g_sync_call;
+__device__ volatile int g_sync_call;     // volatile: read back through the vector path (a scalar load may be served a stale line)
 #define SYNC_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_sync_call < 96) g_sync_times[g_sync_call * 16 + (i)] = wall_clock64(); } while (0)
 #else
 #define SYNC_STAMP(i) do {} while (0)

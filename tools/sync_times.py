@@ -34,10 +34,16 @@ def main():
     assert L.dabhip_debug_sync_times(raw.ctypes.data_as(C.POINTER(C.c_ulonglong))) == 0
     t = raw.reshape(96, 16)[:, :10].astype(np.float64) * 10.0      # wall_clock64: 100 MHz -> ns
     calls = range(16, 60)
-    phases = np.array([[t[c, i + 1] - t[c, i] for i in range(9)] for c in calls]) / 1000.0     # us
+    # stamps 1 .. 8 bracket the phases inside a call; the call's period comes from stamp 0 of successive calls (stamps 0 / 9 come out on another time base
+    # than 1 .. 8 in this build -- not understood --, so the wave-0 bookkeeping at both ends of a call is reported as the remainder)
+    phases = np.array([[t[c, i + 1] - t[c, i] for i in range(1, 8)] for c in calls]) / 1000.0     # us
     per_call = np.array([t[c + 1, 0] - t[c, 0] for c in calls]) / 1000.0
+    inside = {NAMES[i]: round(float(phases[:, i - 1].mean()), 3) for i in range(1, 8)}
     out = {"what": "K1 chain, stream 0, calls 16..59 of the benchmark workload: mean us per phase", "us_per_call": round(float(per_call.mean()), 3),
-           "phases": {NAMES[i]: round(float(phases[:, i].mean()), 3) for i in range(9)}, "stage_ms": {k: round(v, 3) for k, v in eng.stage_ms().items() if k in ("sync",)}}
+           "phases": inside,
+           "bookkeeping_remainder_us": round(float(per_call.mean()) - sum(inside.values()), 3),
+           "remainder_is": "FIFO bookkeeping by the first wave + barrier, descriptor write + barrier, loop overhead",
+           "stage_ms": {k: round(v, 3) for k, v in eng.stage_ms().items() if k in ("sync",)}}
     print(json.dumps(out, indent=1))
 
 
