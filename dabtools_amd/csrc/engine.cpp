@@ -673,7 +673,8 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
     // reference's order, so the result is the same in every case.  (Tried and dropped: the verification on a second stream beside
     // the OFDM stage, and -- after the LDS bank conflicts were gone -- the chain in 2..16 chunks of calls with each chunk's
     // verification beside the next chunk: 1.28 -> 1.30..1.40 ms.  A chain workgroup holds half of a CU's LDS, so the verification
-    // beside it runs at half its rate and slows the chain.)
+    // beside it runs at half its rate and slows the chain.  Round 3, with the fp32 verification (39.5 KB of LDS, 54 VGPRs): on its own stream beside the FIC
+    // symbols' OFDM launch -- step unchanged, 10.4 ms: both are issue-bound, the work only moves.)
     if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), nstreams, max_calls_, -1, -1,
                                 d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), 0, stream_, true),
                "sync chain launch") ||
