@@ -234,10 +234,15 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
     const float re = cur.x * prev.x + cur.y * prev.y;     // Re(cur conj(prev))
     const float im = cur.x * prev.y - cur.y * prev.x;     // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
     if (ak[m] >= 0) {
-      const int q0 = max(-7, min(7, __float2int_rn(re * scale)));
-      const int q1 = max(-7, min(7, __float2int_rn(-im * scale)));
-      dec[ak[m]] = static_cast<uint8_t>(q0 & 15);
-      dec[ak[m] + 96] = static_cast<uint8_t>(q1 & 15);
+      // round-to-nearest-even by the 1.5 x 2^23 trick: the sum's bit pattern is the constant's plus the rounded integer (two's complement), so the clamp to
+      // +-7 is ONE v_med3_i32 on the bits and the nibble their low four -- mul, add, med3, and instead of mul, rndne, cvt, med3, and (same values: the sum
+      // rounds exactly as v_rndne does for |x| < 2^22, and anything larger lands beyond the clamp either way)
+      constexpr float kMagic = 12582912.0f;
+      constexpr int kBits = 0x4B400000;
+      // (product and sum rounded separately, as round(x) of the rounded product was: no contraction into one fused multiply-add)
+      const int b0 = __builtin_bit_cast(int, __fadd_rn(__fmul_rn(re, scale), kMagic)), b1 = __builtin_bit_cast(int, __fadd_rn(__fmul_rn(-im, scale), kMagic));
+      dec[ak[m]] = static_cast<uint8_t>(max(kBits - 7, min(kBits + 7, b0)) & 15);
+      dec[ak[m] + 96] = static_cast<uint8_t>(max(kBits - 7, min(kBits + 7, b1)) & 15);
     }
   }
 }
