@@ -757,6 +757,7 @@ __global__ __launch_bounds__(256, DABHIP_VIT_WAVES) void viterbi_fused_kernel(co
   const int last_word = row_words - 1 - word0;
   uint64_t fifo = 0;
   int have = 0;                              // wave-uniform number of valid bits in fifo
+  // (one word ahead; two -- hard -- and six -- soft -- words ahead measured slower, 5.04 against 4.88 and 6.78 against 6.63 ms)
   uint32_t nextw = src[0];
   int widx = 1;
   auto refill = [&]() {
