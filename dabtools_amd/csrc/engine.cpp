@@ -689,9 +689,8 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
         // fine_freq_shift carried through the calls that did not demodulate (the kernel skips streams with a violation)
         !check(launch_sync_verify(d_iq_ptrs_.get(), d_nbytes_.get(), d_calls_before_.get(), d_states_.get(), d_descs_.get(), nstreams, max_calls_,
                                   d_tw2048_.get(), d_prs_.get(), d_viol_.get(), true, stream_),
-               "sync carry launch") ||
-        !check(hipMemcpyAsync(h_viol_.data(), d_viol_.get(), (nstreams + 1) * sizeof(int), hipMemcpyDeviceToHost, stream_), "violation download"))
-      return false;
+               "sync carry launch"))
+      return false;                                        // (the violation marks come back on the side stream, in fetch(): a copy on the main stream sits between K1 and the first OFDM launch)
     split_scan = true;
   }
   (void)hipEventRecord(ev_[1], stream_);
@@ -701,6 +700,7 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
   // first OFDM launch -- is not waited for)
   auto fetch = [&]() {
     return check(hipStreamWaitEvent(copy_stream_, ev_[1], 0), "scan event") &&
+           (!split_scan || check(hipMemcpyAsync(h_viol_.data(), d_viol_.get(), (nstreams + 1) * sizeof(int), hipMemcpyDeviceToHost, copy_stream_), "violation download")) &&
            check(hipMemcpyAsync(h_info_.data(), d_info_.get(), ndesc * sizeof(int2), hipMemcpyDeviceToHost, copy_stream_), "call info download") &&
            check(hipMemcpyAsync(states, d_states_.get(), nstreams * sizeof(StreamState), hipMemcpyDeviceToHost, copy_stream_), "state download") &&
            check(hipStreamSynchronize(copy_stream_), "sync scan");
@@ -989,7 +989,9 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   // behind it, and the whole pipeline is awaited ONCE
   host_lane_->wait();
   if (gpu_ok && host_ok)
-    gpu_ok = check(hipStreamWaitEvent(stream_, ev_upload_, 0), "work list wait") && msc_launch_async(work);
+    // (the upload is normally through long before this point: then no wait is queued at all -- a wait on an event that has already fired still costs the
+    // main stream a barrier packet, 10 .. 15 us of idle GPU before K4)
+    gpu_ok = (hipEventQuery(ev_upload_) == hipSuccess || check(hipStreamWaitEvent(stream_, ev_upload_, 0), "work list wait")) && msc_launch_async(work);
   if (guard && gpu_ok) gpu_ok = guard_download();        // the entry counts of all guarded launches, behind everything else
   mark("all queued");
   const bool drained = check(hipStreamSynchronize(stream_), "decode");      // also on the error paths: nothing may stay in flight
