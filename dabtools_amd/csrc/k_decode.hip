@@ -445,12 +445,13 @@ __device__ __forceinline__ void acs4(uint32_t ww, pk16 (&pm)[32], pk16 (&pn)[32]
   repair_layout(pl4, pm);
 }
 
-__device__ __forceinline__ void acs4_soft(uint64_t nibs, const SoftLut* lut, pk16 (&pm)[32], pk16 (&pn)[32], pk16 (&pl4)[32], uint4* rec)
+// x0 .. x3: the received 4-bit values of four steps, each step's in the low 16 bits of its own word (values not received: zero nibbles)
+__device__ __forceinline__ void acs4_soft(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, const SoftLut* lut, pk16 (&pm)[32], pk16 (&pn)[32], pk16 (&pl4)[32], uint4* rec)
 {
-  acs_step_soft_any<0>(static_cast<unsigned>(nibs) & 0xffffu, lut, pm, pn);
-  acs_step_soft_any<1>(static_cast<unsigned>(nibs >> 16) & 0xffffu, lut, pn, pm);
-  acs_step_soft_any<2>(static_cast<unsigned>(nibs >> 32) & 0xffffu, lut, pm, pn);
-  acs_step_soft_any<3>(static_cast<unsigned>(nibs >> 48), lut, pn, pl4);
+  acs_step_soft_any<0>(x0, lut, pm, pn);
+  acs_step_soft_any<1>(x1, lut, pn, pm);
+  acs_step_soft_any<2>(x2, lut, pm, pn);
+  acs_step_soft_any<3>(x3, lut, pn, pl4);
   survivor_record(pl4, rec);
   repair_layout(pl4, pm);
 }
@@ -466,13 +467,13 @@ __device__ __forceinline__ void acs_tail(uint32_t ww, int r, pk16 (&pm)[32], pk1
   acs_step<2>((ww >> 16) & 0xff, pm, pn);
   survivor_record(pn, rec);
 }
-__device__ __forceinline__ void acs_tail_soft(uint64_t nibs, int r, const SoftLut* lut, pk16 (&pm)[32], pk16 (&pn)[32], uint4* rec)
+__device__ __forceinline__ void acs_tail_soft(uint32_t x0, uint32_t x1, uint32_t x2, int r, const SoftLut* lut, pk16 (&pm)[32], pk16 (&pn)[32], uint4* rec)
 {
-  acs_step_soft_any<0>(static_cast<unsigned>(nibs) & 0xffffu, lut, pm, pn);
+  acs_step_soft_any<0>(x0, lut, pm, pn);
   if (r == 1) { survivor_record(pn, rec); return; }
-  acs_step_soft_any<1>(static_cast<unsigned>(nibs >> 16) & 0xffffu, lut, pn, pm);
+  acs_step_soft_any<1>(x1, lut, pn, pm);
   if (r == 2) { survivor_record(pm, rec); return; }
-  acs_step_soft_any<2>(static_cast<unsigned>(nibs >> 32) & 0xffffu, lut, pm, pn);
+  acs_step_soft_any<2>(x2, lut, pm, pn);
   survivor_record(pn, rec);
 }
 
@@ -797,23 +798,20 @@ __global__ __launch_bounds__(256, DABHIP_VIT_WAVES) void viterbi_fused_kernel(co
         if (t + 8 <= nsteps) acs8_lut(ww[0], ww[1], lut, pm, pn, pl4, my_rec + blk * 256);
         else if (t < nsteps) acs8_tail_lut(ww[0], ww[1], nsteps - t, lut, pm, pn, pl4, my_rec + blk * 256);
       } else {
-        uint64_t nibs[2];
+        // a step's values straight out of the fifo's low word (4 n <= 16 bits; n wave-uniform): one 32-bit and, one 64-bit shift per step -- collecting
+        // them in 64-bit words first, to be taken apart again by the steps, cost seven instructions more per step (161 -> 150 per step)
+        uint32_t x[8];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          nibs[h] = 0;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int nb = 4 * ((counts >> (3 * (4 * h + g))) & 7);      // bits of this step: 4 per received value
-            if (have < nb) refill();
-            const uint64_t v = fifo & ((1ull << nb) - 1ull);
-            fifo >>= nb;
-            have -= nb;
-            nibs[h] |= v << (16 * g);
-          }
+        for (int g = 0; g < 8; ++g) {
+          const int nb = 4 * ((counts >> (3 * g)) & 7);        // bits of this step: 4 per received value
+          if (have < nb) refill();
+          x[g] = static_cast<uint32_t>(fifo) & ((1u << nb) - 1u);
+          fifo >>= nb;
+          have -= nb;
         }
-        if (t + 4 <= nsteps) acs4_soft(nibs[0], soft_lut, pm, pn, pl4, my_rec + static_cast<size_t>(t >> 2) * 128);
-        if (t + 8 <= nsteps) acs4_soft(nibs[1], soft_lut, pm, pn, pl4, my_rec + static_cast<size_t>((t >> 2) + 1) * 128);
-        else if (t + 4 < nsteps) acs_tail_soft(nibs[1], nsteps - t - 4, soft_lut, pm, pn, my_rec + static_cast<size_t>((t >> 2) + 1) * 128);
+        if (t + 4 <= nsteps) acs4_soft(x[0], x[1], x[2], x[3], soft_lut, pm, pn, pl4, my_rec + static_cast<size_t>(t >> 2) * 128);
+        if (t + 8 <= nsteps) acs4_soft(x[4], x[5], x[6], x[7], soft_lut, pm, pn, pl4, my_rec + static_cast<size_t>((t >> 2) + 1) * 128);
+        else if (t + 4 < nsteps) acs_tail_soft(x[4], x[5], x[6], nsteps - t - 4, soft_lut, pm, pn, my_rec + static_cast<size_t>((t >> 2) + 1) * 128);
       }
       t += 8;
       if ((t & (MetricScale<kScale>::kRebaseSteps - 1)) == 0 && t < nsteps) rebase_metrics<kScale>(pm);
