@@ -131,6 +131,8 @@ _SIGNATURES = {
     "dabhip_host_alloc": (C.c_void_p, [C.c_size_t]),
     "dabhip_host_free": (None, [C.c_void_p]),
     "dabhip_synth_generate_device": (C.c_int, [C.POINTER(SynthCfg), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int]),
+    "dabhip_dab_set_soft": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_engine_demapped_tf": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int8), C.POINTER(C.c_int8)]),
 }
 
 _lib = None
@@ -414,13 +416,16 @@ class Sdr:
 class Dab:
     """init_dab_state + dab_process_frame (dab.h:91-92) for one stream."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, soft=False):
         self.frames = []
         self._cb = ETI_CALLBACK(lambda p: self.frames.append(np.ctypeslib.as_array(p, (ETI_BYTES,)).copy()))
         self._h = lib().dabhip_dab_init(device, self._cb)
         _need(self._h, "dab_init")
         self.fic = np.ctypeslib.as_array(lib().dabhip_dab_tf_fic(self._h), (FIC_BITS,))
         self.msc = np.ctypeslib.as_array(lib().dabhip_dab_tf_msc(self._h), (MSC_BITS,))
+        if soft:       # extension: the hand-off carries signed 4-bit values (int8 views of the same arrays)
+            _need(lib().dabhip_dab_set_soft(self._h, 1) == 0, "dab_set_soft")
+            self.fic, self.msc = self.fic.view(np.int8), self.msc.view(np.int8)
 
     def process_frame(self):
         r = lib().dabhip_dab_process_frame(self._h)
@@ -551,6 +556,12 @@ class Engine:
 
     def eti_count(self, stream):
         return lib().dabhip_engine_eti_count(self._h, stream)
+
+    def demapped_tf(self, stream, tf):
+        """(fic[9216], msc[221184]) int8: what the OFDM stage of the last decode left for that TF (0/1, or -7..7 with soft decisions)."""
+        fic, msc = np.zeros(FIC_BITS, dtype=np.int8), np.zeros(MSC_BITS, dtype=np.int8)
+        _need(lib().dabhip_engine_demapped_tf(self._h, stream, tf, fic.ctypes.data_as(C.POINTER(C.c_int8)), msc.ctypes.data_as(C.POINTER(C.c_int8))) == 0, "demapped_tf")
+        return fic, msc
 
     def eti_device_ptr(self):
         n = C.c_int64(0)

@@ -173,6 +173,12 @@ const void* dabhip_engine_eti_device_ptr(const dabhip_engine* ce, int64_t* nfram
   }
   return e->combined.get();
 }
+int dabhip_engine_demapped_tf(dabhip_engine* e, int stream, int tf, int8_t* fic, int8_t* msc)
+{
+  if (!e || !fic || !msc) { set_error("demapped_tf: null argument"); return -1; }
+  if (stream < 0 || stream >= static_cast<int>(e->lane_of.size())) { set_error("demapped_tf: bad stream"); return -1; }
+  return e->lanes[e->lane_of[stream]]->read_demapped_tf(e->local_of[stream], tf, fic, msc) ? 0 : -1;
+}
 int dabhip_engine_trace(const dabhip_engine* e, int stream, int32_t* ints6, double* ffs, int cap_calls)
 {
   if (!e || !ints6 || stream < 0 || stream >= static_cast<int>(e->lane_of.size())) return -1;
@@ -445,6 +451,13 @@ void dabhip_dab_free(dabhip_dab* d) { delete d; }
 uint8_t* dabhip_dab_tf_fic(dabhip_dab* d) { return d ? d->fic.data() : nullptr; }
 uint8_t* dabhip_dab_tf_msc(dabhip_dab* d) { return d ? d->msc.data() : nullptr; }
 int dabhip_dab_locked(const dabhip_dab* d) { return d && d->plane.locked(); }
+int dabhip_dab_set_soft(dabhip_dab* d, int enable)
+{
+  if (!d) { set_error("dab_set_soft: null handle"); return -1; }
+  if (d->slot != 0 || d->dropped != 0) { set_error("dab_set_soft: only before the first frame"); return -1; }
+  d->eng.set_soft(enable != 0);
+  return d->eng.reserve_tf_slots(kDabSlots) ? 0 : -1;
+}
 int dabhip_dab_last_fibs(const dabhip_dab* d, uint8_t* fibs, uint8_t* crc_ok)
 {
   if (!d || !fibs || !crc_ok) return -1;

@@ -224,22 +224,25 @@ bool Engine::reserve_tf_slots(int nslots, int msc_rows)
 }
 
 // S3: host 0/1 bytes of one TF -> FIC row of `slot`, MSC scattered into the planar logical rows (single stream,
-// CIF 0 at row kRowLead), the same layout demap_kernel<true> produces
+// CIF 0 at row kRowLead), the same layout demap_kernel<true> produces.  With soft decisions on the bytes are signed 4-bit
+// values (-7 .. 7 as int8; > 0: bit 0) and the rows hold a nibble per value: word u / 8 of a plane, nibble u % 8.
 bool Engine::store_tf_bytes(int slot, const uint8_t* fic_bytes, const uint8_t* msc_bytes)
 {
-  if (!hard_only("store_tf_bytes")) return false;
   static const int tmap[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
-  std::vector<uint32_t> f(kFicWords), plane(108);
-  pack_bits(fic_bytes, kFicBits, f.data());
-  if (!check(hipMemcpy(d_fic_bits_.get() + static_cast<size_t>(slot) * kFicWords, f.data(), f.size() * 4, hipMemcpyHostToDevice), "fic upload")) return false;
+  const int bits = soft_bits_ ? 4 : 1, per = 32 / bits;
+  const uint32_t vmask = soft_bits_ ? 15u : 1u;
+  const size_t fic_words = static_cast<size_t>(kFicWords) * bits, row_words = static_cast<size_t>(kCifWords) * bits, plane_words = 108u * bits;
+  std::vector<uint32_t> f(fic_words, 0u), plane(plane_words);
+  for (int i = 0; i < kFicBits; ++i) f[i / per] |= (static_cast<uint32_t>(fic_bytes[i]) & vmask) << (bits * (i % per));
+  if (!check(hipMemcpy(d_fic_bits_.get() + static_cast<size_t>(slot) * fic_words, f.data(), f.size() * 4, hipMemcpyHostToDevice), "fic upload")) return false;
   for (int q = 0; q < 4; ++q) {
     const uint8_t* cif = msc_bytes + static_cast<size_t>(q) * kCifBits;
     for (int r = 0; r < 16; ++r) {
       std::fill(plane.begin(), plane.end(), 0u);
-      for (int u = 0; u < kCifBits / 16; ++u) plane[u >> 5] |= static_cast<uint32_t>(cif[16 * u + r] & 1u) << (u & 31);
+      for (int u = 0; u < kCifBits / 16; ++u) plane[u / per] |= (static_cast<uint32_t>(cif[16 * u + r]) & vmask) << (bits * (u % per));
       const size_t row = static_cast<size_t>(kRowLead + 4 * slot + q - tmap[r]);
-      // plane r occupies words [108 r, 108 r + 108) of the logical row (layout of demap_kernel<true>)
-      if (!check(hipMemcpy(d_msc_bits_.get() + row * kCifWords + r * 108, plane.data(), 108 * 4, hipMemcpyHostToDevice), "msc upload")) return false;
+      // plane r occupies words [108 r, 108 r + 108) (x 4 with soft values) of the logical row (layout of demap_kernel<true>)
+      if (!check(hipMemcpy(d_msc_bits_.get() + row * row_words + r * plane_words, plane.data(), plane_words * 4, hipMemcpyHostToDevice), "msc upload")) return false;
     }
   }
   return true;
@@ -247,18 +250,51 @@ bool Engine::store_tf_bytes(int slot, const uint8_t* fic_bytes, const uint8_t* m
 
 bool Engine::recycle_tf_slots(int used_slots, int keep_slots)
 {
-  if (!hard_only("recycle_tf_slots")) return false;
   // FIC rows / FIB records: the newest keep_slots; logical CIF rows: everything from 15 rows before the oldest kept CIF
+  const size_t bits = soft_bits_ ? 4 : 1;
   const int src_slot = used_slots - keep_slots;
   const size_t row_src = static_cast<size_t>(4 * src_slot), nrows = static_cast<size_t>(4 * keep_slots + kRowLead);
-  if (!d_bytes_.reserve(std::max(nrows * kCifWords * 4, static_cast<size_t>(keep_slots) * kFicWords * 4))) return false;
+  if (!d_bytes_.reserve(std::max(nrows * kCifWords * 4 * bits, static_cast<size_t>(keep_slots) * kFicWords * 4 * bits))) return false;
   auto mv = [&](void* base, size_t unit, size_t src, size_t n) {
     uint8_t* b = static_cast<uint8_t*>(base);
     return check(hipMemcpy(d_bytes_.get(), b + src * unit, n * unit, hipMemcpyDeviceToDevice), "slot move") &&
            check(hipMemcpy(b, d_bytes_.get(), n * unit, hipMemcpyDeviceToDevice), "slot move");
   };
-  return mv(d_fic_bits_.get(), kFicWords * 4, src_slot, keep_slots) && mv(d_fibs_.get(), 384, src_slot, keep_slots) &&
-         mv(d_fib_ok_.get(), 12, src_slot, keep_slots) && mv(d_msc_bits_.get(), kCifWords * 4, row_src, nrows);
+  return mv(d_fic_bits_.get(), kFicWords * 4 * bits, src_slot, keep_slots) && mv(d_fibs_.get(), 384, src_slot, keep_slots) &&
+         mv(d_fib_ok_.get(), 12, src_slot, keep_slots) && mv(d_msc_bits_.get(), kCifWords * 4 * bits, row_src, nrows);
+}
+
+// What the OFDM stage of the LAST decode() / feed() left for transmission frame `tf` (0-based among the stream's TF slots of that
+// decode, carried slots of a session first) of `stream`: the content of tf->fic_symbols_demapped / msc_symbols_demapped (dab.h:27-33)
+// as the batch path holds it -- FIC row in natural order, MSC values gathered back out of the planar logical rows the demapper
+// scattered them into.  Hard decisions: 0 / 1; soft decisions: the signed 4-bit values.
+bool Engine::read_demapped_tf(int stream, int tf, int8_t* fic_out, int8_t* msc_out)
+{
+  static const int tmap[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+  if (stream < 0 || stream >= nstreams_ || static_cast<int>(prev_tf_base_.size()) <= stream || tf < 0 || tf >= prev_used_[stream]) {
+    set_error("demapped_tf: no such stream / transmission frame in the last decode");
+    return false;
+  }
+  if (!check(hipSetDevice(device_), "hipSetDevice")) return false;
+  const int bits = soft_bits_ ? 4 : 1, per = 32 / bits;
+  const size_t fic_words = static_cast<size_t>(kFicWords) * bits, row_words = static_cast<size_t>(kCifWords) * bits, plane_words = 108u * bits;
+  std::vector<uint32_t> f(fic_words), rows(static_cast<size_t>(kRowLead + 4) * row_words);
+  const size_t slot = static_cast<size_t>(prev_tf_base_[stream]) + tf, row0 = static_cast<size_t>(prev_row_base_[stream]) + 4 * tf - kRowLead;
+  if (!check(hipMemcpy(f.data(), d_fic_bits_.get() + slot * fic_words, f.size() * 4, hipMemcpyDeviceToHost), "fic download") ||
+      !check(hipMemcpy(rows.data(), d_msc_bits_.get() + row0 * row_words, rows.size() * 4, hipMemcpyDeviceToHost), "msc download"))
+    return false;
+  auto value = [&](uint32_t w, int k) -> int8_t {
+    const uint32_t v = (w >> (bits * k)) & (soft_bits_ ? 15u : 1u);
+    return static_cast<int8_t>(soft_bits_ ? static_cast<int>(v ^ 8u) - 8 : static_cast<int>(v));
+  };
+  for (int i = 0; i < kFicBits; ++i) fic_out[i] = value(f[i / per], i % per);
+  for (int q = 0; q < 4; ++q)
+    for (int i = 0; i < kCifBits; ++i) {
+      const int r = i & 15, u = i >> 4;
+      const size_t row = static_cast<size_t>(kRowLead + q - tmap[r]);                 // transmitted CIF q of this TF: plane r lives tmap[r] rows earlier
+      msc_out[static_cast<size_t>(q) * kCifBits + i] = value(rows[row * row_words + r * plane_words + u / per], u % per);
+    }
+  return true;
 }
 
 // S2 / stage_demap: the TF was demapped in NATURAL order (demap_kernel<false>) into FIC slot `slot`, CIF rows 4*slot..

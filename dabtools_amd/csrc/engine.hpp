@@ -216,6 +216,8 @@ class Engine {
   bool msc_upload(const MscWork& w, hipStream_t s);
   bool msc_launch(const MscWork& w);
   bool read_eti(int64_t first, int64_t n, uint8_t* dst);
+  // the demapped values (hard: 0 / 1, soft: -7 .. 7) of one TF of the last decode, in the reference's hand-off order (dab.h:27-33)
+  bool read_demapped_tf(int stream, int tf, int8_t* fic_out, int8_t* msc_out);
   // front end on an explicit single stream (S2 seam): calls [call, call+1)
   bool scan_one_call(const uint8_t* iq_virtual_base, int64_t fed_bytes, StreamState* d_state, int call, CallDesc* out);
   bool demod_one_frame(const uint8_t* iq_virtual_base, const CallDesc& desc, uint8_t* fic_bytes, uint8_t* msc_bytes);

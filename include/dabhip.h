@@ -82,6 +82,11 @@ uint8_t *dabhip_dab_tf_msc(dabhip_dab *d);   /* 221184 bytes */
  * times, synchronously, with a pointer to a 6144-byte frame valid during the call. */
 int dabhip_dab_process_frame(dabhip_dab *d);
 int dabhip_dab_locked(const dabhip_dab *d);
+/* Soft-decision extension of this seam (not in the reference: dab.h:27-33 carries 0/1 bytes): after dabhip_dab_set_soft(d, 1) --
+ * before the first frame only -- the two arrays carry signed 4-bit values as int8 (-7 .. 7; > 0: the hard bit would be 0; the
+ * demapper's rule is dabhip_engine_set_soft's) and the FIC / MSC decoders use them as branch metrics.  Lets a test feed the
+ * decoders the very values an independent restatement decodes (oracle/or_soft.c). */
+int dabhip_dab_set_soft(dabhip_dab *d, int enable);
 /* FIBs (12 x 32 bytes) and CRC flags (12) of the TF processed last (struct tf_fibs_t, dab.h:21-25). */
 int dabhip_dab_last_fibs(const dabhip_dab *d, uint8_t *fibs, uint8_t *crc_ok);
 
@@ -216,6 +221,12 @@ int dabhip_stream_ceiling(int device, size_t bytes, int reps, double *gbs);
 void *dabhip_device_alloc(size_t nbytes, int device);
 void dabhip_device_free(void *p);
 int dabhip_device_copy(void *dst, const void *src, size_t nbytes, int to_device);
+
+/* What the OFDM stage of the LAST dabhip_engine_decode left for transmission frame `tf` (0-based among the frames `stream`
+ * demodulated in that decode) -- the content of tf->fic_symbols_demapped[3][3072] and tf->msc_symbols_demapped[72][3072]
+ * (dab.h:27-33, filled at input_sdr.c:146-162) as the batch path holds it: 9216 + 221184 values, 0 / 1 for hard decisions, the
+ * signed 4-bit values (-7 .. 7) with soft decisions on.  Host arrays.  0, <0 on error. */
+int dabhip_engine_demapped_tf(dabhip_engine *e, int stream, int tf, int8_t *fic, int8_t *msc);
 
 /* Per sdr_demod call trace of one stream, for parity with the reference's state after each
  * call: {ok, frame_read, coarse_timeshift, fine_timeshift, coarse_freq_shift, fifo_count}

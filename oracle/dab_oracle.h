@@ -104,11 +104,30 @@ struct or_sdr_trace {
 void or_sdr_get_trace(const struct or_sdr *s, struct or_sdr_trace *t);
 const double *or_sdr_symbols(const struct or_sdr *s); /* [76][2048][2] fftshifted spectra of the last TF */
 const uint8_t *or_sdr_buffer(const struct or_sdr *s); /* the 393216-byte frame buffer after the last read */
+const double *or_sdr_frame(const struct or_sdr *s);   /* [196608][2] the samples of the last processed frame (input_sdr.c:79-82) */
 
 /* whole replay (dab2eti.c:60-130 minus USB and tuner): cu8 stream in 262144-byte chunks -> ETI frames.
  * returns number of ETI frames written (each 6144 B) into eti_out (capacity in frames). */
 int or_replay(const uint8_t *iq, size_t nbytes, uint8_t *eti_out, int cap_frames,
               struct or_sdr_trace *trace, int trace_cap, int *ntrace);
+
+/* ---- soft-decision extension (or_soft.c): NOT reference behaviour -- the reference decodes hard decisions only
+ * (input_sdr.c:157-158, depuncture.c:36-43); the rule is the product's own, restated independently of its kernels ------ */
+#define OR_SOFT_Q4 4        /* signed 4-bit values, what the product computes */
+#define OR_SOFT_Q8 8        /* the same scale in steps of 1/16, +-127/16 (SURVEY.md 8(f) rank 2 names 8 bits) */
+#define OR_SOFT_FLOAT 32    /* no quantisation */
+double or_soft_quantise(double v, int mode);
+void or_soft_demap(const struct or_sdr *s, int mode, float *fic /* 9216 */, float *msc /* 221184 */);   /* input_sdr.c:132-162 with values */
+void or_viterbi_soft(const float *soft, uint8_t *data, int nbits, int mode);                              /* viterbi.c:352-451, metric 28 + sum +-v */
+void or_fic_depuncture_soft(float *out, const float *in);                                                 /* depuncture.c:45-82 */
+int  or_msc_depuncture_soft(float *out, const float *in, const struct or_subch *sc);                      /* depuncture.c:84-132 */
+void or_time_deinterleave_soft(float *dst, const float *const cifs[16]);                                  /* misc.c:29-39 */
+int  or_fic_decode_soft(const float *fic_soft, int mode, uint8_t fib[12][32], uint8_t crc_ok[12]);         /* fic.c:160-208 */
+void or_dab_set_soft(struct or_dab *d, int mode);            /* before the first frame; the TF hand-off then carries values: */
+float *or_dab_tf_sfic(struct or_dab *d);
+float *or_dab_tf_smsc(struct or_dab *d);
+/* or_replay with the soft demapper and decoders; values_out (optional): [TF][9216 + 221184] values of the demodulated TFs */
+int or_replay_soft(const uint8_t *iq, size_t nbytes, int mode, uint8_t *eti_out, int cap_frames, float *values_out, int values_cap_tf, int *ntf);
 
 #ifdef __cplusplus
 }

@@ -313,6 +313,7 @@ struct or_tf {
   uint8_t crc_ok[12];
   int ok_count;
   uint8_t msc[OR_MSC_BITS];
+  float *sfic, *smsc;       /* soft-decision extension (or_soft.c): the same two arrays as values; NULL in the reference's mode */
 };
 
 struct or_dab {
@@ -323,6 +324,8 @@ struct or_dab {
   int ncifs, tfidx, locked, okcount;
   or_eti_cb cb;
   void *user;
+  int soft;                 /* 0 = the reference (hard decisions); else OR_SOFT_* (or_soft.c) */
+  const float *cifs_smsc[16];
 };
 
 struct or_dab *or_dab_new(or_eti_cb cb, void *user)
@@ -336,7 +339,24 @@ struct or_dab *or_dab_new(or_eti_cb cb, void *user)
   d->user = user;
   return d;
 }
-void or_dab_free(struct or_dab *d) { free(d); }
+void or_dab_free(struct or_dab *d)
+{
+  int i;
+  for (i = 0; i < 5; i++) { free(d->tfs[i].sfic); free(d->tfs[i].smsc); }
+  free(d);
+}
+/* soft-decision extension: the TF hand-off carries values (or_dab_tf_sfic / _smsc) instead of 0/1 bytes; before the first frame */
+void or_dab_set_soft(struct or_dab *d, int mode)
+{
+  int i;
+  d->soft = mode;
+  for (i = 0; i < 5; i++) {
+    d->tfs[i].sfic = (float *)calloc(OR_FIC_BITS, sizeof(float));
+    d->tfs[i].smsc = (float *)calloc(OR_MSC_BITS, sizeof(float));
+  }
+}
+float *or_dab_tf_sfic(struct or_dab *d) { return d->tfs[d->tfidx].sfic; }
+float *or_dab_tf_smsc(struct or_dab *d) { return d->tfs[d->tfidx].smsc; }
 uint8_t *or_dab_tf_fic(struct or_dab *d) { return d->tfs[d->tfidx].fic; }
 uint8_t *or_dab_tf_msc(struct or_dab *d) { return d->tfs[d->tfidx].msc; }
 int or_dab_locked(const struct or_dab *d) { return d->locked; }
@@ -351,20 +371,23 @@ static void create_eti(struct or_dab *d)
 {
   static uint8_t cif[OR_CIF_BITS];
   static uint8_t dp[3072 * 4 * 18];
+  static float scif[OR_CIF_BITS], sdp[3072 * 4 * 18];
   uint8_t eti[OR_ETI_BYTES];
   struct or_ens_info *info = &d->ens;
   int e1 = or_init_eti(eti, info), e, i;
   unsigned crc;
   memcpy(eti + e1, d->cifs_fibs[0], 96);
   e = e1 + 96;
-  or_time_deinterleave(cif, d->cifs_msc);
+  if (d->soft) or_time_deinterleave_soft(scif, d->cifs_smsc);
+  else or_time_deinterleave(cif, d->cifs_msc);
   for (i = 0; i < 64; i++) {
     const struct or_subch *sc = &info->sub[i];
     if (sc->id >= 0) {
-      int len = or_msc_depuncture(dp, cif + sc->start_cu * 64, sc);
+      int len = d->soft ? or_msc_depuncture_soft(sdp, scif + sc->start_cu * 64, sc) : or_msc_depuncture(dp, cif + sc->start_cu * 64, sc);
       int bits = len / 4 - 6;
       int obytes = ((bits / 8) + 7) & 0xfff8;
-      or_viterbi(dp, eti + e, bits);
+      if (d->soft) or_viterbi_soft(sdp, eti + e, bits, d->soft);
+      else or_viterbi(dp, eti + e, bits);
       or_descramble(eti + e, obytes);
       e += obytes;
     }
@@ -387,7 +410,7 @@ void or_dab_process_frame(struct or_dab *d)
 {
   struct or_tf *tf = &d->tfs[d->tfidx];
   int i;
-  tf->ok_count = or_fic_decode(tf->fic, tf->fib, tf->crc_ok);
+  tf->ok_count = d->soft ? or_fic_decode_soft(tf->sfic, d->soft, tf->fib, tf->crc_ok) : or_fic_decode(tf->fic, tf->fib, tf->crc_ok);
   if (tf->ok_count > 0) or_fib_decode(&d->tf_info, (const uint8_t(*)[32])tf->fib, tf->crc_ok);
   if (tf->ok_count == 12) {
     d->okcount++;
@@ -405,6 +428,7 @@ void or_dab_process_frame(struct or_dab *d)
   if (d->ncifs < 16) {
     for (i = 0; i < 4; i++) {
       d->cifs_fibs[d->ncifs] = tf->fib[3 * i];
+      if (d->soft) d->cifs_smsc[d->ncifs] = tf->smsc + i * OR_CIF_BITS;
       d->cifs_msc[d->ncifs++] = tf->msc + i * OR_CIF_BITS;
     }
   } else {
@@ -412,8 +436,10 @@ void or_dab_process_frame(struct or_dab *d)
       create_eti(d);
       memmove(d->cifs_fibs, d->cifs_fibs + 1, sizeof d->cifs_fibs[0] * 15);
       memmove(d->cifs_msc, d->cifs_msc + 1, sizeof d->cifs_msc[0] * 15);
+      memmove(d->cifs_smsc, d->cifs_smsc + 1, sizeof d->cifs_smsc[0] * 15);
       d->cifs_fibs[15] = tf->fib[3 * i];
       d->cifs_msc[15] = tf->msc + i * OR_CIF_BITS;
+      if (d->soft) d->cifs_smsc[15] = tf->smsc + i * OR_CIF_BITS;
     }
   }
   d->tfidx = (d->tfidx + 1) % 5;

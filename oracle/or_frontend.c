@@ -293,6 +293,7 @@ void or_sdr_get_trace(const struct or_sdr *s, struct or_sdr_trace *t)
 }
 const double *or_sdr_symbols(const struct or_sdr *s) { return s->symbols; }
 const uint8_t *or_sdr_buffer(const struct or_sdr *s) { return s->buffer; }
+const double *or_sdr_frame(const struct or_sdr *s) { return s->frame; }
 
 /* ------------------------------------------------------------------------- */
 struct sink { uint8_t *out; int cap, n; };

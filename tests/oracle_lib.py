@@ -36,7 +36,7 @@ _ref = {}
 
 def build_oracle():
     so = os.path.join(ORACLE_DIR, "liboracle.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("or_tables.c", "or_backend.c", "or_frontend.c", "dab_oracle.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("or_tables.c", "or_backend.c", "or_frontend.c", "or_soft.c", "dab_oracle.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -74,6 +74,22 @@ def oracle():
         L.or_replay.argtypes = [u8p, C.c_size_t, u8p, C.c_int, C.POINTER(SdrTrace), C.c_int, C.POINTER(C.c_int)]
         L.or_fine_freq_corr.restype = C.c_double
         L.or_coarse_time_sync.restype = C.c_uint32
+        # soft-decision extension (or_soft.c)
+        f32p = C.POINTER(C.c_float)
+        L.or_soft_quantise.restype = C.c_double
+        L.or_soft_quantise.argtypes = [C.c_double, C.c_int]
+        L.or_viterbi_soft.argtypes = [f32p, u8p, C.c_int, C.c_int]
+        L.or_soft_demap.argtypes = [C.c_void_p, C.c_int, f32p, f32p]
+        L.or_fic_decode_soft.restype = C.c_int
+        L.or_fic_decode_soft.argtypes = [f32p, C.c_int, u8p, u8p]
+        L.or_dab_set_soft.argtypes = [C.c_void_p, C.c_int]
+        for f in ("or_dab_tf_sfic", "or_dab_tf_smsc"):
+            getattr(L, f).restype = f32p
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.or_dab_last_fibs.restype = u8p
+        L.or_dab_last_fibs.argtypes = [C.c_void_p, u8p]
+        L.or_replay_soft.restype = C.c_int
+        L.or_replay_soft.argtypes = [u8p, C.c_size_t, C.c_int, u8p, C.c_int, f32p, C.c_int, C.POINTER(C.c_int)]
         _oracle = L
     return _oracle
 
@@ -132,3 +148,53 @@ def or_replay(iq, cap_frames=4096, trace_cap=4096):
     n = oracle().or_replay(_ptr(iq), C.c_size_t(iq.size), _ptr(eti), cap_frames, tr, trace_cap, C.byref(nt))
     assert n <= cap_frames
     return eti[:n], [tr[i] for i in range(min(nt.value, trace_cap))]
+
+
+SOFT_Q4, SOFT_Q8, SOFT_FLOAT = 4, 8, 32
+
+
+def or_viterbi_soft(values, nbits, mode=SOFT_Q4):
+    """values: 4 (nbits + 6) soft values (> 0: bit 0; 0: punctured) -> decoded bytes (or_soft.c)."""
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    assert v.size >= 4 * (nbits + 6)
+    out = np.zeros((nbits + 7) // 8, dtype=np.uint8)
+    oracle().or_viterbi_soft(_ptr(v, C.c_float), _ptr(out), nbits, mode)
+    return out
+
+
+def or_replay_soft(iq, mode=SOFT_Q4, cap_frames=4096, values_tf=0):
+    """(ETI frames, values [TF][9216 + 221184] of the first values_tf demodulated TFs, number of demodulated TFs)."""
+    iq = np.ascontiguousarray(iq, dtype=np.uint8)
+    eti = np.zeros((cap_frames, 6144), dtype=np.uint8)
+    vals = np.zeros((max(values_tf, 1), 9216 + 221184), dtype=np.float32)
+    ntf = C.c_int(0)
+    n = oracle().or_replay_soft(_ptr(iq), C.c_size_t(iq.size), mode, _ptr(eti), cap_frames, _ptr(vals, C.c_float) if values_tf else None,
+                                values_tf, C.byref(ntf))
+    assert n <= cap_frames
+    return eti[:n], vals[:min(values_tf, ntf.value)], ntf.value
+
+
+class SoftDab:
+    """or_dab in soft mode: feed values per TF (fic 9216, msc 221184), collect ETI frames and the FIBs of every TF."""
+
+    def __init__(self, mode=SOFT_Q4):
+        self.frames, self.fibs = [], []
+        self._cbt = C.CFUNCTYPE(None, C.POINTER(C.c_uint8), C.c_void_p)
+        self._cb = self._cbt(lambda p, u: self.frames.append(np.ctypeslib.as_array(p, (6144,)).copy()))
+        self.d = oracle().or_dab_new(C.cast(self._cb, C.c_void_p), None)
+        oracle().or_dab_set_soft(self.d, mode)
+
+    def process(self, fic, msc):
+        O = oracle()
+        f = np.ascontiguousarray(fic, dtype=np.float32)
+        m = np.ascontiguousarray(msc, dtype=np.float32)
+        assert f.size == 9216 and m.size == 221184
+        # the TF that process_frame will decode is tfs[tfidx] BEFORE the call; its FIBs are read from there afterwards
+        C.memmove(O.or_dab_tf_sfic(self.d), _ptr(f, C.c_float), 4 * f.size)
+        C.memmove(O.or_dab_tf_smsc(self.d), _ptr(m, C.c_float), 4 * m.size)
+        O.or_dab_process_frame(self.d)
+
+    def close(self):
+        if self.d:
+            oracle().or_dab_free(self.d)
+            self.d = None

@@ -1,0 +1,111 @@
+"""The soft-decision oracle (oracle/or_soft.c) held against what CAN pin it (CPU only).
+
+The reference has hard decisions only, so the soft rule is the product's own; what anchors its restatement:
+  * with |value| constant the soft metric orders paths exactly like the reference's agreement metric, so or_viterbi_soft must
+    return the bytes of the REAL viterbi.c (oracle/_ref, and the committed known-answer vectors made from it) on hard input,
+    ties and undecodable inputs included -- for every quantisation mode;
+  * on a clean capture the soft replay must reproduce the hard replay's ETI bytes;
+  * the quantisers are what the header says (round-half-even, clamps).
+"""
+import numpy as np
+import pytest
+
+import dabtools_amd as dab
+import oracle_lib as ol
+
+GOLDEN = __import__("os").path.join(ol.ROOT, "tests", "golden")
+
+
+def _hard_to_values(sym, a):
+    """127 / 129 / 128 of depuncture.c:36-43 -> +a (bit 0) / -a (bit 1) / 0 (punctured)."""
+    s = np.asarray(sym, dtype=np.int32)
+    return np.where(s == 128, 0.0, np.where(s < 128, float(a), -float(a))).astype(np.float32)
+
+
+@pytest.mark.parametrize("mode,amps", [(ol.SOFT_Q4, (1, 3, 7)), (ol.SOFT_Q8, (0.0625, 1.5, 7.9375)), (ol.SOFT_FLOAT, (0.37, 5.0))])
+def test_constant_magnitude_values_decode_like_the_real_scalar_decoder(mode, amps):
+    """viterbi.c:352-451 through its own golden vectors: the soft decoder on +-a / 0 == the reference on 127 / 129 / 128."""
+    kat = np.load(__import__("os").path.join(GOLDEN, "backend_kat.npz"))
+    n = int(kat["vit_count"])
+    assert n >= 6
+    for i in range(n):
+        sym, want = kat["vit%d_sym" % i], kat["vit%d_out" % i]
+        nbits = sym.size // 4 - 6
+        for a in amps:
+            got = ol.or_viterbi_soft(_hard_to_values(sym, a), nbits, mode)
+            assert np.array_equal(got, want), (i, a)
+
+
+def test_constant_magnitude_values_against_the_live_reference_on_ties_and_garbage():
+    R = ol.ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built")
+    R.refh_new()          # init_dab_state -> init_viterbi(): fills the reference's metric table (viterbi.c:455-462)
+    rng = np.random.default_rng(5)
+    for nbits, p_erase, p_flip in [(768, 0.3, 0.05), (192, 0.6, 0.2), (1536, 0.0, 0.5), (3072, 0.25, 0.12), (24, 0.9, 0.0), (4608, 0.1, 0.08)]:
+        data = rng.integers(0, 256, nbits // 8, dtype=np.uint8)
+        sym = 127 + 2 * ol.or_encode(data).astype(np.int32)
+        flip = rng.random(sym.size) < p_flip
+        sym = np.where(flip, 256 - sym, sym)
+        sym = np.where(rng.random(sym.size) < p_erase, 128, sym).astype(np.uint8)
+        want = np.zeros(nbits // 8, np.uint8)
+        R.refh_viterbi(None, ol._ptr(sym.copy()), ol._ptr(want), nbits)
+        assert np.array_equal(ol.or_viterbi(sym, nbits), want)
+        for mode, a in ((ol.SOFT_Q4, 7), (ol.SOFT_Q4, 2), (ol.SOFT_Q8, 0.5), (ol.SOFT_FLOAT, 3.3)):
+            assert np.array_equal(ol.or_viterbi_soft(_hard_to_values(sym, a), nbits, mode), want), (nbits, mode, a)
+    # all punctured: every comparison is a tie, the output is the tie rule's (viterbi.c:411 keeps the low predecessor)
+    sym = np.full(4 * (768 + 6), 128, np.uint8)
+    want = np.zeros(96, np.uint8)
+    R.refh_viterbi(None, ol._ptr(sym.copy()), ol._ptr(want), 768)
+    assert np.array_equal(ol.or_viterbi_soft(np.zeros(sym.size, np.float32), 768, ol.SOFT_Q4), want)
+
+
+def test_quantisers():
+    O = ol.oracle()
+    q4 = lambda v: O.or_soft_quantise(v, ol.SOFT_Q4)
+    assert [q4(v) for v in (0.5, 1.5, 2.5, -0.5, -1.5, 6.5, 7.49, 7.5, 99.0, -99.0)] == [0, 2, 2, 0, -2, 6, 7, 7, 7, -7]
+    q8 = lambda v: O.or_soft_quantise(v, ol.SOFT_Q8)
+    assert q8(1.0 / 32) == 0.0 and q8(3.0 / 32) == 2.0 / 16 and q8(100.0) == 127.0 / 16 and q8(-100.0) == -127.0 / 16
+    assert O.or_soft_quantise(1.234567, ol.SOFT_FLOAT) == 1.234567
+
+
+def test_soft_decoder_uses_the_magnitudes():
+    """A weak wrong value must lose against strong right ones where a hard decoder sees a coin toss."""
+    rng = np.random.default_rng(9)
+    data = rng.integers(0, 256, 48, dtype=np.uint8)
+    code = ol.or_encode(data).astype(np.int32)                 # 0 / 1
+    v = np.where(code == 0, 6.0, -6.0).astype(np.float32)
+    bad = rng.random(v.size) < 0.28                            # 28 % of the symbols wrong, but only weakly so
+    v[bad] = -np.sign(v[bad]) * 1.0
+    hard = (127 + 2 * (v < 0)).astype(np.uint8)
+    soft_out = ol.or_viterbi_soft(v, 384, ol.SOFT_Q4)
+    hard_out = ol.or_viterbi(hard, 384)
+    assert np.array_equal(soft_out, data)
+    assert not np.array_equal(hard_out, data)
+
+
+def test_soft_replay_equals_the_hard_replay_on_a_clean_capture_and_beats_it_in_noise():
+    cfg = dab.synth_preset(1, seed=77, cif_count0=1234, skip_samples=31000)
+    iq = dab.synth_generate(cfg, 20)
+    want, _ = ol.or_replay(iq)
+    assert want.shape[0] == 8                                             # a start inside a frame costs a re-synchronisation: 4 (T - 18)
+    for mode in (ol.SOFT_Q4, ol.SOFT_FLOAT):
+        got, vals, ntf = ol.or_replay_soft(iq, mode, values_tf=2)
+        assert np.array_equal(got, want), mode
+        assert ntf >= 15 and vals.shape == (2, 9216 + 221184)
+        if mode == ol.SOFT_Q4:
+            assert np.all(vals == np.rint(vals)) and np.abs(vals).max() <= 7 and 4.0 < np.abs(vals).mean() < 5.0   # mean |v| = 4.5 by design
+    # 6.5 dB: hard decisions lose frames (6 dB => 3 % correct frames), soft ones keep the FIC and most of the payload
+    cfgn = dab.synth_preset(1, seed=78, cif_count0=40, snr_db=6.5)
+    iqn = dab.synth_generate(cfgn, 19)
+    hard, _ = ol.or_replay(iqn)
+    soft, _, _ = ol.or_replay_soft(iqn, ol.SOFT_Q4)
+    from dabtools_amd import payload
+    res = {}
+    for name, frames in (("hard", hard), ("soft", soft)):
+        chk = payload.PayloadCheck()
+        chk.add_stream(dab, cfgn, 19, frames)
+        res[name] = chk.result()
+    assert res["soft"]["frames_out"] >= res["hard"]["frames_out"]
+    assert res["soft"]["frames_out"] == 16
+    assert res["soft"]["payload_ber"] < 0.25 * max(res["hard"]["payload_ber"] or 1.0, 1e-9) or res["hard"]["frames_out"] == 0
