@@ -139,6 +139,7 @@ Engine::Engine(int device, int host_threads) : device_(device)
   const int hw = static_cast<int>(std::thread::hardware_concurrency());
   int nthreads = host_threads > 0 ? std::min(host_threads, 64) : std::min(hw / 2, 24);
   if (const char* env = std::getenv("DABHIP_HOST_THREADS")) nthreads = std::max(1, std::min(64, std::atoi(env)));
+  if (const char* env = std::getenv("DABHIP_VIT_WAVE_MAX")) wave_max_codewords_ = std::max(0, std::atoi(env));
   pool_.reset(new ThreadPool(std::max(0, nthreads - 1)));
   host_lane_.reset(new AsyncLane());
   ok_ = true;
@@ -193,6 +194,23 @@ bool Engine::launch_decode_batch(const DecodeBatch& b, const uint32_t* bits, con
   (void)hipEventRecord(ev_msc_[0], stream_);
   if (!check(launch_regroup(soft_bits_, ids, ntiles, d_jobs_.get(), d_stream_cif_base, bits, d_grouped_.get(), stream_), "regroup launch")) return false;
   (void)hipEventRecord(ev_msc_[1], stream_);
+  int64_t codewords = 0;
+  for (const WaveGroup& g : b.groups) codewords += g.count;
+  if (codewords <= wave_max_codewords_) {
+    // small batch: one wave per code word (k_vitwave.hip), one launch per run of equal length (the groups come longest first), so that a
+    // launch's LDS -- 8 bytes per trellis step and code word -- is sized for its own length
+    for (size_t g0 = 0; g0 < b.groups.size();) {
+      size_t g1 = g0 + 1;
+      while (g1 < b.groups.size() && b.groups[g1].nsteps == b.groups[g0].nsteps) ++g1;
+      if (!check(launch_viterbi_wave(soft_bits_, d_groups_.get() + g0, static_cast<int>(g1 - g0), b.groups[g0].nsteps, ids, d_plans_.get(), d_grouped_.get(), row_words,
+                                     prbs, out, record_stride, stream_),
+                 "viterbi (wave per code word) launch"))
+        return false;
+      g0 = g1;
+    }
+    (void)hipEventRecord(ev_msc_[2], stream_);
+    return true;
+  }
   for (size_t sl = 0; sl + 1 < b.slice_start.size(); ++sl) {
     const int g0 = b.slice_start[sl], n = b.slice_start[sl + 1] - g0;
     if (!check(launch_viterbi_fused(soft_bits_, d_groups_.get() + g0, n, ids, d_plans_.get(), d_grouped_.get(), row_words, d_decisions_.get(), prbs,
@@ -338,8 +356,11 @@ bool Engine::fic_decode_slots_async(int first, int n, uint8_t* fibs_host, uint8_
       !d_grouped_.reserve(static_cast<size_t>(ntiles) * block_words * 64) || !d_decisions_.reserve(static_cast<size_t>(ntiles) * dr * 64))
     return false;
   if (!check(launch_fic_group(d_fic_bits_.get(), 4 * first, nblocks, block_words, d_grouped_.get(), ks), "fic group launch") ||
-      !check(launch_viterbi_fused(soft_bits_, d_groups_.get(), ntiles, d_job_ids_.get(), d_plans_.get(), d_grouped_.get(), block_words,
-                                  d_decisions_.get(), d_prbs_.get(), d_fibs_.get(), 96, ks),
+      !check(nblocks <= wave_max_codewords_
+                 ? launch_viterbi_wave(soft_bits_, d_groups_.get(), ntiles, plan_table_[pid].nsteps, d_job_ids_.get(), d_plans_.get(), d_grouped_.get(), block_words,
+                                       d_prbs_.get(), d_fibs_.get(), 96, ks)
+                 : launch_viterbi_fused(soft_bits_, d_groups_.get(), ntiles, d_job_ids_.get(), d_plans_.get(), d_grouped_.get(), block_words,
+                                        d_decisions_.get(), d_prbs_.get(), d_fibs_.get(), 96, ks),
              "fic viterbi launch"))
     return false;
   if (!check(launch_fib_crc(d_fibs_.get() + static_cast<size_t>(first) * 384, n * 12, d_crc_tab_.get(), d_fib_ok_.get() + static_cast<size_t>(first) * 12, ks), "fib crc launch")) return false;

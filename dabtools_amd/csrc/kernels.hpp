@@ -81,6 +81,11 @@ hipError_t launch_viterbi_fused(int soft_bits, const WaveGroup* groups, int ngro
                                 const uint32_t* grouped, int row_words, uint2* decisions, const uint32_t* prbs_words, uint8_t* out,
                                 int record_stride, hipStream_t stream);
 
+// The low-latency form of the same decoder (k_vitwave.hip): one WAVE per code word, lane = trellis state -- a tenth of the fused kernel's
+// time per code word at six times its lane-ops, for small batches.  Same groups / plans / rows / output; no survivor records in HBM (LDS).
+hipError_t launch_viterbi_wave(int soft_bits, const WaveGroup* groups, int ngroups, int max_nsteps, const int* job_ids, const CodewordPlan* plans,
+                               const uint32_t* grouped, int row_words, const uint32_t* prbs_words, uint8_t* out, int record_stride, hipStream_t stream);
+
 // the one-kernel OFDM stage (k_fused.hip, compiled three times): with the parity guard's test in its symbol loop, without it, and
 // with 4-bit soft values instead of hard decisions.
 // Data symbols [sym_a, sym_b) of every frame (1..3 = FIC, 4..75 = MSC), nparts workgroups per frame; each transforms the symbol before

@@ -61,7 +61,17 @@ def _msc_values(rng, kind):
     raise ValueError(kind)
 
 
-def test_soft_decoders_bit_exact_on_identical_values_all_shapes():
+@pytest.fixture(params=["wave per code word (k_vitwave.hip)", "lane per code word (viterbi_fused_kernel)"])
+def decoder_form(request, monkeypatch):
+    """Both forms of the decoder: small decodes run one wave per code word by default; DABHIP_VIT_WAVE_MAX=0 sends them to the batch form."""
+    if request.param.startswith("lane"):
+        monkeypatch.setenv("DABHIP_VIT_WAVE_MAX", "0")
+    else:
+        monkeypatch.delenv("DABHIP_VIT_WAVE_MAX", raising=False)
+    return request.param
+
+
+def test_soft_decoders_bit_exact_on_identical_values_all_shapes(decoder_form):
     keep = _keep_mask()
     rng = np.random.default_rng(41)
     kinds = ["full", "ties", "zero", "saturated"]
@@ -97,7 +107,7 @@ def test_soft_decoders_bit_exact_on_identical_values_all_shapes():
     assert len(covered) == 64 + 24
 
 
-def test_soft_fic_decoder_bit_exact_on_arbitrary_values():
+def test_soft_fic_decoder_bit_exact_on_arbitrary_values(decoder_form):
     """FIC blocks (768 bits, FIC puncturing) on values that do NOT decode: the FIBs are whatever the tie rule and the metric make of
     them, CRC or not -- the oracle's bytes exactly."""
     O = ol.oracle()
@@ -126,7 +136,7 @@ def _noisy_streams(snr, ntf=20):
 
 
 @pytest.mark.parametrize("snr", [5.0, 7.0])
-def test_soft_demapper_values_within_the_stated_tolerance_and_eti_given_those_values(snr):
+def test_soft_demapper_values_within_the_stated_tolerance_and_eti_given_those_values(snr, decoder_form):
     streams = _noisy_streams(snr)
     eng = dab.Engine(0)
     eng.set_soft(True)
