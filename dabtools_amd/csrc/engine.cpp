@@ -139,7 +139,8 @@ Engine::Engine(int device, int host_threads) : device_(device)
   const int hw = static_cast<int>(std::thread::hardware_concurrency());
   int nthreads = host_threads > 0 ? std::min(host_threads, 64) : std::min(hw / 2, 24);
   if (const char* env = std::getenv("DABHIP_HOST_THREADS")) nthreads = std::max(1, std::min(64, std::atoi(env)));
-  if (const char* env = std::getenv("DABHIP_VIT_WAVE_MAX")) wave_max_codewords_ = std::max(0, std::atoi(env));
+  if (const char* env = std::getenv("DABHIP_VIT_WAVE_MAX")) wave_max_codewords_ = wave_max_fic_blocks_ = std::max(0, std::atoi(env));
+  if (const char* env = std::getenv("DABHIP_FIC_WAVE_MAX")) wave_max_fic_blocks_ = std::max(0, std::atoi(env));
   pool_.reset(new ThreadPool(std::max(0, nthreads - 1)));
   host_lane_.reset(new AsyncLane());
   ok_ = true;
@@ -194,20 +195,12 @@ bool Engine::launch_decode_batch(const DecodeBatch& b, const uint32_t* bits, con
   (void)hipEventRecord(ev_msc_[0], stream_);
   if (!check(launch_regroup(soft_bits_, ids, ntiles, d_jobs_.get(), d_stream_cif_base, bits, d_grouped_.get(), stream_), "regroup launch")) return false;
   (void)hipEventRecord(ev_msc_[1], stream_);
-  int64_t codewords = 0;
-  for (const WaveGroup& g : b.groups) codewords += g.count;
-  if (codewords <= wave_max_codewords_) {
-    // small batch: one wave per code word (k_vitwave.hip), one launch per run of equal length (the groups come longest first), so that a
-    // launch's LDS -- 8 bytes per trellis step and code word -- is sized for its own length
-    for (size_t g0 = 0; g0 < b.groups.size();) {
-      size_t g1 = g0 + 1;
-      while (g1 < b.groups.size() && b.groups[g1].nsteps == b.groups[g0].nsteps) ++g1;
-      if (!check(launch_viterbi_wave(soft_bits_, d_groups_.get() + g0, static_cast<int>(g1 - g0), b.groups[g0].nsteps, ids, d_plans_.get(), d_grouped_.get(), row_words,
-                                     prbs, out, record_stride, stream_),
-                 "viterbi (wave per code word) launch"))
-        return false;
-      g0 = g1;
-    }
+  if (b.wave_form) {
+    // small batch: one wave per code word (k_vitwave.hip), all lengths in one launch (longest first); its decisions use the survivor-record buffer
+    if (!check(launch_viterbi_wave(soft_bits_, d_groups_.get(), static_cast<int>(b.groups.size()), ids, d_plans_.get(), d_grouped_.get(), row_words,
+                                   d_decisions_.get(), prbs, out, record_stride, stream_),
+               "viterbi (wave per code word) launch"))
+      return false;
     (void)hipEventRecord(ev_msc_[2], stream_);
     return true;
   }
@@ -344,7 +337,8 @@ bool Engine::fic_decode_slots_async(int first, int n, uint8_t* fibs_host, uint8_
   std::vector<int> ids(static_cast<size_t>(ntiles) * 64, -1);
   for (int i = 0; i < nblocks; ++i) ids[i] = 4 * first + i;
   std::vector<WaveGroup> groups;
-  const int64_t dr = (plan_table_[pid].nsteps + 7) / 8 * 8;
+  const bool wave_form = nblocks <= wave_max_fic_blocks_;      // few blocks: one wave per block (k_vitwave.hip), rows per block and chunk of steps
+  const int64_t dr = wave_form ? int64_t(64) * ((plan_table_[pid].nsteps + kWaveChunk - 1) / kWaveChunk) : (plan_table_[pid].nsteps + 7) / 8 * 8;
   for (int g = 0; g < ntiles; ++g) groups.push_back(WaveGroup{pid, 64 * g, std::min(64, nblocks - 64 * g), plan_table_[pid].nsteps, 0, g * dr});
   // The FIC kernels run on the side stream as well, behind what the main stream has queued so far (the FIC bits): 1008 waves of 774
   // steps fill a quarter of the chip's wave slots for 0.3 ms, so the main stream goes straight on with the rest of the OFDM stage
@@ -356,9 +350,9 @@ bool Engine::fic_decode_slots_async(int first, int n, uint8_t* fibs_host, uint8_
       !d_grouped_.reserve(static_cast<size_t>(ntiles) * block_words * 64) || !d_decisions_.reserve(static_cast<size_t>(ntiles) * dr * 64))
     return false;
   if (!check(launch_fic_group(d_fic_bits_.get(), 4 * first, nblocks, block_words, d_grouped_.get(), ks), "fic group launch") ||
-      !check(nblocks <= wave_max_codewords_
-                 ? launch_viterbi_wave(soft_bits_, d_groups_.get(), ntiles, plan_table_[pid].nsteps, d_job_ids_.get(), d_plans_.get(), d_grouped_.get(), block_words,
-                                       d_prbs_.get(), d_fibs_.get(), 96, ks)
+      !check(wave_form
+                 ? launch_viterbi_wave(soft_bits_, d_groups_.get(), ntiles, d_job_ids_.get(), d_plans_.get(), d_grouped_.get(), block_words,
+                                       d_decisions_.get(), d_prbs_.get(), d_fibs_.get(), 96, ks)
                  : launch_viterbi_fused(soft_bits_, d_groups_.get(), ntiles, d_job_ids_.get(), d_plans_.get(), d_grouped_.get(), block_words,
                                         d_decisions_.get(), d_prbs_.get(), d_fibs_.get(), 96, ks),
              "fic viterbi launch"))
@@ -379,7 +373,7 @@ bool Engine::msc_prepare(const std::vector<const JobList*>& stream_jobs, const s
     if (trace_host) std::fprintf(stderr, "[host]   msc_prepare %-14s %8.3f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_in).count());
   };
   std::string error;
-  if (prepare_msc_work(plan_table_, *pool_, stream_jobs, planes, stream_row_base, stream_fib_base, kMaxDecisionRows, out, &error, mark)) return true;
+  if (prepare_msc_work(plan_table_, *pool_, stream_jobs, planes, stream_row_base, stream_fib_base, kMaxDecisionRows, out, &error, mark, wave_max_codewords_)) return true;
   set_error(error);
   return false;
 }

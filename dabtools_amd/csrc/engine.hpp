@@ -258,7 +258,7 @@ class Engine {
   int soft_bits_ = 0;
   // Decodes of at most this many code words (MSC: ETI frames x sub-channels; FIC: 4 per TF) run one WAVE per code word (k_vitwave.hip: latency
   // of a code word 0.1 instead of 1.4 ms) instead of one lane per code word (viterbi_fused_kernel: a sixth of the lane-ops).  DABHIP_VIT_WAVE_MAX.
-  int wave_max_codewords_ = 12288;
+  int wave_max_codewords_ = 12288, wave_max_fic_blocks_ = 3072;     // measured crossovers (tools/gpu/wavesweep.sh): MSC 5..6 streams x 64 TF, FIC 12..16
   std::mutex* heavy_mu_ = nullptr;
   std::unique_ptr<ThreadPool> pool_;   // host threads for per-stream control-plane work
   std::unique_ptr<AsyncLane> host_lane_;   // the control-plane pass of a decode, beside its GPU work

@@ -4,9 +4,9 @@
 // traffic, 1.85 wave-instructions per code word and trellis step), but one wave walks its 4614 steps in 1.4 ms whatever the batch.
 // A single live ensemble -- the reference's only use (dab2eti.c:60-115, one demod thread) and BASELINE configs[1] -- has 196 ETI
 // frames x 12 code words per 64-TF decode: 48 waves on a chip with 1024 SIMDs, and the step is that one wave's latency.  Here the
-// 64 states of ONE code word sit in the 64 lanes of a wave ("wavefront-shuffle add-compare-select"): a trellis step is ~10 wave
-// instructions instead of ~118, so a code word is through in a tenth of the time; per code word it costs six times the lane-ops,
-// which is why the engine uses it only below a batch size (Engine::msc_launch_async / fic_decode_slots_async).
+// 64 states of ONE code word sit in the 64 lanes of a wave ("wavefront-shuffle add-compare-select"): a trellis step is 8 wave
+// instructions instead of ~118, so a code word is through in a fraction of the time; per code word it costs four times the lane-ops,
+// which is why the engine uses it only below a batch size (Engine::launch_decode_batch / fic_decode_slots_async).
 //
 // Same decisions as viterbi.c:352-451 (and as the fused kernel): metrics are agreement-minus-disagreement counts (hard) or the sum
 // of the signed soft values (soft) -- the common part of a step's branch metrics cancels in every comparison; the high predecessor
@@ -15,12 +15,13 @@
 // Lane mapping.  State s sits in lane rotl6(s, r_t) with r_t = -t mod 6.  The predecessors of new state i are (i >> 1) and
 // (i >> 1) | 32, and rotl6(p, 1) = (i & ~1) | h: with this rotation both predecessors of the state a lane is about to hold sit in
 // that lane itself and in the lane that differs in ONE bit, j_t = 5 - t mod 6.  A step is therefore one exchange with lane ^ 32, 16,
-// 8, 4, 2, 1 in turn (DPP for 1, 2, 4, 8; LDS swizzle / permute for 16 and 32), never a general permutation.  The two lanes of
-// such a pair are the two ends of one butterfly and share the branch code word, so each computes P = M + g and Q = M' - g
-// (M' the partner's metric, g the code's signed branch metric) and keeps max(P, Q).
+// 8, 4, 2, 1 in turn (v_permlane32_swap / v_permlane16_swap for the first two, DPP for the others), never a general permutation and
+// never through the LDS.  The two lanes of such a pair are the two ends of one butterfly and share the branch code word up to its sign.
+//
+// No per-step scalar work and no branches inside a chunk of 60 steps: a lone wave issues in order, and every VALU -> SALU -> VALU hand-over
+// (compare masks edited on the scalar unit, lane selects through M0, a branch per step) cost it tens of cycles -- the first version of this
+// kernel, written that way, took 450 cycles per step and was SLOWER than the batch form.
 #include <hip/hip_runtime.h>
-
-#include <mutex>
 
 #include "dab_tables.hpp"
 #include "device_types.hpp"
@@ -52,46 +53,45 @@ __host__ __device__ constexpr unsigned vw_code3(unsigned i)
 __host__ __device__ constexpr unsigned vw_rotl6(unsigned s, unsigned j) { return j == 0 ? s & 63u : ((s << j) | (s >> (6 - j))) & 63u; }
 
 constexpr int kInitOther = -(1 << 24);       // "unreachable" start metric of states 1..63 (viterbi.c:387-389): far below what six steps can collect
+constexpr int kChunk = 60;                   // steps per chunk: ten rounds of the six exchange distances; 60 of the 64 lanes prepare a chunk's table words
 
-// the metric of the lane that differs in bit J
+// One trellis step with the exchange over lane bit J.  e: this lane's signed branch metric (see the kernel's phase constants), bsub: lane bit J.
+// dreg collects one bit per step: the survivor decision of the state this lane holds afterwards -- as such for J = 5, 4; for J <= 3 complemented
+// in the lanes whose bit J is set (the chain-back knows: that bit is bit 0 of the state).
+//
+// J = 5, 4 (lane ^ 32, lane ^ 16): v_permlane32_swap / v_permlane16_swap (gfx950) exchange the upper half (the odd rows) of their first operand
+// with the lower half (the even rows) of the second.  Every lane puts M + e into the first and M - e into the second register, e = the metric
+// of the branch LOW predecessor -> its new state: a lane with bit J clear is that low predecessor (its M + e is the low candidate, it needs the
+// partner's M - e), a lane with bit J set is the high predecessor (its M - e is the high candidate, it needs the partner's M + e).  After the
+// swap every lane holds the LOW candidate in the first and the HIGH candidate in the second register, whichever of the two is its own: one
+// compare, strict as in viterbi.c:411, no lane-dependent tie rule.
+// J = 3 .. 0: DPP reads the partner's metric inside the subtract; own candidate p = M + e, the other q = M' - e; which of them is the high
+// predecessor's depends on lane bit J, so the compare is q > p - bit: the decision where the bit is clear, its complement where it is set.
 template <int J>
-__device__ __forceinline__ int partner(int m)
+__device__ __forceinline__ void wave_step(int& m, int e, int bsub, uint32_t& dreg)
 {
-  if (J == 0) return __builtin_amdgcn_update_dpp(0, m, 0xB1, 0xF, 0xF, false);            // quad_perm [1, 0, 3, 2]
-  if (J == 1) return __builtin_amdgcn_update_dpp(0, m, 0x4E, 0xF, 0xF, false);            // quad_perm [2, 3, 0, 1]
-  if (J == 2) {                                                                           // lane ^ 4: two shifts by four, each written to its half of the banks
-    const int a = __builtin_amdgcn_update_dpp(0, m, 0x114, 0xF, 0xA, false);              // row_shr:4 -> lanes 4..7, 12..15 read lane - 4
-    return __builtin_amdgcn_update_dpp(a, m, 0x104, 0xF, 0x5, false);                     // row_shl:4 -> lanes 0..3, 8..11 read lane + 4
+  if (J >= 4) {
+    int a = m + e, b = m - e;
+    // (inline asm: the builtins of this compiler miscompile swaps, see k_fused.hip -- so the hazard recogniser does not see them either: a VALU write
+    // of an operand needs two wait states before the swap reads it, like a DPP read)
+    if (J == 5) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    else asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    m = max(a, b);
+    asm volatile("v_cmp_gt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(dreg) : "v"(b), "v"(a) : "vcc");     // dreg = 2 dreg + (high > low)
+  } else {
+    const int p = m + e;
+    int q;
+    if (J == 0) q = __builtin_amdgcn_update_dpp(0, m, 0xB1, 0xF, 0xF, false) - e;           // quad_perm [1, 0, 3, 2]
+    else if (J == 1) q = __builtin_amdgcn_update_dpp(0, m, 0x4E, 0xF, 0xF, false) - e;      // quad_perm [2, 3, 0, 1]
+    else if (J == 3) q = __builtin_amdgcn_update_dpp(0, m, 0x128, 0xF, 0xF, false) - e;     // row_ror:8 = lane ^ 8 within a row of 16
+    else {                                                                                  // lane ^ 4: two shifts by four, each written to its half of the banks
+      const int x = __builtin_amdgcn_update_dpp(0, m, 0x114, 0xF, 0xA, false);              // row_shr:4 -> lanes 4..7, 12..15 read lane - 4
+      q = __builtin_amdgcn_update_dpp(x, m, 0x104, 0xF, 0x5, false) - e;                    // row_shl:4 -> lanes 0..3, 8..11 read lane + 4
+    }
+    const int ps = p - bsub;
+    m = max(p, q);
+    asm volatile("v_cmp_gt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(dreg) : "v"(q), "v"(ps) : "vcc");
   }
-  if (J == 3) return __builtin_amdgcn_update_dpp(0, m, 0x128, 0xF, 0xF, false);           // row_ror:8 = lane ^ 8 within a row of 16
-  if (J == 4) return __builtin_amdgcn_ds_swizzle(m, 0x401F);                              // bit mode: and 0x1f, or 0, xor 0x10
-  return __builtin_amdgcn_ds_bpermute(static_cast<int>(((threadIdx.x & 63u) ^ 32u) << 2), m);
-}
-
-template <int J>
-__device__ __forceinline__ constexpr uint64_t bit_mask()       // lanes whose bit J is set
-{
-  return J == 0 ? 0xAAAAAAAAAAAAAAAAull : J == 1 ? 0xCCCCCCCCCCCCCCCCull : J == 2 ? 0xF0F0F0F0F0F0F0F0ull : J == 3 ? 0xFF00FF00FF00FF00ull
-       : J == 4 ? 0xFFFF0000FFFF0000ull : 0xFFFFFFFF00000000ull;
-}
-
-// one trellis step.  w: the step's table word (wave-uniform): hard: eight signed 4-bit fields d_c = agreements - disagreements of code c
-// (3 distinct code bits, bit 3 = bit 0) with the received bits; soft: four signed 8-bit fields d_c = sum_j (c_j ? -s_j : s_j), c = 0..3,
-// the complementary code's value being -d_c.  sh / sg: this lane's field and sign in the phase of this step.
-template <int J, int kBits>
-__device__ __forceinline__ void wave_step(int& m, uint32_t w, int sh, int sg, uint32_t& acc_lo, uint32_t& acc_hi, int k)
-{
-  int g = __builtin_amdgcn_sbfe(static_cast<int>(w), sh, kBits == 1 ? 4 : 8);
-  if (kBits != 1) g *= sg;
-  const int p = m + g;                                      // this lane's own metric continues along its branch
-  const int q = partner<J>(m) - g;                          // the partner's along the complementary branch
-  // Which of the two is the HIGH predecessor's?  Lane bit J = bit 0 of the new state = which predecessor this lane's own metric is.
-  // bit clear: own = low, partner = high: decision = q > p.  bit set: own = high: decision = p > q = !(q >= p).   (viterbi.c:411: strictly)
-  const uint64_t gt = __builtin_amdgcn_ballot_w64(q > p), ge = __builtin_amdgcn_ballot_w64(q >= p);
-  const uint64_t dec = (gt & ~bit_mask<J>()) | (~ge & bit_mask<J>());
-  m = max(p, q);
-  acc_lo = write_lane(acc_lo, static_cast<uint32_t>(dec), k);
-  acc_hi = write_lane(acc_hi, static_cast<uint32_t>(dec >> 32), k);
 }
 
 struct WaveSegs {                // the five puncturing segments of a code word (depuncture.c:45-132), wave-uniform
@@ -101,7 +101,9 @@ struct WaveSegs {                // the five puncturing segments of a code word 
   int need[5];                   // received values per unit of 8 steps
 };
 
-// Table words of the 64 steps t0 .. t0 + 63, one per lane, from the received values (n, v) of the lane's step.
+// The table word of a step from its received values (n of them, v): hard: eight signed 4-bit fields d_c = agreements - disagreements of code
+// c (3 distinct code bits, bit 3 = bit 0) with the received bits; soft: four signed 8-bit fields d_c = sum_j (c_j ? -s_j : s_j), c = 0..3, the
+// complementary code's value being -d_c.
 template <int kBits>
 __device__ __forceinline__ uint32_t table_word(int n, uint32_t v)
 {
@@ -145,31 +147,34 @@ __device__ __forceinline__ void step_input(const WaveSegs& sg, int tau, int nste
 }
 
 // One wave = one code word: (group g, lane l of the group) = the job the fused kernel's lane l of wave g would decode.
-// Dynamic LDS: per wave `chunks` x 128 words of decisions (64 steps x 64 states).
+// decisions: per code word one row of 64 x 8 bytes per chunk of 60 steps (two 30-bit decision words per lane), at row grp.dec_base + l x chunks.
 template <int kBits>
 __global__ __launch_bounds__(256) void viterbi_wave_kernel(const WaveGroup* __restrict__ groups, int ngroups, const int* __restrict__ job_ids,
                                                            const CodewordPlan* __restrict__ plans, const uint32_t* __restrict__ grouped, int row_words,
-                                                           const uint32_t* __restrict__ prbs_words, uint8_t* __restrict__ out, int record_stride, int chunks)
+                                                           uint2* __restrict__ decisions, const uint32_t* __restrict__ prbs_words, uint8_t* __restrict__ out,
+                                                           int record_stride)
 {
-  extern __shared__ uint32_t dec_lds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cw = __builtin_amdgcn_readfirstlane(static_cast<int>(blockDim.x >> 6) * blockIdx.x + wave);     // 4, 2 or 1 waves per workgroup (what the LDS allows)
+  const int lane = threadIdx.x & 63;
+  const int cw = __builtin_amdgcn_readfirstlane(static_cast<int>(4 * blockIdx.x + (threadIdx.x >> 6)));
   const int g = cw >> 6, l = cw & 63;
   if (g >= ngroups) return;
   const WaveGroup grp = groups[g];
   if (l >= grp.count) return;
   const CodewordPlan pl = plans[grp.plan];
-  const int nsteps = grp.nsteps;
-  uint32_t* const dec = dec_lds + static_cast<size_t>(wave) * chunks * 128;
+  const int nsteps = grp.nsteps, nchunks = (nsteps + kChunk - 1) / kChunk;
+  uint32_t* const dec = reinterpret_cast<uint32_t*>(decisions + (static_cast<size_t>(grp.dec_base) + static_cast<size_t>(l) * nchunks) * 64);
 
-  // per-lane constants of the six phases: the branch code this lane's butterfly uses when the exchange runs over lane bit j = 5 - phase
-  int sh[6], sgn[6];
+  // per-lane constants of the six phases (phase = step mod 6, exchange over lane bit j = 5 - phase): where this lane's branch metric sits in a
+  // step's table word, its sign (soft values), and lane bit j
+  int sh[6], sgn[6], bit[6];
 #pragma unroll
   for (int ph = 0; ph < 6; ++ph) {
     const unsigned j = 5u - ph;
     const unsigned i = vw_rotl6(static_cast<unsigned>(lane), (6u - j) % 6u);      // the new state this lane will hold
     const unsigned b = (static_cast<unsigned>(lane) >> j) & 1u;                  // = i & 1: own metric is the low (0) / high (1) predecessor's
-    const unsigned c = vw_code3(i) ^ (b ? 7u : 0u);                              // code on the branch own predecessor -> i
+    // j >= 4: the metric of the branch low predecessor -> i for every lane; j <= 3: that of the branch own predecessor -> i
+    const unsigned c = vw_code3(i) ^ ((b && j <= 3) ? 7u : 0u);
+    bit[ph] = static_cast<int>(b);
     if (kBits == 1) { sh[ph] = 4 * static_cast<int>(c); sgn[ph] = 1; }
     else { sh[ph] = 8 * static_cast<int>(c < 4 ? c : c ^ 7u); sgn[ph] = c < 4 ? 1 : -1; }
   }
@@ -204,106 +209,108 @@ __global__ __launch_bounds__(256) void viterbi_wave_kernel(const WaveGroup* __re
   fetch(0);
 
   int m = lane == 0 ? 0 : kInitOther;
-  uint32_t acc_lo = 0, acc_hi = 0, tw = 0;
-  auto begin_chunk = [&](int t0) {
+  for (int c = 0; c < nchunks; ++c) {
     const uint32_t shft = static_cast<uint32_t>(pos * kBits) & 31u;
     const uint32_t v = static_cast<uint32_t>(((static_cast<uint64_t>(w1) << 32) | w0) >> shft) & ((1u << (n * kBits)) - 1u);   // n kBits <= 16
-    tw = table_word<kBits>(n, v);
-    if (t0 + 64 < nsteps) fetch(t0 + 64);
-  };
-  auto end_chunk = [&](int c) {
-    dec[c * 128 + lane] = acc_lo;
-    dec[c * 128 + 64 + lane] = acc_hi;
-  };
-#define DABHIP_WAVE_STEP(J, PH)                                                                                      \
-  {                                                                                                                  \
-    const int k = t & 63;                                                                                            \
-    if (k == 0) begin_chunk(t);                                                                                      \
-    wave_step<J, kBits>(m, static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(tw), k)), sh[PH], sgn[PH], acc_lo, acc_hi, k); \
-    if (k == 63) end_chunk(t >> 6);                                                                                  \
-    if (++t >= nsteps) break;                                                                                        \
+    const uint32_t tw = table_word<kBits>(n, v);           // lane k: the table word of step 60 c + k (steps past the end: nothing received, all metrics 0)
+    if (c + 1 < nchunks) fetch(kChunk * (c + 1));
+    uint32_t d0 = 0, d1 = 0;
+    auto metric = [&](int k, int ph) -> int {
+      const int x = __builtin_amdgcn_sbfe(__builtin_amdgcn_readlane(static_cast<int>(tw), k), sh[ph], kBits == 1 ? 4 : 8);
+      return kBits == 1 ? x : x * sgn[ph];
+    };
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const int k = 6 * r;
+      wave_step<5>(m, metric(k, 0), bit[0], d0);
+      wave_step<4>(m, metric(k + 1, 1), bit[1], d0);
+      wave_step<3>(m, metric(k + 2, 2), bit[2], d0);
+      wave_step<2>(m, metric(k + 3, 3), bit[3], d0);
+      wave_step<1>(m, metric(k + 4, 4), bit[4], d0);
+      wave_step<0>(m, metric(k + 5, 5), bit[5], d0);
+    }
+#pragma unroll
+    for (int r = 5; r < 10; ++r) {
+      const int k = 6 * r;
+      wave_step<5>(m, metric(k, 0), bit[0], d1);
+      wave_step<4>(m, metric(k + 1, 1), bit[1], d1);
+      wave_step<3>(m, metric(k + 2, 2), bit[2], d1);
+      wave_step<2>(m, metric(k + 3, 3), bit[3], d1);
+      wave_step<1>(m, metric(k + 4, 4), bit[4], d1);
+      wave_step<0>(m, metric(k + 5, 5), bit[5], d1);
+    }
+    dec[c * 128 + lane] = d0;                              // step 60 c + k: bit 29 - k of d0 (k < 30), bit 59 - k of d1
+    dec[c * 128 + 64 + lane] = d1;
   }
-  for (int t = 0;;) {
-    DABHIP_WAVE_STEP(5, 0)
-    DABHIP_WAVE_STEP(4, 1)
-    DABHIP_WAVE_STEP(3, 2)
-    DABHIP_WAVE_STEP(2, 3)
-    DABHIP_WAVE_STEP(1, 4)
-    DABHIP_WAVE_STEP(0, 5)
-  }
-#undef DABHIP_WAVE_STEP
-  if (nsteps & 63) end_chunk(nsteps >> 6);
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's own LDS stores are done before it reads them back
+  __threadfence();                                         // the wave reads its own rows back below
 
   // ---- chain back from state 0 (viterbi.c:438-450), descramble (misc.c:41-58), pack MSB first -------------------------------
   const int record = job_ids ? job_ids[grp.first + l] : grp.first + l;
   uint32_t* const dst = reinterpret_cast<uint32_t*>(out + static_cast<size_t>(record) * record_stride + pl.out_offset);
   const int nwords = (nsteps - 6) >> 5;          // data bits are a multiple of 32 (32 x blocks)
   unsigned state = 0;
-  uint32_t bits = 0, outv = 0, lo = 0, hi = 0;
-  int ph = (nsteps - 1) % 6;
-  for (int t = nsteps - 1; t >= 6; --t) {
-    const int k = t & 63;
-    if (k == 63 || t == nsteps - 1) {
-      lo = dec[(t >> 6) * 128 + lane];
-      hi = dec[(t >> 6) * 128 + 64 + lane];
+  uint32_t bits = 0, outv = 0;
+  uint32_t n0 = dec[(nchunks - 1) * 128 + lane], n1 = dec[(nchunks - 1) * 128 + 64 + lane];
+  for (int c = nchunks - 1; c >= 0; --c) {
+    const uint32_t r0 = n0, r1 = n1;
+    if (c > 0) {                                           // the rows of the chunk before, on their way while this one is walked
+      n0 = dec[(c - 1) * 128 + lane];
+      n1 = dec[(c - 1) * 128 + 64 + lane];
     }
-    const unsigned j = 5u - static_cast<unsigned>(ph);
-    const unsigned at = ((state << j) | (state >> (6u - j))) & 63u;              // the lane that held `state` after step t (j = 0: state >> 6 = 0)
-    const uint64_t word = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(hi), k))) << 32) |
-                          static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(lo), k));
-    const unsigned d = static_cast<unsigned>(word >> at) & 1u;
-    state = (state | (d << 6)) >> 1;
-    const int i = t - 6;                                                           // data bit index
-    bits |= d << (8 * ((i >> 3) & 3) + (7 - (i & 7)));
-    if ((i & 31) == 0) {
-      const int wi = i >> 5;
-      outv = write_lane(outv, bits, wi & 63);
-      bits = 0;
-      if ((wi & 63) == 0 && wi + lane < nwords) dst[wi + lane] = outv ^ prbs_words[wi + lane];     // words wi .. wi + 63, complete since the last flush
+    auto walk = [&](int k, int ph, uint32_t row, int top) {
+      const int t = kChunk * c + k;
+      if (t >= nsteps || t < 6) return;                    // steps 0..5 only flush the encoder's initial zeros (viterbi.c:361,431)
+      const unsigned j = 5u - static_cast<unsigned>(ph);
+      const unsigned at = j == 0 ? state : ((state << j) | (state >> (6u - j))) & 63u;      // the lane that held `state` after step t
+      const uint32_t w = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(row), static_cast<int>(at)));
+      unsigned d = (w >> (top - k)) & 1u;
+      if (j <= 3) d ^= state & 1u;                         // recorded complemented where lane bit j (= bit 0 of the state) is set
+      state = (state | (d << 6)) >> 1;
+      const int i = t - 6;                                 // data bit index
+      bits |= d << (8 * ((i >> 3) & 3) + (7 - (i & 7)));
+      if ((i & 31) == 0) {
+        const int wi = i >> 5;
+        outv = write_lane(outv, bits, wi & 63);
+        bits = 0;
+        if ((wi & 63) == 0 && wi + lane < nwords) dst[wi + lane] = outv ^ prbs_words[wi + lane];     // words wi .. wi + 63, complete since the last flush
+      }
+    };
+#pragma unroll 1
+    for (int r = 9; r >= 5; --r) {
+      const int k = 6 * r;
+      walk(k + 5, 5, r1, 59);
+      walk(k + 4, 4, r1, 59);
+      walk(k + 3, 3, r1, 59);
+      walk(k + 2, 2, r1, 59);
+      walk(k + 1, 1, r1, 59);
+      walk(k, 0, r1, 59);
     }
-    ph = ph == 0 ? 5 : ph - 1;
+#pragma unroll 1
+    for (int r = 4; r >= 0; --r) {
+      const int k = 6 * r;
+      walk(k + 5, 5, r0, 29);
+      walk(k + 4, 4, r0, 29);
+      walk(k + 3, 3, r0, 29);
+      walk(k + 2, 2, r0, 29);
+      walk(k + 1, 1, r0, 29);
+      walk(k, 0, r0, 29);
+    }
   }
-}
-
-// dynamic LDS above 64 KB needs the attribute, per DEVICE (several engines of one process may sit on different devices: dabhip_multi)
-template <int kBits>
-hipError_t wave_attr()
-{
-  static std::once_flag once[64];
-  static hipError_t result[64];
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return e;
-  dev &= 63;
-  std::call_once(once[dev], [&]() {
-    result[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(&viterbi_wave_kernel<kBits>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  });
-  return result[dev];
 }
 
 }  // namespace
 
-// groups [0, ngroups) all have at most max_nsteps trellis steps; every (group, valid lane) becomes one wave
-hipError_t launch_viterbi_wave(int soft_bits, const WaveGroup* groups, int ngroups, int max_nsteps, const int* job_ids, const CodewordPlan* plans,
-                               const uint32_t* grouped, int row_words, const uint32_t* prbs_words, uint8_t* out, int record_stride, hipStream_t stream)
+// every (group, valid lane) becomes one wave; decisions: rows of 64 x 8 bytes, group g's at groups[g].dec_base, 64 x ceil(nsteps / 60) of them
+hipError_t launch_viterbi_wave(int soft_bits, const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans,
+                               const uint32_t* grouped, int row_words, uint2* decisions, const uint32_t* prbs_words, uint8_t* out, int record_stride,
+                               hipStream_t stream)
 {
   if (ngroups <= 0) return hipSuccess;
-  const int chunks = (max_nsteps + 63) / 64;
-  // waves per workgroup: as many of 4, 2, 1 as the decisions (512 bytes per 64 steps and wave) leave room for in a CU's 160 KB
-  // (the longest code word, 384 kbit/s = 9222 steps, takes 74 KB)
-  int waves = 4;
-  while (waves > 1 && static_cast<size_t>(waves) * chunks * 512 > 160 * 1024) waves >>= 1;
-  const size_t lds = static_cast<size_t>(waves) * chunks * 512;
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
-  const hipError_t a = soft_bits ? wave_attr<4>() : wave_attr<1>();
-  if (a != hipSuccess) return a;
-  const dim3 grid(static_cast<unsigned>(ngroups) * (64u / waves)), block(64u * waves);
+  const dim3 grid(static_cast<unsigned>(ngroups) * 16u), block(256);
   if (soft_bits)
-    hipLaunchKernelGGL(viterbi_wave_kernel<4>, grid, block, lds, stream, groups, ngroups, job_ids, plans, grouped, row_words, prbs_words, out, record_stride, chunks);
+    hipLaunchKernelGGL(viterbi_wave_kernel<4>, grid, block, 0, stream, groups, ngroups, job_ids, plans, grouped, row_words, decisions, prbs_words, out, record_stride);
   else
-    hipLaunchKernelGGL(viterbi_wave_kernel<1>, grid, block, lds, stream, groups, ngroups, job_ids, plans, grouped, row_words, prbs_words, out, record_stride, chunks);
+    hipLaunchKernelGGL(viterbi_wave_kernel<1>, grid, block, 0, stream, groups, ngroups, job_ids, plans, grouped, row_words, decisions, prbs_words, out, record_stride);
   return hipGetLastError();
 }
 

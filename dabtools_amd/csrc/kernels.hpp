@@ -81,10 +81,13 @@ hipError_t launch_viterbi_fused(int soft_bits, const WaveGroup* groups, int ngro
                                 const uint32_t* grouped, int row_words, uint2* decisions, const uint32_t* prbs_words, uint8_t* out,
                                 int record_stride, hipStream_t stream);
 
-// The low-latency form of the same decoder (k_vitwave.hip): one WAVE per code word, lane = trellis state -- a tenth of the fused kernel's
-// time per code word at six times its lane-ops, for small batches.  Same groups / plans / rows / output; no survivor records in HBM (LDS).
-hipError_t launch_viterbi_wave(int soft_bits, const WaveGroup* groups, int ngroups, int max_nsteps, const int* job_ids, const CodewordPlan* plans,
-                               const uint32_t* grouped, int row_words, const uint32_t* prbs_words, uint8_t* out, int record_stride, hipStream_t stream);
+// The low-latency form of the same decoder (k_vitwave.hip): one WAVE per code word, lane = trellis state -- a fraction of the fused kernel's
+// time per code word at four times its lane-ops, for small batches.  Same groups / plans / rows / output; decisions: rows of 64 x 8 bytes, one per
+// code word and chunk of kWaveChunk steps: group g's 64 x ceil(nsteps / kWaveChunk) rows start at groups[g].dec_base.
+constexpr int kWaveChunk = 60;
+hipError_t launch_viterbi_wave(int soft_bits, const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans,
+                               const uint32_t* grouped, int row_words, uint2* decisions, const uint32_t* prbs_words, uint8_t* out, int record_stride,
+                               hipStream_t stream);
 
 // the one-kernel OFDM stage (k_fused.hip, compiled three times): with the parity guard's test in its symbol loop, without it, and
 // with 4-bit soft values instead of hard decisions.

@@ -34,6 +34,7 @@ struct DecodeBatchT {
   std::vector<int, Alloc<int>> job_ids;              // lanes of group g decode jobs job_ids[g.first .. g.first + g.count); padded to tiles of 64
   std::vector<int> slice_start;                      // launches: groups [slice_start[i], slice_start[i+1]) share the survivor-record buffer
   int64_t max_dec_rows = 0;
+  bool wave_form = false;                            // few code words: decoded one WAVE per code word (k_vitwave.hip), the groups' dec_base laid out for it
 };
 
 // Everything the MSC decode of a set of ETI frames needs, prepared on the host (no GPU work)
@@ -111,14 +112,30 @@ void build_decode_batch(const PlanTable& plans, const std::vector<std::pair<int,
   }
 }
 
-// slices of wave-groups whose survivor records fit `max_rows` (rows of 64 x 8 bytes); record offsets are per slice
+// slices of wave-groups whose survivor records fit `max_rows` (rows of 64 x 8 bytes); record offsets are per slice.
+// At most wave_max_codewords code words in all: the low-latency form instead (one wave per code word, k_vitwave.hip): one launch, every code
+// word its own rows -- one per chunk of wave_chunk trellis steps.
 template <template <class> class Alloc>
-void plan_decode_batch(DecodeBatchT<Alloc>& b, int64_t max_rows)
+void plan_decode_batch(DecodeBatchT<Alloc>& b, int64_t max_rows, int64_t wave_max_codewords = 0, int wave_chunk = 60)
 {
   b.slice_start = {0};
   b.max_dec_rows = 0;
   int64_t dec_rows = 0;
   const int ng = static_cast<int>(b.groups.size());
+  int64_t codewords = 0;
+  for (const WaveGroup& g : b.groups) codewords += g.count;
+  b.wave_form = ng > 0 && codewords <= wave_max_codewords;
+  if (b.wave_form) {
+    for (int g = 0; g < ng; ++g) {
+      b.groups[g].step_base = 0;
+      b.groups[g].dec_base = dec_rows;
+      dec_rows += int64_t(64) * ((b.groups[g].nsteps + wave_chunk - 1) / wave_chunk);
+    }
+    b.slice_start.push_back(ng);
+    b.max_dec_rows = dec_rows;
+    b.job_ids.resize((b.job_ids.size() + 63) / 64 * 64, -1);
+    return;
+  }
   for (int g = 0; g < ng; ++g) {
     const int64_t dr = (b.groups[g].nsteps + 7) / 8 * 8;
     if (g > b.slice_start.back() && dec_rows + dr > max_rows) {
@@ -142,7 +159,7 @@ template <template <class> class Alloc>
 bool prepare_msc_work(PlanTable& plans, ThreadPool& pool, const std::vector<const JobList*>& stream_jobs,
                       const std::vector<const ControlPlane*>& planes, const std::vector<int>& stream_row_base,
                       const std::vector<int>& stream_fib_base, int64_t max_rows, MscWorkT<Alloc>& out, std::string* error,
-                      const std::function<void(const char*)>& mark = nullptr)
+                      const std::function<void(const char*)>& mark = nullptr, int64_t wave_max_codewords = 0)
 {
   size_t nf = 0;
   for (const auto* v : stream_jobs) nf += v->size();
@@ -253,7 +270,7 @@ bool prepare_msc_work(PlanTable& plans, ThreadPool& pool, const std::vector<cons
   for (size_t l = 0; l < layouts.size(); ++l)
     for (int pid : layouts[l].plan_ids) plan_jobs.emplace_back(pid, &layout_frames[l]);
   build_decode_batch(plans, plan_jobs, out.batch);
-  plan_decode_batch(out.batch, max_rows);
+  plan_decode_batch(out.batch, max_rows, wave_max_codewords);
   if (mark) mark("batch");
   return true;
 }
