@@ -37,10 +37,18 @@ REALTIME_FPS = 1000.0 / 24.0
 SIMDS, XCDS = 256 * 4, 8
 # Every roofline input that cannot be measured from inside this script (PMC counters, the effective clock) is read from the tracked
 # profile of the round, produced by tools/refresh_profiles.sh (rocprofv3 passes over THIS script) -- never baked in here.
-PROFILE_PMC = os.path.join(ROOT, "profiles", "r03_pmc_summary.csv")
+PROFILE_PMC = os.path.join(ROOT, "profiles", "r04_pmc_summary.csv")
+# static instruction mix of the fused OFDM kernel's symbol loop, priced in issue cycles (tools/fused_isa_mix.sh; CPU only)
+PROFILE_FUSED_MIX = os.path.join(ROOT, "profiles", "r04_fused_isa_mix.json")
 # issue cost of a wave64 VALU instruction on gfx950 (MI355X_MICROARCH.md, per-instruction table: v_fma_f32 2 cycles; tools/ubench/valu_rates.hip,
 # profiles/r03_valu_rates.txt: plain 32-bit VOP1/VOP2 2, every VOP3 / VOP3P / DPP / 64-bit form 4)
 CYC_SIMPLE, CYC_VOP3 = 2.0, 4.0
+
+
+def counter_busy(prof, kernel):
+    """VALU-busy fraction straight from the counters: SQ_ACTIVE_INST_VALU counts quad-cycles (x 4 = SIMD cycles with a VALU instruction in flight),
+    GRBM_GUI_ACTIVE / 8 XCDs = the kernel's clocks; both from the SAME pass (f1), summed over the kernel's dispatches."""
+    return 4.0 * prof.cell("f1", kernel, "SQ_ACTIVE_INST_VALU") / (SIMDS * prof.cell("f1", kernel, "GRBM_GUI_ACTIVE") / XCDS)
 VIT_ADDS_PER_STEP = 64                     # the v_add_u32 of one trellis step (k_decode.hip butterfly_pair: 4 per register pair x 16), all 2-cycle
 MSC_STEPS_PER_FRAME = 4 * 3078 + 2 * 4614 + 3 * 1542 + 774 + 2 * 198      # 27,336: trellis steps of the 12 sub-channels of the canonical mix
 FIC_STEPS = 774
@@ -274,11 +282,18 @@ def h2d_inclusive(dab, device, tensors, sizes, frames_resident, args):
                    "(98,304 in the steady state of a session); never `value`"}
     eng = dab.Engine(device)
 
+    # the ETI leg: the frames come back into page-locked host memory too -- host -> host, as the CLI contract has it
+    # (dab2eti.c:117-135); in the session their download (dabhip_stream_eti_fetch) runs beside the next segment's upload and decode
+    eti_host = [dab.HostBuffer(max(frames_resident, 1) * 6144) for _ in range(2)]
+    out["eti_leg"] = "included: all frames of a decode / segment downloaded into page-locked host memory (dabhip_engine_eti_fetch / dabhip_stream_eti_fetch)"
+
     def one_shot(ptrs, nb, reps=3):
         best = None
         for _ in range(reps):
             t0 = time.perf_counter()
             n = eng.decode_host_ptrs(ptrs, nb)
+            assert eng.eti_fetch(eti_host[0].ptr, n) == n
+            eng.eti_fetch_wait()
             dt = time.perf_counter() - t0
             st = eng.stage_ms()
             rec = {"value": n / dt, "ms": 1e3 * dt, "eti_frames": n, "h2d_ms": st["h2d"], "h2d_GBps": st["h2d_mbytes"] / max(st["h2d"], 1e-9),
@@ -308,8 +323,10 @@ def h2d_inclusive(dab, device, tensors, sizes, frames_resident, args):
             tk = time.perf_counter()                        # an iteration = hand over segment k + 1, decode segment k
             if k + 1 < len(segs):
                 st.prefetch_ptrs(*segs[k + 1])
-            n = st.feed_ptrs(*segs[k])
+            n = st.feed_ptrs(*segs[k])                      # (its K4 waits for the download of segment k - 1, issued below one iteration ago)
+            st.eti_fetch(eti_host[k & 1].ptr, n)            # segment k's frames on their way while segment k + 1 uploads and decodes
             per_seg.append((n, time.perf_counter() - tk))
+        st.eti_fetch_wait()
         dt = time.perf_counter() - t0
         st.close()
         total = sum(n for n, _ in per_seg)
@@ -325,8 +342,53 @@ def h2d_inclusive(dab, device, tensors, sizes, frames_resident, args):
     # the headline of this object: the sustained host-fed rate (steady state of the session), with the one-shot figure beside it
     out["value"] = (best["steady_state"] or best)["value"]
     out["GBps"] = (best["steady_state"] or best).get("GBps", best["end_to_end_GBps"])
-    for hb in pinned:
+    for hb in pinned + eti_host:
         hb.free()
+    return out
+
+
+def single_ensemble(dab, torch, dev, eng, tensors, args):
+    """BASELINE configs[1]: ONE Mode-I ensemble on one MI355X (the reference's only mode of use: one live ensemble, one demod thread,
+    dab2eti.c:60-115,237).  (a) the batch entry with B = 1, IQ resident: a step is ~30 launches and two host hand-offs whatever the batch, and
+    a code word's latency, not throughput, bounds the decoders -- so small decodes run one WAVE per code word (k_vitwave.hip);
+    (b) a one-stream session fed one transmission frame (96 ms of signal) at a time from page-locked host memory, frames back on the host:
+    what a live receiver sees per segment."""
+    import numpy as np
+    ptr, size = [tensors[0].data_ptr()], [tensors[0].numel()]
+    call = eng.marshal(ptr, size)
+    for _ in range(3):
+        frames = eng.decode_marshalled(call)
+    torch.cuda.synchronize(dev)
+    reps, stage = 20, {}
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        frames = eng.decode_marshalled(call)
+        for k, v in eng.stage_ms().items():
+            stage[k] = stage.get(k, 0.0) + v
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / reps
+    out = {"workload": "BASELINE configs[1]: one synthetic Mode-I ensemble x %d TF (12 sub-channels, 1136 kbit/s), IQ resident in HBM" % args.tfs,
+           "value": frames / dt, "unit": "ETI frames/s", "x_realtime": frames / dt / REALTIME_FPS, "ms_per_decode": 1e3 * dt, "eti_frames_per_decode": frames,
+           "stage_ms": {k: round(v / reps, 4) for k, v in stage.items() if not k.startswith("h2d")},
+           "decoder_form": "one wave per code word (k_vitwave.hip) for the %d MSC code words and %d FIC blocks of this decode" % (12 * frames, 4 * (args.tfs - 1)),
+           "batch_curve": "profiles/r04_batch_curve.json (B = 1 .. 256, tools/batch_curve.py)"}
+    ntf = min(args.tfs, 40)
+    hb = dab.HostBuffer(ntf * dab.TF_BYTES)
+    assert dab.lib().dabhip_device_copy(hb.ptr, tensors[0].data_ptr(), ntf * dab.TF_BYTES, 0) == 0
+    st = dab.Stream(1, device=dev.index or 0)
+    lat, total = [], 0
+    for k in range(ntf):
+        t0 = time.perf_counter()
+        n = st.feed_ptrs([hb.ptr + k * dab.TF_BYTES], [dab.TF_BYTES])
+        if n:
+            st.eti(0)
+        lat.append(1e3 * (time.perf_counter() - t0))
+        total += n
+    st.close()
+    hb.free()
+    warm = lat[18:]
+    out["live_session"] = {"segment": "1 TF = 393,216 B = 96 ms of signal, host -> device -> ETI frames back on the host", "segments": ntf, "eti_frames": total,
+                           "ms_per_segment_median": float(np.median(warm)), "ms_per_segment_max": float(max(warm)), "x_realtime": 96.0 / float(np.median(warm))}
     return out
 
 
@@ -376,6 +438,11 @@ def rooflines(prof, args, world, frames_rank, ntf_rank, stage, fft, stream_ceili
         out["roofline_viterbi"] = {
             "kernel": VIT, "bound": "valu issue", "achieved": cycles * ws / t / 1e9, "peak": SIMDS * clock, "unit": "G issue cycles/s",
             "frac": cycles * ws / t / 1e9 / (SIMDS * clock),
+            "frac_if_every_instruction_took_2_cycles": CYC_SIMPLE * insts * ws / t / 1e9 / (SIMDS * clock),
+            "frac_from_counters": {"value": counter_busy(prof, VIT), "from": prof.ref("f1", VIT, "SQ_ACTIVE_INST_VALU") + " x 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8) of the same pass",
+                                   "note": "the profiled run's own busy fraction (SQ_ACTIVE_INST_VALU is quad-granular), beside the priced figure of THIS run"},
+            "cost_model": "64 v_add_u32 per step at 2 cycles, every other instruction (v_pk_max_u16, v_perm_b32, LDS-table words, ...) at 4: tools/ubench/valu_rates.hip measures 2.4 .. 2.9 / 4.2 .. 4.5 "
+                          "clocks; MI355X_MICROARCH.md prices every wave64 VALU instruction at 2 cycles, which gives the lower figure beside it",
             "inputs": {
                 "valu_insts_per_wave_step": {"value": insts, "from": prof.ref("clk", VIT, "SQ_INSTS_VALU") + " / (meta full_decodes x viterbi_wave_steps_per_decode + viterbi_wave_steps_setup)"},
                 "effective_clock_ghz": {"value": clock, "from": prof.ref("clk", VIT, "GRBM_GUI_ACTIVE") + " / 8 XCDs / DURATION_NS of the same pass (dense VALU: the chip clocks below its 2.4 GHz)"},
@@ -395,14 +462,22 @@ def rooflines(prof, args, world, frames_rank, ntf_rank, stage, fft, stream_ceili
         t = stage["fft"] * 1e-3
         hbm = FUSED_BYTES_PER_TF * ntf_rank / t / 1e9
         tfs_prof = decodes * prof.meta("tf_per_decode") + prof.meta("tf_setup")
+        mix = json.load(open(PROFILE_FUSED_MIX))
+        # issue cycles of one 2048-point transform + demap per wave: the symbol loop's static mix on its steady-state path (weights in the file),
+        # and what the measured count has beyond that (the guard's per-bin repeats, prologue) at the repeat blocks' mean cost
+        cyc_transform = mix["issue_cycles_per_unit"] + max(0.0, insts - mix["valu_per_unit"]) * mix["remainder_cycles_per_valu"]
         out["roofline_ofdm_fused"] = {
-            "kernel": FUSED + " (transform + DQPSK + demap + de-interleave scatter, parity guard's test inline)", "bound": "valu issue / lds",
-            "achieved": 4.0 * insts * transforms / t / 1e9, "unit": "G wave-instructions/s",
+            "kernel": FUSED + " (transform + DQPSK + demap + de-interleave scatter, parity guard's test inline)", "bound": "valu issue",
+            "achieved": 4.0 * cyc_transform * transforms / t / 1e9, "peak": SIMDS * clock,
+            "unit": "G issue cycles/s", "frac": 4.0 * cyc_transform * transforms / t / 1e9 / (SIMDS * clock),
+            "frac_from_counters": {"value": counter_busy(prof, FUSED), "from": prof.ref("f1", FUSED, "SQ_ACTIVE_INST_VALU") + " x 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8) of the same pass"},
             "valu_issue": {"insts_per_wave_per_transform": insts, "from": prof.ref("clk", FUSED, "SQ_INSTS_VALU") + " / 4 waves / transforms of the profiled run",
+                           "issue_cycles_per_wave_per_transform": cyc_transform,
+                           "mix": {"file": os.path.relpath(PROFILE_FUSED_MIX, ROOT), "static_per_transform": mix["per_unit"], "static_valu": mix["valu_per_unit"],
+                                   "static_cycles": mix["issue_cycles_per_unit"], "remainder_cycles_per_valu": mix["remainder_cycles_per_valu"], "cost_model": mix["cost_model"]},
                            "effective_clock_ghz": clock, "clock_from": prof.ref("clk", FUSED, "GRBM_GUI_ACTIVE") + " / 8 / DURATION_NS",
-                           "frac_if_all_4_cycle": 4.0 * insts * transforms * CYC_VOP3 / t / 1e9 / (SIMDS * clock),
-                           "frac_if_all_2_cycle": 4.0 * insts * transforms * CYC_SIMPLE / t / 1e9 / (SIMDS * clock),
-                           "note": "the mix of 2- and 4-cycle forms is not counted separately: the issue-time fraction lies between the two figures"},
+                           "note": "instruction mix of the symbol loop from the compiler's assembly (tools/isa_mix.py: packed fp32 5, VOP3 forms 4, plain 32-bit forms 2 cycles), "
+                                   "scaled to the measured instruction count"},
             "lds": {"bank_conflict_pct": 100.0 * prof.cell("f2", FUSED, "SQ_LDS_BANK_CONFLICT") / prof.cell("f2", FUSED, "SQ_LDS_IDX_ACTIVE"),
                     "from": prof.ref("f2", FUSED, "SQ_LDS_BANK_CONFLICT") + " / SQ_LDS_IDX_ACTIVE",
                     "wait_inst_lds_pct_of_wave_cycles": 100.0 * prof.cell("f1", FUSED, "SQ_WAIT_INST_LDS") / prof.cell("clk", FUSED, "SQ_WAVE_CYCLES")},
@@ -535,6 +610,11 @@ def run_rank(args, coord):
                              "note": "dabhip_engine_set_fused(0): K2 (cu8 -> complex64 spectra) + K2b (spectra -> bits) as two kernels, "
                                      "identical ETI bytes; this rank only, untimed against the other ranks"}
                 eng.set_fused(True)
+            if not args.soft and not args.subchannels and not args.no_variants:
+                try:
+                    extra["single_ensemble"] = single_ensemble(dab, torch, dev, eng, tensors, args)
+                except Exception as e:                                        # a side measurement: never takes `value` down with it
+                    extra["single_ensemble"] = {"error": "%s: %s" % (type(e).__name__, e)}
             extra["data"] = (("synthetic (%d distinct ensembles per GPU tiled to %d streams, host modulator)" % (ndistinct, args.streams)) if args.host_synth
                              else ("synthetic (%d distinct ensembles per GPU, device-side modulator, %.1f s)" % (args.streams, t_gen)))
             if args.snr < 100.0:
@@ -597,7 +677,7 @@ def run_rank(args, coord):
         if args.snr < 100.0:
             out["config"]["snr_db"] = args.snr
             out["config"]["decisions"] = "soft (4-bit)" if args.soft else "hard"
-        for k in ("parity_guard", "parity_guard_off_variant", "payload", "h2d_inclusive", "cpu_baseline", "profile_meta"):
+        for k in ("parity_guard", "parity_guard_off_variant", "single_ensemble", "payload", "h2d_inclusive", "cpu_baseline", "profile_meta"):
             if k in extra:
                 out[k] = extra[k]
         print(json.dumps(out))

@@ -132,6 +132,10 @@ _SIGNATURES = {
     "dabhip_host_free": (None, [C.c_void_p]),
     "dabhip_synth_generate_device": (C.c_int, [C.POINTER(SynthCfg), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int]),
     "dabhip_dab_set_soft": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_engine_eti_fetch": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "dabhip_engine_eti_fetch_wait": (C.c_int, [C.c_void_p]),
+    "dabhip_stream_eti_fetch": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "dabhip_stream_eti_fetch_wait": (C.c_int, [C.c_void_p]),
     "dabhip_engine_demapped_tf": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int8), C.POINTER(C.c_int8)]),
 }
 
@@ -557,6 +561,15 @@ class Engine:
     def eti_count(self, stream):
         return lib().dabhip_engine_eti_count(self._h, stream)
 
+    def eti_fetch(self, dst_ptr, cap_frames):
+        """dabhip_engine_eti_fetch: all frames of the last decode (stream-major) on their way to (page-locked) host memory."""
+        n = lib().dabhip_engine_eti_fetch(self._h, dst_ptr, cap_frames)
+        _need(n >= 0, "eti_fetch")
+        return n
+
+    def eti_fetch_wait(self):
+        _need(lib().dabhip_engine_eti_fetch_wait(self._h) == 0, "eti_fetch_wait")
+
     def demapped_tf(self, stream, tf):
         """(fic[9216], msc[221184]) int8: what the OFDM stage of the last decode left for that TF (0/1, or -7..7 with soft decisions)."""
         fic, msc = np.zeros(FIC_BITS, dtype=np.int8), np.zeros(MSC_BITS, dtype=np.int8)
@@ -778,6 +791,15 @@ class Stream:
         p = (C.c_void_p * len(ptrs))(*ptrs)
         s = (C.c_size_t * len(sizes))(*sizes)
         _need(lib().dabhip_stream_prefetch(self._h, p, s, 1 if on_device else 0) == 0, "stream_prefetch")
+
+    def eti_fetch(self, dst_ptr, cap_frames):
+        """dabhip_stream_eti_fetch: all frames of the segment fed last on their way to (page-locked) host memory; returns their number."""
+        n = lib().dabhip_stream_eti_fetch(self._h, dst_ptr, cap_frames)
+        _need(n >= 0, "stream_eti_fetch")
+        return n
+
+    def eti_fetch_wait(self):
+        _need(lib().dabhip_stream_eti_fetch_wait(self._h) == 0, "stream_eti_fetch_wait")
 
     def eti(self, stream):
         n = lib().dabhip_stream_eti_count(self._h, stream)

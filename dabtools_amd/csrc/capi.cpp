@@ -133,6 +133,17 @@ int64_t dabhip_engine_eti_read(dabhip_engine* e, int stream, uint8_t* dst, int64
   if (stream < 0 || stream >= static_cast<int>(e->lane_of.size())) { set_error("eti_read: bad stream"); return -1; }
   return e->lanes[e->lane_of[stream]]->eti_read(e->local_of[stream], dst, cap_frames);
 }
+int64_t dabhip_engine_eti_fetch(dabhip_engine* e, uint8_t* dst, int64_t cap_frames)
+{
+  if (!e || !dst) { set_error("eti_fetch: null argument"); return -1; }
+  if (e->lanes.size() != 1) { set_error("eti_fetch: one lane only (DABHIP_LANES unset)"); return -1; }
+  return e->first().eti_fetch_async(dst, cap_frames);
+}
+int dabhip_engine_eti_fetch_wait(dabhip_engine* e)
+{
+  if (!e) { set_error("eti_fetch_wait: null handle"); return -1; }
+  return e->first().eti_fetch_wait() ? 0 : -1;
+}
 int64_t dabhip_engine_eti_drain(dabhip_engine* e, dabhip_eti_sink sink, void* user)
 {
   if (!e || !sink) { set_error("eti_drain: null argument"); return -1; }
@@ -817,6 +828,16 @@ extern "C" int64_t dabhip_stream_eti_read(dabhip_stream* s, int stream, uint8_t*
 {
   if (!s || !dst) { set_error("stream_eti_read: null argument"); return -1; }
   return s->eng.eti_read(stream, dst, cap_frames);
+}
+extern "C" int64_t dabhip_stream_eti_fetch(dabhip_stream* s, uint8_t* dst, int64_t cap_frames)
+{
+  if (!s) { set_error("stream_eti_fetch: null handle"); return -1; }
+  return s->eng.eti_fetch_async(dst, cap_frames);
+}
+extern "C" int dabhip_stream_eti_fetch_wait(dabhip_stream* s)
+{
+  if (!s) { set_error("stream_eti_fetch_wait: null handle"); return -1; }
+  return s->eng.eti_fetch_wait() ? 0 : -1;
 }
 extern "C" int64_t dabhip_stream_eti_drain(dabhip_stream* s, dabhip_eti_sink sink, void* user)
 {

@@ -15,6 +15,9 @@
 // 262,144-byte calls exactly as librtlsdr would deliver it (dab2eti.c:117-130,238), without tuner
 // feedback (a file has no tuner).  Several files are decoded as one batch of
 // independent ensembles; their frames are emitted file by file.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <condition_variable>
@@ -28,17 +31,54 @@
 #include "../../include/dabhip.h"
 
 namespace {
-void to_stdout(const uint8_t* eti, int /*stream*/, void* /*user*/)
+void write_all(const uint8_t* p, size_t n)
 {
-  size_t done = 0;
-  while (done < DABHIP_ETI_BYTES) {
-    const ssize_t n = write(1, eti + done, DABHIP_ETI_BYTES - done);
-    if (n <= 0) { std::perror("dab2eti-hip: write"); std::exit(1); }
-    done += static_cast<size_t>(n);
+  while (n) {
+    const ssize_t w = write(1, p, n);
+    if (w <= 0) { std::perror("dab2eti-hip: write"); std::_Exit(1); }
+    p += w;
+    n -= static_cast<size_t>(w);
   }
 }
+// frame sink of the drain calls: the same bytes as one write(1, eti, 6144) per frame (dab2eti.c:132-135), 512 frames to a system call
+std::vector<uint8_t> g_out;
+void flush_stdout()
+{
+  write_all(g_out.data(), g_out.size());
+  g_out.clear();
+}
+void to_stdout(const uint8_t* eti, int /*stream*/, void* /*user*/)
+{
+  g_out.insert(g_out.end(), eti, eti + DABHIP_ETI_BYTES);
+  if (g_out.size() >= size_t(512) * DABHIP_ETI_BYTES) flush_stdout();
+}
+// a capture file mapped read-only: no copy on the way in (the engine's staging pool reads the page cache directly)
+struct Mapped {
+  const uint8_t* p = nullptr;
+  size_t n = 0;
+};
+bool map_file(const char* name, Mapped* m)
+{
+  const int fd = open(name, O_RDONLY);
+  if (fd < 0) { std::perror(name); return false; }
+  struct stat st;
+  if (fstat(fd, &st) != 0) { std::perror(name); close(fd); return false; }
+  m->n = static_cast<size_t>(st.st_size);
+  if (m->n) {
+    void* p = mmap(nullptr, m->n, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (p == MAP_FAILED) { std::perror(name); close(fd); return false; }
+    (void)madvise(p, m->n, MADV_SEQUENTIAL);
+    m->p = static_cast<const uint8_t*>(p);
+  }
+  close(fd);
+  return true;
+}
 
-// streaming mode: double-buffered page-locked segments, one reader thread
+// Streaming mode: three page-locked input buffers (one being decoded, one uploading, one being read into) filled by up to 16 reader threads
+// (each owns some of the inputs: one thread's read() of cached files is an order of magnitude below the PCIe rate the decode sustains), and
+// two page-locked output buffers: the frames of a segment come back in ONE asynchronous copy (dabhip_stream_eti_fetch) that runs beside the next
+// segment's decode, and a writer thread puts them on fd 1 in large writes -- the same bytes in the same order as one 6144-byte write per frame
+// (dab2eti.c:132-135), stream by stream within a segment.
 int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool afc, bool soft, const std::vector<int32_t>& subch, int device)
 {
   const int n = static_cast<int>(names.size());
@@ -52,34 +92,71 @@ int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool 
   if (afc) dabhip_stream_set_afc(s, 1);
   if (soft) dabhip_stream_set_soft(s, 1);
   if (!subch.empty()) dabhip_stream_set_subchannels(s, subch.data(), static_cast<int>(subch.size()));
-  // three page-locked buffers: one being decoded, one uploading (dabhip_stream_prefetch), one being read into
-  constexpr int kBufs = 3;
+  constexpr int kBufs = 3, kOut = 2;
   uint8_t* buf[kBufs];
   for (auto& b : buf)
     if (!(b = static_cast<uint8_t*>(dabhip_host_alloc(seg_bytes * n)))) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); return 2; }
+  // frames a segment can yield per stream: 4 per transmission frame it completes, plus what the backlog of the segment before adds
+  const int64_t out_frames = static_cast<int64_t>(n) * (4 * static_cast<int64_t>(seg_bytes / DABHIP_TF_BYTES + 2));
+  uint8_t* out[kOut];
+  for (auto& o : out)
+    if (!(o = static_cast<uint8_t*>(dabhip_host_alloc(static_cast<size_t>(out_frames) * DABHIP_ETI_BYTES)))) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); return 2; }
   std::vector<size_t> got[kBufs];
   for (auto& g : got) g.assign(n, 0);
   std::mutex mu;
   std::condition_variable cv;
   int filled[kBufs] = {0, 0, 0};   // 0 = free, 1 = full, 2 = full and last
-  std::thread reader([&]() {
-    std::vector<bool> eof(n, false);
-    for (int k = 0;; k = (k + 1) % kBufs) {
-      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return filled[k] == 0; }); }
-      bool all_eof = true;
-      for (int i = 0; i < n; ++i) {
-        size_t done = 0;
-        while (!eof[i] && done < seg_bytes) {
-          const size_t r = std::fread(buf[k] + seg_bytes * i + done, 1, seg_bytes - done, in[i]);
-          if (r == 0) eof[i] = true;
-          done += r;
+  // A buffer is filled once per generation (the main loop opens the next one when it has consumed the buffer) by ALL readers, each reading its own
+  // inputs' parts; the reader that finishes a buffer publishes it -- as the last one when every reader found all of its inputs at their end.
+  int gen[kBufs] = {0, 0, 0}, readers_done[kBufs] = {0, 0, 0}, readers_at_eof[kBufs] = {0, 0, 0};
+  bool stop = false;
+  const int nreaders = std::max(1, std::min(n, 16));
+  std::vector<std::thread> readers;
+  for (int r = 0; r < nreaders; ++r)
+    readers.emplace_back([&, r]() {
+      std::vector<bool> eof(n, false);
+      int my_gen[kBufs] = {0, 0, 0};
+      for (int k = 0;; k = (k + 1) % kBufs) {
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return stop || (filled[k] == 0 && gen[k] == my_gen[k]); });
+          if (stop) return;
         }
-        got[k][i] = done;
-        all_eof = all_eof && eof[i];
+        bool all_mine_eof = true;
+        for (int i = r; i < n; i += nreaders) {
+          size_t done = 0;
+          while (!eof[i] && done < seg_bytes) {
+            const size_t got_now = std::fread(buf[k] + seg_bytes * i + done, 1, seg_bytes - done, in[i]);
+            if (got_now == 0) eof[i] = true;
+            done += got_now;
+          }
+          got[k][i] = done;
+          all_mine_eof = all_mine_eof && eof[i];
+        }
+        ++my_gen[k];
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          readers_at_eof[k] += all_mine_eof ? 1 : 0;
+          if (++readers_done[k] == nreaders) filled[k] = readers_at_eof[k] == nreaders ? 2 : 1;
+        }
+        cv.notify_all();
       }
-      { std::lock_guard<std::mutex> lk(mu); filled[k] = all_eof ? 2 : 1; }
+    });
+  // writer: the output buffers in order, each once its download has arrived
+  struct OutItem { int o; int64_t frames; bool last; };
+  std::vector<OutItem> queue;
+  bool out_free[kOut] = {true, true};
+  std::thread writer([&]() {
+    for (;;) {
+      OutItem it;
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !queue.empty(); }); it = queue.front(); queue.erase(queue.begin()); }
+      if (it.frames > 0) {
+        if (dabhip_stream_eti_fetch_wait(s) != 0) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); std::_Exit(2); }
+        write_all(out[it.o], static_cast<size_t>(it.frames) * DABHIP_ETI_BYTES);
+      }
+      { std::lock_guard<std::mutex> lk(mu); out_free[it.o] = true; }
       cv.notify_all();
-      if (all_eof) return;
+      if (it.last) return;
     }
   });
   std::vector<long long> total(n, 0);
@@ -87,7 +164,7 @@ int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool 
   for (int k = 0; k < kBufs; ++k)
     for (int i = 0; i < n; ++i) ptrs[k][i] = buf[k] + seg_bytes * i;
   bool prefetched[kBufs] = {false, false, false};
-  int rc = 0;
+  int rc = 0, o = 0;
   for (int k = 0;; k = (k + 1) % kBufs) {
     int state, next_state;
     const int kn = (k + 1) % kBufs;
@@ -104,16 +181,24 @@ int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool 
     }
     const int64_t frames = rc ? -1 : dabhip_stream_feed(s, ptrs[k].data(), got[k].data(), 0);
     prefetched[k] = false;
-    if (frames < 0 || dabhip_stream_eti_drain(s, to_stdout, nullptr) != frames) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); rc = 2; }
-    for (int i = 0; i < n && rc == 0; ++i) total[i] += dabhip_stream_eti_count(s, i);
-    { std::lock_guard<std::mutex> lk(mu); filled[k] = 0; }
+    if (frames < 0) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); rc = 2; }
+    if (!rc) {
+      if (frames > out_frames) { std::fprintf(stderr, "dab2eti-hip: a segment produced more frames than planned for\n"); rc = 2; }
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return out_free[o]; }); out_free[o] = false; }
+      if (!rc && frames > 0 && dabhip_stream_eti_fetch(s, out[o], frames) != frames) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); rc = 2; }
+      for (int i = 0; i < n && rc == 0; ++i) total[i] += dabhip_stream_eti_count(s, i);
+    }
+    if (rc) std::_Exit(rc);        // readers may be blocked in fread, the writer on its queue
+    { std::lock_guard<std::mutex> lk(mu); queue.push_back(OutItem{o, frames, state == 2}); filled[k] = 0; readers_done[k] = 0; readers_at_eof[k] = 0; ++gen[k]; stop = state == 2; }
     cv.notify_all();
-    if (state == 2 || rc) break;
+    o = (o + 1) % kOut;
+    if (state == 2) break;
   }
-  if (rc) std::_Exit(rc);          // the reader may be blocked in fread
-  reader.join();
+  writer.join();
+  for (auto& t : readers) t.join();
   for (int i = 0; i < n; ++i) std::fprintf(stderr, "%s: %lld ETI frames\n", names[i], total[i]);
   for (auto& b : buf) dabhip_host_free(b);
+  for (auto& ob : out) dabhip_host_free(ob);
   dabhip_stream_destroy(s);
   return 0;
 }
@@ -161,21 +246,12 @@ int main(int argc, char** argv)
   if (streaming) return run_streaming(names, seg_calls * 262144, afc, soft, subch, devices.empty() ? 0 : devices[0]);
   argc = static_cast<int>(names.size()) + 1;
   for (int i = 1; i < argc; ++i) argv[i] = const_cast<char*>(names[i - 1]);
-  std::vector<std::vector<uint8_t>> files;
-  for (int i = 1; i < argc; ++i) {
-    FILE* f = std::fopen(argv[i], "rb");
-    if (!f) { std::perror(argv[i]); return 1; }
-    std::fseek(f, 0, SEEK_END);
-    const long n = std::ftell(f);
-    std::fseek(f, 0, SEEK_SET);
-    std::vector<uint8_t> buf(static_cast<size_t>(n));
-    if (n > 0 && std::fread(buf.data(), 1, buf.size(), f) != buf.size()) { std::fprintf(stderr, "%s: short read\n", argv[i]); return 1; }
-    std::fclose(f);
-    files.push_back(std::move(buf));
-  }
+  std::vector<Mapped> files(static_cast<size_t>(argc - 1));
+  for (int i = 1; i < argc; ++i)
+    if (!map_file(argv[i], &files[static_cast<size_t>(i - 1)])) return 1;
   std::vector<const uint8_t*> ptrs;
   std::vector<size_t> sizes;
-  for (const auto& b : files) { ptrs.push_back(b.data()); sizes.push_back(b.size()); }
+  for (const auto& b : files) { ptrs.push_back(b.p); sizes.push_back(b.n); }
   if (!devices.empty()) {
     // several devices (or an explicit one): the files are dealt to them in contiguous slices, all slices decode at once
     dabhip_multi* m = dabhip_multi_create(devices.data(), static_cast<int>(devices.size()));
@@ -191,6 +267,7 @@ int main(int argc, char** argv)
       std::fprintf(stderr, "%s: %lld ETI frames (device %d)\n", argv[b + 1], static_cast<long long>(dabhip_multi_eti_count(m, static_cast<int>(b))), dev);
     }
     if (dabhip_multi_eti_drain(m, to_stdout, nullptr) != n) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); return 2; }
+    flush_stdout();
     dabhip_multi_destroy(m);
     return 0;
   }
@@ -203,7 +280,13 @@ int main(int argc, char** argv)
   if (n < 0) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); return 2; }
   for (size_t b = 0; b < files.size(); ++b)
     std::fprintf(stderr, "%s: %lld ETI frames\n", argv[b + 1], static_cast<long long>(dabhip_engine_eti_count(e, static_cast<int>(b))));
-  if (dabhip_engine_eti_drain(e, to_stdout, nullptr) != n) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); return 2; }
+  // all frames, file by file in emission order, in ONE download into page-locked memory and one run of large writes
+  if (n > 0) {
+    uint8_t* host = static_cast<uint8_t*>(dabhip_host_alloc(static_cast<size_t>(n) * DABHIP_ETI_BYTES));
+    if (!host || dabhip_engine_eti_fetch(e, host, n) != n || dabhip_engine_eti_fetch_wait(e) != 0) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); return 2; }
+    write_all(host, static_cast<size_t>(n) * DABHIP_ETI_BYTES);
+    dabhip_host_free(host);
+  }
   dabhip_engine_destroy(e);
   return 0;
 }

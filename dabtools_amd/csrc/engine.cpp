@@ -89,6 +89,9 @@ Engine::Engine(int device, int host_threads) : device_(device)
     if (!check(hipEventCreate(&e), "hipEventCreate")) return;
   for (auto& e : stage_ev_)
     if (!check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) return;
+  if (!check(hipStreamCreateWithFlags(&d2h_stream_, hipStreamNonBlocking), "hipStreamCreate") ||
+      !check(hipEventCreateWithFlags(&ev_eti_fetch_, hipEventDisableTiming), "hipEventCreate"))
+    return;
 
   std::vector<double2> tw2048(2048), tw1536(1536);
   std::vector<float2> twf(2048);
@@ -164,6 +167,8 @@ Engine::~Engine()
     if (e) (void)hipEventDestroy(e);
   for (auto& e : stage_ev_)
     if (e) (void)hipEventDestroy(e);
+  if (d2h_stream_) { (void)hipStreamSynchronize(d2h_stream_); (void)hipStreamDestroy(d2h_stream_); }
+  if (ev_eti_fetch_) (void)hipEventDestroy(ev_eti_fetch_);
   if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -392,6 +397,8 @@ bool Engine::msc_launch_async(const MscWork& w)
   const size_t nf = w.nframes;
   msc_queued_ = false;
   if (nf == 0) return true;
+  // a fetch of the previous decode's frames may still be reading the ETI buffer these launches rewrite (eti_fetch_async)
+  if (eti_fetch_pending_ && !check(hipStreamWaitEvent(stream_, ev_eti_fetch_, 0), "eti fetch wait")) return false;
   if (!launch_decode_batch(w.batch, d_msc_bits_.get(), d_stream_cif_base_.get(), d_prbs_.get(), d_eti_.get(), kEtiBytes)) return false;
   if (!check(launch_eti_finish(d_meta_.get(), static_cast<int>(nf), d_headers_.get(), w.header_stride, d_fibs_.get(), d_crc_tab_.get(), d_crc_shift_.get(), d_eti_.get(), stream_), "eti finish launch"))
     return false;
@@ -1083,6 +1090,25 @@ int64_t Engine::eti_read(int stream, uint8_t* dst, int64_t cap_frames)
   if (stream < 0 || stream >= nstreams_) { set_error("eti_read: bad stream"); return -1; }
   const int64_t n = std::min(cap_frames, eti_count_[stream]);
   return read_eti(eti_base_[stream], n, dst) ? n : -1;
+}
+
+int64_t Engine::eti_fetch_async(uint8_t* dst, int64_t cap_frames)
+{
+  if (!dst) { set_error("eti_fetch: null destination"); return -1; }
+  if (!check(hipSetDevice(device_), "hipSetDevice")) return -1;
+  const int64_t n = std::min(cap_frames, total_eti_);
+  // (decode() has returned: the frames are complete; the copy is ordered before the next decode's K4 by ev_eti_fetch_)
+  if (n > 0 && !check(hipMemcpyAsync(dst, d_eti_.get(), static_cast<size_t>(n) * kEtiBytes, hipMemcpyDeviceToHost, d2h_stream_), "eti fetch")) return -1;
+  if (!check(hipEventRecord(ev_eti_fetch_, d2h_stream_), "eti fetch event")) return -1;
+  eti_fetch_pending_ = true;
+  return n;
+}
+
+bool Engine::eti_fetch_wait()
+{
+  if (!eti_fetch_pending_) return true;
+  eti_fetch_pending_ = false;
+  return check(hipSetDevice(device_), "hipSetDevice") && check(hipEventSynchronize(ev_eti_fetch_), "eti fetch");
 }
 
 const uint8_t* Engine::eti_device(int64_t* nframes) const

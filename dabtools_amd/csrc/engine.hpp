@@ -12,6 +12,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <map>
 #include <functional>
@@ -179,6 +180,11 @@ class Engine {
   int64_t stream_need_from(int stream) const;   // oldest stream byte the next segment may still read
   int64_t eti_count(int stream) const;
   int64_t eti_read(int stream, uint8_t* dst, int64_t cap_frames);
+  // All frames of the last decode / segment (stream-major, emission order) to host memory on a stream of their own, without waiting: the copy
+  // runs beside the NEXT decode's scan and OFDM stage (only its K4, which rewrites the ETI buffer, waits for it).  dst should be page-locked.
+  // eti_fetch_wait() returns when the bytes are there.  The output side of the CLI contract (dab2eti.c:132-135) at the link's rate.
+  int64_t eti_fetch_async(uint8_t* dst, int64_t cap_frames);
+  bool eti_fetch_wait();
   const uint8_t* eti_device(int64_t* nframes) const;
   int trace(int stream, int32_t* ints6, double* ffs, int cap_calls) const;
   const StageTimes& stage_times() const { return times_; }
@@ -268,6 +274,9 @@ class Engine {
   hipEvent_t ev_upload_ = nullptr, ev_fic_ = nullptr, ev_fic_done_ = nullptr, ev_fibs_ = nullptr, ev_part0_ = nullptr, ev_chain_ = nullptr, ev_info_ = nullptr;
   hipEvent_t ev_msc_[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_h2d_[2] = {nullptr, nullptr};
+  hipStream_t d2h_stream_ = nullptr;           // eti_fetch_async
+  hipEvent_t ev_eti_fetch_ = nullptr;
+  std::atomic<bool> eti_fetch_pending_{false};   // (cleared by whichever thread waits for the copy: the CLI's writer thread)
   // page-locked staging ring for uploads from pageable memory: the host pool copies piece n + 1 into one buffer while the DMA of
   // piece n drains another
   static constexpr int kStageBufs = 4;

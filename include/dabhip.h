@@ -110,6 +110,13 @@ int64_t dabhip_engine_eti_read(dabhip_engine *e, int stream, uint8_t *dst, int64
 /* Deliver all frames, stream by stream in emission order, to a sink (stdout contract helper). */
 int64_t dabhip_engine_eti_drain(dabhip_engine *e, dabhip_eti_sink sink, void *user);
 const void *dabhip_engine_eti_device_ptr(const dabhip_engine *e, int64_t *nframes); /* all frames, stream-major */
+/* The output leg of the CLI contract (eti_callback -> write(1, eti, 6144), dab2eti.c:132-135) without a stall: ALL frames of the last decode,
+ * stream by stream in emission order (the order dabhip_engine_eti_drain delivers them in), copied to dst -- page-locked memory from
+ * dabhip_host_alloc for a true asynchronous DMA -- on a stream of their own.  Returns at once with the number of frames on their way (<= cap_frames);
+ * the copy runs beside the NEXT decode (only that decode's ETI-writing launches wait for it); dabhip_engine_eti_fetch_wait returns when the
+ * bytes have arrived.  dst must stay untouched in between. */
+int64_t dabhip_engine_eti_fetch(dabhip_engine *e, uint8_t *dst, int64_t cap_frames);
+int dabhip_engine_eti_fetch_wait(dabhip_engine *e);
 
 /* Software AFC (beyond the reference's file-less operation): when enabled every stream gets an NCO
  * steered by the tuner feedback rule of dab2eti.c:76-103 (coarse offset > 1 carrier: +-1000 Hz; = 1: a random step
@@ -204,6 +211,9 @@ int dabhip_stream_prefetch(dabhip_stream *s, const uint8_t *const *iq, const siz
 int64_t dabhip_stream_eti_count(const dabhip_stream *s, int stream);
 int64_t dabhip_stream_eti_read(dabhip_stream *s, int stream, uint8_t *dst, int64_t cap_frames);
 int64_t dabhip_stream_eti_drain(dabhip_stream *s, dabhip_eti_sink sink, void *user);
+/* as dabhip_engine_eti_fetch / _wait, for the frames of the segment fed last: its download overlaps the next segment's upload and decode */
+int64_t dabhip_stream_eti_fetch(dabhip_stream *s, uint8_t *dst, int64_t cap_frames);
+int dabhip_stream_eti_fetch_wait(dabhip_stream *s);
 int dabhip_stream_set_afc(dabhip_stream *s, int enable);
 int dabhip_stream_set_subchannels(dabhip_stream *s, const int32_t *ids, int n);   /* before the first segment only */
 int dabhip_stream_set_soft(dabhip_stream *s, int enable);   /* before the first segment only */

@@ -160,3 +160,42 @@ def test_stream_session_with_prefetched_segments_equals_one_shot_decode():
     for _, _, hbs in segs:
         for hb in hbs:
             hb.free()
+
+
+def test_eti_fetch_is_the_drain_order_and_overlaps_the_next_segment():
+    """dabhip_engine_eti_fetch / dabhip_stream_eti_fetch (the output leg of dab2eti.c:132-135 without a stall): one asynchronous download of ALL
+    frames, stream by stream in emission order = the bytes eti_read returns per stream, also when the next segment is fed before the wait."""
+    cfgs = [dab.synth_preset(1, seed=610 + i, cif_count0=33 * i, skip_samples=(0, 91000, 0)[i]) for i in range(3)]
+    streams = [dab.synth_generate(c, 24) for c in cfgs]
+    eng = dab.Engine(0)
+    total = eng.decode(streams)
+    hb = dab.HostBuffer(total * 6144)
+    assert eng.eti_fetch(hb.ptr, total) == total
+    eng.eti_fetch_wait()
+    got = np.array(hb.array[:total * 6144]).reshape(total, 6144)
+    want = np.concatenate([eng.eti(b) for b in range(3)])
+    assert np.array_equal(got, want)
+    eng.close()
+    # session: the download of segment k is waited for only AFTER segment k + 1 has been fed (it overlaps that segment's upload and decode;
+    # only the K4 of segment k + 1, which rewrites the ETI buffer, is ordered behind it)
+    st = dab.Stream(3, device=0)
+    cuts = [0, 7 * dab.TF_BYTES, 15 * dab.TF_BYTES + 1234, 20 * dab.TF_BYTES, 24 * dab.TF_BYTES]
+    bufs = [dab.HostBuffer(64 * 3 * 6144) for _ in range(2)]
+    pending = None                                   # (buffer, frames, expected bytes) of the segment before
+    nframes = 0
+    for k, (a, z) in enumerate(zip(cuts, cuts[1:])):
+        n = st.feed([s[a:min(z, s.size)] for s in streams])
+        if pending is not None:
+            st.eti_fetch_wait()
+            assert np.array_equal(np.array(bufs[pending[0]].array[:pending[1] * 6144]).reshape(-1, 6144), pending[2])
+        expect = np.concatenate([st.eti(b) for b in range(3)]) if n else np.zeros((0, 6144), np.uint8)
+        assert expect.shape[0] == n
+        assert st.eti_fetch(bufs[k & 1].ptr, n) == n
+        pending = (k & 1, n, expect)
+        nframes += n
+    st.eti_fetch_wait()
+    assert np.array_equal(np.array(bufs[pending[0]].array[:pending[1] * 6144]).reshape(-1, 6144), pending[2])
+    assert nframes == total
+    st.close()
+    for b in bufs + [hb]:
+        b.free()

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""tools/cli_throughput.py -- host -> host throughput of the CLI contract.
+
+north_star: "emits ETI-NI frames through the existing dab2eti CLI/stdout contract" (dab2eti.c:117-135: 262,144-byte buffers in, one
+write(1, eti, 6144) per frame out).  Here: N synthetic captures written to files (page cache), then
+
+    dab2eti-hip --stream --segment-calls C cap*.cu8 > /dev/null      (segment pipeline: read -> upload -> decode -> download -> write)
+    dab2eti-hip cap*.cu8 > /dev/null                                  (one batch: mmap -> upload -> decode -> download -> write)
+    cat cap0.cu8 | dab2eti-hip - > /dev/null                          (one live stream through a pipe)
+
+wall clock of the whole process (start-up, library load and lock-in included) and ETI frames per second; for a small case the
+bytes on stdout are compared with the frames the library returns in memory.  One JSON document (profiles/r04_cli_throughput.json).
+"""
+import argparse
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CLI = os.path.join(ROOT, "dabtools_amd", "dab2eti-hip")
+
+
+def run(cmd, stdin=None, capture=False):
+    t0 = time.perf_counter()
+    res = subprocess.run(cmd, stdin=stdin, stdout=subprocess.PIPE if capture else subprocess.DEVNULL, stderr=subprocess.PIPE)
+    dt = time.perf_counter() - t0
+    if res.returncode != 0:
+        raise RuntimeError("%s: rc %d: %s" % (" ".join(cmd[:4]), res.returncode, res.stderr.decode()[-400:]))
+    frames = sum(int(l.split(":")[-1].split()[0]) for l in res.stderr.decode().splitlines() if "ETI frames" in l)
+    return dt, frames, res.stdout if capture else None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=128)
+    ap.add_argument("--tfs", type=int, default=64)
+    ap.add_argument("--segment-calls", type=int, default=12, help="262,144-byte calls per stream and segment (12 = 8 TF)")
+    ap.add_argument("--dir", type=str, default="")
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    import dabtools_amd as dab
+    from dabtools_amd import payload
+
+    tmp = args.dir or tempfile.mkdtemp(prefix="dabhip_cli_")
+    os.makedirs(tmp, exist_ok=True)
+    free = shutil.disk_usage(tmp).free
+    need = args.streams * args.tfs * dab.TF_BYTES
+    if free < 1.2 * need:
+        raise SystemExit("cli_throughput: %s has %.1f GB free, the captures need %.1f" % (tmp, free / 1e9, need / 1e9))
+    dev = torch.device("cuda", 0)
+    cfgs = [payload.bench_cfg(dab, i) for i in range(args.streams)]
+    tensors = [torch.empty(dab.synth_bytes(c, args.tfs), dtype=torch.uint8, device=dev) for c in cfgs]
+    dab.synth_generate_device(cfgs, args.tfs, [t.data_ptr() for t in tensors], 0)
+    torch.cuda.synchronize()
+    files = []
+    for i, t in enumerate(tensors):
+        path = os.path.join(tmp, "cap%04d.cu8" % i)
+        t.cpu().numpy().tofile(path)
+        files.append(path)
+    # what the library returns in memory for the first streams (the check of the bytes on stdout)
+    eng = dab.Engine(0)
+    ncheck = min(4, args.streams)
+    eng.decode_device([t.data_ptr() for t in tensors[:ncheck]], [t.numel() for t in tensors[:ncheck]])
+    want = [eng.eti(b) for b in range(ncheck)]
+    eng.close()
+    del tensors
+    torch.cuda.empty_cache()
+    out = {"what": "dab2eti-hip as a process: files (page cache) in, 6144-byte ETI frames on stdout (/dev/null) out; wall clock of the whole process",
+           "streams": args.streams, "tf_per_stream": args.tfs, "input_bytes": need}
+    # bytes on stdout == frames in memory: batch mode (file by file) and streaming mode of ONE file
+    _, _, blob = run([CLI] + files[:ncheck], capture=True)
+    got = np.frombuffer(blob, dtype=np.uint8).reshape(-1, 6144)
+    out["batch_stdout_equals_library_frames"] = bool(got.shape[0] == sum(w.shape[0] for w in want) and np.array_equal(got, np.concatenate(want)))
+    _, _, blob1 = run([CLI, "--stream", "--segment-calls", str(args.segment_calls), files[0]], capture=True)
+    out["stream_stdout_equals_library_frames"] = bool(np.array_equal(np.frombuffer(blob1, dtype=np.uint8).reshape(-1, 6144), want[0]))
+    with open(files[0], "rb") as f:
+        _, _, blob2 = run([CLI, "-"], stdin=f, capture=True)
+    out["stdin_stdout_equals_library_frames"] = bool(np.array_equal(np.frombuffer(blob2, dtype=np.uint8).reshape(-1, 6144), want[0]))
+    out["stdout_sha256_first_stream"] = hashlib.sha256(blob1).hexdigest()
+    for name, cmd in (("stream_pipeline", [CLI, "--stream", "--segment-calls", str(args.segment_calls)] + files), ("one_batch", [CLI] + files)):
+        best = None
+        for _ in range(2):
+            dt, frames, _ = run(cmd)
+            rec = {"seconds": dt, "eti_frames": frames, "eti_frames_per_s": frames / dt, "input_GBps": need / dt / 1e9, "x_realtime_aggregate": frames / dt * 0.024}
+            if best is None or rec["eti_frames_per_s"] > best["eti_frames_per_s"]:
+                best = rec
+        out[name] = best
+    with open(files[0], "rb") as f:
+        dt, frames, _ = run([CLI, "-"], stdin=f)
+    out["one_stream_from_stdin"] = {"seconds": dt, "eti_frames": frames, "eti_frames_per_s": frames / dt, "x_realtime": frames / dt * 0.024,
+                                    "note": "a single ensemble read from stdin in 16 MiB segments; process start-up and library load are in the time"}
+    # the same without process start-up: the first run pays the code-object load (~0.5 s)
+    out["note"] = ("frames/s include process start, library load, page-locked buffer allocation and the 16 TF of lock-in per stream; the steady-state session rate "
+                   "without them is bench.py's h2d_inclusive.session_prefetch")
+    if not args.dir:
+        shutil.rmtree(tmp, ignore_errors=True)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
