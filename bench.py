@@ -259,6 +259,28 @@ def cpu_baseline(tensors, ntf, nsample, ber_first_stream=-1, snr=1000.0):
     return json.loads(res.stdout.strip().splitlines()[-1])
 
 
+def cli_leg(streams, tfs):
+    """tools/cli_throughput.py as a CHILD process: the dab2eti-hip executable, capture files in, 6144-byte frames on stdout out (the reference's
+    CLI contract, dab2eti.c:117-135), on a reduced sample of the workload so that the default run stays short; the full-size figures are tracked in
+    profiles/r04_cli_throughput.json."""
+    d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    with tempfile.TemporaryDirectory(prefix="dabhip_cli_", dir=d) as tmp:
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_throughput.py"), "--streams", str(streams), "--tfs", str(tfs), "--dir", tmp],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    if res.returncode != 0:
+        return {"error": res.stderr[-400:]}
+    r = json.loads(res.stdout)
+    sp = r["stream_pipeline"]
+    return {"command": "dab2eti-hip --stream --segment-calls 12 cap0000.cu8 .. cap%04d.cu8 > /dev/null   (files in %s)" % (streams - 1, d),
+            "value": sp["inside_the_process"]["steady_frames_per_s"], "unit": "ETI frames/s",
+            "value_is": "steady state inside the process: frames of all segments after the first productive one / time until the last byte is written",
+            "whole_process": {"seconds": sp["seconds"], "eti_frames_per_s": sp["eti_frames_per_s"], "setup_s": sp["inside_the_process"]["setup_s"],
+                              "note": "process start, HIP initialisation, page-locking the five segment buffers and lock-in included"},
+            "one_batch": r["one_batch"], "one_stream_from_stdin": r["one_stream_from_stdin"],
+            "stdout_bytes_equal_library_frames": bool(r["batch_stdout_equals_library_frames"] and r["stream_stdout_equals_library_frames"] and r["stdin_stdout_equals_library_frames"]),
+            "streams": streams, "tf_per_stream": tfs, "full_size": "profiles/r04_cli_throughput.json (256 streams x 256 TF = 25.8 GB of captures: 567 k ETI frames/s steady state)"}
+
+
 def workload_text(args):
     if args.snr < 100.0:
         return ("BASELINE configs[4]: batch=%d synthetic Mode-I streams x %d TF per GPU, AWGN %.1f dB, %s-decision Viterbi, 12 sub-channels "
@@ -627,6 +649,10 @@ def run_rank(args, coord):
                     extra["h2d_inclusive"] = h2d_inclusive(dab, local_rank, tensors, sizes, frames, args)
                 except Exception as e:                                        # a side measurement (6.4 GB of page-locked host memory): never takes `value` down with it
                     extra["h2d_inclusive"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                try:
+                    extra["h2d_inclusive"]["cli"] = cli_leg(min(args.streams, 128), args.tfs)
+                except Exception as e:
+                    extra["h2d_inclusive"]["cli"] = {"error": "%s: %s" % (type(e).__name__, e)}
             if not args.no_cpu_baseline and world == 1:
                 if args.snr < 100.0:                                          # configs[4]: CPU BER on the 16 streams the GPU payload was checked on
                     extra["cpu_baseline"] = cpu_baseline(tensors, args.tfs, min(16, args.streams), ber_first_stream=rank * args.streams, snr=args.snr)

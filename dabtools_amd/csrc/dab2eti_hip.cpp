@@ -20,6 +20,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -79,8 +80,12 @@ bool map_file(const char* name, Mapped* m)
 // two page-locked output buffers: the frames of a segment come back in ONE asynchronous copy (dabhip_stream_eti_fetch) that runs beside the next
 // segment's decode, and a writer thread puts them on fd 1 in large writes -- the same bytes in the same order as one 6144-byte write per frame
 // (dab2eti.c:132-135), stream by stream within a segment.
+bool g_stats = false;                            // --stats: phase times on stderr (one JSON line), for tools/cli_throughput.py
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool afc, bool soft, const std::vector<int32_t>& subch, int device)
 {
+  const double t_start = now_s();
   const int n = static_cast<int>(names.size());
   std::vector<FILE*> in(n);
   for (int i = 0; i < n; ++i) {
@@ -94,13 +99,18 @@ int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool 
   if (!subch.empty()) dabhip_stream_set_subchannels(s, subch.data(), static_cast<int>(subch.size()));
   constexpr int kBufs = 3, kOut = 2;
   uint8_t* buf[kBufs];
-  for (auto& b : buf)
-    if (!(b = static_cast<uint8_t*>(dabhip_host_alloc(seg_bytes * n)))) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); return 2; }
   // frames a segment can yield per stream: 4 per transmission frame it completes, plus what the backlog of the segment before adds
   const int64_t out_frames = static_cast<int64_t>(n) * (4 * static_cast<int64_t>(seg_bytes / DABHIP_TF_BYTES + 2));
   uint8_t* out[kOut];
-  for (auto& o : out)
-    if (!(o = static_cast<uint8_t*>(dabhip_host_alloc(static_cast<size_t>(out_frames) * DABHIP_ETI_BYTES)))) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); return 2; }
+  {
+    // page-locking gigabytes takes a noticeable part of a second: the five buffers at once
+    std::vector<std::thread> alloc;
+    for (auto& b : buf) alloc.emplace_back([&b, seg_bytes, n]() { b = static_cast<uint8_t*>(dabhip_host_alloc(seg_bytes * n)); });
+    for (auto& ob : out) alloc.emplace_back([&ob, out_frames]() { ob = static_cast<uint8_t*>(dabhip_host_alloc(static_cast<size_t>(out_frames) * DABHIP_ETI_BYTES)); });
+    for (auto& t : alloc) t.join();
+    for (auto* b : buf) if (!b) { std::fprintf(stderr, "dab2eti-hip: page-locked input buffer: %s\n", dabhip_last_error()); return 2; }
+    for (auto* ob : out) if (!ob) { std::fprintf(stderr, "dab2eti-hip: page-locked output buffer: %s\n", dabhip_last_error()); return 2; }
+  }
   std::vector<size_t> got[kBufs];
   for (auto& g : got) g.assign(n, 0);
   std::mutex mu;
@@ -165,6 +175,9 @@ int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool 
     for (int i = 0; i < n; ++i) ptrs[k][i] = buf[k] + seg_bytes * i;
   bool prefetched[kBufs] = {false, false, false};
   int rc = 0, o = 0;
+  const double t_ready = now_s();
+  std::vector<double> seg_done;                  // when each segment's feed returned
+  std::vector<long long> seg_frames;
   for (int k = 0;; k = (k + 1) % kBufs) {
     int state, next_state;
     const int kn = (k + 1) % kBufs;
@@ -187,6 +200,8 @@ int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool 
       { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return out_free[o]; }); out_free[o] = false; }
       if (!rc && frames > 0 && dabhip_stream_eti_fetch(s, out[o], frames) != frames) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); rc = 2; }
       for (int i = 0; i < n && rc == 0; ++i) total[i] += dabhip_stream_eti_count(s, i);
+      seg_done.push_back(now_s());
+      seg_frames.push_back(frames);
     }
     if (rc) std::_Exit(rc);        // readers may be blocked in fread, the writer on its queue
     { std::lock_guard<std::mutex> lk(mu); queue.push_back(OutItem{o, frames, state == 2}); filled[k] = 0; readers_done[k] = 0; readers_at_eof[k] = 0; ++gen[k]; stop = state == 2; }
@@ -195,8 +210,20 @@ int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool 
     if (state == 2) break;
   }
   writer.join();
+  const double t_written = now_s();
   for (auto& t : readers) t.join();
   for (int i = 0; i < n; ++i) std::fprintf(stderr, "%s: %lld ETI frames\n", names[i], total[i]);
+  if (g_stats) {
+    // steady state: from the first segment that produced frames to the last, the frames of the segments after that first one
+    size_t first = 0;
+    while (first < seg_frames.size() && seg_frames[first] == 0) ++first;
+    long long steady_frames = 0, all = 0;
+    for (size_t i = 0; i < seg_frames.size(); ++i) { all += seg_frames[i]; if (i > first) steady_frames += seg_frames[i]; }
+    const double steady_s = first < seg_done.size() ? t_written - seg_done[first] : 0.0;
+    std::fprintf(stderr, "{\"mode\": \"stream\", \"streams\": %d, \"segments\": %zu, \"segment_bytes_per_stream\": %zu, \"setup_s\": %.4f, \"run_s\": %.4f, \"eti_frames\": %lld, "
+                         "\"steady_frames\": %lld, \"steady_s\": %.4f, \"steady_frames_per_s\": %.1f}\n",
+                 n, seg_frames.size(), seg_bytes, t_ready - t_start, t_written - t_ready, all, steady_frames, steady_s, steady_s > 0 ? steady_frames / steady_s : 0.0);
+  }
   for (auto& b : buf) dabhip_host_free(b);
   for (auto& ob : out) dabhip_host_free(ob);
   dabhip_stream_destroy(s);
@@ -213,6 +240,7 @@ int main(int argc, char** argv)
   std::vector<const char*> names;
   for (int i = 1; i < argc; ++i) {
     if (std::strcmp(argv[i], "--stream") == 0) streaming = true;
+    else if (std::strcmp(argv[i], "--stats") == 0) g_stats = true;
     else if (std::strcmp(argv[i], "--afc") == 0) afc = true;          // software AFC: captures with a carrier offset (no tuner to steer)
     else if (std::strcmp(argv[i], "--soft") == 0) soft = true;        // 4-bit soft decisions (not the reference's hard ones)
     else if (std::strcmp(argv[i], "--subch") == 0 && i + 1 < argc) {
@@ -246,6 +274,7 @@ int main(int argc, char** argv)
   if (streaming) return run_streaming(names, seg_calls * 262144, afc, soft, subch, devices.empty() ? 0 : devices[0]);
   argc = static_cast<int>(names.size()) + 1;
   for (int i = 1; i < argc; ++i) argv[i] = const_cast<char*>(names[i - 1]);
+  const double t_start = now_s();
   std::vector<Mapped> files(static_cast<size_t>(argc - 1));
   for (int i = 1; i < argc; ++i)
     if (!map_file(argv[i], &files[static_cast<size_t>(i - 1)])) return 1;
@@ -276,8 +305,10 @@ int main(int argc, char** argv)
   if (afc) dabhip_engine_set_afc(e, 1);
   if (soft) dabhip_engine_set_soft(e, 1);
   if (!subch.empty()) dabhip_engine_set_subchannels(e, subch.data(), static_cast<int>(subch.size()));
+  const double t_ready = now_s();
   const int64_t n = dabhip_engine_decode(e, ptrs.data(), sizes.data(), static_cast<int>(ptrs.size()), 0);
   if (n < 0) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); return 2; }
+  const double t_decoded = now_s();
   for (size_t b = 0; b < files.size(); ++b)
     std::fprintf(stderr, "%s: %lld ETI frames\n", argv[b + 1], static_cast<long long>(dabhip_engine_eti_count(e, static_cast<int>(b))));
   // all frames, file by file in emission order, in ONE download into page-locked memory and one run of large writes
@@ -287,6 +318,9 @@ int main(int argc, char** argv)
     write_all(host, static_cast<size_t>(n) * DABHIP_ETI_BYTES);
     dabhip_host_free(host);
   }
+  if (g_stats)
+    std::fprintf(stderr, "{\"mode\": \"batch\", \"streams\": %zu, \"setup_s\": %.4f, \"upload_decode_s\": %.4f, \"download_write_s\": %.4f, \"eti_frames\": %lld}\n", files.size(),
+                 t_ready - t_start, t_decoded - t_ready, now_s() - t_decoded, static_cast<long long>(n));
   dabhip_engine_destroy(e);
   return 0;
 }
