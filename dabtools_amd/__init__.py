@@ -15,6 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DABHIP_LIB") or os.path.join(_HERE, "libdabhip.so")   # override: experiments with another build
 
+STREAM_MUX_OVERFLOW, STREAM_SUBCH_OUTSIDE_CIF, STREAM_EEP_OPTION = 1, 2, 4
 TF_BYTES = 393216
 CHUNK_BYTES = 262144
 FIC_BITS = 9216
@@ -35,7 +36,15 @@ class SubChCfg(C.Structure):
 class SynthCfg(C.Structure):
     _fields_ = [("eid", C.c_uint32), ("nsub", C.c_int32), ("sub", SubChCfg * 64), ("seed", C.c_uint64),
                 ("cif_count0", C.c_int32), ("skip_samples", C.c_int32), ("amplitude", C.c_double),
-                ("snr_db", C.c_double), ("cfo_hz", C.c_double)]
+                ("snr_db", C.c_double), ("cfo_hz", C.c_double),
+                ("fib_patch_len", C.c_int32), ("fib_patch_from_cif", C.c_int32), ("fib_patch", C.c_uint8 * 32)]
+
+    def set_fib_patch(self, data, from_cif=0):
+        """Third FIB of every CIF from `from_cif` on = these bytes (<= 30) under a valid CRC: hostile / non-standard FIGs for tests."""
+        data = bytes(data)[:30]
+        self.fib_patch_len, self.fib_patch_from_cif = len(data), from_cif
+        for i, b in enumerate(data):
+            self.fib_patch[i] = b
 
 
 ETI_CALLBACK = C.CFUNCTYPE(None, u8p)
@@ -132,6 +141,10 @@ _SIGNATURES = {
     "dabhip_host_free": (None, [C.c_void_p]),
     "dabhip_synth_generate_device": (C.c_int, [C.POINTER(SynthCfg), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int]),
     "dabhip_dab_set_soft": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_engine_stream_status": (C.c_uint32, [C.c_void_p, C.c_int]),
+    "dabhip_multi_stream_status": (C.c_uint32, [C.c_void_p, C.c_int]),
+    "dabhip_stream_status": (C.c_uint32, [C.c_void_p, C.c_int]),
+    "dabhip_dab_status": (C.c_uint32, [C.c_void_p]),
     "dabhip_engine_eti_fetch": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64]),
     "dabhip_engine_eti_fetch_wait": (C.c_int, [C.c_void_p]),
     "dabhip_stream_eti_fetch": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64]),
@@ -440,6 +453,10 @@ class Dab:
     def locked(self):
         return bool(lib().dabhip_dab_locked(self._h))
 
+    @property
+    def status(self):
+        return int(lib().dabhip_dab_status(self._h))
+
     def last_fibs(self):
         fibs = np.zeros((12, 32), dtype=np.uint8)
         ok = np.zeros(12, dtype=np.uint8)
@@ -560,6 +577,10 @@ class Engine:
 
     def eti_count(self, stream):
         return lib().dabhip_engine_eti_count(self._h, stream)
+
+    def stream_status(self, stream):
+        """dabhip_engine_stream_status: 0 = fine, else STREAM_* fault bits (the stream emitted no frames while its multiplex was un-assemblable)."""
+        return int(lib().dabhip_engine_stream_status(self._h, stream))
 
     def eti_fetch(self, dst_ptr, cap_frames):
         """dabhip_engine_eti_fetch: all frames of the last decode (stream-major) on their way to (page-locked) host memory."""
@@ -791,6 +812,9 @@ class Stream:
         p = (C.c_void_p * len(ptrs))(*ptrs)
         s = (C.c_size_t * len(sizes))(*sizes)
         _need(lib().dabhip_stream_prefetch(self._h, p, s, 1 if on_device else 0) == 0, "stream_prefetch")
+
+    def status(self, stream):
+        return int(lib().dabhip_stream_status(self._h, stream))
 
     def eti_fetch(self, dst_ptr, cap_frames):
         """dabhip_stream_eti_fetch: all frames of the segment fed last on their way to (page-locked) host memory; returns their number."""

@@ -127,6 +127,11 @@ int64_t dabhip_engine_eti_count(const dabhip_engine* e, int stream)
   if (!e || stream < 0 || stream >= static_cast<int>(e->lane_of.size())) return -1;
   return e->lanes[e->lane_of[stream]]->eti_count(e->local_of[stream]);
 }
+uint32_t dabhip_engine_stream_status(const dabhip_engine* e, int stream)
+{
+  if (!e || stream < 0 || stream >= static_cast<int>(e->lane_of.size())) return 0xffffffffu;
+  return e->lanes[e->lane_of[stream]]->stream_status(e->local_of[stream]);
+}
 int64_t dabhip_engine_eti_read(dabhip_engine* e, int stream, uint8_t* dst, int64_t cap_frames)
 {
   if (!e || !dst) { set_error("eti_read: null argument"); return -1; }
@@ -462,6 +467,7 @@ void dabhip_dab_free(dabhip_dab* d) { delete d; }
 uint8_t* dabhip_dab_tf_fic(dabhip_dab* d) { return d ? d->fic.data() : nullptr; }
 uint8_t* dabhip_dab_tf_msc(dabhip_dab* d) { return d ? d->msc.data() : nullptr; }
 int dabhip_dab_locked(const dabhip_dab* d) { return d && d->plane.locked(); }
+uint32_t dabhip_dab_status(const dabhip_dab* d) { return d ? d->plane.fault() : 0xffffffffu; }
 int dabhip_dab_set_soft(dabhip_dab* d, int enable)
 {
   if (!d) { set_error("dab_set_soft: null handle"); return -1; }
@@ -824,6 +830,7 @@ extern "C" int64_t dabhip_stream_feed(dabhip_stream* s, const uint8_t* const* iq
   return frames;
 }
 extern "C" int64_t dabhip_stream_eti_count(const dabhip_stream* s, int stream) { return s ? s->eng.eti_count(stream) : -1; }
+extern "C" uint32_t dabhip_stream_status(const dabhip_stream* s, int stream) { return s ? s->eng.stream_status(stream) : 0xffffffffu; }
 extern "C" int64_t dabhip_stream_eti_read(dabhip_stream* s, int stream, uint8_t* dst, int64_t cap_frames)
 {
   if (!s || !dst) { set_error("stream_eti_read: null argument"); return -1; }

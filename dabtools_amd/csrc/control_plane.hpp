@@ -190,6 +190,30 @@ class JobList {
   std::vector<uint8_t> bytes_;
 };
 
+// What a signalled multiplex must satisfy for the reference's create_eti (misc.c:218-314) to stay inside its own arrays.  The FIC is protected by a
+// 16-bit CRC only: at low SNR a corrupted FIB passes it every few ten thousand FIBs, and fib_parse (fic.c:47-130) validates nothing -- the reference
+// then reads past cif_time_deinterleaved[55296] (depuncture.c:84-132 from start_cu * 64), indexes eeptable[] past its 8 rows (fic.c:84) or writes past
+// eti[6144] (misc.c:233,246-296): undefined behaviour, no parity target.  A batch engine must not let one such ensemble take the others down: the
+// ensemble is flagged and emits no frames while its multiplex is in that state (it never leaves it: sub-channels are only ever added, misc.c:14-21).
+enum StreamFault : uint32_t {
+  kFaultMuxOverflow = 1,        // header + FIC + sub-channel bytes + trailer exceed 6144 bytes
+  kFaultOutsideCif = 2,         // a sub-channel's transmitted bits end beyond CU 863
+  kFaultEepOption = 4,          // EEP option > 1 (protection level index >= 8): not in ETSI EN 300 401, past the reference's table
+};
+inline uint32_t layout_fault(const std::vector<SubChannel>& active, int header_len)
+{
+  uint32_t f = 0;
+  int bytes = header_len + 96;
+  for (const SubChannel& sc : active) {
+    if (sc.slform && sc.protlev >= 8) { f |= kFaultEepOption; continue; }
+    const PuncturePlan pp = puncture_plan(sc);
+    if (sc.start_cu * 64 + pp.coded_bits() > kCifBits) f |= kFaultOutsideCif;
+    bytes += (((pp.trellis_steps() - 6) / 8) + 7) & 0xfff8;          // misc.c:259-260: obytes
+  }
+  if (bytes + 8 > 6144) f |= kFaultMuxOverflow;                       // EOF (4) + TIST (4), misc.c:281-292
+  return f;
+}
+
 class ControlPlane {
  public:
   ControlPlane()
@@ -235,6 +259,8 @@ class ControlPlane {
       hdr_valid_ = false;
       std::vector<SubChannel> active;
       for_each_slot(ens_.present & keep_, [&](int i) { active.push_back(ens_.sub[i]); });
+      layout_fault_ = layout_fault(active, 8 + 4 * static_cast<int>(active.size()) + 4);
+      fault_ |= layout_fault_;
       layouts_.push_back(std::move(active));
     }
 
@@ -244,16 +270,19 @@ class ControlPlane {
       return 0;
     }
     for (int i = 0; i < 4; ++i) {    // emit the oldest CIF, then slide (dab.c:85-95)
-      jobs.emplace(ring_first_++, static_cast<int32_t>(layouts_.size()) - 1, [&](uint8_t* dst) { return frame_header(dst); });
+      // (a multiplex the reference could not assemble inside its arrays: ring and counter move on, no frame is made -- see StreamFault)
+      if (!layout_fault_) jobs.emplace(ring_first_, static_cast<int32_t>(layouts_.size()) - 1, [&](uint8_t* dst) { return frame_header(dst); });
+      ++ring_first_;
       if (++ens_.cif_lo == 250) {
         ens_.cif_lo = 0;
         if (++ens_.cif_hi == 20) ens_.cif_hi = 0;
       }
     }
-    return 4;
+    return layout_fault_ ? 0 : 4;
   }
 
   bool locked() const { return locked_; }
+  uint32_t fault() const { return fault_; }          // StreamFault bits seen so far (sticky)
   const std::vector<std::vector<SubChannel>>& layouts() const { return layouts_; }
   // streaming use: CIF indices are rebased when old TF slots are dropped
   void rebase(int cif_shift) { ring_first_ -= cif_shift; }
@@ -312,6 +341,7 @@ class ControlPlane {
   bool locked_ = false;
   uint64_t keep_ = ~0ull;
   int okcount_ = 0, ncifs_ = 0, ring_first_ = 0;
+  uint32_t fault_ = 0, layout_fault_ = 0;
   std::vector<std::vector<SubChannel>> layouts_;
   bool hdr_valid_ = false;
   int hdr_len_ = 0;

@@ -573,6 +573,7 @@ bool Engine::begin_decode(int nstreams, bool cont)
   nstreams_ = nstreams;
   eti_base_.assign(nstreams, 0);
   eti_count_.assign(nstreams, 0);
+  if (!cont || static_cast<int>(stream_status_.size()) != nstreams) stream_status_.assign(nstreams, 0);
   total_eti_ = 0;
   if (!cont) {
     planes_.resize(nstreams);                  // re-initialised by the control-plane pass itself (planes_fresh_): 0.2 ms that would otherwise delay K1
@@ -1028,6 +1029,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
       job_ptrs[b] = &stream_jobs[b];
       eti_base_[b] = total_eti_;
       eti_count_[b] = static_cast<int64_t>(stream_jobs[b].size());
+      stream_status_[b] = planes[b].fault();
       total_eti_ += eti_count_[b];
     }
     planes_fresh_ = false;
@@ -1084,6 +1086,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
 }
 
 int64_t Engine::eti_count(int stream) const { return (stream >= 0 && stream < nstreams_) ? eti_count_[stream] : -1; }
+uint32_t Engine::stream_status(int stream) const { return (stream >= 0 && stream < static_cast<int>(stream_status_.size())) ? stream_status_[stream] : 0xffffffffu; }
 
 int64_t Engine::eti_read(int stream, uint8_t* dst, int64_t cap_frames)
 {

@@ -179,6 +179,9 @@ class Engine {
   int64_t feed(const uint8_t* const* iq_virtual, const size_t* avail, int nstreams, bool first_segment);
   int64_t stream_need_from(int stream) const;   // oldest stream byte the next segment may still read
   int64_t eti_count(int stream) const;
+  // StreamFault bits (control_plane.hpp) of the stream's multiplex in the last decode / so far in the session: such a stream emits no frames while
+  // its signalled multiplex is one the reference could not assemble inside its own arrays; every other stream of the batch is unaffected
+  uint32_t stream_status(int stream) const;
   int64_t eti_read(int stream, uint8_t* dst, int64_t cap_frames);
   // All frames of the last decode / segment (stream-major, emission order) to host memory on a stream of their own, without waiting: the copy
   // runs beside the NEXT decode's scan and OFDM stage (only its K4, which rewrites the ETI buffer, waits for it).  dst should be page-locked.
@@ -349,6 +352,7 @@ class Engine {
   int max_calls_ = 0, nstreams_ = 0, last_ntf_ = 0;
   float scan_setup_ms_ = 0;
   std::vector<int64_t> eti_base_, eti_count_;
+  std::vector<uint32_t> stream_status_;
   int64_t total_eti_ = 0;
   StageTimes times_;
   int64_t fft_launches_ = 0, fft_tfs_ = 0;

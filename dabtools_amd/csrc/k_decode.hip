@@ -753,7 +753,9 @@ __global__ __launch_bounds__(256, DABHIP_VIT_WAVES) void viterbi_fused_kernel(co
   uint4* my_rec = reinterpret_cast<uint4*>(decisions + grp.dec_base * 64) + lane;
 
   // received words of this lane's record: tile = grp.first / 64 (job lists are padded to tiles of 64)
-  const int word0 = (pl.start_bit * kBits) >> 5;
+  // (a plan whose first word lies outside the row cannot arrive any more: the control plane drops such multiplexes, control_plane.hpp StreamFault;
+  // the clamp keeps even a corrupted plan inside the tile's rows)
+  const int word0 = min((pl.start_bit * kBits) >> 5, row_words - 1);
   const uint32_t* src = grouped + (static_cast<size_t>(grp.first >> 6) * row_words + word0) * 64 + lane;
   const int last_word = row_words - 1 - word0;
   uint64_t fifo = 0;

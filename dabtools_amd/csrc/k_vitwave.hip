@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void viterbi_wave_kernel(const WaveGroup* __re
     }
   }
   // the code word's received values: word w of its row at src[64 w] (rows of 64 records interleaved word by word, regroup_kernel / fic_group_kernel)
-  const int word0 = (pl.start_bit * kBits) >> 5;
+  const int word0 = min((pl.start_bit * kBits) >> 5, row_words - 1);      // (clamped like in the batch form: see there)
   const uint32_t* src = grouped + (static_cast<size_t>(grp.first >> 6) * row_words + word0) * 64 + l;
   const int last_word = row_words - 1 - word0;
 

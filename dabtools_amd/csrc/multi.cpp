@@ -136,6 +136,12 @@ int64_t dabhip_multi_eti_count(const dabhip_multi* m, int stream)
   return s ? dabhip_engine_eti_count(s->eng, stream - s->first) : -1;
 }
 
+uint32_t dabhip_multi_stream_status(const dabhip_multi* m, int stream)
+{
+  const dabhip_multi::Slice* s = m ? m->slice_of(stream) : nullptr;
+  return s ? dabhip_engine_stream_status(s->eng, stream - s->first) : 0xffffffffu;
+}
+
 int64_t dabhip_multi_eti_read(dabhip_multi* m, int stream, uint8_t* dst, int64_t cap_frames)
 {
   if (!m || !dst) { set_error("multi_eti_read: null argument"); return -1; }

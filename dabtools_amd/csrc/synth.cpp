@@ -121,6 +121,10 @@ void build_fibs(const dabhip_synth_cfg& cfg, int cif, uint8_t* out96)
       fib[hdr] = static_cast<uint8_t>(len);   // FIG type 0, length
       fib[hdr + 1] = 0x01;                    // C/N=0 OE=0 P/D=0 extension 1
     }
+    if (f == 2 && cfg.fib_patch_len > 0 && cif >= cfg.fib_patch_from_cif && pos == 0) {      // test vector: this FIB's content verbatim (dabhip.h)
+      pos = std::min(cfg.fib_patch_len, 30);
+      std::memcpy(fib, cfg.fib_patch, static_cast<size_t>(pos));
+    }
     if (pos < 30) fib[pos] = 0xff;            // end marker, rest zero padding
     const uint16_t crc = static_cast<uint16_t>(~crc16_ccitt(fib, 30));
     fib[30] = static_cast<uint8_t>(crc >> 8);

@@ -82,6 +82,9 @@ uint8_t *dabhip_dab_tf_msc(dabhip_dab *d);   /* 221184 bytes */
  * times, synchronously, with a pointer to a 6144-byte frame valid during the call. */
 int dabhip_dab_process_frame(dabhip_dab *d);
 int dabhip_dab_locked(const dabhip_dab *d);
+/* as dabhip_engine_stream_status for this seam: with a flagged multiplex dabhip_dab_process_frame invokes the callback 0 times where
+ * dab_process_frame (dab.c:85-95 -> misc.c:218-314) would run off its arrays */
+uint32_t dabhip_dab_status(const dabhip_dab *d);
 /* Soft-decision extension of this seam (not in the reference: dab.h:27-33 carries 0/1 bytes): after dabhip_dab_set_soft(d, 1) --
  * before the first frame only -- the two arrays carry signed 4-bit values as int8 (-7 .. 7; > 0: the hard bit would be 0; the
  * demapper's rule is dabhip_engine_set_soft's) and the FIC / MSC decoders use them as branch metrics.  Lets a test feed the
@@ -105,6 +108,16 @@ void dabhip_engine_destroy(dabhip_engine *e);
 int64_t dabhip_engine_decode(dabhip_engine *e, const uint8_t *const *iq, const size_t *nbytes, int nstreams,
                              int on_device);
 int64_t dabhip_engine_eti_count(const dabhip_engine *e, int stream);      /* frames of one stream */
+/* Per-stream status of the last decode (fault isolation).  The FIC carries a 16-bit CRC and fib_parse (fic.c:47-130) validates nothing: a corrupted
+ * FIB that passes the CRC can signal a multiplex the reference cannot assemble inside its own arrays -- create_eti then writes past eti[6144]
+ * (misc.c:233,246-296), uep_/eep_depuncture read past cif_time_deinterleaved[55296] (depuncture.c:84-132), eeptable[] is indexed past its 8 rows
+ * (fic.c:84): undefined behaviour, no parity target.  Here such a stream is flagged and emits NO frames while its multiplex is in that state (for
+ * good: the reference only ever adds sub-channels, misc.c:14-21); lock rule, CIF ring and frame counter move on as they would; every other stream
+ * of the batch decodes exactly as if it were alone.  0 = fine; 0xffffffff = no such stream. */
+#define DABHIP_STREAM_MUX_OVERFLOW 1u       /* header + FIC + sub-channel bytes + trailer exceed 6144 bytes */
+#define DABHIP_STREAM_SUBCH_OUTSIDE_CIF 2u  /* a sub-channel's transmitted bits end beyond capacity unit 863 */
+#define DABHIP_STREAM_EEP_OPTION 4u         /* EEP protection option > 1: outside ETSI EN 300 401 and past the reference's table */
+uint32_t dabhip_engine_stream_status(const dabhip_engine *e, int stream);
 /* Copy the ETI frames of one stream (in emission order) to host memory. */
 int64_t dabhip_engine_eti_read(dabhip_engine *e, int stream, uint8_t *dst, int64_t cap_frames);
 /* Deliver all frames, stream by stream in emission order, to a sink (stdout contract helper). */
@@ -176,6 +189,7 @@ int dabhip_multi_slices(const dabhip_multi *m);
 int dabhip_multi_slice_of(const dabhip_multi *m, int stream, int *device);
 int64_t dabhip_multi_decode(dabhip_multi *m, const uint8_t *const *iq, const size_t *nbytes, int nstreams, int on_device);
 int64_t dabhip_multi_eti_count(const dabhip_multi *m, int stream);
+uint32_t dabhip_multi_stream_status(const dabhip_multi *m, int stream);   /* as dabhip_engine_stream_status, global stream index */
 int64_t dabhip_multi_eti_read(dabhip_multi *m, int stream, uint8_t *dst, int64_t cap_frames);
 int64_t dabhip_multi_eti_drain(dabhip_multi *m, dabhip_eti_sink sink, void *user);   /* all frames, global stream order */
 int dabhip_multi_trace(const dabhip_multi *m, int stream, int32_t *ints6, double *ffs, int cap_calls);
@@ -209,6 +223,7 @@ int64_t dabhip_stream_feed(dabhip_stream *s, const uint8_t *const *iq, const siz
  * stay untouched until the feed that consumes them has returned.  Returns 0, <0 on error. */
 int dabhip_stream_prefetch(dabhip_stream *s, const uint8_t *const *iq, const size_t *nbytes, int on_device);
 int64_t dabhip_stream_eti_count(const dabhip_stream *s, int stream);
+uint32_t dabhip_stream_status(const dabhip_stream *s, int stream);        /* as dabhip_engine_stream_status, sticky over the session's segments */
 int64_t dabhip_stream_eti_read(dabhip_stream *s, int stream, uint8_t *dst, int64_t cap_frames);
 int64_t dabhip_stream_eti_drain(dabhip_stream *s, dabhip_eti_sink sink, void *user);
 /* as dabhip_engine_eti_fetch / _wait, for the frames of the segment fed last: its download overlaps the next segment's upload and decode */
@@ -332,6 +347,12 @@ typedef struct dabhip_synth_cfg {
   double amplitude;       /* LSB per unit carrier of the unnormalised IDFT (1.0 -> ~28 LSB rms per rail) */
   double snr_db;          /* signal/noise power over the 2.048 MHz band; >= 100 -> no noise */
   double cfo_hz;          /* carrier frequency offset applied to the whole capture (0 = none) */
+  /* Test vectors for FIC content the presets do not produce (non-standard or hostile FIGs): when fib_patch_len > 0, the THIRD FIB of every CIF
+   * from fib_patch_from_cif on carries these bytes (FIGs, then end marker / padding) under a VALID CRC -- what a corrupted FIB that passes the
+   * 16-bit CRC looks like to fib_parse (fic.c:47-130).  The MSC content is unaffected.  0-initialised = off. */
+  int32_t fib_patch_len;  /* 0..30 */
+  int32_t fib_patch_from_cif;
+  uint8_t fib_patch[32];
 } dabhip_synth_cfg;
 
 /* preset 0: 12 sub-channels, 1136 kbit/s, 862 CU (the benchmark mix); 1: 4 light sub-channels. */

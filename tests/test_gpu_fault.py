@@ -1,0 +1,210 @@
+"""Fault isolation and hostile FIC content.
+
+The FIC is protected by a 16-bit CRC and fib_parse (fic.c:47-130) validates nothing, so a corrupted FIB that passes the CRC can signal a
+multiplex create_eti (misc.c:218-314) cannot assemble inside its arrays: eti[6144] overrun (misc.c:233,246-296), reads past
+cif_time_deinterleaved[55296] (depuncture.c:84-132), eeptable[] indexed past its rows (fic.c:84).  The reference is undefined there -- no parity
+target -- but in a batch one such ensemble must not take the others down:
+
+  * one poisoned stream in a batch of 32: the decode succeeds, that stream is flagged and stops emitting, the other 31 streams' bytes are those
+    of the same batch without the poison;
+  * CRC-valid RANDOM FIBs through the S3 seam: never a fault; equal to the REAL reference (oracle/_ref) wherever the signalled multiplex keeps
+    the reference inside its arrays (overlapping sub-channels, unknown FIG types, lengths running past the FIB, ... included), flagged and silent
+    where it does not.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import dabtools_amd as dab
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+FIG01 = lambda entries: bytes([len(entries) + 1, 0x01]) + bytes(entries)        # type 0, extension 1
+UEP = lambda sid, cu, idx: [(sid << 2) | (cu >> 8), cu & 0xff, idx & 0x3f]
+EEP = lambda sid, cu, protlev, size: [(sid << 2) | (cu >> 8), cu & 0xff, 0x80 | ((protlev >> 2) << 4) | ((protlev & 3) << 2) | (size >> 8), size & 0xff]
+
+POISONS = {
+    "outside_cif": (FIG01(UEP(40, 1000, 63)), dab.STREAM_SUBCH_OUTSIDE_CIF),                               # 384 kbit/s from CU 1000: past CU 863
+    "mux_overflow": (FIG01(sum((UEP(50 + k, 0, 63) for k in range(9)), [])), dab.STREAM_MUX_OVERFLOW),     # + 9 x 1152 bytes: past eti[6144]
+    "eep_option": (FIG01(EEP(41, 400, 9, 24)), dab.STREAM_EEP_OPTION),                                     # option 2: eeptable[9]
+}
+
+
+@pytest.mark.parametrize("kind", sorted(POISONS))
+def test_one_poisoned_stream_does_not_touch_the_other_31(kind):
+    patch, flag = POISONS[kind]
+    ntf, nstreams, victim = 22, 32, 13
+    cfgs = [dab.synth_preset(1, seed=8000 + i, cif_count0=111 * i, skip_samples=(0, 60001)[i % 2]) for i in range(nstreams)]
+    clean = [dab.synth_generate(c, ntf) for c in cfgs]
+    bad_cfg = dab.synth_preset(1, seed=8000 + victim, cif_count0=111 * victim, skip_samples=(0, 60001)[victim % 2])
+    bad_cfg.set_fib_patch(patch, from_cif=4 * 17)            # the multiplex turns un-assemblable at TF 17, after the first frames have left
+    poisoned = list(clean)
+    poisoned[victim] = dab.synth_generate(bad_cfg, ntf)
+    eng = dab.Engine(0)
+    total_clean = eng.decode(clean)
+    want = [eng.eti(b) for b in range(nstreams)]
+    assert all(eng.stream_status(b) == 0 for b in range(nstreams))
+    total = eng.decode(poisoned)                             # does NOT fail
+    got = [eng.eti(b) for b in range(nstreams)]
+    for b in range(nstreams):
+        if b == victim:
+            assert eng.stream_status(b) == flag
+            assert 0 < got[b].shape[0] < want[b].shape[0]                     # frames until the poison took effect, none after
+            assert np.array_equal(got[b], want[b][:got[b].shape[0]])
+        else:
+            assert eng.stream_status(b) == 0
+            assert np.array_equal(got[b], want[b]), "stream %d changed because stream %d was poisoned" % (b, victim)
+    assert total == total_clean - (want[victim].shape[0] - got[victim].shape[0])
+    # the same through a session: the flag is sticky, the others keep decoding
+    st = dab.Stream(3, device=0)
+    seg = 8 * dab.TF_BYTES
+    trio = [clean[0], poisoned[victim], clean[2]]
+    frames = [[], [], []]
+    for a in range(0, max(t.size for t in trio), seg):
+        st.feed([t[a:a + seg] for t in trio])
+        for b in range(3):
+            frames[b].append(st.eti(b))
+    assert st.status(0) == 0 and st.status(1) == flag and st.status(2) == 0
+    assert np.array_equal(np.concatenate(frames[0]), want[0]) and np.array_equal(np.concatenate(frames[2]), want[2])
+    assert np.array_equal(np.concatenate(frames[1]), got[victim])
+    st.close()
+    eng.close()
+
+
+def _coded_bits(uep, slform, idx_or_lev, size):
+    """Transmitted bits a sub-channel takes from the CIF (depuncture.c:84-132), and its bytes in the ETI frame (misc.c:259-260)."""
+    if not slform:
+        row = uep[idx_or_lev]
+        blocks, pis = list(row[3:7]), list(row[7:11])
+    else:
+        mult = [12, 8, 6, 4, 27, 21, 18, 15][idx_or_lev & 7]
+        e = [(6, -3, 0, 3, 24, 23), (2, -3, 4, 3, 14, 13), (6, -3, 0, 3, 8, 7), (4, -3, 2, 3, 3, 2),
+             (24, -3, 0, 3, 10, 9), (24, -3, 0, 3, 6, 5), (24, -3, 0, 3, 4, 3), (24, -3, 0, 3, 2, 1)][idx_or_lev & 7]
+        n = size // mult
+        bitrate = n * (32 if idx_or_lev & 4 else 8)
+        if bitrate == 8 and idx_or_lev == 1:
+            blocks, pis = [5, 1, 0, 0], [4, 13, 1, 1]
+        else:
+            blocks, pis = [max(e[0] * n + e[1], 0), max(e[2] * n + e[3], 0), 0, 0], [e[4], e[5], 1, 1]
+    coded = 12 + sum(b * 4 * (8 + (p if p else 1)) for b, p in zip(blocks, pis))
+    bits = 32 * sum(blocks)
+    return coded, ((bits // 8) + 7) & 0xfff8
+
+
+def _multiplex_fits(sub_rows, uep):
+    """True when create_eti stays inside its arrays for this merged sub-channel table (the rule of control_plane.hpp: layout_fault)."""
+    active = [r for r in sub_rows if r[0] >= 0]
+    total = 8 + 4 * len(active) + 4 + 96 + 8
+    for (sid, slform, uidx, start, size, bitrate, protlev, ascty) in active:
+        if slform and protlev >= 8:
+            return False
+        coded, obytes = _coded_bits(uep, slform, uidx if not slform else protlev, size)
+        if start * 64 + coded > 55296:
+            return False
+        total += obytes
+    return total <= 6144
+
+
+def _random_fib(rng, uep, hostile, overrun_ok=True):
+    """30 bytes of FIGs: sub-channel entries that fit (or, hostile, anything), FIG 0/2 entries, unknown types, lengths past the end."""
+    out = []
+    while len(out) < 24:
+        kind = rng.integers(0, 10)
+        if kind == 9 and not overrun_ok:
+            kind = 8
+        if kind < 3:                                         # FIG 0/1 with 1..2 entries
+            ents = []
+            for _ in range(int(rng.integers(1, 3))):
+                sid = int(rng.integers(0, 64))
+                if rng.integers(0, 2):
+                    idx = int(rng.integers(0, 64 if hostile else 40))
+                    size = int(uep[idx][1])
+                    cu = int(rng.integers(0, 1024)) if hostile else int(rng.integers(0, 865 - size))
+                    ents += UEP(sid, cu, idx)
+                else:
+                    lev = int(rng.integers(0, 32 if hostile else 8))
+                    mult = [12, 8, 6, 4, 27, 21, 18, 15][lev & 7]
+                    size = int(rng.integers(0, 1024)) if hostile else mult * int(rng.integers(1, 4))
+                    cu = int(rng.integers(0, 1024)) if hostile else int(rng.integers(0, 865 - size))
+                    ents += EEP(sid, cu, lev, size)
+            out += list(FIG01(ents))
+        elif kind < 6:                                       # FIG 0/2: service with 1..2 components (audio, ASCTy)
+            ncomp = int(rng.integers(1, 3))
+            body = [int(rng.integers(0, 256)), int(rng.integers(0, 256)), ncomp]
+            for _ in range(ncomp):
+                body += [int(rng.integers(0, 64)), int(rng.integers(0, 256)) & 0xfc | 2]
+            out += [len(body) + 1, 0x02] + body
+        elif kind == 8:                                      # a FIG type the parser skips (1..7), honest length
+            n = int(rng.integers(1, 8))
+            out += [(int(rng.integers(1, 8)) << 5) | n] + [int(x) for x in rng.integers(0, 256, n)]
+        else:                                                # a FIG 0/x with a length that runs past the end of the FIB
+            out += [31, int(rng.integers(3, 32))] + [int(x) for x in rng.integers(0, 256, 4)]
+    return bytes(out[:30])
+
+
+def test_crc_valid_random_fibs_through_the_s3_seam():
+    R = ol.ref()
+    O = ol.oracle()
+    uep = dab.host_table(0)
+    dep = np.zeros(3096, np.uint8)
+    O.or_fic_depuncture(ol._ptr(dep), ol._ptr(np.zeros(2304, np.uint8)))
+    keep = dep != 128
+    rng = np.random.default_rng(77)
+    compared = flagged = 0
+    for trial in range(28):
+        hostile = trial % 4 == 3
+        # the 12 FIBs of a TF: FIB 0 of every CIF = FIG 0/0 (+ random FIGs behind it), the others random; the same content every TF but the counter
+        # (no over-long FIG in the last FIB: fic.c:47-130 would read on past struct tf_fibs_t into whatever follows it in memory)
+        tails = [_random_fib(rng, uep, hostile, overrun_ok=k < 11) for k in range(12)]
+
+        def tf_fibs(t):
+            fibs = np.zeros((12, 32), np.uint8)
+            for q in range(4):
+                count = (3000 + 4 * t + q) % 5000
+                fig00 = bytes([0x05, 0x00, 0xC1, 0x81, count // 250, count % 250])
+                for f in range(3):
+                    body = (fig00 + tails[3 * q + f][:24]) if f == 0 else tails[3 * q + f]
+                    # cut at a FIG boundary is not required: the parser must cope with whatever follows
+                    fib = np.frombuffer(body[:30].ljust(30, b"\xff" if len(body) < 30 else b"\x00"), np.uint8).copy()
+                    crc = (~O.or_crc16_ccitt(ol._ptr(fib), 30, 0xffff)) & 0xffff
+                    fibs[3 * q + f, :30] = fib
+                    fibs[3 * q + f, 30], fibs[3 * q + f, 31] = crc >> 8, crc & 0xff
+            return fibs
+
+        hdr, sub = dab.host_parse_fibs(tf_fibs(0), np.ones(12, np.uint8))
+        fits = _multiplex_fits([tuple(int(v) for v in r) for r in sub], uep)
+        d = dab.Dab(0)
+        H = R.refh_new() if (R is not None and fits) else None
+        for t in range(16):
+            fibs = tf_fibs(t)
+            fic = np.zeros(9216, np.uint8)
+            for q in range(4):
+                blk = fibs[3 * q:3 * q + 3].reshape(96).copy()
+                O.or_descramble(ol._ptr(blk), 96)
+                fic[2304 * q:2304 * (q + 1)] = ol.or_encode(blk)[keep]
+            msc = rng.integers(0, 2, 221184, dtype=np.uint8)
+            d.fic[:] = fic
+            d.msc[:] = msc
+            d.process_frame()                                # never raises, whatever the FIBs say
+            if H is not None:
+                C.memmove(R.refh_tf_fic(H), ol._ptr(fic), fic.size)
+                C.memmove(R.refh_tf_msc(H), ol._ptr(msc), msc.size)
+                R.refh_process(H)
+        got = np.array(d.frames).reshape(-1, 6144)
+        if fits:
+            assert d.status == 0, trial
+            assert got.shape[0] == 12, (trial, got.shape)
+            if H is not None:
+                n = R.refh_neti(H)
+                want = np.ctypeslib.as_array(R.refh_eti(H), (n, 6144))
+                assert n == 12 and np.array_equal(got, want), "trial %d: differs from the real reference on a multiplex it can assemble" % trial
+                compared += 1
+        else:
+            assert d.status != 0 and got.shape[0] == 0, (trial, d.status, got.shape)
+            flagged += 1
+        d.close()
+    assert flagged >= 3 and (R is None or compared >= 12), (flagged, compared)
+    if R is None:
+        pytest.skip("no comparison with the real reference: oracle/_ref not built on this box")
