@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DABHIP_LIB") or os.path.join(_HERE, "libdabhip.so")   # override: experiments with another build
 
-STREAM_MUX_OVERFLOW, STREAM_SUBCH_OUTSIDE_CIF, STREAM_EEP_OPTION = 1, 2, 4
+STREAM_MUX_OVERFLOW, STREAM_SUBCH_OUTSIDE_CIF, STREAM_EEP_OPTION, STREAM_SUBCH_SIZE = 1, 2, 4, 8
 TF_BYTES = 393216
 CHUNK_BYTES = 262144
 FIC_BITS = 9216

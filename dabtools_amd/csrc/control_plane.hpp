@@ -199,6 +199,8 @@ enum StreamFault : uint32_t {
   kFaultMuxOverflow = 1,        // header + FIC + sub-channel bytes + trailer exceed 6144 bytes
   kFaultOutsideCif = 2,         // a sub-channel's transmitted bits end beyond CU 863
   kFaultEepOption = 4,          // EEP option > 1 (protection level index >= 8): not in ETSI EN 300 401, past the reference's table
+  kFaultSubchSize = 8,          // EEP size below one unit of its protection level (bit rate 0): the reference's frame then carries uninitialised stack
+                                // bytes -- viterbi() clears (bits + 7) / 8 bytes, dab_descramble_bytes runs over obytes = 16 of them (misc.c:259-264)
 };
 inline uint32_t layout_fault(const std::vector<SubChannel>& active, int header_len)
 {
@@ -206,6 +208,7 @@ inline uint32_t layout_fault(const std::vector<SubChannel>& active, int header_l
   int bytes = header_len + 96;
   for (const SubChannel& sc : active) {
     if (sc.slform && sc.protlev >= 8) { f |= kFaultEepOption; continue; }
+    if (sc.slform && sc.bitrate <= 0) { f |= kFaultSubchSize; continue; }
     const PuncturePlan pp = puncture_plan(sc);
     if (sc.start_cu * 64 + pp.coded_bits() > kCifBits) f |= kFaultOutsideCif;
     bytes += (((pp.trellis_steps() - 6) / 8) + 7) & 0xfff8;          // misc.c:259-260: obytes

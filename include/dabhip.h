@@ -117,6 +117,7 @@ int64_t dabhip_engine_eti_count(const dabhip_engine *e, int stream);      /* fra
 #define DABHIP_STREAM_MUX_OVERFLOW 1u       /* header + FIC + sub-channel bytes + trailer exceed 6144 bytes */
 #define DABHIP_STREAM_SUBCH_OUTSIDE_CIF 2u  /* a sub-channel's transmitted bits end beyond capacity unit 863 */
 #define DABHIP_STREAM_EEP_OPTION 4u         /* EEP protection option > 1: outside ETSI EN 300 401 and past the reference's table */
+#define DABHIP_STREAM_SUBCH_SIZE 8u         /* EEP size below one unit of its level (bit rate 0): the reference's frame carries uninitialised stack bytes there */
 uint32_t dabhip_engine_stream_status(const dabhip_engine *e, int stream);
 /* Copy the ETI frames of one stream (in emission order) to host memory. */
 int64_t dabhip_engine_eti_read(dabhip_engine *e, int stream, uint8_t *dst, int64_t cap_frames);

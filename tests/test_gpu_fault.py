@@ -98,7 +98,7 @@ def _multiplex_fits(sub_rows, uep):
     active = [r for r in sub_rows if r[0] >= 0]
     total = 8 + 4 * len(active) + 4 + 96 + 8
     for (sid, slform, uidx, start, size, bitrate, protlev, ascty) in active:
-        if slform and protlev >= 8:
+        if slform and (protlev >= 8 or bitrate <= 0):
             return False
         coded, obytes = _coded_bits(uep, slform, uidx if not slform else protlev, size)
         if start * 64 + coded > 55296:
@@ -173,8 +173,15 @@ def test_crc_valid_random_fibs_through_the_s3_seam():
                     fibs[3 * q + f, 30], fibs[3 * q + f, 31] = crc >> 8, crc & 0xff
             return fibs
 
-        hdr, sub = dab.host_parse_fibs(tf_fibs(0), np.ones(12, np.uint8))
-        fits = _multiplex_fits([tuple(int(v) for v in r) for r in sub], uep)
+        # the ensemble only ever grows (misc.c:14-21), and a FIG that runs over its FIB's CRC bytes reads something else every TF: the
+        # multiplex has to fit after EVERY frame for the reference to be run at all
+        merged, fits = {}, True
+        for t in range(16):
+            _, sub = dab.host_parse_fibs(tf_fibs(t), np.ones(12, np.uint8))
+            for r in sub:
+                if r[0] >= 0:
+                    merged[int(r[0])] = tuple(int(v) for v in r)
+            fits = fits and _multiplex_fits(list(merged.values()), uep)
         d = dab.Dab(0)
         H = R.refh_new() if (R is not None and fits) else None
         for t in range(16):
@@ -202,7 +209,7 @@ def test_crc_valid_random_fibs_through_the_s3_seam():
                 assert n == 12 and np.array_equal(got, want), "trial %d: differs from the real reference on a multiplex it can assemble" % trial
                 compared += 1
         else:
-            assert d.status != 0 and got.shape[0] == 0, (trial, d.status, got.shape)
+            assert d.status != 0 and got.shape[0] < 12, (trial, d.status, got.shape)
             flagged += 1
         d.close()
     assert flagged >= 3 and (R is None or compared >= 12), (flagged, compared)

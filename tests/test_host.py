@@ -299,3 +299,25 @@ def test_integration_shims_are_built_against_the_reference_callers():
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         for name in set(re.findall(r"\b(dabhip_[a-z0-9_]+)\s*\(", src)):
             assert name in declared, (f, name)
+
+
+def test_control_plane_silences_a_multiplex_the_reference_cannot_assemble():
+    """Fault isolation on the host (no GPU): CRC-valid FIBs that signal a sub-channel past the CIF / a frame past 6144 bytes / a non-standard EEP
+    option -- where misc.c:233,246-296, depuncture.c:84-132 and fic.c:84 run off their arrays -- make the control plane stop emitting frames for
+    that ensemble (ring and counter move on) instead of handing the decoders an impossible plan."""
+    uep = lambda sid, cu, idx: [(sid << 2) | (cu >> 8), cu & 0xff, idx & 0x3f]
+    eep = lambda sid, cu, lev, size: [(sid << 2) | (cu >> 8), cu & 0xff, 0x80 | ((lev >> 2) << 4) | ((lev & 3) << 2) | (size >> 8), size & 0xff]
+    fig01 = lambda e: bytes([len(e) + 1, 0x01]) + bytes(e)
+    cases = {"clean": None, "outside": fig01(uep(40, 1000, 63)), "overflow": fig01(sum((uep(50 + k, 0, 63) for k in range(9)), [])),
+             "option": fig01(eep(41, 400, 9, 24)), "size0": fig01(eep(42, 300, 5, 13)), "overlap_but_fine": fig01(uep(33, 0, 35))}
+    counts = {}
+    for name, patch in cases.items():
+        cfg = dab.synth_preset(1, seed=5, cif_count0=100)
+        if patch:
+            cfg.set_fib_patch(patch, from_cif=4 * 16)
+        fibs = np.array([[dab.synth_fibs(cfg, 4 * t + q) for q in range(4)] for t in range(24)], dtype=np.uint8).reshape(24, 384)
+        first, hdrs = dab.host_control_replay(fibs, np.ones((24, 12), np.uint8))
+        counts[name] = len(first)
+    assert counts["clean"] == 4 * (24 - 13) and counts["overlap_but_fine"] == counts["clean"]
+    for name in ("outside", "overflow", "option", "size0"):
+        assert counts[name] == 4 * (16 - 13), (name, counts)      # the frames before the poisoned FIBs arrived, none after
