@@ -141,6 +141,11 @@ _SIGNATURES = {
     "dabhip_host_free": (None, [C.c_void_p]),
     "dabhip_synth_generate_device": (C.c_int, [C.POINTER(SynthCfg), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int]),
     "dabhip_dab_set_soft": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_multi_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dabhip_multi_slice_cpus": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int)]),
+    "dabhip_engine_create_on_cpus": (C.c_void_p, [C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int]),
+    "dabhip_engine_host_cpus": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int)]),
+    "dabhip_host_placement_plan": (C.c_int, [C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_int32), C.c_int]),
     "dabhip_engine_stream_status": (C.c_uint32, [C.c_void_p, C.c_int]),
     "dabhip_multi_stream_status": (C.c_uint32, [C.c_void_p, C.c_int]),
     "dabhip_stream_status": (C.c_uint32, [C.c_void_p, C.c_int]),
@@ -332,6 +337,16 @@ def host_control_replay(fibs, crc_ok):
                                          hlen.ctypes.data_as(C.POINTER(C.c_int32)), cap)
     _need(n >= 0, "host_control_replay")
     return first[:n], [hdrs[i, :hlen[i]].copy() for i in range(n)]
+
+
+def host_placement_plan(slice_node, node_cpulist, ncpu):
+    """dabhip_host_placement_plan: cpu_slice[c] = slice CPU c is given to (-1: none), for slices on NUMA nodes slice_node[i]."""
+    nodes = (C.c_int32 * len(slice_node))(*slice_node)
+    lists = (C.c_char_p * len(node_cpulist))(*[s.encode() for s in node_cpulist])
+    out = (C.c_int32 * ncpu)()
+    n = lib().dabhip_host_placement_plan(nodes, len(slice_node), lists, len(node_cpulist), out, ncpu)
+    _need(n >= 0, "host_placement_plan")
+    return n, list(out)
 
 
 def host_table(which):
@@ -718,6 +733,19 @@ class Multi:
         _need(n >= 0, "multi_decode")
         self.nstreams = len(ptrs)
         return n
+
+    def plan(self, nstreams, stream):
+        """(slice, device) that will decode `stream` of a batch of `nstreams` (dabhip_multi_plan: the dealing rule, before any decode)."""
+        sl, dev = C.c_int(-1), C.c_int(-1)
+        _need(lib().dabhip_multi_plan(self._h, nstreams, stream, C.byref(sl), C.byref(dev)) == 0, "multi_plan")
+        return sl.value, dev.value
+
+    def slice_cpus(self, slice_index):
+        """(cpus, numa_node) the host threads of a slice are bound to ([] = unbound)."""
+        buf, node = (C.c_int32 * 4096)(), C.c_int(-1)
+        n = lib().dabhip_multi_slice_cpus(self._h, slice_index, buf, 4096, C.byref(node))
+        _need(n >= 0, "multi_slice_cpus")
+        return list(buf[:n]), node.value
 
     def slice_of(self, stream):
         """(slice, device) of a stream in a decode of the last decode's size."""

@@ -15,6 +15,7 @@
 #include "engine.hpp"
 #include "fifo_view.hpp"
 #include "kernels.hpp"
+#include "placement.hpp"
 
 using namespace dabhip;
 
@@ -30,12 +31,12 @@ struct dabhip_engine {
   float wall_ms = 0;
   int device = 0;
 
-  explicit dabhip_engine(int dev, int host_threads = 0) : device(dev)
+  explicit dabhip_engine(int dev, int host_threads = 0, const std::vector<int>& cpus = {}) : device(dev)
   {
     int nl = 1;   // measured on MI355X: splitting the batch costs more (two shorter Viterbi launches, two scans) than the overlap wins
     if (const char* env = std::getenv("DABHIP_LANES")) nl = std::max(1, std::min(4, std::atoi(env)));
     for (int l = 0; l < nl; ++l) {
-      lanes.emplace_back(new Engine(dev, host_threads));
+      lanes.emplace_back(new Engine(dev, host_threads, cpus));
       if (!lanes.back()->ok()) break;
     }
     for (auto& l : lanes) l->set_heavy_lock(lanes.size() > 1 ? &heavy : nullptr);
@@ -113,6 +114,39 @@ dabhip_engine* dabhip_engine_create_ex(int device, int host_threads)
   dabhip_engine* e = new (std::nothrow) dabhip_engine(device, host_threads);
   if (e && !e->ok()) { delete e; return nullptr; }
   return e;
+}
+dabhip_engine* dabhip_engine_create_on_cpus(int device, int host_threads, const int32_t* cpus, int ncpus)
+{
+  std::vector<int> list;
+  for (int i = 0; cpus && i < ncpus; ++i) list.push_back(cpus[i]);
+  dabhip_engine* e = new (std::nothrow) dabhip_engine(device, host_threads, list);
+  if (!e) return nullptr;
+  if (!e->ok()) { delete e; return nullptr; }
+  return e;
+}
+int dabhip_engine_host_cpus(const dabhip_engine* e, int32_t* cpus, int cap, int* numa_node)
+{
+  if (!e || e->lanes.empty()) return -1;
+  const std::vector<int>& c = e->lanes[0]->host_cpus();
+  if (numa_node) *numa_node = e->lanes[0]->numa_node();
+  for (int i = 0; cpus && i < cap && i < static_cast<int>(c.size()); ++i) cpus[i] = c[static_cast<size_t>(i)];
+  return static_cast<int>(c.size());
+}
+int dabhip_host_placement_plan(const int32_t* slice_node, int nslices, const char* const* node_cpulist, int nnodes, int32_t* cpu_slice, int ncpu)
+{
+  if (!slice_node || !node_cpulist || !cpu_slice || nslices <= 0 || nnodes <= 0 || ncpu <= 0) { set_error("placement_plan: bad argument"); return -1; }
+  std::vector<int> nodes(slice_node, slice_node + nslices);
+  std::vector<std::vector<int>> node_cpus;
+  for (int n = 0; n < nnodes; ++n) node_cpus.push_back(dabhip::parse_cpulist(node_cpulist[n] ? node_cpulist[n] : ""));
+  const std::vector<std::vector<int>> plan = dabhip::plan_placement(nodes, node_cpus);
+  for (int c = 0; c < ncpu; ++c) cpu_slice[c] = -1;
+  int bound = 0;
+  for (int i = 0; i < nslices; ++i) {
+    bound += plan[static_cast<size_t>(i)].empty() ? 0 : 1;
+    for (int c : plan[static_cast<size_t>(i)])
+      if (c >= 0 && c < ncpu) cpu_slice[c] = i;       // (fewer CPUs than slices on a node: the later slice is the one recorded)
+  }
+  return bound;
 }
 void dabhip_engine_destroy(dabhip_engine* e) { delete e; }
 
@@ -658,6 +692,9 @@ struct dabhip_stream {
   std::vector<int64_t> base, avail;            // per stream: first stream byte still held, bytes received (fed) so far
   std::vector<size_t> org;                     // per stream: offset, in the newest fed window, of stream byte base[b]
   uint64_t fed = 0, queued = 0;                // segments fed / handed over (fed <= queued <= fed + 2)
+  // A feed that fails after it has started to move the session on (windows, offsets, the engine's carried state) leaves a session nobody can
+  // re-feed correctly: it is marked and refuses everything but its destruction -- an honest error instead of frames decoded at the wrong offsets.
+  bool failed = false;
   // prefetch uploads run on a stream of their own.  Measured on the 256-stream workload, 8-TF segments (805 MB each): one gather kernel
   // per segment 56.5 GB/s, 256 copy commands on one stream 54.0, dealt to two / four streams 25 / 36 (they get in each other's way)
   static constexpr int kUpStreams = 1;
@@ -767,6 +804,7 @@ extern "C" int dabhip_stream_set_soft(dabhip_stream* s, int on)
 extern "C" int dabhip_stream_prefetch(dabhip_stream* s, const uint8_t* const* iq, const size_t* nbytes, int on_device)
 {
   if (!s || !iq || !nbytes) { set_error("stream_prefetch: null argument"); return -1; }
+  if (s->failed) { set_error("stream_prefetch: an earlier feed of this session failed half-way -- destroy the session"); return -1; }
   if (s->queued - s->fed >= 2) { set_error("stream_prefetch: two segments are already waiting to be fed"); return -1; }
   if (hipSetDevice(s->eng.device()) != hipSuccess) { set_error("stream_prefetch: hipSetDevice failed"); return -1; }
   const int w = static_cast<int>(s->queued % 3);
@@ -782,7 +820,13 @@ extern "C" int dabhip_stream_prefetch(dabhip_stream* s, const uint8_t* const* iq
 extern "C" int64_t dabhip_stream_feed(dabhip_stream* s, const uint8_t* const* iq, const size_t* nbytes, int on_device)
 {
   if (!s || !iq || !nbytes) { set_error("stream_feed: null argument"); return -1; }
+  if (s->failed) { set_error("stream_feed: an earlier feed of this session failed half-way; its state is not trustworthy any more -- destroy the session"); return -1; }
   if (hipSetDevice(s->eng.device()) != hipSuccess) { set_error("stream_feed: hipSetDevice failed"); return -1; }
+  auto broken = [s](const char* msg) -> int64_t {          // from here on an error leaves the session's books half-updated
+    s->failed = true;
+    if (msg) set_error(msg);
+    return -1;
+  };
   const int w = static_cast<int>(s->fed % 3), wprev = static_cast<int>((s->fed + 2) % 3);
   hipStream_t st = s->eng.stream();
   if (s->queued > s->fed) {                    // this segment was prefetched: it must be the one handed over first
@@ -792,7 +836,7 @@ extern "C" int64_t dabhip_stream_feed(dabhip_stream* s, const uint8_t* const* iq
     for (int i = 0; i < dabhip_stream::kUpStreams; ++i)
       if (hipStreamWaitEvent(st, s->up_done[w][i], 0) != hipSuccess) { set_error("stream_feed: event wait failed"); return -1; }
   } else {
-    if (!s->upload(w, iq, nbytes, on_device != 0, st)) return -1;
+    if (!s->upload(w, iq, nbytes, on_device != 0, st)) return broken(nullptr);
     ++s->queued;
   }
   std::vector<const uint8_t*> virt(s->n);
@@ -806,18 +850,16 @@ extern "C" int64_t dabhip_stream_feed(dabhip_stream* s, const uint8_t* const* iq
     if (kept > kWindowReserve) {
       // more history than the reserve holds (not seen in practice): move the segment into a larger window
       std::unique_ptr<DeviceBuffer<uint8_t>> big(new DeviceBuffer<uint8_t>());
-      if (!big->reserve(kept + std::max<size_t>(nbytes[b], 16))) return -1;
-      if (nbytes[b] && hipMemcpyAsync(big->get() + kept, to->get() + kWindowReserve, nbytes[b], hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("stream_feed: window move failed"); return -1; }
-      if (hipStreamSynchronize(st) != hipSuccess) { set_error("stream_feed: window move failed"); return -1; }
+      if (!big->reserve(kept + std::max<size_t>(nbytes[b], 16))) return broken(nullptr);
+      if (nbytes[b] && hipMemcpyAsync(big->get() + kept, to->get() + kWindowReserve, nbytes[b], hipMemcpyDeviceToDevice, st) != hipSuccess) return broken("stream_feed: window move failed");
+      if (hipStreamSynchronize(st) != hipSuccess) return broken("stream_feed: window move failed");
       s->win[w][b] = std::move(big);
       to = s->win[w][b].get();
       at = kept;
     }
     // stream byte x of the bytes still held lives at from + org + (x - base)
-    if (kept && hipMemcpyAsync(to->get() + at - kept, from.get() + s->org[b] + (need - s->base[b]), kept, hipMemcpyDeviceToDevice, st) != hipSuccess) {
-      set_error("stream_feed: window move failed");
-      return -1;
-    }
+    if (kept && hipMemcpyAsync(to->get() + at - kept, from.get() + s->org[b] + (need - s->base[b]), kept, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return broken("stream_feed: window move failed");
     s->org[b] = at - kept;
     s->base[b] = need;
     s->avail[b] += static_cast<int64_t>(nbytes[b]);
@@ -826,7 +868,8 @@ extern "C" int64_t dabhip_stream_feed(dabhip_stream* s, const uint8_t* const* iq
   }
   ++s->fed;
   const int64_t frames = s->eng.feed(virt.data(), avail.data(), s->n, s->first);
-  if (frames >= 0) s->first = false;
+  if (frames < 0) return broken(nullptr);        // (the engine's error text stands)
+  s->first = false;
   return frames;
 }
 extern "C" int64_t dabhip_stream_eti_count(const dabhip_stream* s, int stream) { return s ? s->eng.eti_count(stream) : -1; }

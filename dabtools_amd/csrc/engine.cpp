@@ -14,6 +14,7 @@
 #include "dab_bits.hpp"
 #include "dab_tables.hpp"
 #include "fifo_view.hpp"
+#include "placement.hpp"
 #include "../../include/dabhip.h"
 #include "kernels.hpp"
 
@@ -61,8 +62,11 @@ bool Engine::check(hipError_t e, const char* what)
   set_error(std::string(what) + ": " + hipGetErrorString(e));
   return false;
 }
+// event records and queries on the decode path: a record that fails would silently corrupt a stage time or -- ev_part0_, ev_chain_ -- an ordering
+bool Engine::record(hipEvent_t e, hipStream_t s) { return check(hipEventRecord(e, s), "hipEventRecord"); }
+bool Engine::elapsed(float* ms, hipEvent_t a, hipEvent_t b) { return check(hipEventElapsedTime(ms, a, b), "hipEventElapsedTime"); }
 
-Engine::Engine(int device, int host_threads) : device_(device)
+Engine::Engine(int device, int host_threads, std::vector<int> cpus) : device_(device), host_cpus_(std::move(cpus))
 {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device: libdabhip has no CPU fallback"); return; }
@@ -142,10 +146,23 @@ Engine::Engine(int device, int host_threads) : device_(device)
   const int hw = static_cast<int>(std::thread::hardware_concurrency());
   int nthreads = host_threads > 0 ? std::min(host_threads, 64) : std::min(hw / 2, 24);
   if (const char* env = std::getenv("DABHIP_HOST_THREADS")) nthreads = std::max(1, std::min(64, std::atoi(env)));
+  // host placement (placement.hpp): the device's NUMA node; without an explicit CPU list the host threads go to that node's CPUs when the machine
+  // has more than one node with CPUs (on a single-socket box there is nothing to choose)
+  {
+    char bdf[32] = {0};
+    if (numa_enabled() && hipDeviceGetPCIBusId(bdf, sizeof bdf, device) == hipSuccess) numa_node_ = numa_node_of_pci(bdf);
+    else (void)hipGetLastError();
+    if (host_cpus_.empty() && numa_enabled() && numa_node_ >= 0) {
+      const std::vector<std::vector<int>> nodes = system_node_cpus();
+      int populated = 0;
+      for (const auto& n : nodes) populated += n.empty() ? 0 : 1;
+      if (populated > 1 && numa_node_ < static_cast<int>(nodes.size())) host_cpus_ = nodes[static_cast<size_t>(numa_node_)];
+    }
+  }
   if (const char* env = std::getenv("DABHIP_VIT_WAVE_MAX")) wave_max_codewords_ = wave_max_fic_blocks_ = std::max(0, std::atoi(env));
   if (const char* env = std::getenv("DABHIP_FIC_WAVE_MAX")) wave_max_fic_blocks_ = std::max(0, std::atoi(env));
-  pool_.reset(new ThreadPool(std::max(0, nthreads - 1)));
-  host_lane_.reset(new AsyncLane());
+  pool_.reset(new ThreadPool(std::max(0, nthreads - 1), host_cpus_));
+  host_lane_.reset(new AsyncLane(host_cpus_));
   ok_ = true;
 }
 
@@ -189,24 +206,24 @@ bool Engine::launch_decode_batch(const DecodeBatch& b, const uint32_t* bits, con
                                  int record_stride)
 {
   if (b.groups.empty()) {                                 // nothing to decode: the three stamps still exist for msc_collect
-    (void)hipEventRecord(ev_msc_[0], stream_);
-    (void)hipEventRecord(ev_msc_[1], stream_);
-    (void)hipEventRecord(ev_msc_[2], stream_);
+    if (!record(ev_msc_[0], stream_)) return false;
+    if (!record(ev_msc_[1], stream_)) return false;
+    if (!record(ev_msc_[2], stream_)) return false;
     return true;
   }
   const int* ids = d_job_ids_.get();
   const int row_words = kCifWords * (soft_bits_ ? 4 : 1);
   const int ntiles = static_cast<int>(b.job_ids.size() / 64);
-  (void)hipEventRecord(ev_msc_[0], stream_);
+  if (!record(ev_msc_[0], stream_)) return false;
   if (!check(launch_regroup(soft_bits_, ids, ntiles, d_jobs_.get(), d_stream_cif_base, bits, d_grouped_.get(), stream_), "regroup launch")) return false;
-  (void)hipEventRecord(ev_msc_[1], stream_);
+  if (!record(ev_msc_[1], stream_)) return false;
   if (b.wave_form) {
     // small batch: one wave per code word (k_vitwave.hip), all lengths in one launch (longest first); its decisions use the survivor-record buffer
     if (!check(launch_viterbi_wave(soft_bits_, d_groups_.get(), static_cast<int>(b.groups.size()), ids, d_plans_.get(), d_grouped_.get(), row_words,
                                    d_decisions_.get(), prbs, out, record_stride, stream_),
                "viterbi (wave per code word) launch"))
       return false;
-    (void)hipEventRecord(ev_msc_[2], stream_);
+    if (!record(ev_msc_[2], stream_)) return false;
     return true;
   }
   for (size_t sl = 0; sl + 1 < b.slice_start.size(); ++sl) {
@@ -216,7 +233,7 @@ bool Engine::launch_decode_batch(const DecodeBatch& b, const uint32_t* bits, con
                "viterbi launch"))
       return false;
   }
-  (void)hipEventRecord(ev_msc_[2], stream_);
+  if (!record(ev_msc_[2], stream_)) return false;
   return true;
 }
 
@@ -402,7 +419,7 @@ bool Engine::msc_launch_async(const MscWork& w)
   if (!launch_decode_batch(w.batch, d_msc_bits_.get(), d_stream_cif_base_.get(), d_prbs_.get(), d_eti_.get(), kEtiBytes)) return false;
   if (!check(launch_eti_finish(d_meta_.get(), static_cast<int>(nf), d_headers_.get(), w.header_stride, d_fibs_.get(), d_crc_tab_.get(), d_crc_shift_.get(), d_eti_.get(), stream_), "eti finish launch"))
     return false;
-  (void)hipEventRecord(ev_msc_[3], stream_);
+  if (!record(ev_msc_[3], stream_)) return false;
   msc_queued_ = true;
   return true;
 }
@@ -412,9 +429,9 @@ void Engine::msc_collect()
   if (!msc_queued_) return;
   msc_queued_ = false;
   float ms = 0;
-  if (hipEventElapsedTime(&ms, ev_msc_[0], ev_msc_[1]) == hipSuccess) times_.gather += ms;
-  if (hipEventElapsedTime(&ms, ev_msc_[1], ev_msc_[2]) == hipSuccess) times_.viterbi += ms;
-  if (hipEventElapsedTime(&ms, ev_msc_[2], ev_msc_[3]) == hipSuccess) times_.eti += ms;
+  if (elapsed(&ms, ev_msc_[0], ev_msc_[1])) times_.gather += ms;
+  if (elapsed(&ms, ev_msc_[1], ev_msc_[2])) times_.viterbi += ms;
+  if (elapsed(&ms, ev_msc_[2], ev_msc_[3])) times_.eti += ms;
 }
 
 bool Engine::msc_launch(const MscWork& w)
@@ -503,6 +520,9 @@ bool Engine::guard_begin(int ntf_in_launch, GuardArgs* out)
       !check(hipMemsetAsync(d_guard_counter_.get(), 0, h_guard_counts_.size() * sizeof(uint32_t), stream_), "guard counters"))
     return false;
   guard_counters_clear_ = false;
+  // the capacity THIS launch was given (a later launch of the same decode may find the list re-reserved and larger): guard_check compares with it
+  if (guard_caps_.size() <= static_cast<size_t>(guard_launches_)) guard_caps_.resize(static_cast<size_t>(guard_launches_) + 1);
+  guard_caps_[static_cast<size_t>(guard_launches_)] = guard_cap_;
   *out = GuardArgs{d_delta_.get(), kSymbolsPerTf, guard_cap_, d_guard_list_.get(), d_guard_counter_.get() + static_cast<size_t>(guard_launches_) * kGuardSlotWords};
   return true;
 }
@@ -534,7 +554,7 @@ bool Engine::guard_check()
 {
   for (int i = 0; i < guard_launches_; ++i) {
     const uint32_t count = h_guard_counts_[static_cast<size_t>(i) * kGuardSlotWords];
-    if (count > guard_cap_) ++guard_overflows_;       // that launch was decided again in full: still exact, only slow
+    if (count > guard_caps_[static_cast<size_t>(i)]) ++guard_overflows_;       // that launch was decided again in full: still exact, only slow
     guard_flagged_ += count;
   }
   guard_launches_ = 0;
@@ -596,7 +616,7 @@ bool Engine::begin_decode(int nstreams, bool cont)
 bool Engine::upload_iq(const uint8_t* const* iq, const size_t* nbytes, int nstreams, const uint8_t** ptrs)
 {
   constexpr size_t kStageBytes = size_t(32) << 20, kPiece = size_t(1) << 20;
-  (void)hipEventRecord(ev_h2d_[0], stream_);
+  if (!record(ev_h2d_[0], stream_)) return false;
   size_t off = 0;
   int next_buf = 0;
   size_t fill = 0;                             // bytes staged in the current buffer, not yet queued
@@ -651,7 +671,7 @@ bool Engine::upload_iq(const uint8_t* const* iq, const size_t* nbytes, int nstre
     off += padded;
   }
   if (!flush()) return false;
-  (void)hipEventRecord(ev_h2d_[1], stream_);
+  if (!record(ev_h2d_[1], stream_)) return false;
   return true;
 }
 
@@ -716,7 +736,7 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
   if (!h_descs_.resize(ndesc) || !h_info_.resize(ndesc)) return false;
   sync_rescanned_ = 0;
   bool split_scan = false;
-  (void)hipEventRecord(ev_[0], stream_);
+  if (!record(ev_[0], stream_)) return false;
   if (afc_ || full_scan) {
     // the reference's order, call after call: with the software AFC every call's NCO depends on the estimates of the call
     // before; and the fallback when the split scan's assumption failed
@@ -752,7 +772,7 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
       return false;                                        // (the violation marks come back on the side stream, in fetch(): a copy on the main stream sits between K1 and the first OFDM launch)
     split_scan = true;
   }
-  (void)hipEventRecord(ev_[1], stream_);
+  if (!record(ev_[1], stream_)) return false;
   // The host only needs {status, ordinal} of every call to lay the frames out: K1 writes those 8 bytes per call to a
   // compact array that comes back first; the full descriptors (trace API) follow on the side stream.
   // (on the side stream, behind the scan's last kernel: what the layout callback may have queued on the main stream meanwhile -- the
@@ -775,19 +795,23 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
     times_.sync_fp64_calls = static_cast<float>(h_viol_[nstreams]);
     if (!redo.empty()) {                                   // rare: those streams again, in the reference's order, from their incoming state
       // (what the first layout queued -- its set-up kernel reads the page-locked frame lists when it RUNS -- is through before the lists are rewritten)
+      // (the guarded launches of the first layout have run; they are made again for the new frame list: their counters and counts start over --
+      // the second layout's set-up kernel clears the device side again)
+      guard_launches_ = 0;
+      guard_counters_clear_ = false;
       if (!check(hipStreamSynchronize(stream_), "before the rescan") || !d_redo_.upload(redo, stream_) ||
           !check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), static_cast<int>(redo.size()), max_calls_,
                                   -1, -1, d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), 0, stream_, false, d_states_prev_.get(), d_redo_.get()),
                  "sync rescan launch"))
         return false;
-      (void)hipEventRecord(ev_[1], stream_);
+      if (!record(ev_[1], stream_)) return false;
       if (!fetch() || !layout()) return false;             // the frames of those streams may have changed
     }
   }
   if (!check(hipStreamWaitEvent(copy_stream_, ev_[1], 0), "desc download") ||
       !check(hipMemcpyAsync(h_descs_.data(), d_descs_.get(), ndesc * sizeof(CallDesc), hipMemcpyDeviceToHost, copy_stream_), "desc download"))
     return false;
-  (void)hipEventElapsedTime(&times_.sync, ev_[0], ev_[1]);
+  if (!elapsed(&times_.sync, ev_[0], ev_[1])) return false;
   for (int b = 0; b < nstreams; ++b)
     if (states[b].overflow) { set_error("sync scan: stale-tail bookkeeping overflow (more than kMaxSeg nested short reads)"); return false; }
   return true;
@@ -916,7 +940,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     if (!h_fibs_.resize(static_cast<size_t>(nslots) * 384) || !h_fib_ok_.resize(static_cast<size_t>(nslots) * 12)) return false;
     fibs = h_fibs_.data();
     ok = h_fib_ok_.data();
-    (void)hipEventRecord(ev_[3], stream_);
+    if (!record(ev_[3], stream_)) return false;
     if (energies && !d_delta_.reserve(static_cast<size_t>(ntf) * kSymbolsPerTf)) return false;
     if (guard && guard_launches_ == 0 && !guard_counters_clear_ && !guard_reserve_counters(ntf)) return false;
     soft_args.delta = d_delta_.get();
@@ -938,7 +962,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
         if (guard && !guard_finish(true, first, n, 1, 4, false)) return false;
       }
     }
-    (void)hipEventRecord(ev_part0_, stream_);
+    if (!record(ev_part0_, stream_)) return false;
     return true;
   };
   const bool early_a = !cont;
@@ -966,32 +990,32 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   }
   for (int c = 0; c < nchunks && gpu_ok; ++c) {
     const int first = c * chunk, n = std::min(chunk, ntf - first);
-    (void)hipEventRecord(chunk_ev_[3 * c], stream_);
+    gpu_ok = record(chunk_ev_[3 * c], stream_);
     if (one_kernel) {
       // the 72 MSC symbols (the FIC symbols ran before the FIC decode was queued); workgroups per frame: measurement knob
       static const int msc_wgs = std::getenv("DABHIP_FUSED_MSC_WGS") ? std::max(1, std::min(8, std::atoi(std::getenv("DABHIP_FUSED_MSC_WGS")))) : 1;
-      gpu_ok = fused_parts(first, n, 4, 76, msc_wgs);
-      (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
+      gpu_ok = gpu_ok && fused_parts(first, n, 4, 76, msc_wgs);
+      gpu_ok = gpu_ok && record(chunk_ev_[3 * c + 1], stream_);
     } else {
       GuardArgs ga = soft ? soft_args : GuardArgs{};   // (hard decisions: a non-null delta switches the guard's listing on)
       if (guard && !guard_begin(n, &ga)) { gpu_ok = false; break; }
       // with the guard on (or soft decisions), K2 also leaves the per-symbol sample energies K2b decides with
-      gpu_ok = check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(), stream_,
-                                     energies ? d_delta_.get() : nullptr),
-                     "fft launch");
-      (void)hipEventRecord(chunk_ev_[3 * c + 1], stream_);
+      gpu_ok = gpu_ok && check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(), stream_,
+                                               energies ? d_delta_.get() : nullptr),
+                               "fft launch");
+      gpu_ok = gpu_ok && record(chunk_ev_[3 * c + 1], stream_);
       gpu_ok = gpu_ok && check(launch_demap(true, soft_bits_, d_spectra_.get(), first, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_), "demap launch");
       if (guard) gpu_ok = gpu_ok && guard_finish(true, first, n, 1, kSymbolsPerTf, true);     // timed with the demapper; the FIC symbols belong to the pre-pass
     }
-    (void)hipEventRecord(chunk_ev_[3 * c + 2], stream_);
+    gpu_ok = gpu_ok && record(chunk_ev_[3 * c + 2], stream_);
   }
   mark("ofdm queued");
   if (!check(hipEventSynchronize(ev_fibs_), "fic decode")) return -1;
   mark("fibs on host");
   {
     float part0_ms = 0, fic_ms = 0;
-    (void)hipEventElapsedTime(&part0_ms, ev_[3], ev_part0_);
-    (void)hipEventElapsedTime(&fic_ms, ev_part0_, ev_fic_done_);   // beside the OFDM stage since round 2: no longer a term of the step
+    // (the FIC decode runs beside the OFDM stage since round 2: no longer a term of the step.  A failed query: the decode fails below, after the drain)
+    if (!elapsed(&part0_ms, ev_[3], ev_part0_) || !elapsed(&fic_ms, ev_part0_, ev_fic_done_)) gpu_ok = false;
     times_.fic = fic_ms + (one_kernel ? 0.0f : part0_ms);   // the pre-pass of the two-kernel stage is FIC work; the FIC symbols' launch of the fused kernel is OFDM work
     if (one_kernel) times_.fft += part0_ms;
   }
@@ -1061,8 +1085,8 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
   if (!host_ok) { set_error(host_error); return -1; }
   for (int c = 0; c < nchunks; ++c) {
     float a = 0, d = 0;
-    (void)hipEventElapsedTime(&a, chunk_ev_[3 * c], chunk_ev_[3 * c + 1]);
-    (void)hipEventElapsedTime(&d, chunk_ev_[3 * c + 1], chunk_ev_[3 * c + 2]);
+    if (!elapsed(&a, chunk_ev_[3 * c], chunk_ev_[3 * c + 1]) || !elapsed(&d, chunk_ev_[3 * c + 1], chunk_ev_[3 * c + 2])) return -1;
+
     times_.fft += a;
     times_.demap += d;
     fft_ms_ += a;
@@ -1070,7 +1094,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     fft_tfs_ += std::min(chunk, ntf - c * chunk);
   }
   msc_collect();
-  if (!on_device && times_.h2d_bytes > 0) (void)hipEventElapsedTime(&times_.h2d, ev_h2d_[0], ev_h2d_[1]);
+  if (!on_device && times_.h2d_bytes > 0 && !elapsed(&times_.h2d, ev_h2d_[0], ev_h2d_[1])) return -1;
   if (guard && !guard_check()) return -1;
   // what the next segment of a session starts from
   for (int b = 0; b < nstreams; ++b) {
@@ -1150,12 +1174,12 @@ int Engine::fft_roofline(int reps, int64_t* launches, int64_t* tfs, double* ms)
   for (int r = -1; r < reps; ++r) {                      // r = -1: untimed
     for (int first = 0; first < ntf; first += chunk) {
       const int n = std::min(chunk, ntf - first);
-      (void)hipEventRecord(ev_[0], stream_);
+      if (!record(ev_[0], stream_)) return -1;
       if (!check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(), stream_), "fft launch")) return -1;
-      (void)hipEventRecord(ev_[1], stream_);
+      if (!record(ev_[1], stream_)) return -1;
       if (!check(hipEventSynchronize(ev_[1]), "fft")) return -1;
       float t = 0;
-      (void)hipEventElapsedTime(&t, ev_[0], ev_[1]);
+      if (!elapsed(&t, ev_[0], ev_[1])) return -1;
       if (r >= 0) { total += t; ++nl; nt += n; }
     }
   }
@@ -1199,13 +1223,13 @@ int Engine::stage_ofdm_fft(const uint8_t* frames, int nframes, float* spectra, b
   reps = std::max(reps, 1);
   // one untimed launch first when timing
   if (reps > 1 && !check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), nframes, d_frames_.get(), 0, nframes, d_spectra_.get(), d_twf_.get(), stream_), "fft launch")) return -1;
-  (void)hipEventRecord(ev_[0], stream_);
+  if (!record(ev_[0], stream_)) return -1;
   for (int r = 0; r < reps; ++r)
     if (!check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), nframes, d_frames_.get(), 0, nframes, d_spectra_.get(), d_twf_.get(), stream_), "fft launch")) return -1;
-  (void)hipEventRecord(ev_[1], stream_);
+  if (!record(ev_[1], stream_)) return -1;
   if (!check(hipEventSynchronize(ev_[1]), "fft")) return -1;
   float ms = 0;
-  (void)hipEventElapsedTime(&ms, ev_[0], ev_[1]);
+  if (!elapsed(&ms, ev_[0], ev_[1])) return -1;
   if (kernel_ms) *kernel_ms = ms / reps;
   if (spectra && !check(hipMemcpy(spectra, d_spectra_.get(), nspec * sizeof(float2), hipMemcpyDeviceToHost), "spectra download")) return -1;
   return nframes;

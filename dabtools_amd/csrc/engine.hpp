@@ -143,7 +143,11 @@ using MscWork = MscWorkT<PinnedAllocator>;
 class Engine {
  public:
   // host_threads: threads of the per-stream control-plane pool (0 = half the cores, at most 24; DABHIP_HOST_THREADS overrides)
-  explicit Engine(int device, int host_threads = 0);
+  // cpus: the CPUs this engine's host threads (control-plane pool, host lane) are bound to; empty = those of the device's NUMA node on a machine
+  // with more than one (placement.hpp), or none
+  explicit Engine(int device, int host_threads = 0, std::vector<int> cpus = {});
+  const std::vector<int>& host_cpus() const { return host_cpus_; }
+  int numa_node() const { return numa_node_; }
   ~Engine();
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
@@ -235,6 +239,8 @@ class Engine {
 
  private:
   bool check(hipError_t e, const char* what);
+  bool record(hipEvent_t e, hipStream_t s);
+  bool elapsed(float* ms, hipEvent_t a, hipEvent_t b);
   bool hard_only(const char* what);
   int64_t decode_impl(const uint8_t* const* iq, const size_t* nbytes, int nstreams, bool on_device, bool cont, bool full_scan = false);
   bool begin_decode(int nstreams, bool cont);
@@ -271,7 +277,8 @@ class Engine {
   std::mutex* heavy_mu_ = nullptr;
   std::unique_ptr<ThreadPool> pool_;   // host threads for per-stream control-plane work
   std::unique_ptr<AsyncLane> host_lane_;   // the control-plane pass of a decode, beside its GPU work
-  int device_ = 0;
+  int device_ = 0, numa_node_ = -1;
+  std::vector<int> host_cpus_;
   hipStream_t stream_ = nullptr, copy_stream_ = nullptr;   // copy_stream_: work-list uploads from the control-plane thread
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_upload_ = nullptr, ev_fic_ = nullptr, ev_fic_done_ = nullptr, ev_fibs_ = nullptr, ev_part0_ = nullptr, ev_chain_ = nullptr, ev_info_ = nullptr;
@@ -339,6 +346,7 @@ class Engine {
   int guard_launches_ = 0;
   bool guard_counters_clear_ = false;   // the layout kernel of this decode has cleared the device counters
   uint32_t guard_cap_ = 0, guard_cap_override_ = 0;
+  std::vector<uint32_t> guard_caps_;   // per guarded launch of the decode: the list capacity it ran with
   int64_t guard_flagged_ = 0, guard_decisions_ = 0;
   int guard_overflows_ = 0;          // launches of the last decode whose list overflowed (decided again in full, fp64)
   DeviceBuffer<uint8_t> d_carry_;

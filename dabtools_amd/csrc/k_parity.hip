@@ -349,13 +349,13 @@ hipError_t launch_exact_decide_all(const unsigned* counter, unsigned cap, const 
                                    hipStream_t stream)
 {
   if (nframes <= 0) return hipSuccess;
-  static bool attr_set = false;
+  static std::once_flag once[64];
+  static hipError_t result[64];
   const size_t lds = sizeof(double2) * (2048 + 2048 + 1024);
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(exact_decide_all_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  const hipError_t attr = once_per_device(once, result, [lds]() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(exact_decide_all_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+  });
+  if (attr != hipSuccess) return attr;
   hipLaunchKernelGGL(exact_decide_all_kernel, dim3(std::min(nframes, 512)), dim3(kFft64Threads), lds, stream, counter, cap, iq, descs, max_calls, frames, first,
                      nframes, sym_a, sym_b, tw2048, qpsk_of_carrier, frame_slot, frame_cif_row, planar ? 1 : 0, skip_fic ? 1 : 0, fic_bits, msc_bits);
   return hipGetLastError();
@@ -365,13 +365,13 @@ hipError_t launch_decision_audit(const uint8_t* frames_iq, int nframes, const fl
                                  const double2* tw2048, const uint16_t* qpsk_of_carrier, void* out, hipStream_t stream)
 {
   if (nframes <= 0) return hipSuccess;
-  static bool attr_set = false;
+  static std::once_flag once[64];
+  static hipError_t result[64];
   const size_t lds = sizeof(double2) * (2048 + 2048 + 1024);
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decision_audit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  const hipError_t attr = once_per_device(once, result, [lds]() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(decision_audit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+  });
+  if (attr != hipSuccess) return attr;
   hipLaunchKernelGGL(decision_audit_kernel, dim3(nframes), dim3(kFft64Threads), lds, stream, frames_iq, spectra, fic_bits, msc_bits, tw2048,
                      qpsk_of_carrier, static_cast<AuditOut*>(out));
   return hipGetLastError();

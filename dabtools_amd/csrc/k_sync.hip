@@ -776,15 +776,16 @@ static size_t sync_verify32_lds_bytes() { return sizeof(float2) * (kVerify32Poin
 
 static hipError_t sync_attr()
 {
-  static bool attr_set = false;
-  if (attr_set) return hipSuccess;
-  const int lds = static_cast<int>(sync_scan_lds_bytes());
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_scan_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_scan_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_verify_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_verify32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sync_verify32_lds_bytes()));
-  if (e == hipSuccess) attr_set = true;
-  return e;
+  static std::once_flag once[64];
+  static hipError_t result[64];
+  return once_per_device(once, result, []() {
+    const int lds = static_cast<int>(sync_scan_lds_bytes());
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_scan_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_scan_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_verify_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_verify32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sync_verify32_lds_bytes()));
+    return e;
+  });
 }
 
 // Everything a scan needs on the device before its first kernel, in ONE launch: the per-stream arrays straight out of the caller's page-locked

@@ -5,10 +5,24 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <mutex>
 
 #include "device_types.hpp"
 
 namespace dabhip {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: several engines of one process may sit on different devices (dabhip_multi), each with
+// its own host thread.  fn() runs once per device (the current one), its result is kept; callers on other threads of the same device wait for it.
+template <class F>
+inline hipError_t once_per_device(std::once_flag (&once)[64], hipError_t (&result)[64], F&& fn)
+{
+  int dev = 0;
+  const hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  dev &= 63;
+  std::call_once(once[dev], [&]() { result[dev] = fn(); });
+  return result[dev];
+}
 
 // the scan's device-side preparation in one launch (k_sync.hip): h_* are page-locked host arrays the kernel reads directly
 struct ScanSetupArgs {

@@ -1,8 +1,9 @@
 // multi.cpp — the batch engine over several MI355X of one node (include/dabhip.h: dabhip_multi_*).
 //
 // Ensembles are independent end to end, so a batch shards by stream with no data-path exchange: the
-// streams are dealt to the listed devices in contiguous slices (stream s of B on n devices -> slice s / ceil(B / n), the
-// low slices taking the remainder: 2048 streams on 8 devices = 256 each, stream s on device s / 256), every slice is one
+// streams are dealt to the listed devices in contiguous slices -- slice i of n takes B / n streams, the first B mod n slices one more
+// (dabhip_multi_plan says which, before or after a decode: 2048 streams on 8 devices = 256 each, stream s on device s / 256; 10 on 4 =
+// 3, 3, 2, 2) --, every slice is one
 // complete batch engine with its own persistent host thread, HIP streams and control-plane pool, and the slices run
 // concurrently.  No collective, no peer access, no RCCL.  The ETI frames come back in stream order whatever device made
 // them.  This is the single-process form of what bench.py does with one process per GPU; dab2eti.c:237,279-302 (one demod
@@ -17,7 +18,10 @@
 #include <thread>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>
+
 #include "../../include/dabhip.h"
+#include "placement.hpp"
 #include "thread_pool.hpp"
 
 namespace dabhip {
@@ -31,6 +35,8 @@ struct dabhip_multi {
     int device = 0;
     dabhip_engine* eng = nullptr;
     std::unique_ptr<AsyncLane> lane;     // the slice's host thread: its decode calls run here
+    std::vector<int> cpus;               // the CPUs its host threads are bound to (placement.hpp); empty = unbound
+    int numa_node = -1;
     int first = 0, count = 0;            // streams [first, first + count) of the last decode
     int64_t frames = 0;
     float wall_ms = 0;
@@ -67,12 +73,29 @@ dabhip_multi* dabhip_multi_create(const int* devices, int n)
   const int hw = static_cast<int>(std::thread::hardware_concurrency());
   const int host_threads = std::max(2, std::min(24, hw / (2 * n)));
   m->slices.resize(n);
+  // host placement (placement.hpp): every slice's threads -- its decode thread here, the engine's control-plane pool and host lane -- on the NUMA
+  // node of its device, the node's CPUs dealt to the slices on it in disjoint chunks; page-locked buffers are allocated by those threads, i.e. there
+  std::vector<int> nodes(static_cast<size_t>(n), -1);
+  if (dabhip::numa_enabled())
+    for (int i = 0; i < n; ++i) {
+      char bdf[32] = {0};
+      if (hipDeviceGetPCIBusId(bdf, sizeof bdf, devices[i]) == hipSuccess) nodes[static_cast<size_t>(i)] = dabhip::numa_node_of_pci(bdf);
+      else (void)hipGetLastError();
+    }
+  const std::vector<std::vector<int>> node_cpus = dabhip::system_node_cpus();
+  int populated = 0;
+  for (const auto& c : node_cpus) populated += c.empty() ? 0 : 1;
+  std::vector<std::vector<int>> plan(static_cast<size_t>(n));
+  if (populated > 1) plan = dabhip::plan_placement(nodes, node_cpus);          // a single-socket machine: nothing to choose, nothing bound
   for (int i = 0; i < n; ++i) {
     dabhip_multi::Slice& s = m->slices[i];
     s.device = devices[i];
-    s.eng = dabhip_engine_create_ex(devices[i], host_threads);
+    s.cpus = plan[static_cast<size_t>(i)];
+    s.numa_node = nodes[static_cast<size_t>(i)];
+    std::vector<int32_t> c32(s.cpus.begin(), s.cpus.end());
+    s.eng = dabhip_engine_create_on_cpus(devices[i], host_threads, c32.data(), static_cast<int>(c32.size()));
     if (!s.eng) return nullptr;            // dabhip_last_error() says why (bad index, no GPU: there is no CPU fallback)
-    s.lane.reset(new AsyncLane());
+    s.lane.reset(new AsyncLane(s.cpus));
   }
   return m.release();
 }
@@ -80,6 +103,27 @@ dabhip_multi* dabhip_multi_create(const int* devices, int n)
 void dabhip_multi_destroy(dabhip_multi* m) { delete m; }
 
 int dabhip_multi_slices(const dabhip_multi* m) { return m ? static_cast<int>(m->slices.size()) : -1; }
+
+// The dealing rule as a pure function of (number of slices, batch size): usable BEFORE the first decode, e.g. to put stream b's samples on the
+// right device for an on_device decode.  Slice i takes nstreams / n streams, the first nstreams % n slices one more.
+int dabhip_multi_plan(const dabhip_multi* m, int nstreams, int stream, int* slice, int* device)
+{
+  if (!m || nstreams <= 0 || stream < 0 || stream >= nstreams) { set_error("multi_plan: bad argument"); return -1; }
+  const int n = static_cast<int>(m->slices.size()), base = nstreams / n, rem = nstreams % n;
+  // the first rem slices hold base + 1 streams each
+  const int i = stream < rem * (base + 1) ? stream / (base + 1) : rem + (stream - rem * (base + 1)) / std::max(base, 1);
+  if (slice) *slice = i;
+  if (device) *device = m->slices[static_cast<size_t>(i)].device;
+  return 0;
+}
+int dabhip_multi_slice_cpus(const dabhip_multi* m, int slice, int32_t* cpus, int cap, int* numa_node)
+{
+  if (!m || slice < 0 || slice >= static_cast<int>(m->slices.size())) return -1;
+  const dabhip_multi::Slice& s = m->slices[static_cast<size_t>(slice)];
+  if (numa_node) *numa_node = s.numa_node;
+  for (int i = 0; cpus && i < cap && i < static_cast<int>(s.cpus.size()); ++i) cpus[i] = s.cpus[static_cast<size_t>(i)];
+  return static_cast<int>(s.cpus.size());
+}
 
 int dabhip_multi_slice_of(const dabhip_multi* m, int stream, int* device)
 {

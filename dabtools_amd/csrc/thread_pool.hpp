@@ -9,13 +9,16 @@
 #include <thread>
 #include <vector>
 
+#include "placement.hpp"
+
 namespace dabhip {
 
 class ThreadPool {
  public:
-  explicit ThreadPool(int nthreads)
+  // cpus: the CPUs the workers are bound to before they do (or allocate) anything; empty = wherever the scheduler puts them (placement.hpp)
+  explicit ThreadPool(int nthreads, std::vector<int> cpus = {}) : cpus_(std::move(cpus))
   {
-    for (int t = 0; t < nthreads; ++t) workers_.emplace_back([this] { loop(); });
+    for (int t = 0; t < nthreads; ++t) workers_.emplace_back([this] { (void)bind_this_thread(cpus_); loop(); });
   }
   ~ThreadPool()
   {
@@ -29,10 +32,13 @@ class ThreadPool {
   ThreadPool(const ThreadPool&) = delete;
   ThreadPool& operator=(const ThreadPool&) = delete;
 
-  // fn(i) for every i in [0, n); the calling thread takes part; returns when all are done
+  // fn(i) for every i in [0, n); the calling thread takes part; returns when all are done.  One parallel_for at a time: the pool has ONE job slot
+  // (the engine calls it from its decode thread -- upload staging -- and from its host lane -- control plane, work lists -- which never overlap by
+  // construction; a second caller that did arrive simply waits its turn here)
   void parallel_for(int n, const std::function<void(int)>& fn)
   {
     if (n <= 0) return;
+    std::lock_guard<std::mutex> one_caller(call_mu_);
     Job job;
     {
       std::lock_guard<std::mutex> lk(mu_);
@@ -90,8 +96,9 @@ class ThreadPool {
     }
   }
 
+  std::vector<int> cpus_;             // (before workers_: the threads read it)
   std::vector<std::thread> workers_;
-  std::mutex mu_;
+  std::mutex mu_, call_mu_;
   std::condition_variable cv_, done_;
   Job job_;
   std::atomic<uint64_t> ticket_{0};   // epoch << 32 | next index
@@ -104,7 +111,7 @@ class ThreadPool {
 // work of the same decode (it used to be a std::thread created and joined per decode).
 class AsyncLane {
  public:
-  AsyncLane() : worker_([this] { loop(); }) {}
+  explicit AsyncLane(std::vector<int> cpus = {}) : cpus_(std::move(cpus)), worker_([this] { (void)bind_this_thread(cpus_); loop(); }) {}
   ~AsyncLane()
   {
     {
@@ -161,6 +168,7 @@ class AsyncLane {
   std::vector<std::function<void()>> queue_;
   uint64_t posted_ = 0, finished_ = 0;
   bool stop_ = false;
+  std::vector<int> cpus_;
   std::thread worker_;                       // last member: starts after the state it uses exists
 };
 

@@ -11,7 +11,7 @@ def bench_cfg(dab, global_stream, snr_db=1000.0):
 
 class PayloadCheck:
     def __init__(self):
-        self.frames = self.good = self.bit_err = self.bits = self.streams = self.expected = 0
+        self.frames = self.good = self.bit_err = self.bits = self.streams = self.expected = self.compared = 0
 
     def add_stream(self, dab, cfg, ntf, eti_frames):
         """eti_frames: iterable of 6144-byte uint8 arrays, the frames one decoder produced for this stream."""
@@ -24,7 +24,8 @@ class PayloadCheck:
             pos = 12 + 4 * nst
             cif = fib_index.get(e[pos:pos + 96].tobytes())
             if cif is None or nst != cfg.nsub:
-                continue
+                continue                                   # (counted: frames_unmatched in result())
+            self.compared += 1
             pos += 96
             wrong = 0
             for k in range(nst):
@@ -36,5 +37,13 @@ class PayloadCheck:
             self.good += int(wrong == 0)
 
     def result(self):
+        # The payload of a frame can only be looked up when its 96 FIC bytes name a CIF of the ensemble exactly: frames with a damaged FIC (or a
+        # different NST) are NOT in payload_ber -- at 5 dB that is most frames of a hard-decision decoder, so the figure flatters it; frames_compared
+        # and frames_unmatched say how many frames the BER stands on, payload_ber_unmatched_as_half counts every unmatched frame as coin tosses
+        unmatched = self.frames - self.compared
+        per_frame = (self.bits / self.compared) if self.compared else 0.0
         return {"streams_checked": self.streams, "frames_expected_if_locked": self.expected, "frames_out": self.frames,
-                "error_free_frames": self.good, "payload_ber": (self.bit_err / self.bits) if self.bits else None}
+                "frames_compared": self.compared, "frames_unmatched": unmatched,
+                "error_free_frames": self.good, "payload_ber": (self.bit_err / self.bits) if self.bits else None,
+                "payload_ber_is": "bit errors / payload bits over the frames_compared FIC-matched frames",
+                "payload_ber_unmatched_as_half": ((self.bit_err + 0.5 * per_frame * unmatched) / (self.bits + per_frame * unmatched)) if self.bits else None}

@@ -99,6 +99,10 @@ dabhip_engine *dabhip_engine_create(int device);
 /* The same with an explicit size for the engine's host thread pool (per-stream control plane, work lists, staging copies);
  * 0 = automatic (half the cores, at most 24).  Several engines in one process should share the host between them. */
 dabhip_engine *dabhip_engine_create_ex(int device, int host_threads);
+/* The same with the engine's host threads bound to the listed CPUs (ncpus = 0: to the CPUs of the device's NUMA node on a machine with several,
+ * else unbound).  dabhip_engine_host_cpus reports what was applied. */
+dabhip_engine *dabhip_engine_create_on_cpus(int device, int host_threads, const int32_t *cpus, int ncpus);
+int dabhip_engine_host_cpus(const dabhip_engine *e, int32_t *cpus, int cap, int *numa_node);
 void dabhip_engine_destroy(dabhip_engine *e);
 
 /* Decode B independent cu8 streams (the replay loop of dab2eti.c:60-130 per stream, in
@@ -176,9 +180,9 @@ int dabhip_engine_set_fused(dabhip_engine *e, int enable);
 
 /* ---- several devices of one node (BASELINE configs[3]: 2048 streams = 256 per GPU x 8) --------------
  * dab2eti.c:237,279-302 drives ONE device from one demod thread.  A batch of independent ensembles shards by stream with no
- * data exchange at all: the streams of a decode are dealt to the listed devices in contiguous slices (stream s of B on n
- * devices belongs to slice s / ceil(B / n), the low slices taking the remainder -- 2048 on 8 = stream s on device s / 256),
- * every slice is a complete batch engine with its own persistent host thread and HIP streams, and all slices decode at
+ * data exchange at all: the streams of a decode are dealt to the listed devices in contiguous slices (slice i of n takes B / n
+ * streams, the first B mod n slices one more: 2048 on 8 = stream s on device s / 256; 10 on 4 = 3, 3, 2, 2 -- dabhip_multi_plan
+ * answers for any batch size, before the decode), every slice is a complete batch engine with its own persistent host thread and HIP streams, and all slices decode at
  * once.  No collective, no peer access.  Frames are read back per GLOBAL stream index, or drained in stream order.
  * A device may be listed more than once (each entry is its own slice).  iq[b]: host pointers, or -- on_device != 0 --
  * device pointers that live on the device of stream b's slice (dabhip_multi_slice_of). */
@@ -186,8 +190,16 @@ typedef struct dabhip_multi dabhip_multi;
 dabhip_multi *dabhip_multi_create(const int *devices, int n);
 void dabhip_multi_destroy(dabhip_multi *m);
 int dabhip_multi_slices(const dabhip_multi *m);
-/* Slice (and its device) that decodes `stream` in a decode of the size of the LAST dabhip_multi_decode. */
+/* Slice and device that decode `stream` of a batch of `nstreams` -- the dealing rule itself, valid before the first decode (device pointers of
+ * an on_device decode must live on that device).  0, <0 on error. */
+int dabhip_multi_plan(const dabhip_multi *m, int nstreams, int stream, int *slice, int *device);
+/* The same for the size of the LAST dabhip_multi_decode (-1 before the first one). */
 int dabhip_multi_slice_of(const dabhip_multi *m, int stream, int *device);
+/* Host placement of a slice (dab2eti.c:237 is the one unplaced demod thread this replaces): its decode thread, control-plane pool and host lane are
+ * bound to a chunk of the CPUs of its device's NUMA node (/sys/bus/pci/devices/<bdf>/numa_node; the slices of a node get disjoint chunks), and its
+ * page-locked buffers are allocated by those threads.  Returns the number of CPUs (0 = unbound: single-socket machine, node unknown, DABHIP_NUMA=0)
+ * and writes up to cap of them. */
+int dabhip_multi_slice_cpus(const dabhip_multi *m, int slice, int32_t *cpus, int cap, int *numa_node);
 int64_t dabhip_multi_decode(dabhip_multi *m, const uint8_t *const *iq, const size_t *nbytes, int nstreams, int on_device);
 int64_t dabhip_multi_eti_count(const dabhip_multi *m, int stream);
 uint32_t dabhip_multi_stream_status(const dabhip_multi *m, int stream);   /* as dabhip_engine_stream_status, global stream index */
@@ -308,6 +320,11 @@ int dabhip_host_eti_header(const int32_t *hdr3, const int32_t *sub, uint8_t *out
  * (272-byte rows) + lengths.  Returns the number of ETI frames. */
 int dabhip_host_control_replay(const uint8_t *fibs, const uint8_t *crc_ok, int ntf, int32_t *first_cif,
                                uint8_t *headers, int32_t *header_len, int cap_frames);
+
+/* The placement rule by itself (no GPU, no sysfs): slice i sits on NUMA node slice_node[i] (< 0: unknown); node_cpulist[n] is node n's CPU list in
+ * the kernel's notation ("0-63,128-191").  cpu_slice[c] = the slice CPU c is given to, -1 = none; the slices of a node get disjoint contiguous
+ * chunks of its list.  Returns the number of slices that got CPUs. */
+int dabhip_host_placement_plan(const int32_t *slice_node, int nslices, const char *const *node_cpulist, int nnodes, int32_t *cpu_slice, int ncpu);
 
 /* The constant tables the kernels are built from (dab_tables.hpp generates them from the ETSI rules), so that tests can
  * hold them against the reference's literal arrays: which = 0: the 64 UEP profiles of ueptable (dab_tables.c:16-81) as rows

@@ -73,6 +73,46 @@ static void test_pool_and_lane()
   int sum = 0;
   solo.parallel_for(10, [&](int i) { sum += i; });
   CHECK(sum == 45);
+  // host placement (placement.hpp): workers and lanes are bound to their CPU list before they run anything.  (The CPU this process may use: what
+  // the container's cpuset leaves; bind to the first one of it.)
+  cpu_set_t allowed;
+  CHECK(sched_getaffinity(0, sizeof allowed, &allowed) == 0);
+  int cpu0 = -1;
+  for (int c = 0; c < CPU_SETSIZE && cpu0 < 0; ++c)
+    if (CPU_ISSET(c, &allowed)) cpu0 = c;
+  CHECK(cpu0 >= 0);
+  {
+    ThreadPool bound(3, std::vector<int>{cpu0});
+    std::atomic<int> elsewhere{0}, by_workers{0};
+    const std::thread::id me = std::this_thread::get_id();
+    for (int round = 0; round < 20; ++round)
+      bound.parallel_for(64, [&](int) {
+        if (std::this_thread::get_id() == me) return;                  // the caller takes part and is not bound
+        ++by_workers;
+        if (sched_getcpu() != cpu0) ++elsewhere;
+      });
+    CHECK(elsewhere.load() == 0);
+    AsyncLane on_cpu(std::vector<int>{cpu0});
+    int where = -1;
+    on_cpu.post([&]() { where = sched_getcpu(); });
+    on_cpu.wait();
+    CHECK(where == cpu0);
+  }
+  // two callers of one pool (the engine's decode thread and its host lane never overlap, but nothing must break if they did)
+  {
+    ThreadPool shared(4);
+    std::vector<int> a(500, 0), b(500, 0);
+    std::thread other([&]() { for (int r = 0; r < 50; ++r) shared.parallel_for(500, [&](int i) { a[static_cast<size_t>(i)] += 1; }); });
+    for (int r = 0; r < 50; ++r) shared.parallel_for(500, [&](int i) { b[static_cast<size_t>(i)] += 1; });
+    other.join();
+    for (int i = 0; i < 500; ++i) CHECK(a[static_cast<size_t>(i)] == 50 && b[static_cast<size_t>(i)] == 50);
+  }
+  // the plan itself: disjoint chunks of a node's CPUs
+  {
+    const std::vector<std::vector<int>> plan = plan_placement({0, 1, 0, -1, 0}, {parse_cpulist("0-3,8-11"), parse_cpulist("4-7")});
+    CHECK(plan.size() == 5 && plan[3].empty() && plan[1] == (std::vector<int>{4, 5, 6, 7}));
+    CHECK(plan[0] == (std::vector<int>{0, 1}) && plan[2] == (std::vector<int>{2, 3, 8}) && plan[4] == (std::vector<int>{9, 10, 11}));
+  }
 }
 
 // the FIBs and CRC flags of `ntf` transmission frames of one synthetic ensemble, as the FIC decode hands them to the control plane

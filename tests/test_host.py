@@ -321,3 +321,25 @@ def test_control_plane_silences_a_multiplex_the_reference_cannot_assemble():
     assert counts["clean"] == 4 * (24 - 13) and counts["overlap_but_fine"] == counts["clean"]
     for name in ("outside", "overflow", "option", "size0"):
         assert counts[name] == 4 * (16 - 13), (name, counts)      # the frames before the poisoned FIBs arrived, none after
+
+
+def test_host_placement_plan_masks_are_numa_local_and_disjoint():
+    """VERDICT r3 item 7 (no GPU, no sysfs needed): 8 slices on a two-socket node -- GPUs 0..3 on node 0, 4..7 on node 1, the kernel's usual
+    interleaved SMT numbering -- get disjoint, equally sized CPU chunks of their own node; a slice on an unknown node stays unbound."""
+    lists = ["0-63,128-191", "64-127,192-255"]
+    n, cpu_slice = dab.host_placement_plan([0, 0, 0, 0, 1, 1, 1, 1], lists, 256)
+    assert n == 8
+    node_of = lambda c: 0 if (c % 128) < 64 else 1
+    per = {}
+    for c, sl in enumerate(cpu_slice):
+        assert sl >= 0, "every CPU of a node with slices is handed out"
+        assert node_of(c) == (0 if sl < 4 else 1), "CPU %d (node %d) given to slice %d" % (c, node_of(c), sl)
+        per.setdefault(sl, []).append(c)
+    assert sorted(per) == list(range(8)) and all(len(v) == 32 for v in per.values())          # disjoint by construction of the map, balanced
+    # uneven: three slices on one node, one unknown, a node without slices keeps its CPUs
+    n, cpu_slice = dab.host_placement_plan([1, -1, 1, 1], ["0-3", "4-13"], 16)
+    assert n == 3 and cpu_slice[:4] == [-1] * 4 and cpu_slice[14:] == [-1, -1]
+    assert [cpu_slice[4:14].count(s) for s in (0, 2, 3)] == [3, 3, 4] and 1 not in cpu_slice
+    # more slices than CPUs on a node: nobody goes unbound
+    n, _ = dab.host_placement_plan([0, 0, 0], ["5-6"], 8)
+    assert n == 3
