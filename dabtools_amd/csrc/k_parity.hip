@@ -352,7 +352,7 @@ hipError_t launch_exact_decide_all(const unsigned* counter, unsigned cap, const 
   static std::once_flag once[64];
   static hipError_t result[64];
   const size_t lds = sizeof(double2) * (2048 + 2048 + 1024);
-  const hipError_t attr = once_per_device(once, result, [lds]() {
+  const hipError_t attr = once_per_device(once, result, []() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(exact_decide_all_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   });
   if (attr != hipSuccess) return attr;
@@ -368,7 +368,7 @@ hipError_t launch_decision_audit(const uint8_t* frames_iq, int nframes, const fl
   static std::once_flag once[64];
   static hipError_t result[64];
   const size_t lds = sizeof(double2) * (2048 + 2048 + 1024);
-  const hipError_t attr = once_per_device(once, result, [lds]() {
+  const hipError_t attr = once_per_device(once, result, []() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(decision_audit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   });
   if (attr != hipSuccess) return attr;

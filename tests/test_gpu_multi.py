@@ -139,3 +139,51 @@ def test_bench_in_process_mode_and_config3_tool_at_reduced_size():
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["eti_frames"] == 24 * 16 and d["all_streams_full_count"] and d["oracle_byte_equal"].startswith("3 of 3") and d["sharding_rule_ok"]
+
+
+def test_plan_before_the_decode_uneven_batch_with_device_pointers():
+    """the dealing rule must be usable BEFORE the first decode (an on_device caller has to put stream b's samples on the device
+    of its slice).  10 streams on 4 slices = 3, 3, 2, 2: dabhip_multi_plan says so up front, the samples go where it says (device buffers),
+    the decode agrees (slice_of) and the bytes are the single engine's."""
+    caps = _captures(10)
+    multi = dab.Multi([0] * 4)
+    plan = [multi.plan(len(caps), b) for b in range(len(caps))]
+    assert [p[0] for p in plan] == [0, 0, 0, 1, 1, 1, 2, 2, 3, 3]
+    assert [multi.plan(2048, s)[0] for s in (0, 255, 256, 2047)] == [0, 0, 1, 3] and multi.plan(3, 2)[0] == 2
+    for rank in range(4):
+        assert [b for b in range(10) if plan[b][0] == rank] == list(shard.shard_streams(10, 4, rank))
+    bufs = []
+    for b, iq in enumerate(caps):
+        buf = dab.DeviceBuffer(iq.size, device=plan[b][1])       # on the device the plan names
+        buf.upload(iq)
+        bufs.append(buf)
+    total = multi.decode_device([x.ptr for x in bufs], [iq.size for iq in caps])
+    single = dab.Engine(0)
+    assert total == single.decode(caps)
+    for b in range(len(caps)):
+        assert multi.slice_of(b) == plan[b]
+        assert np.array_equal(multi.eti(b), single.eti(b))
+    # host placement: reported per slice; on a one-socket box nothing is bound, on a two-socket one the chunks are disjoint and on the GPU's node
+    seen = set()
+    for sl in range(4):
+        cpus, node = multi.slice_cpus(sl)
+        assert not (seen & set(cpus)), "slices share CPUs"
+        seen |= set(cpus)
+    for x in bufs:
+        x.free()
+    single.close()
+    multi.close()
+
+
+def test_two_distinct_devices_get_their_own_kernel_attributes():
+    """The > 64 KB dynamic-LDS attribute of the scan / guard kernels is per device: a second device must work too."""
+    if dab.lib().dabhip_device_count() < 2:
+        pytest.skip("one GPU on this box")
+    caps = _captures(4)
+    multi = dab.Multi([0, 1])
+    single = dab.Engine(0)
+    assert multi.decode(caps) == single.decode(caps)
+    for b in range(4):
+        assert np.array_equal(multi.eti(b), single.eti(b))
+    single.close()
+    multi.close()
