@@ -94,9 +94,13 @@ __host__ __device__ __forceinline__ float guard_threshold(float n1c, float n1p, 
 }
 // Soft decisions (extension): value = round(soft_scale x) clamped to +-7, x = Re / Im of cur conj(prev).  The scale is made of
 // the two symbols' sample energies -- on a noise-free Mode-I signal mean |x| = (2048 / 1536) s(l) s(l-1) / sqrt(2), s = sqrt(sum_n
-// |x_n|^2), which the factor below maps to 4.5 -- so it is known before a symbol is transformed (the one-kernel OFDM stage cannot
+// |x_n|^2), which the factor below maps to 7.0 (= the clamp: see below) -- so it is known before a symbol is transformed (the one-kernel OFDM stage cannot
 // wait for a mean over its own output) and is the same in every kernel that demaps.  dc, dp = kGuardC s of the two symbols.
-constexpr float kSoftGain = 4.5f / 0.94280904f;
+// Round 4: the gain was 4.5 until the soft rule got an oracle (oracle/or_soft.c) that can be run in any quantisation: a sweep of the gain on the CPU
+// (tools/soft_quant_loss.py --gain, 14 captures x 24 TF per point) put the optimum of the 4-bit values at 6.5 .. 7 -- a clean value AT the clamp: range is
+// worth less than resolution near zero, where the decisions are made.  Payload BER 4-bit / unquantised at 5, 6, 7 dB: 1.17, 1.14, 1.82 at gain 4.5;
+// 1.06, 1.06, ~1.3 at 7.0 (profiles/r04_soft_quantisation.json, profiles/r04_soft_gain_sweep.txt).
+constexpr float kSoftGain = 7.0f / 0.94280904f;
 __host__ __device__ inline float soft_scale(float dc, float dp)
 {
   const float prod = dc * dp;

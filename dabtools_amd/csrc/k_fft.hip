@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kThreads, 4) void fic_fft_kernel(const uint8_t* con
 // of 6 consecutive words instead of 96 isolated ones).  A complete logical row is then exactly the reference's cif_time_deinterleaved:
 // out[i] = bit ((i >> 4) & 31) of row word ((i >> 9) * 16 + (i & 15)).
 // kBits = 1: hard decisions (the reference); kBits = 4: signed 4-bit soft values (extension):
-// value = round(4.5 x / mean|x|) clamped to +-7 with x = Re(cur conj(prev)) for the first bit and Im(cur conj(prev)) for
+// value = round(7 x / mean|x|) clamped to +-7 (soft_scale, device_types.hpp) with x = Re(cur conj(prev)) for the first bit and Im(cur conj(prev)) for
 // the second, i.e. positive = "bit 0"; the mean is taken over the 3072 components of the OFDM symbol.
 template <bool kPlanar, int kBits>
 __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restrict__ spectra, int syms_per_tf, int group_syms,

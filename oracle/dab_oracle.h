@@ -117,6 +117,7 @@ int or_replay(const uint8_t *iq, size_t nbytes, uint8_t *eti_out, int cap_frames
 #define OR_SOFT_Q8 8        /* the same scale in steps of 1/16, +-127/16 (SURVEY.md 8(f) rank 2 names 8 bits) */
 #define OR_SOFT_FLOAT 32    /* no quantisation */
 double or_soft_quantise(double v, int mode);
+void or_soft_set_gain(double mean_abs_value);                /* experiments (tools/soft_quant_loss.py --gain); <= 0: the product's 7.0 */
 void or_soft_demap(const struct or_sdr *s, int mode, float *fic /* 9216 */, float *msc /* 221184 */);   /* input_sdr.c:132-162 with values */
 void or_viterbi_soft(const float *soft, uint8_t *data, int nbits, int mode);                              /* viterbi.c:352-451, metric 28 + sum +-v */
 void or_fic_depuncture_soft(float *out, const float *in);                                                 /* depuncture.c:45-82 */

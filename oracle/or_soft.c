@@ -10,8 +10,8 @@
  *
  *   soft value   v = q(g x / (s(l) s(l-1))),   x = Re resp. -Im_stored of cur conj(prev) of a carrier (the two quantities whose
  *                signs the reference tests, input_sdr.c:135-143,157-158; v > 0 <=> the hard bit would be 0),
- *                s(l) = sqrt(sum over the 2048 samples of symbol l's FFT window of re^2 + im^2), g = 4.5 / 0.94280904
- *                (device_types.hpp: soft_scale -- a noise-free Mode-I symbol then has mean |v| = 4.5),
+ *                s(l) = sqrt(sum over the 2048 samples of symbol l's FFT window of re^2 + im^2), g = 7.0 / 0.94280904
+ *                (device_types.hpp: soft_scale -- a noise-free Mode-I symbol then has mean |x g / (s s')| = 7.0, the clamp),
  *                q = round to nearest (ties to even) and clamp to +-7            (OR_SOFT_Q4, what the product computes)
  *                q = the same in steps of 1/16, clamp +-127/16                   (OR_SOFT_Q8: the 8 bits SURVEY 8(f) names)
  *                q = identity                                                    (OR_SOFT_FLOAT: no quantisation at all)
@@ -33,7 +33,11 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define SOFT_GAIN (4.5 / 0.94280904)
+#define SOFT_GAIN_DEFAULT (7.0 / 0.94280904)
+static double soft_gain = SOFT_GAIN_DEFAULT;
+#define SOFT_GAIN soft_gain
+/* experiments only (tools/soft_quant_loss.py --gain): the product's gain is the default */
+void or_soft_set_gain(double mean_abs_value) { soft_gain = mean_abs_value > 0 ? mean_abs_value / 0.94280904 : SOFT_GAIN_DEFAULT; }
 
 double or_soft_quantise(double v, int mode)
 {

@@ -149,7 +149,7 @@ def test_plan_before_the_decode_uneven_batch_with_device_pointers():
     multi = dab.Multi([0] * 4)
     plan = [multi.plan(len(caps), b) for b in range(len(caps))]
     assert [p[0] for p in plan] == [0, 0, 0, 1, 1, 1, 2, 2, 3, 3]
-    assert [multi.plan(2048, s)[0] for s in (0, 255, 256, 2047)] == [0, 0, 1, 3] and multi.plan(3, 2)[0] == 2
+    assert [multi.plan(2048, s)[0] for s in (0, 511, 512, 2047)] == [0, 0, 1, 3] and multi.plan(3, 2)[0] == 2
     for rank in range(4):
         assert [b for b in range(10) if plan[b][0] == rank] == list(shard.shard_streams(10, 4, rank))
     bufs = []

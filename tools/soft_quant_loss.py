@@ -17,11 +17,17 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+GAIN = 0.0
+
+
 def one(job):
     snr, g, ntf = job
+    import ctypes
     import dabtools_amd as dab
     import oracle_lib as ol
     from dabtools_amd import payload
+    if GAIN > 0:
+        ol.oracle().or_soft_set_gain(ctypes.c_double(GAIN))
     cfg = payload.bench_cfg(dab, g, snr)
     iq = dab.synth_generate(cfg, ntf)
     out = {}
@@ -39,7 +45,10 @@ def main():
     ap.add_argument("--streams", type=int, default=8)
     ap.add_argument("--tfs", type=int, default=24)
     ap.add_argument("--workers", type=int, default=min(8, os.cpu_count() or 1))
+    ap.add_argument("--gain", type=float, default=0.0, help="experiment: mean |value| of a clean symbol (the product's rule: 7.0)")
     args = ap.parse_args()
+    global GAIN
+    GAIN = args.gain
     snrs = [float(x) for x in args.snrs.split(",")]
     jobs = [(s, g, args.tfs) for s in snrs for g in range(args.streams)]
     acc = {s: {} for s in snrs}
@@ -62,7 +71,7 @@ def main():
         rows.append(row)
     print(json.dumps({"what": "payload BER of the oracle's soft rule in three quantisations and of the reference's hard decisions, same captures, same decoder",
                       "workload": "benchmark ensemble (12 sub-channels, 1136 kbit/s), %d captures x %d TF per SNR, AWGN over the 2.048 MHz band" % (args.streams, args.tfs),
-                      "scale": "v = 4.5 / 0.9428 x Re|Im(cur conj(prev)) / (s(l) s(l-1)): mean |v| = 4.5 on a clean symbol; 4-bit clamps at +-7, 8-bit at +-7.94",
+                      "scale": "v = %.2f / 0.9428 x Re|Im(cur conj(prev)) / (s(l) s(l-1)): mean |v| = %.2f on a clean symbol; 4-bit clamps at +-7, 8-bit at +-7.94" % (args.gain or 7.0, args.gain or 7.0),
                       "rows": rows}, indent=1))
 
 
