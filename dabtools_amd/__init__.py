@@ -141,6 +141,7 @@ _SIGNATURES = {
     "dabhip_host_free": (None, [C.c_void_p]),
     "dabhip_synth_generate_device": (C.c_int, [C.POINTER(SynthCfg), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int]),
     "dabhip_dab_set_soft": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_engine_trace_nco": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_int]),
     "dabhip_multi_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dabhip_multi_slice_cpus": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int)]),
     "dabhip_engine_create_on_cpus": (C.c_void_p, [C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int]),
@@ -624,6 +625,13 @@ class Engine:
                                       ffs.ctypes.data_as(C.POINTER(C.c_double)), ncalls)
         _need(n >= 0, "engine_trace")
         return ints[:n], ffs[:n]
+
+    def trace_nco(self, stream, ncalls):
+        """per call: the re-tuning in Hz the software AFC applied to that call's samples (dabhip_engine_trace_nco)"""
+        out = np.zeros(ncalls, dtype=np.int32)
+        n = lib().dabhip_engine_trace_nco(self._h, stream, out.ctypes.data_as(C.POINTER(C.c_int32)), ncalls)
+        _need(n >= 0, "trace_nco")
+        return out[:n]
 
     def stage_ms(self):
         names = (C.c_char_p * 16)()

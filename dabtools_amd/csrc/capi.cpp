@@ -234,6 +234,11 @@ int dabhip_engine_trace(const dabhip_engine* e, int stream, int32_t* ints6, doub
   if (!e || !ints6 || stream < 0 || stream >= static_cast<int>(e->lane_of.size())) return -1;
   return e->lanes[e->lane_of[stream]]->trace(e->local_of[stream], ints6, ffs, cap_calls);
 }
+int dabhip_engine_trace_nco(const dabhip_engine* e, int stream, int32_t* nco_hz, int cap_calls)
+{
+  if (!e || stream < 0 || stream >= static_cast<int>(e->lane_of.size())) return -1;
+  return e->lanes[e->lane_of[stream]]->trace_nco(e->local_of[stream], nco_hz, cap_calls);
+}
 int dabhip_engine_stage_ms(const dabhip_engine* e, const char** names, float* ms, int cap)
 {
   if (!e) return -1;

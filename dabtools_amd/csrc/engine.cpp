@@ -1158,6 +1158,14 @@ int Engine::trace(int stream, int32_t* ints6, double* ffs, int cap_calls) const
   return n;
 }
 
+int Engine::trace_nco(int stream, int32_t* nco_hz, int cap_calls) const
+{
+  if (stream < 0 || stream >= nstreams_ || !nco_hz) return -1;
+  int n = 0;
+  for (int k = 0; k < max_calls_ && n < cap_calls; ++k, ++n) nco_hz[k] = h_descs_[static_cast<size_t>(stream) * max_calls_ + k].nco_hz;
+  return n;
+}
+
 // K2 (ofdm_fft_kernel) alone over the frames of the last decode: the same IQ, the same frame list and the same launch
 // shape (chunks of kFftChunkTfs) as the two-kernel OFDM stage, whatever stage the decode itself used.  This is the
 // HBM-roofline measurement of SURVEY.md 8(d): 311,296 B read + 1,245,184 B written per TF.

@@ -194,6 +194,7 @@ class Engine {
   bool eti_fetch_wait();
   const uint8_t* eti_device(int64_t* nframes) const;
   int trace(int stream, int32_t* ints6, double* ffs, int cap_calls) const;
+  int trace_nco(int stream, int32_t* nco_hz, int cap_calls) const;      // software AFC: the frequency each call's samples were de-rotated by
   const StageTimes& stage_times() const { return times_; }
   void fft_stats(int64_t* launches, int64_t* tfs, double* ms) const;
   int fft_roofline(int reps, int64_t* launches, int64_t* tfs, double* ms);   // K2 alone over the last decode's frames

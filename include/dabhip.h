@@ -270,6 +270,9 @@ int dabhip_engine_demapped_tf(dabhip_engine *e, int stream, int tf, int8_t *fic,
  * call: {ok, frame_read, coarse_timeshift, fine_timeshift, coarse_freq_shift, fifo_count}
  * as int32[6] per call plus fine_freq_shift as double per call. */
 int dabhip_engine_trace(const dabhip_engine *e, int stream, int32_t *ints6, double *ffs, int cap_calls);
+/* With the software AFC on: the re-tuning (Hz, relative to nominal) in effect during each call -- sdr->frequency of dab2eti.c:76-103 as the NCO
+ * applied it to that call's samples; 0 everywhere in parity mode. */
+int dabhip_engine_trace_nco(const dabhip_engine *e, int stream, int32_t *nco_hz, int cap_calls);
 
 /* Timing of the stages of the last decode (milliseconds, HIP events on the engine's stream).
  * names: "sync", "fft", "demap", "fic", "control", "gather", "viterbi", "eti", then host wall-clock

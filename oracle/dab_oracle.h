@@ -110,6 +110,13 @@ const double *or_sdr_frame(const struct or_sdr *s);   /* [196608][2] the samples
  * returns number of ETI frames written (each 6144 B) into eti_out (capacity in frames). */
 int or_replay(const uint8_t *iq, size_t nbytes, uint8_t *eti_out, int cap_frames,
               struct or_sdr_trace *trace, int trace_cap, int *ntrace);
+/* The same WITH the tuner feedback of demod_thread_fn (dab2eti.c:76-103) -- steering an NCO over the samples instead of the dongle's tuner, the one
+ * thing a file replay has to substitute (the product's dabhip_engine_set_afc).  nco_hz[call]: the frequency that call's frame was de-rotated by. */
+void or_sdr_set_afc(struct or_sdr *s, int on);
+int32_t or_sdr_nco_hz(const struct or_sdr *s);
+void or_afc_step(struct or_sdr *s);                                                /* dab2eti.c:76-103 */
+int or_replay_afc(const uint8_t *iq, size_t nbytes, uint8_t *eti_out, int cap_frames,
+                  struct or_sdr_trace *trace, int32_t *nco_hz, int trace_cap, int *ntrace);
 
 /* ---- soft-decision extension (or_soft.c): NOT reference behaviour -- the reference decodes hard decisions only
  * (input_sdr.c:157-158, depuncture.c:36-43); the rule is the product's own, restated independently of its kernels ------ */

@@ -183,6 +183,9 @@ struct or_sdr {
   double fine_freq_shift;
   int32_t startup_delay, force_timesync;
   int32_t last_ok, last_read;
+  /* software AFC (or_replay_afc below): the tuner of dab2eti.c:76-103 replaced by an NCO */
+  int32_t afc, tuner_hz, nco_hz_used;
+  uint32_t rng;
 };
 
 struct or_sdr *or_sdr_new(void)
@@ -230,6 +233,7 @@ int or_sdr_demod(struct or_sdr *s, const uint8_t *chunk, int len, uint8_t *fic_b
   s->last_ok = 0;
   s->last_read = 0;
   s->coarse_freq_shift = 0;
+  s->nco_hz_used = s->afc ? s->tuner_hz : 0;
   fifo_write(s, chunk, len);
   if (s->count < OR_TF_SAMPLES * 3) return 0;
   fifo_read_shifted(s, OR_TF_BYTES, s->coarse_timeshift + s->fine_timeshift, s->buffer);
@@ -243,6 +247,16 @@ int or_sdr_demod(struct or_sdr *s, const uint8_t *chunk, int len, uint8_t *fic_b
   s->force_timesync = 0;
   if (s->coarse_timeshift) return 0;
   for (j = 0; j < OR_TF_SAMPLES; j++) { s->frame[2 * j] = s->real[j]; s->frame[2 * j + 1] = s->imag[j]; }
+  if (s->afc && s->tuner_hz != 0) {
+    /* NOT in the reference (its tuner moves, dab2eti.c:76-103; a file has none): the frame de-rotated by exp(-2 pi i f n / fs), n = sample index in
+     * the frame buffer, f = the re-tuning accumulated so far.  The null-symbol test above ran on the raw samples, as in the product. */
+    for (j = 0; j < OR_TF_SAMPLES; j++) {
+      const double a = -2.0 * M_PI * (double)s->tuner_hz * (double)j / 2048000.0, c = cos(a), sn = sin(a);
+      const double xr = s->frame[2 * j], xi = s->frame[2 * j + 1];
+      s->frame[2 * j] = xr * c - xi * sn;
+      s->frame[2 * j + 1] = xr * sn + xi * c;
+    }
+  }
   s->fine_timeshift = or_fine_time_sync(s->frame);
   /* input_sdr.c:86-88 is dead code: coarse_freq_shift was zeroed above */
   or_dft(2048, s->frame + 2 * (2656 + 505 + s->fine_timeshift), tmp, -1);
@@ -296,6 +310,28 @@ const uint8_t *or_sdr_buffer(const struct or_sdr *s) { return s->buffer; }
 const double *or_sdr_frame(const struct or_sdr *s) { return s->frame; }
 
 /* ------------------------------------------------------------------------- */
+/* The tuner feedback of demod_thread_fn, dab2eti.c:76-103, after EVERY sdr_demod call (also those that produced no frame: coarse_freq_shift is 0
+ * then, fine_freq_shift stale), on the accumulated re-tuning instead of sdr->frequency:
+ *   |coarse| > 1            -> -+1000 Hz                                   (dab2eti.c:77-85)
+ *   |coarse| == 1           -> -+ (rand() % 1000) Hz                       (:87-97; rand() is the C library's: restated with the LCG the product uses,
+ *                                                                            x <- 1103515245 x + 12345, step = (x >> 16) % 1000, x0 = 0)
+ *   coarse == 0 and abs(fine) > 50  -> + fine / 3                          (:98-103; abs() is the INT one: the double is truncated first; the sum is
+ *                                                                            stored into the unsigned sdr->frequency: floor) */
+void or_sdr_set_afc(struct or_sdr *s, int on) { s->afc = on; }
+int32_t or_sdr_nco_hz(const struct or_sdr *s) { return s->nco_hz_used; }   /* the frequency the LAST call's samples were de-rotated by */
+void or_afc_step(struct or_sdr *s)
+{
+  const int c = s->coarse_freq_shift;
+  if (abs(c) > 1) s->tuner_hz += c < 0 ? -1000 : 1000;
+  if (abs(c) == 1) {
+    int step;
+    s->rng = s->rng * 1103515245u + 12345u;
+    step = (int)((s->rng >> 16) % 1000u);
+    s->tuner_hz += c < 0 ? -step : step;
+  }
+  if (c == 0 && abs((int)s->fine_freq_shift) > 50) s->tuner_hz += (int)floor(s->fine_freq_shift / 3);
+}
+
 struct sink { uint8_t *out; int cap, n; };
 static void sink_cb(const uint8_t *eti, void *user)
 {
@@ -304,23 +340,39 @@ static void sink_cb(const uint8_t *eti, void *user)
   k->n++;
 }
 
-/* dab2eti.c:60-130 without USB, threads and tuner feedback */
-int or_replay(const uint8_t *iq, size_t nbytes, uint8_t *eti_out, int cap_frames,
-              struct or_sdr_trace *trace, int trace_cap, int *ntrace)
+/* dab2eti.c:60-130 without USB and threads; afc = 0: without the tuner feedback (a file has no tuner: the reference's behaviour on a recording);
+ * afc != 0: with the feedback of dab2eti.c:76-103 steering an NCO (nco_hz[call] = the frequency that call's samples were de-rotated by) */
+static int replay(const uint8_t *iq, size_t nbytes, int afc, uint8_t *eti_out, int cap_frames,
+                  struct or_sdr_trace *trace, int32_t *nco_hz, int trace_cap, int *ntrace)
 {
   struct sink k = {eti_out, cap_frames, 0};
   struct or_sdr *s = or_sdr_new();
   struct or_dab *d = or_dab_new(sink_cb, &k);
   size_t off;
   int nt = 0;
+  or_sdr_set_afc(s, afc);
   for (off = 0; off + OR_CHUNK_BYTES <= nbytes; off += OR_CHUNK_BYTES) {
     int ok = or_sdr_demod(s, iq + off, OR_CHUNK_BYTES, or_dab_tf_fic(d), or_dab_tf_msc(d));
     if (trace && nt < trace_cap) or_sdr_get_trace(s, &trace[nt]);
+    if (nco_hz && nt < trace_cap) nco_hz[nt] = or_sdr_nco_hz(s);
     nt++;
     if (ok) or_dab_process_frame(d);
+    if (afc) or_afc_step(s);
   }
   if (ntrace) *ntrace = nt;
   or_dab_free(d);
   or_sdr_free(s);
   return k.n;
+}
+
+int or_replay(const uint8_t *iq, size_t nbytes, uint8_t *eti_out, int cap_frames,
+              struct or_sdr_trace *trace, int trace_cap, int *ntrace)
+{
+  return replay(iq, nbytes, 0, eti_out, cap_frames, trace, NULL, trace_cap, ntrace);
+}
+
+int or_replay_afc(const uint8_t *iq, size_t nbytes, uint8_t *eti_out, int cap_frames,
+                  struct or_sdr_trace *trace, int32_t *nco_hz, int trace_cap, int *ntrace)
+{
+  return replay(iq, nbytes, 1, eti_out, cap_frames, trace, nco_hz, trace_cap, ntrace);
 }

@@ -88,6 +88,8 @@ def oracle():
             getattr(L, f).argtypes = [C.c_void_p]
         L.or_dab_last_fibs.restype = u8p
         L.or_dab_last_fibs.argtypes = [C.c_void_p, u8p]
+        L.or_replay_afc.restype = C.c_int
+        L.or_replay_afc.argtypes = [u8p, C.c_size_t, u8p, C.c_int, C.POINTER(SdrTrace), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int)]
         L.or_replay_soft.restype = C.c_int
         L.or_replay_soft.argtypes = [u8p, C.c_size_t, C.c_int, u8p, C.c_int, f32p, C.c_int, C.POINTER(C.c_int)]
         _oracle = L
@@ -198,3 +200,16 @@ class SoftDab:
         if self.d:
             oracle().or_dab_free(self.d)
             self.d = None
+
+
+def or_replay_afc(iq, cap_frames=4096, trace_cap=4096):
+    """or_replay with the tuner feedback of dab2eti.c:76-103 steering an NCO: (ETI frames, per-call traces, per-call NCO frequency)."""
+    iq = np.ascontiguousarray(iq, dtype=np.uint8)
+    eti = np.zeros((cap_frames, 6144), dtype=np.uint8)
+    tr = (SdrTrace * trace_cap)()
+    nco = np.zeros(trace_cap, dtype=np.int32)
+    nt = C.c_int(0)
+    n = oracle().or_replay_afc(_ptr(iq), C.c_size_t(iq.size), _ptr(eti), cap_frames, tr, nco.ctypes.data_as(C.POINTER(C.c_int32)), trace_cap, C.byref(nt))
+    assert n <= cap_frames
+    k = min(nt.value, trace_cap)
+    return eti[:n], [tr[i] for i in range(k)], nco[:k]

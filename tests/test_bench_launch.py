@@ -106,9 +106,28 @@ def test_roofline_objects_are_computable_from_the_tracked_profile():
     cycles = 2 * 64 + 4 * (insts - 64)
     assert abs(v["frac"] - cycles * bench.wave_steps(frames, 0) / 5.0e-3 / (1024 * clock * 1e9)) < 1e-9
     assert v["survivor_traffic"]["x_stage_io"] > 10
+    assert v["frac_if_every_instruction_took_2_cycles"] < v["frac"] and 0.3 < v["frac_from_counters"]["value"] < 1.0
     f = out["roofline_ofdm_fused"]
-    assert f["bound"] == "valu issue / lds" and 5 < f["lds"]["bank_conflict_pct"] < 40 and f["hbm"]["frac"] < 0.3
-    assert f["valu_issue"]["frac_if_all_2_cycle"] < f["valu_issue"]["frac_if_all_4_cycle"] < 1.2
+    assert f["bound"] == "valu issue" and 5 < f["lds"]["bank_conflict_pct"] < 40 and f["hbm"]["frac"] < 0.3
+    # ONE number: the instruction mix of the symbol loop priced in issue cycles -- no bracket -- and the counters' own busy
+    # fraction beside it; the two are independent and have to tell the same story
+    import json
+    assert "frac_if_all" not in json.dumps(f)
+    mix = json.load(open(bench.PROFILE_FUSED_MIX))
+    insts = f["valu_issue"]["insts_per_wave_per_transform"]
+    cyc = mix["issue_cycles_per_unit"] + max(0.0, insts - mix["valu_per_unit"]) * mix["remainder_cycles_per_valu"]
+    assert abs(f["valu_issue"]["issue_cycles_per_wave_per_transform"] - cyc) < 1e-6 and 250 < mix["valu_per_unit"] < insts < 400
+    assert 0.4 < f["frac_from_counters"]["value"] < 1.0
+    # (stage time of this call is made up: compare the model with the counters on the profiled run's own time instead)
+    t_prof = prof.cell("clk", "ofdm_demap_kernel<false>", "DURATION_NS") * 1e-9
+    tr_prof = prof.meta("full_decodes") * prof.meta("ofdm_transforms_per_decode") + prof.meta("ofdm_transforms_setup")
+    clock = prof.cell("clk", "ofdm_demap_kernel<false>", "GRBM_GUI_ACTIVE") / 8 / prof.cell("clk", "ofdm_demap_kernel<false>", "DURATION_NS")
+    model = 4.0 * cyc * tr_prof / t_prof / 1e9 / (1024 * clock)
+    assert abs(model - f["frac_from_counters"]["value"]) < 0.12, (model, f["frac_from_counters"]["value"])
+    # the mix file belongs to THIS tree's kernel sources
+    import hashlib
+    src = b"".join(open(os.path.join(ROOT, "dabtools_amd", "csrc", n), "rb").read() for n in ("k_fused.hip", "fft_core.hpp", "device_types.hpp"))
+    assert mix["source_sha256"] == hashlib.sha256(src).hexdigest(), "profiles/r04_fused_isa_mix.json is stale: run tools/fused_isa_mix.sh"
     # a missing profile, or a missing cell, is an error that says what to do
     import pytest
     with pytest.raises(SystemExit, match="refresh_profiles"):

@@ -460,6 +460,33 @@ def test_software_afc_decodes_offset_captures():
     eng.close()
 
 
+def test_software_afc_trace_equals_the_oracles_tuner_rule():
+    """the AFC is trace-checked, not only property-checked.  or_replay_afc restates the tuner feedback of demod_thread_fn
+    (dab2eti.c:76-103: |coarse| > 1 -> -+1000 Hz, == 1 -> a random step below 1 kHz, else fine / 3 beyond 50 Hz, after EVERY call) on an fp64 NCO;
+    call by call the GPU's re-tuning sequence, the integer shifts, the call at which each frame is accepted and the ETI bytes are the oracle's.
+    (The frequency estimate is compared to 1e-6 Hz: K1 de-rotates in fp64 like the oracle.)"""
+    ntf = 40
+    cfgs = [dab.synth_preset(1, seed=450 + i, cif_count0=77 * i, cfo_hz=cfo, snr_db=snr, skip_samples=skip)
+            for i, (cfo, snr, skip) in enumerate(((3400.0, 25.0, 0), (-1700.0, 25.0, 30000), (1100.0, 1000.0, 0), (-260.0, 15.0, 0), (0.0, 1000.0, 0)))]
+    streams = [dab.synth_generate(c, ntf) for c in cfgs]
+    eng = dab.Engine(0)
+    eng.set_afc(True)
+    eng.decode(streams)
+    for b, iq in enumerate(streams):
+        want_eti, want_tr, want_nco = ol.or_replay_afc(iq)
+        ints, ffs = eng.trace(b, len(want_tr))
+        nco = eng.trace_nco(b, len(want_tr))
+        assert len(ints) == len(want_tr)
+        assert np.array_equal(nco, want_nco), (b, list(nco[:30]), list(want_nco[:30]))
+        for k, t in enumerate(want_tr):
+            assert tuple(ints[k][:5]) == (t.ok, t.read_frame, t.coarse_timeshift, t.fine_timeshift, t.coarse_freq_shift), (b, k)
+            assert ints[k][5] == t.fifo_count and abs(ffs[k] - t.fine_freq_shift) < 1e-6, (b, k, ffs[k], t.fine_freq_shift)
+        if b < 4:
+            assert len(set(want_nco.tolist())) > 2                      # the rule did move the NCO
+        assert np.array_equal(eng.eti(b), want_eti), "stream %d: ETI differs from the oracle's AFC replay" % b
+    eng.close()
+
+
 def _payload_errors(eti, cfg, ntf):
     """(frames, frames whose MST differs from what was sent, wrong payload bits, payload bits) over the decoded frames"""
     import eti_check
