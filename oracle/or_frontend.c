@@ -314,10 +314,10 @@ const double *or_sdr_frame(const struct or_sdr *s) { return s->frame; }
  * then, fine_freq_shift stale), on the accumulated re-tuning instead of sdr->frequency:
  *   |coarse| > 1            -> -+1000 Hz                                   (dab2eti.c:77-85)
  *   |coarse| == 1           -> -+ (rand() % 1000) Hz                       (:87-97; rand() is the C library's: restated with the LCG the product uses,
- *                                                                            x <- 1103515245 x + 12345, step = (x >> 16) % 1000, x0 = 0)
+ *                                                                            x <- 1103515245 x + 12345, step = (x >> 16) % 1000, x0 = 1 = srand's default seed)
  *   coarse == 0 and abs(fine) > 50  -> + fine / 3                          (:98-103; abs() is the INT one: the double is truncated first; the sum is
  *                                                                            stored into the unsigned sdr->frequency: floor) */
-void or_sdr_set_afc(struct or_sdr *s, int on) { s->afc = on; }
+void or_sdr_set_afc(struct or_sdr *s, int on) { s->afc = on; s->rng = 1; }
 int32_t or_sdr_nco_hz(const struct or_sdr *s) { return s->nco_hz_used; }   /* the frequency the LAST call's samples were de-rotated by */
 void or_afc_step(struct or_sdr *s)
 {
