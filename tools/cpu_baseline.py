@@ -129,7 +129,21 @@ def main():
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = ncores
-    k = args.cores or usable              # BASELINE.md section 3 asks for "x cores": the box's, not a sample of them (round 3 used 32 of 256)
+    # BASELINE.md section 3 asks for "x cores": every CPU this process is ALLOWED to use -- its affinity mask, capped by the container's CFS quota
+    # (cgroup cpu.max: on the GPU boxes of this pool 16 CPUs' worth of time on a 256-thread host; 256 processes would only take turns on them)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, -(-int(q) // int(per)))
+    except (OSError, ValueError):
+        try:
+            q, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, -(-q // per))
+        except (OSError, ValueError):
+            pass
+    k = args.cores or min(usable, quota or usable)
     caps = [np.fromfile(p, dtype=np.uint8)[: args.tfs * 393216] for p in args.iq]
 
     # 1. whole path, CPU restatement, one core
@@ -141,7 +155,7 @@ def main():
         "value": neti / dt, "unit": "ETI frames/s", "cores": 1, "kind": "port",
         "sample": "oracle/or_replay (whole path IQ -> ETI, scalar viterbi.c semantics, own fp64 DFT: libfftw3 absent) on %d streams x %d TF "
                   "of the same workload: %d ETI frames in %.2f s on 1 of %d host cores" % (len(caps), args.tfs, neti, dt, ncores),
-        "host_cores": ncores,
+        "host_cores": ncores, "usable_cpus": usable, "cfs_quota_cpus": quota,
     }
 
     # the same on every core at once: one process per core, two captures each (the oracle is re-entrant, but the reference it stands for is not:
@@ -157,8 +171,8 @@ def main():
         rate = sum(r[0] / r[1] for r in res)
         overlap = min(r[3] for r in res) - max(r[2] for r in res)
         out["all_cores"] = {"value": rate, "unit": "ETI frames/s", "cores": k, "per_core": rate / k, "kind": "port",
-                            "sample": "%d processes at once (one per usable CPU of %d), each oracle/or_replay of two %d-TF captures of the workload: sum of the per-process "
-                                      "rates; all ran concurrently for %.2f s of the slowest one's %.2f s" % (k, ncores, args.tfs, max(overlap, 0.0), max(r[1] for r in res))}
+                            "sample": "%d processes at once (one per CPU this container may use: affinity %d, CFS quota %s, host %d), each oracle/or_replay of two %d-TF captures of the workload: sum of the per-process "
+                                      "rates; all ran concurrently for %.2f s of the slowest one's %.2f s" % (k, usable, quota, ncores, args.tfs, max(overlap, 0.0), max(r[1] for r in res))}
 
     # demapped frames of a few captures (untimed; oracle front end), shared with the forked workers
     O = oracle_lib.oracle()
