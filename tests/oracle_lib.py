@@ -126,6 +126,58 @@ def ref(sse=False):
     return _ref[key]
 
 
+_ref_frontend = []
+
+
+def ref_frontend():
+    """The REAL reference front end (input_sdr.c, sdr_sync.c, sdr_fifo.c, unmodified) with its FFTW3 calls served by the image's hipFFTW
+    (oracle/_ref/libdabref_frontend.so; see oracle/ref_frontend_harness.c), or None when it was not built.  Needs a GPU at run time."""
+    if not _ref_frontend:
+        so = os.path.join(ORACLE_DIR, "_ref", "libdabref_frontend.so")
+        if not os.path.exists(so):
+            _ref_frontend.append(None)
+        else:
+            L = C.CDLL(so)
+            L.reff_new.restype = C.c_void_p
+            L.reff_free.argtypes = [C.c_void_p]
+            L.reff_demod.restype = C.c_int
+            L.reff_demod.argtypes = [C.c_void_p, u8p, C.c_int, u8p, u8p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+            L.reff_symbols.restype = C.POINTER(C.c_double)
+            L.reff_symbols.argtypes = [C.c_void_p]
+            L.reff_buffer.restype = u8p
+            L.reff_buffer.argtypes = [C.c_void_p]
+            _ref_frontend.append(L)
+    return _ref_frontend[0]
+
+
+def ref_frontend_replay(iq, with_backend=True):
+    """dab2eti's loop (dab2eti.c:60-75, no tuner) over the REAL reference objects: sdr_demod of libdabref_frontend.so per 262,144-byte buffer and,
+    for every frame it returns, dab_process_frame of libdabref.so.  -> (ETI frames, per-call (ok, cts, fts, cfs, fifo_count, ffs), per-frame bits)"""
+    F = ref_frontend()
+    R = ref() if with_backend else None
+    iq = np.ascontiguousarray(iq, dtype=np.uint8)
+    h = F.reff_new()
+    H = R.refh_new() if R is not None else None
+    fic, msc = np.zeros(9216, np.uint8), np.zeros(221184, np.uint8)
+    ints, ffs = (C.c_int32 * 6)(), C.c_double(0)
+    calls, frames = [], []
+    for off in range(0, iq.size - 262144 + 1, 262144):
+        ok = F.reff_demod(h, _ptr(iq[off:off + 262144]), 262144, _ptr(fic), _ptr(msc), ints, C.byref(ffs))
+        calls.append((ints[0], ints[2], ints[3], ints[4], ints[5], ffs.value))
+        if ok:
+            frames.append((fic.copy(), msc.copy()))
+            if H is not None:
+                C.memmove(R.refh_tf_fic(H), _ptr(fic), fic.size)
+                C.memmove(R.refh_tf_msc(H), _ptr(msc), msc.size)
+                R.refh_process(H)
+    eti = None
+    if H is not None:
+        n = R.refh_neti(H)
+        eti = np.ctypeslib.as_array(R.refh_eti(H), (max(n, 1), 6144))[:n].copy()
+    F.reff_free(h)
+    return eti, calls, frames
+
+
 # ---- thin numpy wrappers around the oracle -------------------------------------------
 def or_viterbi(symbols, nbits):
     sym = np.ascontiguousarray(symbols, dtype=np.uint8)
