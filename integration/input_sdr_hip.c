@@ -3,9 +3,9 @@
  * transform, DQPSK demap, frequency de-interleave) on the GPU.  Replaces input_sdr.o sdr_sync.o sdr_fifo.o and with them
  * the libfftw3 dependency; dab2eti.c:68,234 are its callers.
  *
- * NOT compiled in this repository: the reference's input_sdr.h includes <fftw3.h>, which the build image lacks (a
- * stand-in header would prove nothing).  The same calls in the same order are exercised through ctypes by
- * tests/test_gpu_parity.py::test_seams_s2_s3_streaming_match_oracle.
+ * Compiled by oracle/Makefile into oracle/_ref/libdabref_hipS2.so against the reference's own dab.h / input_sdr.h (whose <fftw3.h> resolves to the
+ * FFTW3-API header the image's ROCm ships, hipfft/hipfftw.h -- for the types of struct sdr_state_t only: nothing here calls an FFT) and run under the
+ * same harness as the reference's real front end: tests/test_gpu_frontend_ref.py::test_seam_s2_binding_under_the_reference_harness.
  */
 #include "dab.h"
 #include "input_sdr.h"

@@ -14,14 +14,16 @@
  *   lock FSM, CIF ring, time de-interleave, ETI assembly): PINNED against the
  *   real reference objects built from /root/reference/src into
  *   oracle/_ref/libdabref.so (tests/test_oracle_vs_ref.py, tests/golden/).
- *   front end (sdr_demod, sdr_sync): PARITY UNPINNED.  input_sdr.c and
- *   sdr_sync.c need <fftw3.h> (libfftw3, version unpinned in the reference's
- *   Makefile:3), which this image lacks, so they cannot be built here.  The
- *   restatement follows the reference line by line with its own
- *   double-precision DFT and is anchored indirectly: synthetic IQ ->
- *   front-end restatement -> REAL reference back end yields byte-correct ETI
- *   carrying the modulated payload.  sdr_fifo.c (the timing actuator) does
- *   build and pins or_fifo_*.
+ *   front end (sdr_demod, sdr_sync): input_sdr.c and sdr_sync.c need <fftw3.h> / libfftw3 (version unpinned in
+ *   the reference's Makefile:3), which this image lacks.  Since round 4 they ARE built all the same: unmodified,
+ *   against AMD's implementation of the FFTW3 API that the image's ROCm installation ships (hipfft/hipfftw.h,
+ *   libhipfftw.so; oracle/Makefile: _ref/libdabref_frontend.so, oracle/ref_frontend_harness.c), and this
+ *   restatement is held against that object code call by call -- return value, both time shifts, coarse frequency
+ *   shift, FIFO count, fine frequency estimate, all 230,400 bits of every frame (tests/test_gpu_frontend_ref.py;
+ *   on a GPU box only: hipFFTW executes its plans on the device).  PINNED up to the FFT library: the DFT behind
+ *   fftw_execute is hipFFTW's, not libfftw3's -- a third party's in both cases, agreeing to ~1e-13.  Older anchors
+ *   remain: synthetic IQ -> front-end restatement -> REAL back end yields byte-correct ETI; sdr_fifo.c (the timing
+ *   actuator) pins or_fifo_*; numpy.fft and a NumPy restatement (tests/test_frontend_anchors.py).
  */
 #ifndef DAB_ORACLE_H
 #define DAB_ORACLE_H

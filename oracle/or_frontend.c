@@ -3,12 +3,13 @@
  * (input_sdr.c, sdr_sync.c, sdr_fifo.c) and of the replay loop of dab2eti.c.
  * TEST INFRASTRUCTURE ONLY (see dab_oracle.h).
  *
- * PARITY UNPINNED for the FFT-consuming parts: the reference calls libfftw3 (double,
- * version unpinned, Makefile:3) at input_sdr.c:91-93,116-119 and sdr_sync.c:93-95,
- * 167-169,223-225; libfftw3 is not in this image, so input_sdr.c / sdr_sync.c cannot be
- * built.  FFTW's published contract is restated by or_dft(): out[k] = sum_j in[j]
- * exp(sign 2 pi i jk/n), unnormalised.  Only signs and arg-maxima of DFT outputs are
- * consumed downstream.  The byte FIFO (sdr_fifo.c) does build and pins or_fifo_*.
+ * Pinning: the reference calls libfftw3 (double, version unpinned, Makefile:3) at input_sdr.c:91-93,116-119 and
+ * sdr_sync.c:93-95,167-169,223-225; libfftw3 is not in this image.  FFTW's published contract is restated by or_dft():
+ * out[k] = sum_j in[j] exp(sign 2 pi i jk/n), unnormalised; only signs and arg-maxima of DFT outputs are consumed
+ * downstream.  Since round 4 the reference's own input_sdr.c / sdr_sync.c / sdr_fifo.c, unmodified, are built against the
+ * FFTW3-API library the image DOES have (AMD's hipFFTW, oracle/_ref/libdabref_frontend.so) and this file is held against
+ * that object code call by call and bit by bit (tests/test_gpu_frontend_ref.py, GPU box only).  The byte FIFO (sdr_fifo.c)
+ * also builds by itself and pins or_fifo_* on the CPU.
  */
 #include "dab_oracle.h"
 

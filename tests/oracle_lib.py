@@ -126,16 +126,17 @@ def ref(sse=False):
     return _ref[key]
 
 
-_ref_frontend = []
+_ref_frontend = {}
 
 
-def ref_frontend():
-    """The REAL reference front end (input_sdr.c, sdr_sync.c, sdr_fifo.c, unmodified) with its FFTW3 calls served by the image's hipFFTW
-    (oracle/_ref/libdabref_frontend.so; see oracle/ref_frontend_harness.c), or None when it was not built.  Needs a GPU at run time."""
-    if not _ref_frontend:
-        so = os.path.join(ORACLE_DIR, "_ref", "libdabref_frontend.so")
+def ref_frontend(which="frontend"):
+    """which = "frontend": the REAL reference front end (input_sdr.c, sdr_sync.c, sdr_fifo.c, unmodified) with its FFTW3 calls served by the image's
+    hipFFTW (oracle/_ref/libdabref_frontend.so; see oracle/ref_frontend_harness.c); which = "hipS2": the same harness over integration/input_sdr_hip.c
+    (seam S2 over libdabhip).  None when it was not built.  Both need a GPU at run time."""
+    if which not in _ref_frontend:
+        so = os.path.join(ORACLE_DIR, "_ref", "libdabref_%s.so" % which)
         if not os.path.exists(so):
-            _ref_frontend.append(None)
+            _ref_frontend[which] = None
         else:
             L = C.CDLL(so)
             L.reff_new.restype = C.c_void_p
@@ -146,14 +147,14 @@ def ref_frontend():
             L.reff_symbols.argtypes = [C.c_void_p]
             L.reff_buffer.restype = u8p
             L.reff_buffer.argtypes = [C.c_void_p]
-            _ref_frontend.append(L)
-    return _ref_frontend[0]
+            _ref_frontend[which] = L
+    return _ref_frontend[which]
 
 
-def ref_frontend_replay(iq, with_backend=True):
+def ref_frontend_replay(iq, with_backend=True, which="frontend"):
     """dab2eti's loop (dab2eti.c:60-75, no tuner) over the REAL reference objects: sdr_demod of libdabref_frontend.so per 262,144-byte buffer and,
     for every frame it returns, dab_process_frame of libdabref.so.  -> (ETI frames, per-call (ok, cts, fts, cfs, fifo_count, ffs), per-frame bits)"""
-    F = ref_frontend()
+    F = ref_frontend(which)
     R = ref() if with_backend else None
     iq = np.ascontiguousarray(iq, dtype=np.uint8)
     h = F.reff_new()
@@ -173,7 +174,7 @@ def ref_frontend_replay(iq, with_backend=True):
     eti = None
     if H is not None:
         n = R.refh_neti(H)
-        eti = np.ctypeslib.as_array(R.refh_eti(H), (max(n, 1), 6144))[:n].copy()
+        eti = np.ctypeslib.as_array(R.refh_eti(H), (n, 6144)).copy() if n else np.zeros((0, 6144), np.uint8)
     F.reff_free(h)
     return eti, calls, frames
 
