@@ -6,7 +6,7 @@
  *
  * Only the reference files that build with gcc alone are used: viterbi.c depuncture.c
  * dab_tables.c fic.c misc.c dab.c sdr_fifo.c (and the viterbi_spiral*.c pair for the SSE
- * variant).  input_sdr.c / sdr_sync.c need libfftw3 and are NOT built.
+ * variant).  input_sdr.c / sdr_sync.c need an FFTW3 library: see ref_frontend_harness.c.
  */
 #include <stdint.h>
 #include <stdlib.h>

@@ -1,11 +1,12 @@
-"""Independent anchors for the front end, whose reference (input_sdr.c / sdr_sync.c) cannot be built here (libfftw3 is
-absent) and therefore stays PARITY UNPINNED.  Nothing below shares code with oracle/or_frontend.c or with the kernels:
+"""Independent anchors for the front end that run WITHOUT a GPU.  The reference's input_sdr.c / sdr_sync.c need an FFTW3 library; libfftw3 is absent,
+and the build of them over AMD's hipFFTW (tests/test_gpu_frontend_ref.py, round 4: the real pin) executes on the GPU.  So the CPU suite keeps these.
+Nothing below shares code with oracle/or_frontend.c or with the kernels:
 
   * numpy.fft (pocketfft, fp64) against the oracle's own mixed-radix DFT, both signs, the three sizes used;
   * a NumPy restatement of dab_coarse_time_sync / dab_fine_time_sync / dab_coarse_freq_sync_2 / dab_fine_freq_corr and of
     the OFDM + DQPSK + demap loop, written from sdr_sync.c / input_sdr.c by reading, with the PRS and the frequency
     de-interleaver taken from the reference's literal arrays (tests/golden/tables.npz), against or_* on seeded frames.
-These narrow what a consistent misreading could hide; they do not replace a run of the real front end."""
+These narrow what a consistent misreading could hide; the run of the real front end is tests/test_gpu_frontend_ref.py."""
 import ctypes as C
 import os
 

@@ -145,8 +145,9 @@ def test_reference_eti_frames_parse_with_the_validator():
 def test_front_end_trace_matches_the_survey_probe():
     """the surveyor drove the reference's own input_sdr.c / sdr_sync.c (with a throw-away DFT behind
     fftw3's API) over this recipe and observed fine_timeshift = 16, -12, -2, 22, -8, -2, 20, -10, -2, 20 on the aligned
-    stream, 4*(T-15) ETI frames (T=40 -> 100), and 92 frames for a 50,000-sample offset.  The front-end restatement has
-    no stronger anchor (libfftw3 is absent: parity unpinned), so at least those observations are held here."""
+    stream, 4*(T-15) ETI frames (T=40 -> 100), and 92 frames for a 50,000-sample offset.  The CPU suite has no
+    stronger anchor for the front-end restatement (libfftw3 is absent; the build over hipFFTW, tests/test_gpu_frontend_ref.py, needs the GPU), so
+    those observations are held here."""
     import dabtools_amd as dab
     cfg = dab.synth_preset(1, seed=1)
     eti, trace = ol.or_replay(dab.synth_generate(cfg, 40))
