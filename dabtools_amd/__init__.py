@@ -150,6 +150,7 @@ _SIGNATURES = {
     "dabhip_engine_stream_status": (C.c_uint32, [C.c_void_p, C.c_int]),
     "dabhip_multi_stream_status": (C.c_uint32, [C.c_void_p, C.c_int]),
     "dabhip_stream_status": (C.c_uint32, [C.c_void_p, C.c_int]),
+    "dabhip_stream_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
     "dabhip_dab_status": (C.c_uint32, [C.c_void_p]),
     "dabhip_engine_eti_fetch": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64]),
     "dabhip_engine_eti_fetch_wait": (C.c_int, [C.c_void_p]),
@@ -851,6 +852,12 @@ class Stream:
 
     def status(self, stream):
         return int(lib().dabhip_stream_status(self._h, stream))
+
+    def stage_ms(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = lib().dabhip_stream_stage_ms(self._h, names, ms, 16)
+        return {names[i].decode(): ms[i] for i in range(n)}
 
     def eti_fetch(self, dst_ptr, cap_frames):
         """dabhip_stream_eti_fetch: all frames of the segment fed last on their way to (page-locked) host memory; returns their number."""

@@ -762,9 +762,29 @@ struct dabhip_stream {
            launch_host_gather(d_gather_descs[w].get(), static_cast<int>(descs.size()), wgs, up_stream[0]) == hipSuccess;
   }
   // segment -> window w of every stream, behind the reserve; on stream `one`, or dealt round-robin to the upload streams
+  // segments that already are in device memory: one launch copies them all (256 copy commands cost 2.9 ms back to back and as much on the host)
+  bool copy_by_kernel(int w, const uint8_t* const* iq, const size_t* nbytes, hipStream_t st)
+  {
+    HostList<CopyDesc>& descs = gather_descs[w];
+    descs.clear();
+    uint32_t longest = 0;
+    for (int b = 0; b < n; ++b) {
+      DeviceBuffer<uint8_t>& to = *win[w][b];
+      if (nbytes[b] >= (size_t(1) << 32)) return false;
+      if (!to.reserve(kWindowReserve + std::max<size_t>(nbytes[b], 16))) return false;
+      if (nbytes[b] == 0) continue;
+      descs.push_back(CopyDesc{iq[b], to.get() + kWindowReserve, static_cast<uint32_t>(nbytes[b]), 0});
+      longest = std::max(longest, static_cast<uint32_t>(nbytes[b]));
+    }
+    if (descs.empty()) return true;
+    return d_gather_descs[w].upload(descs, st) && launch_device_gather(d_gather_descs[w].get(), static_cast<int>(descs.size()), longest, st) == hipSuccess;
+  }
+  HostList<CopyDesc> history_descs;            // the bytes of earlier segments moved in front of the segment being fed (dabhip_stream_feed)
+  DeviceBuffer<CopyDesc> d_history_descs;
   bool upload(int w, const uint8_t* const* iq, const size_t* nbytes, bool on_device, hipStream_t one)
   {
     if (!one && !on_device && upload_by_kernel(w, iq, nbytes)) return true;
+    if (on_device && copy_by_kernel(w, iq, nbytes, one ? one : up_stream[0])) return true;
     for (int b = 0; b < n; ++b) {
       DeviceBuffer<uint8_t>& to = *win[w][b];
       hipStream_t st = one ? one : up_stream[b % kUpStreams];
@@ -846,6 +866,9 @@ extern "C" int64_t dabhip_stream_feed(dabhip_stream* s, const uint8_t* const* iq
   }
   std::vector<const uint8_t*> virt(s->n);
   std::vector<size_t> avail(s->n);
+  HostList<CopyDesc>& moves = s->history_descs;
+  moves.clear();
+  uint32_t longest_move = 0;
   for (int b = 0; b < s->n; ++b) {
     const int64_t need = s->first ? 0 : std::min(s->eng.stream_need_from(b), s->avail[b]);
     const size_t kept = static_cast<size_t>(s->avail[b] - need);
@@ -862,15 +885,20 @@ extern "C" int64_t dabhip_stream_feed(dabhip_stream* s, const uint8_t* const* iq
       to = s->win[w][b].get();
       at = kept;
     }
-    // stream byte x of the bytes still held lives at from + org + (x - base)
-    if (kept && hipMemcpyAsync(to->get() + at - kept, from.get() + s->org[b] + (need - s->base[b]), kept, hipMemcpyDeviceToDevice, st) != hipSuccess)
-      return broken("stream_feed: window move failed");
+    // stream byte x of the bytes still held lives at from + org + (x - base); all streams' moves go in one launch behind the loop
+    if (kept) {
+      moves.push_back(CopyDesc{from.get() + s->org[b] + (need - s->base[b]), to->get() + at - kept, static_cast<uint32_t>(kept), 0});
+      longest_move = std::max(longest_move, static_cast<uint32_t>(kept));
+    }
     s->org[b] = at - kept;
     s->base[b] = need;
     s->avail[b] += static_cast<int64_t>(nbytes[b]);
     virt[b] = to->get() + at - kept - need;    // byte x of the stream lives at virt[b][x]
     avail[b] = static_cast<size_t>(s->avail[b]);
   }
+  if (!moves.empty() && !(s->d_history_descs.upload(moves, st) &&
+                          launch_device_gather(s->d_history_descs.get(), static_cast<int>(moves.size()), longest_move, st) == hipSuccess))
+    return broken("stream_feed: window move failed");
   ++s->fed;
   const int64_t frames = s->eng.feed(virt.data(), avail.data(), s->n, s->first);
   if (frames < 0) return broken(nullptr);        // (the engine's error text stands)
@@ -878,6 +906,20 @@ extern "C" int64_t dabhip_stream_feed(dabhip_stream* s, const uint8_t* const* iq
   return frames;
 }
 extern "C" int64_t dabhip_stream_eti_count(const dabhip_stream* s, int stream) { return s ? s->eng.eti_count(stream) : -1; }
+// stage times of the segment fed last (the names of dabhip_engine_stage_ms; "wall" = the engine's part of the feed, without the window moves)
+extern "C" int dabhip_stream_stage_ms(const dabhip_stream* s, const char** names, float* ms, int cap)
+{
+  if (!s) return -1;
+  static const char* kNames[12] = {"sync", "fft", "demap", "fic", "control", "gather", "viterbi", "eti", "host_setup", "host_frames", "host_worklist", "wall"};
+  const StageTimes& t = s->eng.stage_times();
+  const float v[12] = {t.sync, t.fft, t.demap, t.fic, t.control, t.gather, t.viterbi, t.eti, t.setup, t.frames, t.worklist, t.wall};
+  int n = 0;
+  for (; n < 12 && n < cap; ++n) {
+    if (names) names[n] = kNames[n];
+    if (ms) ms[n] = v[n];
+  }
+  return n;
+}
 extern "C" uint32_t dabhip_stream_status(const dabhip_stream* s, int stream) { return s ? s->eng.stream_status(stream) : 0xffffffffu; }
 extern "C" int64_t dabhip_stream_eti_read(dabhip_stream* s, int stream, uint8_t* dst, int64_t cap_frames)
 {

@@ -460,7 +460,9 @@ bool Engine::carry_and_reserve(const std::vector<int>& tf_base, const std::vecto
 {
   const size_t bits = soft_bits_ ? 4 : 1;
   const size_t unit[4] = {kFicWords * 4 * bits, 384, 12, kCifWords * 4 * bits};
-  std::vector<CopyDesc> out, in;
+  HostList<CopyDesc>&out = carry_out_descs_, &in = carry_in_descs_;   // (the previous segment's lists were consumed before its feed returned)
+  out.clear();
+  in.clear();
   size_t tmp_bytes = 0;
   const int n = static_cast<int>(carry_keep_.size());
   uint8_t* base[4] = {reinterpret_cast<uint8_t*>(d_fic_bits_.get()), d_fibs_.get(), d_fib_ok_.get(), reinterpret_cast<uint8_t*>(d_msc_bits_.get())};
@@ -482,8 +484,11 @@ bool Engine::carry_and_reserve(const std::vector<int>& tf_base, const std::vecto
   if (!pieces.empty()) {
     if (!d_carry_.reserve(tmp_bytes)) return false;
     for (const Piece& p : pieces) out.push_back(CopyDesc{base[p.which] + p.src, d_carry_.get() + p.tmp, static_cast<uint32_t>(p.bytes)});
+    // (the copy out must be over before a growing buffer is given back; when nothing grows -- every segment of a session but the first few --
+    // stream order alone keeps the two copies apart, and the host does not wait)
+    const bool grows = nslots > tf_slots_ || (nrows < 0 ? 4 * nslots + kRowLead + 1 : nrows) > msc_rows_;
     if (!d_copy_descs_.upload(out, stream_) || !check(launch_batched_copy(d_copy_descs_.get(), static_cast<int>(out.size()), stream_), "carry out") ||
-        !check(hipStreamSynchronize(stream_), "carry out"))
+        (grows && !check(hipStreamSynchronize(stream_), "carry out")))
       return false;
   }
   if (!reserve_tf_slots(nslots, nrows)) return false;

@@ -352,6 +352,7 @@ class Engine {
   int guard_overflows_ = 0;          // launches of the last decode whose list overflowed (decided again in full, fp64)
   DeviceBuffer<uint8_t> d_carry_;
   DeviceBuffer<CopyDesc> d_copy_descs_;
+  HostList<CopyDesc> carry_out_descs_, carry_in_descs_;   // page-locked: they go up without the host waiting for the stream
 
   PlanTable plan_table_;
 

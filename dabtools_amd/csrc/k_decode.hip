@@ -31,6 +31,7 @@
 // steps, the same volume as one bit per state and step) and the nibbles are cleared with the re-pairing.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <utility>
 
 #include "dab_tables.hpp"
@@ -967,6 +968,28 @@ __global__ __launch_bounds__(256) void eti_finish_kernel(const EtiFrameMeta* __r
 // all streams -- a few hundred copy commands of a few MB each cost the copy engines ~8 us apiece on top of the transfer.  A small
 // persistent grid (the link, not the CUs, is the limit; the decode of the previous segment runs beside it): workgroup w takes pieces
 // w, w + G, ... of 64 KB; 16-byte nontemporal loads and stores, byte tails by the piece's first lanes.
+// one piece of a copy, any alignment of source and destination: the destination is brought to a 16-byte boundary by the piece's first lanes, the body
+// goes as 16-byte loads from wherever the source then stands (gfx950 serves unaligned global loads; the compiler emits global_load_dwordx4 for them)
+// and aligned nontemporal 16-byte stores, the tail bytes by the first lanes again
+struct __attribute__((packed, aligned(1))) Unaligned16 { vuint4 v; };
+__device__ __forceinline__ void copy_piece(const uint8_t* __restrict__ s, uint8_t* __restrict__ t, uint32_t n)
+{
+  const uint32_t head = min(n, static_cast<uint32_t>(-reinterpret_cast<uintptr_t>(t)) & 15u);
+  if (threadIdx.x < head) t[threadIdx.x] = s[threadIdx.x];
+  s += head;
+  t += head;
+  n -= head;
+  const uint32_t nv = n >> 4;
+  if ((reinterpret_cast<uintptr_t>(s) & 15u) == 0) {
+    for (uint32_t v = threadIdx.x; v < nv; v += 256u)
+      __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const vuint4*>(s) + v), reinterpret_cast<vuint4*>(t) + v);
+  } else {
+    for (uint32_t v = threadIdx.x; v < nv; v += 256u)
+      __builtin_nontemporal_store(reinterpret_cast<const Unaligned16*>(s + 16u * v)->v, reinterpret_cast<vuint4*>(t) + v);
+  }
+  for (uint32_t b = (nv << 4) + threadIdx.x; b < n; b += 256u) t[b] = s[b];
+}
+
 __global__ __launch_bounds__(256) void host_gather_kernel(const CopyDesc* __restrict__ descs, int ndesc)
 {
   constexpr uint32_t kPiece = 64u << 10;
@@ -977,26 +1000,34 @@ __global__ __launch_bounds__(256) void host_gather_kernel(const CopyDesc* __rest
     // pieces of this descriptor that belong to this workgroup: global index = piece0 + p, taken when (piece0 + p) % gridDim.x == blockIdx.x
     uint32_t p = (blockIdx.x + gridDim.x - piece0 % gridDim.x) % gridDim.x;
     for (; p < npieces; p += gridDim.x) {
-      const uint32_t off = p * kPiece, n = min(kPiece, d.nbytes - off);
-      const uint8_t* s = d.src + off;
-      uint8_t* t = d.dst + off;
-      if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(t)) & 15u) == 0) {
-        const uint32_t nv = n >> 4;
-        for (uint32_t v = threadIdx.x; v < nv; v += 256u)
-          __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const vuint4*>(s) + v), reinterpret_cast<vuint4*>(t) + v);
-        for (uint32_t b = (nv << 4) + threadIdx.x; b < n; b += 256u) t[b] = s[b];
-      } else {
-        for (uint32_t b = threadIdx.x; b < n; b += 256u) t[b] = s[b];
-      }
+      const uint32_t off = p * kPiece;
+      copy_piece(d.src + off, d.dst + off, min(kPiece, d.nbytes - off));
     }
     piece0 += npieces;
   }
+}
+
+// The same for copies inside the device (a session fed from device memory: the segments into their windows, the history in front of them --
+// 2 x 256 copy commands of 5 .. 12 us each otherwise, one after the other): grid (piece slot, descriptor), pieces of 64 KB
+__global__ __launch_bounds__(256) void device_gather_kernel(const CopyDesc* __restrict__ descs)
+{
+  constexpr uint32_t kPiece = 64u << 10;
+  const CopyDesc d = descs[blockIdx.y];
+  for (uint32_t off = blockIdx.x * kPiece; off < d.nbytes; off += gridDim.x * kPiece) copy_piece(d.src + off, d.dst + off, min(kPiece, d.nbytes - off));
 }
 
 hipError_t launch_host_gather(const CopyDesc* descs, int n, int workgroups, hipStream_t stream)
 {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(host_gather_kernel, dim3(workgroups), dim3(256), 0, stream, descs, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_device_gather(const CopyDesc* descs, int n, uint32_t max_bytes, hipStream_t stream)
+{
+  if (n <= 0) return hipSuccess;
+  const uint32_t pieces = (max_bytes + (64u << 10) - 1) / (64u << 10);
+  hipLaunchKernelGGL(device_gather_kernel, dim3(std::max(1u, std::min(pieces, 64u)), n), dim3(256), 0, stream, descs);
   return hipGetLastError();
 }
 

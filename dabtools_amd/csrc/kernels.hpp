@@ -132,6 +132,8 @@ hipError_t launch_decision_audit(const uint8_t* frames_iq, int nframes, const fl
 hipError_t launch_batched_copy(const CopyDesc* descs, int n, hipStream_t stream);
 // the descriptors' sources may be page-locked HOST memory (read over PCIe by a small persistent grid); nbytes < 4 GiB each
 hipError_t launch_host_gather(const CopyDesc* descs, int n, int workgroups, hipStream_t stream);
+// n copies inside the device in one launch, any alignment; max_bytes = the longest of them
+hipError_t launch_device_gather(const CopyDesc* descs, int n, uint32_t max_bytes, hipStream_t stream);
 hipError_t launch_fib_crc(const uint8_t* fibs, int nfib, const uint16_t* crc_tab, uint8_t* ok, hipStream_t stream);
 
 // K5: ETI header/FIB copy, EOF CRC, trailer

@@ -236,6 +236,7 @@ int64_t dabhip_stream_feed(dabhip_stream *s, const uint8_t *const *iq, const siz
  * stay untouched until the feed that consumes them has returned.  Returns 0, <0 on error. */
 int dabhip_stream_prefetch(dabhip_stream *s, const uint8_t *const *iq, const size_t *nbytes, int on_device);
 int64_t dabhip_stream_eti_count(const dabhip_stream *s, int stream);
+int dabhip_stream_stage_ms(const dabhip_stream *s, const char **names, float *ms, int cap);   /* of the segment fed last; names as dabhip_engine_stage_ms */
 uint32_t dabhip_stream_status(const dabhip_stream *s, int stream);        /* as dabhip_engine_stream_status, sticky over the session's segments */
 int64_t dabhip_stream_eti_read(dabhip_stream *s, int stream, uint8_t *dst, int64_t cap_frames);
 int64_t dabhip_stream_eti_drain(dabhip_stream *s, dabhip_eti_sink sink, void *user);

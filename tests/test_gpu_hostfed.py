@@ -145,6 +145,28 @@ def test_stream_session_with_prefetched_segments_equals_one_shot_decode():
     for b, w in enumerate(want):
         assert np.array_equal(np.concatenate(got[b]), w), b
     st.close()
+    # ... and fed directly (one copy kernel per feed for the segments, one for the history in front of them), from addresses of every alignment
+    st = dab.Stream(len(caps))
+    got = [[] for _ in caps]
+    odd = []
+    for k, (ptrs_k, sizes_k, hbs) in enumerate(segs):
+        bufs = [dab.DeviceBuffer(max(n, 16) + 32) for n in sizes_k]
+        shift = [(3 * b + 5 * k + 1) % 17 for b in range(len(bufs))]
+        for buf, hb, n, sh in zip(bufs, hbs, sizes_k, shift):
+            if n:
+                tmp = np.zeros(n + 32, np.uint8)
+                tmp[sh:sh + n] = hb.array[:n]
+                buf.upload(tmp)
+        odd.append(bufs)
+        st.feed_ptrs([b.ptr + sh for b, sh in zip(bufs, shift)], sizes_k, on_device=True)
+        for b in range(len(caps)):
+            got[b].append(st.eti(b))
+    for b, w in enumerate(want):
+        assert np.array_equal(np.concatenate(got[b]), w), b
+    st.close()
+    for bufs in odd:
+        for buf in bufs:
+            buf.free()
     for _, _, bufs in dsegs:
         for buf in bufs:
             buf.free()
