@@ -1027,7 +1027,8 @@ hipError_t launch_device_gather(const CopyDesc* descs, int n, uint32_t max_bytes
 {
   if (n <= 0) return hipSuccess;
   const uint32_t pieces = (max_bytes + (64u << 10) - 1) / (64u << 10);
-  hipLaunchKernelGGL(device_gather_kernel, dim3(std::max(1u, std::min(pieces, 64u)), n), dim3(256), 0, stream, descs);
+  for (int i = 0; i < n; i += 65535)          // (grid.y holds 65,535 descriptors)
+    hipLaunchKernelGGL(device_gather_kernel, dim3(std::max(1u, std::min(pieces, 64u)), std::min(n - i, 65535)), dim3(256), 0, stream, descs + i);
   return hipGetLastError();
 }
 
