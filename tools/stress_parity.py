@@ -28,10 +28,21 @@ def oracle_job(args):
     return eti, [(t.ok, t.read_frame, t.coarse_timeshift, t.fine_timeshift, t.coarse_freq_shift, t.fifo_count) for t in trace]
 
 
-def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None):
+def reference_job(args):
+    """The checker of --reference: dab2eti's own loop over the reference's REAL front end (oracle/_ref/libdabref_frontend.so: input_sdr.c, sdr_sync.c,
+    sdr_fifo.c unmodified over hipFFTW) and REAL back end (oracle/_ref/libdabref.so).  read_frame is not visible from outside sdr_demod: -1."""
+    import oracle_lib as ol
+    path, = args
+    iq = np.load(path)
+    eti, calls, _ = ol.ref_frontend_replay(iq)
+    return eti, [(c[0], -1, c[1], c[2], c[3], c[4]) for c in calls]
+
+
+def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None, reference=False):
     """The sweep itself -> result dict (one record per capture under "cases")."""
     import dabtools_amd as dab
     workers = workers or min(32, os.cpu_count() or 1)
+    job = reference_job if reference else oracle_job
     rng = np.random.default_rng(seed)
     tmp = "/tmp/stress_parity_%d" % os.getpid()
     os.makedirs(tmp, exist_ok=True)
@@ -56,7 +67,7 @@ def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None):
                 p = os.path.join(tmp, "s%d.npy" % i)
                 np.save(p, iq)
                 cfgs.append(cfg); paths.append(p); iqs.append(iq); ragged.append(cut)
-            pending = pool.map_async(oracle_job, [(p,) for p in paths], chunksize=1)
+            pending = pool.map_async(job, [(p,) for p in paths], chunksize=1)
             eng.decode(iqs)
             got = [(eng.eti(b), eng.trace(b, iqs[b].size // 262144)[0]) for b in range(len(iqs))]
             want = pending.get()
@@ -64,6 +75,8 @@ def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None):
                 eti, trace = got[b]
                 weti, wtrace = want[b]
                 gtrace = [tuple(int(x) for x in t) for t in trace]
+                if reference:
+                    gtrace = [(t[0], -1) + t[2:] for t in gtrace]
                 total_frames += len(weti)
                 total_calls += len(wtrace)
                 equal = eti.shape == weti.shape and np.array_equal(eti, weti) and gtrace == wtrace
@@ -80,7 +93,8 @@ def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None):
     for f in os.listdir(tmp):
         os.remove(os.path.join(tmp, f))
     os.rmdir(tmp)
-    return {"rounds": rounds, "streams_per_round": streams, "eti_frames_compared": total_frames, "calls_compared": total_calls,
+    return {"checker": "the reference itself: real front end over hipFFTW + real back end (oracle/_ref)" if reference else "oracle/or_replay",
+            "rounds": rounds, "streams_per_round": streams, "eti_frames_compared": total_frames, "calls_compared": total_calls,
             "differences": bad, "seconds": round(time.time() - t0, 1), "seed": seed, "cases": cases}
 
 
@@ -91,8 +105,10 @@ def main():
     ap.add_argument("--tfs", type=int, default=24)
     ap.add_argument("--workers", type=int, default=min(32, os.cpu_count() or 1))
     ap.add_argument("--seed", type=int, default=20261002)
+    ap.add_argument("--reference", action="store_true", help="check against the reference's real front end + back end (needs oracle/_ref/libdabref_frontend.so; "
+                                                             "every worker opens the GPU for hipFFTW: keep --workers small)")
     args = ap.parse_args()
-    res = run(args.rounds, args.streams, args.tfs, args.workers, args.seed, log=sys.stderr)
+    res = run(args.rounds, args.streams, args.tfs, args.workers, args.seed, log=sys.stderr, reference=args.reference)
     print(json.dumps(res))
     sys.exit(1 if res["differences"] else 0)
 
