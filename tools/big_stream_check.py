@@ -22,11 +22,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--tfs", type=int, default=11200)
-    ap.add_argument("--oracle-tfs", type=int, default=400)
-    args = ap.parse_args()
+def run(tfs=11200, oracle_tfs=400):
+    class args:
+        pass
+    args.tfs, args.oracle_tfs = tfs, oracle_tfs
     import dabtools_amd as dab
     cfg = dab.synth_preset(0, seed=31337, cif_count0=4321, snr_db=14.0)
     nbytes = dab.synth_bytes(cfg, args.tfs)
@@ -87,8 +86,17 @@ def main():
         ok = ok and eq
     buf.free()
     out["ok"] = bool(ok)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tfs", type=int, default=11200)
+    ap.add_argument("--oracle-tfs", type=int, default=400)
+    a = ap.parse_args()
+    out = run(a.tfs, a.oracle_tfs)
     print(json.dumps(out))
-    sys.exit(0 if ok else 1)
+    sys.exit(0 if out["ok"] else 1)
 
 
 if __name__ == "__main__":
