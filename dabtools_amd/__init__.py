@@ -150,6 +150,8 @@ _SIGNATURES = {
     "dabhip_engine_stream_status": (C.c_uint32, [C.c_void_p, C.c_int]),
     "dabhip_multi_stream_status": (C.c_uint32, [C.c_void_p, C.c_int]),
     "dabhip_stream_status": (C.c_uint32, [C.c_void_p, C.c_int]),
+    "dabhip_stream_feed_resident": (C.c_int64, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "dabhip_stream_need_from": (C.c_int64, [C.c_void_p, C.c_int]),
     "dabhip_stream_stage_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
     "dabhip_dab_status": (C.c_uint32, [C.c_void_p]),
     "dabhip_engine_eti_fetch": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64]),
@@ -843,6 +845,18 @@ class Stream:
         n = lib().dabhip_stream_feed(self._h, p, s, 1 if on_device else 0)
         _need(n >= 0, "stream_feed")
         return n
+
+    def feed_resident(self, base_ptrs, avail):
+        """dabhip_stream_feed_resident: the streams live in device memory (base_ptrs[b] + x = byte x of stream b) and are read in place;
+        avail[b] = bytes there now."""
+        p = (C.c_void_p * len(base_ptrs))(*base_ptrs)
+        a = (C.c_size_t * len(avail))(*avail)
+        n = lib().dabhip_stream_feed_resident(self._h, p, a)
+        _need(n >= 0, "stream_feed_resident")
+        return n
+
+    def need_from(self, stream):
+        return int(lib().dabhip_stream_need_from(self._h, stream))
 
     def prefetch_ptrs(self, ptrs, sizes, on_device=False):
         """dabhip_stream_prefetch: start uploading the segment a later feed_ptrs() with the same arguments will consume."""

@@ -700,6 +700,7 @@ struct dabhip_stream {
   // A feed that fails after it has started to move the session on (windows, offsets, the engine's carried state) leaves a session nobody can
   // re-feed correctly: it is marked and refuses everything but its destruction -- an honest error instead of frames decoded at the wrong offsets.
   bool failed = false;
+  bool resident = false;                       // fed through dabhip_stream_feed_resident: the caller's buffers are read in place, no windows
   // prefetch uploads run on a stream of their own.  Measured on the 256-stream workload, 8-TF segments (805 MB each): one gather kernel
   // per segment 56.5 GB/s, 256 copy commands on one stream 54.0, dealt to two / four streams 25 / 36 (they get in each other's way)
   static constexpr int kUpStreams = 1;
@@ -830,6 +831,7 @@ extern "C" int dabhip_stream_prefetch(dabhip_stream* s, const uint8_t* const* iq
 {
   if (!s || !iq || !nbytes) { set_error("stream_prefetch: null argument"); return -1; }
   if (s->failed) { set_error("stream_prefetch: an earlier feed of this session failed half-way -- destroy the session"); return -1; }
+  if (s->resident) { set_error("stream_prefetch: this session is fed through dabhip_stream_feed_resident"); return -1; }
   if (s->queued - s->fed >= 2) { set_error("stream_prefetch: two segments are already waiting to be fed"); return -1; }
   if (hipSetDevice(s->eng.device()) != hipSuccess) { set_error("stream_prefetch: hipSetDevice failed"); return -1; }
   const int w = static_cast<int>(s->queued % 3);
@@ -846,6 +848,7 @@ extern "C" int64_t dabhip_stream_feed(dabhip_stream* s, const uint8_t* const* iq
 {
   if (!s || !iq || !nbytes) { set_error("stream_feed: null argument"); return -1; }
   if (s->failed) { set_error("stream_feed: an earlier feed of this session failed half-way; its state is not trustworthy any more -- destroy the session"); return -1; }
+  if (s->resident) { set_error("stream_feed: this session is fed through dabhip_stream_feed_resident"); return -1; }
   if (hipSetDevice(s->eng.device()) != hipSuccess) { set_error("stream_feed: hipSetDevice failed"); return -1; }
   auto broken = [s](const char* msg) -> int64_t {          // from here on an error leaves the session's books half-updated
     s->failed = true;
@@ -904,6 +907,31 @@ extern "C" int64_t dabhip_stream_feed(dabhip_stream* s, const uint8_t* const* iq
   if (frames < 0) return broken(nullptr);        // (the engine's error text stands)
   s->first = false;
   return frames;
+}
+// A session over streams that LIVE in device memory, without any copy: base[b][x] is byte x of stream b counted from the session's start, of which
+// the first avail[b] are there now (avail never shrinks).  The caller keeps the bytes from dabhip_stream_need_from(s, b) on in place -- a linear
+// buffer that is appended to -- and may recycle what lies below.  base may change between calls as long as those bytes stay addressable through it.
+// Not to be mixed with dabhip_stream_feed / _prefetch on the same session (those own their windows).
+extern "C" int64_t dabhip_stream_feed_resident(dabhip_stream* s, const uint8_t* const* base, const size_t* avail)
+{
+  if (!s || !base || !avail) { set_error("stream_feed_resident: null argument"); return -1; }
+  if (s->failed) { set_error("stream_feed_resident: an earlier feed of this session failed half-way -- destroy the session"); return -1; }
+  if (s->queued > 0) { set_error("stream_feed_resident: this session is fed through dabhip_stream_feed (windows)"); return -1; }
+  if (hipSetDevice(s->eng.device()) != hipSuccess) { set_error("stream_feed_resident: hipSetDevice failed"); return -1; }
+  for (int b = 0; b < s->n; ++b)
+    if (static_cast<int64_t>(avail[b]) < s->avail[b]) { set_error("stream_feed_resident: a stream's byte count went down"); return -1; }
+  const int64_t frames = s->eng.feed(base, avail, s->n, s->first);
+  if (frames < 0) { s->failed = true; return -1; }     // (the engine's error text stands)
+  for (int b = 0; b < s->n; ++b) s->avail[b] = static_cast<int64_t>(avail[b]);
+  s->resident = true;
+  s->first = false;
+  return frames;
+}
+// oldest byte of stream b a later segment may still read (FIFO backlog and stale-tail sources of the front end): everything below may go
+extern "C" int64_t dabhip_stream_need_from(const dabhip_stream* s, int stream)
+{
+  if (!s || stream < 0 || stream >= s->n) return -1;
+  return s->first ? 0 : std::min(s->eng.stream_need_from(stream), s->avail[stream]);
 }
 extern "C" int64_t dabhip_stream_eti_count(const dabhip_stream* s, int stream) { return s ? s->eng.eti_count(stream) : -1; }
 // stage times of the segment fed last (the names of dabhip_engine_stage_ms; "wall" = the engine's part of the feed, without the window moves)

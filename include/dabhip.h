@@ -235,6 +235,12 @@ int64_t dabhip_stream_feed(dabhip_stream *s, const uint8_t *const *iq, const siz
  * two segments may be waiting.  Host segments must be page-locked (dabhip_host_alloc) for the copy to run asynchronously and must
  * stay untouched until the feed that consumes them has returned.  Returns 0, <0 on error. */
 int dabhip_stream_prefetch(dabhip_stream *s, const uint8_t *const *iq, const size_t *nbytes, int on_device);
+/* The same session over streams that LIVE in device memory, read in place (no copy into windows): base[b][x] (device memory) is byte x of stream b
+ * counted from the session's start, avail[b] the bytes that are there now (it only grows).  The caller keeps the bytes from
+ * dabhip_stream_need_from(s, b) on where they are -- a linear buffer that is appended to -- and may recycle everything below.  Not to be mixed
+ * with dabhip_stream_feed / _prefetch on one session.  Returns the ETI frames produced by the new bytes, <0 on error. */
+int64_t dabhip_stream_feed_resident(dabhip_stream *s, const uint8_t *const *base, const size_t *avail);
+int64_t dabhip_stream_need_from(const dabhip_stream *s, int stream);   /* oldest stream byte a later segment may still read; <0: bad argument */
 int64_t dabhip_stream_eti_count(const dabhip_stream *s, int stream);
 int dabhip_stream_stage_ms(const dabhip_stream *s, const char **names, float *ms, int cap);   /* of the segment fed last; names as dabhip_engine_stage_ms */
 uint32_t dabhip_stream_status(const dabhip_stream *s, int stream);        /* as dabhip_engine_stream_status, sticky over the session's segments */

@@ -221,3 +221,53 @@ def test_eti_fetch_is_the_drain_order_and_overlaps_the_next_segment():
     st.close()
     for b in bufs + [hb]:
         b.free()
+
+
+def test_resident_session_reads_the_streams_in_place():
+    """dabhip_stream_feed_resident: the captures live in device memory and grow; nothing is copied.  Frames of all feeds == one decode; what lies
+    below dabhip_stream_need_from is really not read any more (it is overwritten between the feeds); a session cannot mix the two ways of feeding."""
+    caps = _caps()
+    eng = dab.Engine(0)
+    eng.decode(caps)
+    want = [eng.eti(b) for b in range(len(caps))]
+    eng.close()
+    bufs = [dab.DeviceBuffer(max(c.size, 16) + 64) for c in caps]
+    shift = [(5 * b + 3) % 16 for b in range(len(caps))]                  # base addresses of every alignment
+    for buf, c, sh in zip(bufs, caps, shift):
+        if c.size:
+            tmp = np.zeros(c.size + sh, np.uint8)
+            tmp[sh:] = c
+            buf.upload(tmp)
+    base = [buf.ptr + sh for buf, sh in zip(bufs, shift)]
+    st = dab.Stream(len(caps))
+    rng = np.random.default_rng(99)
+    avail = [0] * len(caps)
+    got = [[] for _ in caps]
+    prev_need = [0] * len(caps)
+    feeds = 0
+    while any(a < c.size for a, c in zip(avail, caps)):
+        avail = [min(c.size, a + int(rng.integers(1, 3_000_000))) for a, c in zip(avail, caps)]
+        st.feed_resident(base, avail)
+        feeds += 1
+        for b in range(len(caps)):
+            got[b].append(st.eti(b))
+            need = st.need_from(b)
+            assert prev_need[b] <= need <= avail[b], (b, prev_need[b], need, avail[b])
+            prev_need[b] = need
+            # the caller may recycle what lies below need_from: scribble over it
+            if need > 4096:
+                junk = np.full(need - (need % 2), 0xA5, np.uint8)
+                assert dab.lib().dabhip_device_copy(base[b], junk.ctypes.data, junk.size, 1) == 0
+    assert feeds > 5
+    for b, w in enumerate(want):
+        assert np.array_equal(np.concatenate(got[b]), w), b
+    with pytest.raises(dab.DabhipError, match="feed_resident"):
+        st.feed([c[:0] for c in caps])
+    st.close()
+    st = dab.Stream(1)
+    st.feed([caps[0][:500000]])
+    with pytest.raises(dab.DabhipError, match="windows"):
+        st.feed_resident([base[0]], [600000])
+    st.close()
+    for buf in bufs:
+        buf.free()
