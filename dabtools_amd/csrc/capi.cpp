@@ -920,6 +920,16 @@ extern "C" int64_t dabhip_stream_feed_resident(dabhip_stream* s, const uint8_t* 
   if (hipSetDevice(s->eng.device()) != hipSuccess) { set_error("stream_feed_resident: hipSetDevice failed"); return -1; }
   for (int b = 0; b < s->n; ++b)
     if (static_cast<int64_t>(avail[b]) < s->avail[b]) { set_error("stream_feed_resident: a stream's byte count went down"); return -1; }
+  if (s->first)                                // the kernels dereference these addresses: a host pointer here would be a fault on the device, not an error code
+    for (int b = 0; b < s->n; ++b) {
+      if (avail[b] == 0) continue;
+      hipPointerAttribute_t attr;
+      if (hipPointerGetAttributes(&attr, base[b]) != hipSuccess || (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged)) {
+        (void)hipGetLastError();
+        set_error("stream_feed_resident: base[" + std::to_string(b) + "] is not device memory");
+        return -1;
+      }
+    }
   const int64_t frames = s->eng.feed(base, avail, s->n, s->first);
   if (frames < 0) { s->failed = true; return -1; }     // (the engine's error text stands)
   for (int b = 0; b < s->n; ++b) s->avail[b] = static_cast<int64_t>(avail[b]);

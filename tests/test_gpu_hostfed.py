@@ -265,6 +265,8 @@ def test_resident_session_reads_the_streams_in_place():
         st.feed([c[:0] for c in caps])
     st.close()
     st = dab.Stream(1)
+    with pytest.raises(dab.DabhipError, match="not device memory"):
+        st.feed_resident([caps[0].ctypes.data], [caps[0].size])           # a host address
     st.feed([caps[0][:500000]])
     with pytest.raises(dab.DabhipError, match="windows"):
         st.feed_resident([base[0]], [600000])
