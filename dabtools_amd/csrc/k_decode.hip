@@ -826,6 +826,9 @@ __global__ __launch_bounds__(256, DABHIP_VIT_WAVES) void viterbi_fused_kernel(co
   if (lane < grp.count && !(kBits == 1 && DABHIP_VIT_NOSTORE == 2 && nsteps > 800)) {     // (NOSTORE == 2: ... and without the chain-back)
     const int record = job_ids ? job_ids[grp.first + lane] : grp.first + lane;
     uint32_t* dst = reinterpret_cast<uint32_t*>(out + static_cast<size_t>(record) * record_stride + pl.out_offset);
+#if defined(DABHIP_CB_PRIO)
+    __builtin_amdgcn_s_setprio(DABHIP_CB_PRIO);          // experiment (tools/gpu/cbprio.sh, round 4): the chain-back's few instructions ahead of the others' forward passes -- priority 1 and 3 measured the same as none (4.86 .. 4.95 ms all three, three rounds on one box)
+#endif
     if (kBits == 1) chain_back8(my_rec, nsteps, prbs_words, dst);
     else chain_back(my_rec, nsteps, prbs_words, dst);
   }
