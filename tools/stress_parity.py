@@ -38,7 +38,7 @@ def reference_job(args):
     return eti, [(c[0], -1, c[1], c[2], c[3], c[4]) for c in calls]
 
 
-def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None, reference=False):
+def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None, reference=False, harsh=False):
     """The sweep itself -> result dict (one record per capture under "cases")."""
     import dabtools_amd as dab
     workers = workers or min(32, os.cpu_count() or 1)
@@ -54,10 +54,16 @@ def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None, ref
         for r in range(rounds):
             cfgs, paths, iqs, ragged = [], [], [], []
             for i in range(streams):
-                snr = float(rng.choice([1000.0, 1000.0, 20.0, 14.0, 11.0, 9.0]))
-                cfg = dab.synth_preset(int(rng.integers(0, 2)), seed=int(rng.integers(1, 1 << 30)), cif_count0=int(rng.integers(0, 5000)),
-                                       skip_samples=int(rng.choice([0, 0, int(rng.integers(1, 196608))])), snr_db=snr,
-                                       amplitude=float(rng.choice([1.0, 0.8, 0.5, 0.35])), cfo_hz=float(rng.choice([0.0, 0.0, rng.uniform(-400, 400)])))
+                if harsh:       # where the receiver is fragile: noise down to 5 dB (lock comes and goes), up to 1.4 carriers off tune (forced re-synchronisation), weak and clipped signals
+                    snr = float(rng.choice([1000.0, 12.0, 9.0, 8.0, 7.0, 6.0, 5.0]))
+                    cfg = dab.synth_preset(int(rng.integers(0, 2)), seed=int(rng.integers(1, 1 << 30)), cif_count0=int(rng.integers(0, 5000)),
+                                           skip_samples=int(rng.choice([0, int(rng.integers(1, 196608))])), snr_db=snr,
+                                           amplitude=float(rng.choice([2.5, 1.0, 0.5, 0.2, 0.08])), cfo_hz=float(rng.choice([0.0, rng.uniform(-400, 400), rng.uniform(-1400, 1400)])))
+                else:
+                    snr = float(rng.choice([1000.0, 1000.0, 20.0, 14.0, 11.0, 9.0]))
+                    cfg = dab.synth_preset(int(rng.integers(0, 2)), seed=int(rng.integers(1, 1 << 30)), cif_count0=int(rng.integers(0, 5000)),
+                                           skip_samples=int(rng.choice([0, 0, int(rng.integers(1, 196608))])), snr_db=snr,
+                                           amplitude=float(rng.choice([1.0, 0.8, 0.5, 0.35])), cfo_hz=float(rng.choice([0.0, 0.0, rng.uniform(-400, 400)])))
                 ntf = int(tfs + rng.integers(0, 5))
                 iq = dab.synth_generate(cfg, ntf)
                 cut = 0
@@ -93,7 +99,8 @@ def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None, ref
     for f in os.listdir(tmp):
         os.remove(os.path.join(tmp, f))
     os.rmdir(tmp)
-    return {"checker": "the reference itself: real front end over hipFFTW + real back end (oracle/_ref)" if reference else "oracle/or_replay",
+    return {"mix": "harsh (5 dB ... clean, up to 1.4 carriers off tune, amplitudes 0.08 ... 2.5)" if harsh else "default",
+            "checker": "the reference itself: real front end over hipFFTW + real back end (oracle/_ref)" if reference else "oracle/or_replay",
             "rounds": rounds, "streams_per_round": streams, "eti_frames_compared": total_frames, "calls_compared": total_calls,
             "differences": bad, "seconds": round(time.time() - t0, 1), "seed": seed, "cases": cases}
 
@@ -107,8 +114,9 @@ def main():
     ap.add_argument("--seed", type=int, default=20261002)
     ap.add_argument("--reference", action="store_true", help="check against the reference's real front end + back end (needs oracle/_ref/libdabref_frontend.so; "
                                                              "every worker opens the GPU for hipFFTW: keep --workers small)")
+    ap.add_argument("--harsh", action="store_true", help="the mix where the receiver is fragile: 5 dB ... clean, up to 1.4 carriers off tune, weak and clipped signals")
     args = ap.parse_args()
-    res = run(args.rounds, args.streams, args.tfs, args.workers, args.seed, log=sys.stderr, reference=args.reference)
+    res = run(args.rounds, args.streams, args.tfs, args.workers, args.seed, log=sys.stderr, reference=args.reference, harsh=args.harsh)
     print(json.dumps(res))
     sys.exit(1 if res["differences"] else 0)
 
