@@ -38,7 +38,46 @@ def reference_job(args):
     return eti, [(c[0], -1, c[1], c[2], c[3], c[4]) for c in calls]
 
 
-def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None, reference=False, harsh=False):
+UEP_SIZE_CU = None
+EEP_SIZE_MUL = [12, 8, 6, 4, 27, 21, 18, 15]        # CUs per n for protection levels 1-A .. 4-A, 1-B .. 4-B (dab_tables.c eeptable / fic.c:84-94)
+
+
+def random_layout(dab, cfg, rng):
+    """A random multiplex in place of the preset's: 1 .. 16 sub-channels, UEP rows and EEP levels / sizes drawn at random, random SubChIds, gaps between
+    the sub-channels, inside 864 CUs and one ETI frame."""
+    global UEP_SIZE_CU
+    if UEP_SIZE_CU is None:
+        t = np.load(os.path.join(ROOT, "tests", "golden", "tables.npz"))["ueptable"]
+        UEP_SIZE_CU = [(int(r[0]), int(r[1])) for r in t]           # (bitrate, size) of the 64 rows
+    want = int(rng.integers(1, 17))
+    ids = rng.permutation(64)[:want]
+    cu, kbps, k = int(rng.integers(0, 40)), 0, 0
+    cfg.nsub = 0
+    for sid in sorted(int(x) for x in ids):
+        if rng.integers(0, 2):
+            idx = int(rng.integers(0, 64))
+            rate, size = UEP_SIZE_CU[idx]
+            slform, lev = 0, 0
+        else:
+            lev = int(rng.integers(0, 8))
+            n = int(rng.integers(1, 13 if lev < 4 else 5))
+            size, rate, slform, idx = n * EEP_SIZE_MUL[lev], n * (8 if lev < 4 else 32), 1, 0
+        if cu + size > 864 or 3 * (kbps + rate) + 8 + 4 * (k + 1) + 4 + 96 + 8 > 6000:
+            continue
+        sc = cfg.sub[k]
+        sc.id, sc.start_cu, sc.slform, sc.uep_index, sc.eep_protlev, sc.size_cu = sid, cu, slform, idx, lev, size
+        cu += size + int(rng.integers(0, 6))
+        kbps += rate
+        k += 1
+    if k == 0:                                                       # nothing fitted: one small sub-channel
+        sc = cfg.sub[0]
+        sc.id, sc.start_cu, sc.slform, sc.uep_index, sc.eep_protlev, sc.size_cu = 7, 0, 1, 0, 2, 6
+        k = 1
+    cfg.nsub = k
+    return cfg
+
+
+def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None, reference=False, harsh=False, layouts=False):
     """The sweep itself -> result dict (one record per capture under "cases")."""
     import dabtools_amd as dab
     workers = workers or min(32, os.cpu_count() or 1)
@@ -64,6 +103,8 @@ def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None, ref
                     cfg = dab.synth_preset(int(rng.integers(0, 2)), seed=int(rng.integers(1, 1 << 30)), cif_count0=int(rng.integers(0, 5000)),
                                            skip_samples=int(rng.choice([0, 0, int(rng.integers(1, 196608))])), snr_db=snr,
                                            amplitude=float(rng.choice([1.0, 0.8, 0.5, 0.35])), cfo_hz=float(rng.choice([0.0, 0.0, rng.uniform(-400, 400)])))
+                if layouts:
+                    random_layout(dab, cfg, rng)
                 ntf = int(tfs + rng.integers(0, 5))
                 iq = dab.synth_generate(cfg, ntf)
                 cut = 0
@@ -86,7 +127,7 @@ def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None, ref
                 total_frames += len(weti)
                 total_calls += len(wtrace)
                 equal = eti.shape == weti.shape and np.array_equal(eti, weti) and gtrace == wtrace
-                cases.append({"round": r, "stream": b, "preset": 0 if cfgs[b].nsub == 12 else 1, "seed": int(cfgs[b].seed), "cif_count0": int(cfgs[b].cif_count0),
+                cases.append({"round": r, "stream": b, "preset": 0 if cfgs[b].nsub == 12 else 1, "subchannels": int(cfgs[b].nsub), "seed": int(cfgs[b].seed), "cif_count0": int(cfgs[b].cif_count0),
                               "skip_samples": int(cfgs[b].skip_samples), "snr_db": float(cfgs[b].snr_db), "amplitude": float(cfgs[b].amplitude),
                               "cfo_hz": round(float(cfgs[b].cfo_hz), 2), "bytes_cut": ragged[b], "calls": len(wtrace), "eti_frames": int(len(weti)),
                               "resyncs": int(sum(1 for t in wtrace[2:] if t[2] != 0)), "equal": bool(equal)})
@@ -99,7 +140,8 @@ def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None, ref
     for f in os.listdir(tmp):
         os.remove(os.path.join(tmp, f))
     os.rmdir(tmp)
-    return {"mix": "harsh (5 dB ... clean, up to 1.4 carriers off tune, amplitudes 0.08 ... 2.5)" if harsh else "default",
+    return {"layouts": "random multiplexes (1 .. 16 sub-channels, any UEP row / EEP level and size)" if layouts else "the two presets",
+            "mix": "harsh (5 dB ... clean, up to 1.4 carriers off tune, amplitudes 0.08 ... 2.5)" if harsh else "default",
             "checker": "the reference itself: real front end over hipFFTW + real back end (oracle/_ref)" if reference else "oracle/or_replay",
             "rounds": rounds, "streams_per_round": streams, "eti_frames_compared": total_frames, "calls_compared": total_calls,
             "differences": bad, "seconds": round(time.time() - t0, 1), "seed": seed, "cases": cases}
@@ -115,8 +157,9 @@ def main():
     ap.add_argument("--reference", action="store_true", help="check against the reference's real front end + back end (needs oracle/_ref/libdabref_frontend.so; "
                                                              "every worker opens the GPU for hipFFTW: keep --workers small)")
     ap.add_argument("--harsh", action="store_true", help="the mix where the receiver is fragile: 5 dB ... clean, up to 1.4 carriers off tune, weak and clipped signals")
+    ap.add_argument("--layouts", action="store_true", help="every capture its own random multiplex instead of one of the two presets")
     args = ap.parse_args()
-    res = run(args.rounds, args.streams, args.tfs, args.workers, args.seed, log=sys.stderr, reference=args.reference, harsh=args.harsh)
+    res = run(args.rounds, args.streams, args.tfs, args.workers, args.seed, log=sys.stderr, reference=args.reference, harsh=args.harsh, layouts=args.layouts)
     print(json.dumps(res))
     sys.exit(1 if res["differences"] else 0)
 
