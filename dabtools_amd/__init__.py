@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("DABHIP_LIB") or os.path.join(_HERE, "libdabhip.so")  
 STREAM_MUX_OVERFLOW, STREAM_SUBCH_OUTSIDE_CIF, STREAM_EEP_OPTION, STREAM_SUBCH_SIZE = 1, 2, 4, 8
 TF_BYTES = 393216
 CHUNK_BYTES = 262144
+TAIL_BYTES = 1536      # the last bytes of sdr->buffer, kept as bytes beside the views (csrc/device_types.hpp: kTailBytes)
 FIC_BITS = 9216
 MSC_BITS = 221184
 ETI_BYTES = 6144
@@ -33,11 +34,34 @@ class SubChCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("id", "start_cu", "slform", "uep_index", "eep_protlev", "size_cu")]
 
 
+class ReconfCfg(C.Structure):
+    _fields_ = [("at_cif", C.c_int32), ("fic_lead", C.c_int32), ("nsub", C.c_int32), ("pad", C.c_int32), ("sub", SubChCfg * 64)]
+
+
+class ChannelCfg(C.Structure):
+    _fields_ = [("sro_ppm", C.c_double), ("echo_delay", C.c_int32 * 2), ("echo_gain", C.c_double * 2), ("echo_phase", C.c_double * 2),
+                ("echo_doppler_hz", C.c_double * 2), ("fade_depth", C.c_double), ("fade_hz", C.c_double),
+                ("iq_gain_db", C.c_double), ("iq_phase_deg", C.c_double)]
+
+
 class SynthCfg(C.Structure):
     _fields_ = [("eid", C.c_uint32), ("nsub", C.c_int32), ("sub", SubChCfg * 64), ("seed", C.c_uint64),
                 ("cif_count0", C.c_int32), ("skip_samples", C.c_int32), ("amplitude", C.c_double),
                 ("snr_db", C.c_double), ("cfo_hz", C.c_double),
-                ("fib_patch_len", C.c_int32), ("fib_patch_from_cif", C.c_int32), ("fib_patch", C.c_uint8 * 32)]
+                ("fib_patch_len", C.c_int32), ("fib_patch_from_cif", C.c_int32), ("fib_patch", C.c_uint8 * 32),
+                ("reconf", ReconfCfg * 2), ("channel", ChannelCfg)]
+
+    def set_reconf(self, k, at_cif, subs, fic_lead=0):
+        """Reconfiguration k (0 / 1): from logical CIF at_cif on the multiplex is `subs`, a list of (id, start_cu, slform, uep_index, eep_protlev,
+        size_cu); the FIC announces it fic_lead CIFs earlier."""
+        r = self.reconf[k]
+        r.at_cif, r.fic_lead, r.nsub = at_cif, fic_lead, len(subs)
+        for i, t in enumerate(subs):
+            r.sub[i].id, r.sub[i].start_cu, r.sub[i].slform, r.sub[i].uep_index, r.sub[i].eep_protlev, r.sub[i].size_cu = t
+
+    def multiplex(self):
+        """The initial multiplex as the tuples set_reconf takes."""
+        return [(s.id, s.start_cu, s.slform, s.uep_index, s.eep_protlev, s.size_cu) for s in self.sub[: self.nsub]]
 
     def set_fib_patch(self, data, from_cif=0):
         """Third FIB of every CIF from `from_cif` on = these bytes (<= 30) under a valid CRC: hostile / non-standard FIGs for tests."""
@@ -109,7 +133,8 @@ _SIGNATURES = {
     "dabhip_host_table": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.c_int]),
     "dabhip_host_fifo_new": (C.c_void_p, []),
     "dabhip_host_fifo_free": (None, [C.c_void_p]),
-    "dabhip_host_fifo_call": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "dabhip_host_fifo_call": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, u8p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                                        C.POINTER(C.c_int32), u8p]),
     "dabhip_synth_preset": (C.c_int, [C.c_int, C.POINTER(SynthCfg)]),
     "dabhip_synth_bytes": (C.c_size_t, [C.POINTER(SynthCfg), C.c_int]),
     "dabhip_synth_generate": (C.c_int64, [C.POINTER(SynthCfg), C.c_int, u8p, C.c_size_t]),
@@ -222,6 +247,9 @@ def synth_generate(cfg, ntf):
     n = lib().dabhip_synth_bytes(C.byref(cfg), ntf)
     iq = np.empty(n, dtype=np.uint8)
     got = lib().dabhip_synth_generate(C.byref(cfg), ntf, _p(iq), n)
+    if cfg.channel.sro_ppm != 0.0:             # the resampler decides the count; n is the capacity
+        _need(0 < got <= n, "synth_generate")
+        return iq[:got].copy()
     _need(got == n, "synth_generate")
     return iq
 
@@ -370,25 +398,30 @@ class HostFifo:
         self._h = lib().dabhip_host_fifo_new()
         _need(self._h, "host_fifo_new")
 
-    def call(self, coarse_timeshift, fine_timeshift):
-        """One sdr_demod call -> (status 0/1/2, [(seg_end, seg_src), ...], fifo_count)."""
+    def call(self, coarse_timeshift, fine_timeshift, stream=None, chunk_bytes=CHUNK_BYTES):
+        """One sdr_demod call appending chunk_bytes -> (status 0/1/2, [(seg_end, seg_src), ...], fifo_count).  stream (uint8 array holding at least
+        the bytes fed so far): the last 1536 bytes of sdr->buffer are tracked as bytes and left in self.tail."""
         nseg, cnt = C.c_int32(0), C.c_int32(0)
         ends = np.zeros(12, dtype=np.int32)
         srcs = np.zeros(12, dtype=np.int64)
-        r = lib().dabhip_host_fifo_call(self._h, coarse_timeshift, fine_timeshift, C.byref(nseg), ends.ctypes.data_as(C.POINTER(C.c_int32)),
-                                        srcs.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(cnt))
+        self.tail = np.zeros(TAIL_BYTES, dtype=np.uint8) if stream is not None else None
+        r = lib().dabhip_host_fifo_call(self._h, coarse_timeshift, fine_timeshift, chunk_bytes, _p(stream) if stream is not None else None, C.byref(nseg),
+                                        ends.ctypes.data_as(C.POINTER(C.c_int32)), srcs.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(cnt),
+                                        _p(self.tail) if stream is not None else None)
         _need(r >= 0, "host_fifo_call")
         return r, [(int(ends[i]), int(srcs[i])) for i in range(nseg.value)], cnt.value
 
     @staticmethod
-    def materialise(stream, view):
-        """The 393216 bytes of sdr->buffer a view describes."""
+    def materialise(stream, view, tail=None):
+        """The 393216 bytes of sdr->buffer a view (and the tail bytes kept beside it) describe."""
         buf = np.zeros(TF_BYTES, dtype=np.uint8)
         lo = 0
         for end, src in view:
             if src >= 0:
                 buf[lo:end] = stream[src + lo:src + end]
             lo = end
+        if tail is not None:
+            buf[TF_BYTES - TAIL_BYTES:] = tail
         return buf
 
     def close(self):

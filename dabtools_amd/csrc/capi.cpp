@@ -411,6 +411,7 @@ struct dabhip_sdr {
   Engine eng;
   DeviceBuffer<uint8_t> window;      // the most recent IQ bytes, device resident
   DeviceBuffer<StreamState> state;
+  DeviceBuffer<uint8_t> tail;        // the last kTailBytes of sdr->buffer (device_types.hpp)
   int64_t base = 0;                  // stream offset of window[0]
   int64_t fed = 0;                   // bytes received so far
   int call = 0;
@@ -429,11 +430,15 @@ dabhip_sdr* dabhip_sdr_init(int device)
 {
   dabhip_sdr* s = new (std::nothrow) dabhip_sdr(device);
   if (!s) return nullptr;
-  if (!s->eng.ok() || !s->window.reserve(kWindowBytes) || !s->state.reserve(1)) { delete s; return nullptr; }
+  if (!s->eng.ok() || !s->window.reserve(kWindowBytes) || !s->state.reserve(1) || !s->tail.reserve(kTailBytes)) { delete s; return nullptr; }
   StreamState st;
   std::memset(&st, 0, sizeof st);
   fifo_reset(st);
-  if (hipMemcpy(s->state.get(), &st, sizeof st, hipMemcpyHostToDevice) != hipSuccess) { set_error("sdr_init: state upload failed"); delete s; return nullptr; }
+  if (hipMemcpy(s->state.get(), &st, sizeof st, hipMemcpyHostToDevice) != hipSuccess || hipMemset(s->tail.get(), 0, kTailBytes) != hipSuccess) {
+    set_error("sdr_init: state upload failed");
+    delete s;
+    return nullptr;
+  }
   std::memset(&s->last, 0, sizeof s->last);
   return s;
 }
@@ -441,9 +446,13 @@ void dabhip_sdr_free(dabhip_sdr* s) { delete s; }
 
 int dabhip_sdr_demod(dabhip_sdr* s, const uint8_t* input_buffer, int input_buffer_len, uint8_t* fic, uint8_t* msc)
 {
-  if (!s || !input_buffer || !fic || !msc) { set_error("sdr_demod: null argument"); return -1; }
-  // The scan kernel advances in whole DEFAULT_BUF_LENGTH calls, which is what librtlsdr delivers (dab2eti.c:238).
-  if (input_buffer_len != kChunkBytes) { set_error("sdr_demod: input_buffer_len must be 262144 (DEFAULT_BUF_LENGTH)"); return -1; }
+  if (!s || (!input_buffer && input_buffer_len != 0) || !fic || !msc) { set_error("sdr_demod: null argument"); return -1; }
+  // sdr_demod appends whatever the callback left, input_buffer_len bytes (input_sdr.c:36-38; librtlsdr delivers DEFAULT_BUF_LENGTH = 262144,
+  // dab2eti.c:125-126,238, a file's last buffer is shorter).  Whole I/Q pairs only: the kernels read the stream two bytes at a time.
+  if (input_buffer_len < 0 || input_buffer_len > kChunkBytes || (input_buffer_len & 1)) {
+    set_error("sdr_demod: input_buffer_len must be an even number of bytes, 0 .. 262144 (sizeof sdr->input_buffer, input_sdr.h:14)");
+    return -1;
+  }
   if (s->fed - s->base + input_buffer_len > kWindowBytes) {   // slide the device window
     const int64_t keep_from = s->fed - kKeepBytes;
     DeviceBuffer<uint8_t> tmp;
@@ -455,13 +464,13 @@ int dabhip_sdr_demod(dabhip_sdr* s, const uint8_t* input_buffer, int input_buffe
     }
     s->base = keep_from;
   }
-  if (hipMemcpy(s->window.get() + (s->fed - s->base), input_buffer, input_buffer_len, hipMemcpyHostToDevice) != hipSuccess) {
+  if (input_buffer_len && hipMemcpy(s->window.get() + (s->fed - s->base), input_buffer, input_buffer_len, hipMemcpyHostToDevice) != hipSuccess) {
     set_error("sdr_demod: IQ upload failed");
     return -1;
   }
   s->fed += input_buffer_len;
   const uint8_t* virtual_base = s->window.get() - s->base;    // stream offset x lives at virtual_base + x
-  if (!s->eng.scan_one_call(virtual_base, s->fed, s->state.get(), s->call, &s->last)) return -1;
+  if (!s->eng.scan_one_call(virtual_base, s->state.get(), s->tail.get(), s->call, input_buffer_len, &s->last)) return -1;
   ++s->call;
   if (s->last.status != 2) return 0;
   for (int i = 0; i < s->last.view.nseg; ++i)
@@ -642,27 +651,36 @@ extern "C" int dabhip_host_table(int which, int32_t* out, int cap)
 // ---- FIFO / frame-buffer bookkeeping of K1 on the host (fifo_view.hpp), callable without a GPU ---------
 struct dabhip_fifo {
   StreamState st;
+  uint8_t tail[kTailBytes];          // the last kTailBytes of sdr->buffer, kept as bytes (device_types.hpp)
 };
 extern "C" dabhip_fifo* dabhip_host_fifo_new(void)
 {
   dabhip_fifo* f = new (std::nothrow) dabhip_fifo;
   if (!f) return nullptr;
   std::memset(&f->st, 0, sizeof f->st);
+  std::memset(f->tail, 0, sizeof f->tail);
   fifo_reset(f->st);
   return f;
 }
 extern "C" void dabhip_host_fifo_free(dabhip_fifo* f) { delete f; }
-extern "C" int dabhip_host_fifo_call(dabhip_fifo* f, int32_t coarse_timeshift, int32_t fine_timeshift, int32_t* nseg, int32_t* seg_end,
-                                     int64_t* seg_src, int32_t* fifo_count)
+extern "C" int dabhip_host_fifo_call(dabhip_fifo* f, int32_t coarse_timeshift, int32_t fine_timeshift, int32_t chunk_bytes, const uint8_t* stream,
+                                     int32_t* nseg, int32_t* seg_end, int64_t* seg_src, int32_t* fifo_count, uint8_t* tail)
 {
   if (!f || !nseg || !seg_end || !seg_src) { set_error("host_fifo_call: null argument"); return -1; }
+  if (chunk_bytes < 0 || chunk_bytes > kChunkBytes || (chunk_bytes & 1)) { set_error("host_fifo_call: chunk_bytes must be even, 0 .. 262144"); return -1; }
   f->st.coarse_timeshift = coarse_timeshift;
   f->st.fine_timeshift = fine_timeshift;
-  const FifoCall c = fifo_call(f->st);
+  const FifoCall c = fifo_call(f->st, chunk_bytes);
   if (f->st.overflow) { set_error("host_fifo_call: more than kMaxSeg nested short reads"); return -1; }
+  if (c.status && stream)                                  // the rule K1 applies to its registers (sync_scan_kernel), byte by byte
+    for (int p = kTailStart; p < kTfBytes; ++p) {
+      const int64_t src = read_source(f->st.view, c.fresh, p);
+      if (src >= 0) f->tail[p - kTailStart] = stream[src];
+    }
   *nseg = f->st.view.nseg;
   for (int i = 0; i < kMaxSeg; ++i) { seg_end[i] = f->st.view.seg_end[i]; seg_src[i] = f->st.view.seg_src[i]; }
   if (fifo_count) *fifo_count = c.fifo_count;
+  if (tail) std::memcpy(tail, f->tail, kTailBytes);
   return c.status ? (c.do_sync ? 2 : 1) : 0;
 }
 

@@ -8,17 +8,46 @@
 namespace dabhip {
 
 constexpr int kMaxSeg = 12;
+// The last kTailBytes of the frame buffer are kept as BYTES, not as views (round 5).  A negative time shift makes sdr_read_fifo read short and
+// leave the end of sdr->buffer as it was (sdr_fifo.c:56-59); the fine time shift is at least (768 - 1536) * 2 bytes (sdr_sync.c:197-201) and the
+// coarse one is never negative, so a locked receiver's stale data lives in buffer[393216 - 1536 ..).  A receiver whose sample clock runs fast
+// against the transmitter's reads short on EVERY call: described as views, the sources of those bytes never age out (a session would have to keep
+// the whole stream) and the views nest without bound.  So K1 carries these 1536 bytes along (768 two-byte words in registers of the stream's
+// workgroup, sync_scan_kernel) and leaves every frame its own copy (FrameView::tail); views describe the rest of the buffer, where stale data only
+// appears after a read that ran the FIFO dry (a large coarse correction) and is overwritten by the next ordinary read.
+constexpr int kTailBytes = 1536;
+constexpr int kTailStart = 196608 * 2 - kTailBytes;
 
 // How the 393216-byte frame buffer of the reference (sdr->buffer, input_sdr.h:16) looks
 // after one sdr_read_fifo() call, expressed as views into the never-modified IQ stream:
 // buffer position p in [seg_end[i-1], seg_end[i]) holds stream byte seg_src[i] + p
 // (seg_src < 0: the calloc'ed zero byte).  Segment 0 is what this call read; later
-// segments are the stale tail left by earlier, longer reads (sdr_fifo.c:56-59).
+// segments are the stale data left by earlier, longer reads (sdr_fifo.c:56-59).
+// tail != nullptr: positions p >= kTailStart hold tail[p - kTailStart], whatever the segments say (where segment 0 covers them, the same bytes).
 struct FrameView {
   int32_t nseg;
   int32_t seg_end[kMaxSeg];
   int64_t seg_src[kMaxSeg];
+  const uint8_t* tail;
 };
+// buffer position p of a frame -> its byte (the one rule every kernel reads the frame buffer by)
+__host__ __device__ __forceinline__ int frame_byte(const uint8_t* stream, const FrameView& v, int p)
+{
+  if (p >= kTailStart && v.tail) return v.tail[p - kTailStart];
+  int i = 0;
+  while (i < v.nseg - 1 && p >= v.seg_end[i]) ++i;
+  const int64_t s = v.seg_src[i];
+  return s < 0 ? 0 : stream[s + p];
+}
+// two bytes at an even position (segment boundaries and sources are even: both bytes come from the same place), little endian
+__host__ __device__ __forceinline__ unsigned frame_u16(const uint8_t* stream, const FrameView& v, int p)
+{
+  if (p >= kTailStart && v.tail) return *reinterpret_cast<const uint16_t*>(v.tail + (p - kTailStart));
+  int i = 0;
+  while (i < v.nseg - 1 && p >= v.seg_end[i]) ++i;
+  const int64_t s = v.seg_src[i];
+  return s < 0 ? 0u : *reinterpret_cast<const uint16_t*>(stream + s + p);
+}
 
 // Result of one sdr_demod() call (input_sdr.c:27-165) for one stream.
 struct CallDesc {
@@ -29,7 +58,9 @@ struct CallDesc {
   int32_t nco_hz;        // software AFC: frequency the samples of this frame were de-rotated by (0 in parity mode)
   int32_t pad;
   FrameView view;
+  int64_t pad16;         // (cleared and copied in 16-byte pieces)
 };
+static_assert(sizeof(CallDesc) % 16 == 0, "CallDesc is cleared in 16-byte pieces");
 
 // Front-end state carried from call to call (struct sdr_state_t, input_sdr.h:12-41)
 struct StreamState {

@@ -708,6 +708,10 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
   if (!cont) std::fill(states, states + nstreams, initial_state());
   static_assert(sizeof(CallDesc) % 16 == 0, "cleared in 16-byte pieces");
   if (!d_states_.reserve(nstreams) || !d_iq_ptrs_.reserve(nstreams) || !d_nbytes_.reserve(nstreams) || !d_descs_.reserve(ndesc) || !d_info_.reserve(ndesc + 1)) return false;
+  if (!d_tail_state_.reserve(static_cast<size_t>(nstreams) * kTailBytes) || !d_tail_images_.reserve(ndesc * kTailBytes) ||
+      (split_wanted && !d_tail_prev_.reserve(static_cast<size_t>(nstreams) * kTailBytes)))
+    return false;
+  const SyncTails tails{d_tail_state_.get(), d_tail_state_.get(), d_tail_images_.get(), kChunkBytes};
   if (split_wanted) {
     // d_viol_[0 .. nstreams): first call of a stream that broke the chain's assumption; [nstreams]: calls the fp32 pass of the
     // verification left to the fp64 pass
@@ -734,6 +738,8 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
     a.info = reinterpret_cast<uint4*>(d_info_.get());
     a.info_vec = (ndesc + 1) / 2;
     a.nstreams = nstreams;
+    a.tail_state = d_tail_state_.get();
+    a.tail_state_prev = split_wanted ? d_tail_prev_.get() : nullptr;
     if (!check(launch_scan_setup(a, stream_), "scan setup launch")) return false;
   }
   scan_setup_ms_ = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
@@ -746,7 +752,7 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
     // the reference's order, call after call: with the software AFC every call's NCO depends on the estimates of the call
     // before; and the fallback when the split scan's assumption failed
     if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), nstreams, max_calls_, -1, -1,
-                                d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), afc_ ? 1 : 0, stream_),
+                                d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), afc_ ? 1 : 0, stream_, false, nullptr, nullptr, tails),
                "sync scan launch"))
       return false;
   } else {
@@ -760,7 +766,7 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
     // beside it runs at half its rate and slows the chain.  Round 3, with the fp32 verification (39.5 KB of LDS, 54 VGPRs): on its own stream beside the FIC
     // symbols' OFDM launch -- step unchanged, 10.4 ms: both are issue-bound, the work only moves.)
     if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), nstreams, max_calls_, -1, -1,
-                                d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), 0, stream_, true),
+                                d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), 0, stream_, true, nullptr, nullptr, tails),
                "sync chain launch") ||
         // {status, ordinal} of every call are final once the chain is through (a stream that breaks its assumption is scanned again
         // below): they come back on the side stream while the verification runs, and the caller lays the frames out beside it
@@ -806,7 +812,8 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
       guard_counters_clear_ = false;
       if (!check(hipStreamSynchronize(stream_), "before the rescan") || !d_redo_.upload(redo, stream_) ||
           !check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), static_cast<int>(redo.size()), max_calls_,
-                                  -1, -1, d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), 0, stream_, false, d_states_prev_.get(), d_redo_.get()),
+                                  -1, -1, d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), 0, stream_, false, d_states_prev_.get(), d_redo_.get(),
+                                  SyncTails{d_tail_prev_.get(), d_tail_state_.get(), d_tail_images_.get(), kChunkBytes}),
                  "sync rescan launch"))
         return false;
       if (!record(ev_[1], stream_)) return false;
@@ -1395,14 +1402,15 @@ int Engine::viterbi_batch(const uint8_t* symbols, uint8_t* data, int framebits, 
 
 // ---------------------------------------------------------------------------------------------
 // S2 building blocks: one sdr_demod call on an explicit stream
-bool Engine::scan_one_call(const uint8_t* iq_virtual_base, int64_t fed_bytes, StreamState* d_state, int call, CallDesc* out)
+bool Engine::scan_one_call(const uint8_t* iq_virtual_base, StreamState* d_state, uint8_t* d_tail, int call, int chunk, CallDesc* out)
 {
   std::vector<const uint8_t*> ptrs = {iq_virtual_base};
-  std::vector<int64_t> nb = {fed_bytes};
-  if (!d_iq_ptrs_.upload(ptrs, stream_) || !d_nbytes_.upload(nb, stream_) || !d_descs_.reserve(1)) return false;
-  // the kernel indexes descs[stream * max_calls + call]; with max_calls = 0 and the pointer moved back by `call` it hits slot 0
+  std::vector<int64_t> nb = {static_cast<int64_t>(call + 1) * kChunkBytes};     // (only bounds the kernel's call loop: this is call number `call`, whatever its length)
+  if (!d_iq_ptrs_.upload(ptrs, stream_) || !d_nbytes_.upload(nb, stream_) || !d_descs_.reserve(1) || !d_tail_images_.reserve(kTailBytes)) return false;
+  // the kernel indexes descs[stream * max_calls + call]; with max_calls = 0 and the pointer moved back by `call` it hits slot 0 (the tail copy likewise)
   if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_state, d_descs_.get() - call, nullptr, 1, 0, call, call + 1, d_tw2048_.get(),
-                              d_tw1536_.get(), d_prs_.get(), 0, stream_),
+                              d_tw1536_.get(), d_prs_.get(), 0, stream_, false, nullptr, nullptr,
+                              SyncTails{d_tail, d_tail, d_tail_images_.get() - static_cast<ptrdiff_t>(call) * kTailBytes, chunk}),
              "sync scan launch"))
     return false;
   return check(hipMemcpyAsync(out, d_descs_.get(), sizeof(CallDesc), hipMemcpyDeviceToHost, stream_), "desc download") &&

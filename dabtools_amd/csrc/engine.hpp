@@ -233,7 +233,8 @@ class Engine {
   // the demapped values (hard: 0 / 1, soft: -7 .. 7) of one TF of the last decode, in the reference's hand-off order (dab.h:27-33)
   bool read_demapped_tf(int stream, int tf, int8_t* fic_out, int8_t* msc_out);
   // front end on an explicit single stream (S2 seam): calls [call, call+1)
-  bool scan_one_call(const uint8_t* iq_virtual_base, int64_t fed_bytes, StreamState* d_state, int call, CallDesc* out);
+  // d_tail: the seam's kTailBytes tail bytes (device, zero at sdr_init); chunk: bytes this call appended (input_buffer_len)
+  bool scan_one_call(const uint8_t* iq_virtual_base, StreamState* d_state, uint8_t* d_tail, int call, int chunk, CallDesc* out);
   bool demod_one_frame(const uint8_t* iq_virtual_base, const CallDesc& desc, uint8_t* fic_bytes, uint8_t* msc_bytes);
   hipStream_t stream() const { return stream_; }
   int device() const { return device_; }
@@ -308,6 +309,8 @@ class Engine {
   DeviceBuffer<const uint8_t*> d_iq_ptrs_;
   DeviceBuffer<int64_t> d_nbytes_;
   DeviceBuffer<StreamState> d_states_, d_states_prev_;
+  // the streams' tail bytes (device_types.hpp: kTailBytes): carried like the states, the incoming ones kept for a rescan, and one copy per call
+  DeviceBuffer<uint8_t> d_tail_state_, d_tail_prev_, d_tail_images_;
   DeviceBuffer<int> d_viol_, d_redo_, d_calls_before_;
   PinnedBuffer<int> h_viol_, h_calls_before_;
   int sync_rescanned_ = 0;            // streams the split scan had to scan again in full (last decode)

@@ -86,13 +86,7 @@ __device__ __forceinline__ void dft4(float2& x0, float2& x1, float2& x2, float2&
   x0 = F(d0 + d1); x2 = F(d0 - d1); x1 = F(add_mi(d2, d13)); x3 = F(sub_mi(d2, d13));
 }
 
-__device__ __forceinline__ int view_byte(const uint8_t* stream, const FrameView& v, int p)
-{
-  int i = 0;
-  while (i < v.nseg - 1 && p >= v.seg_end[i]) ++i;
-  const int64_t s = v.seg_src[i];
-  return s < 0 ? 0 : stream[s + p];
-}
+__device__ __forceinline__ int view_byte(const uint8_t* stream, const FrameView& v, int p) { return frame_byte(stream, v, p); }
 __device__ __forceinline__ float rail(int byte) { return static_cast<float>(static_cast<int8_t>(static_cast<uint8_t>(byte - 127))); }
 // one IQ sample, I in byte 0 and Q in byte 1 of w (upper half clear): (float)(int8)(byte - 127) each (input_sdr.c:60-63).
 // - 127 = + 0x81 mod 256, added without a carry into the byte that is read; the conversion sign-extends that byte itself

@@ -7,7 +7,8 @@
 // is described as a FrameView (device_types.hpp): which stream byte every buffer position holds after the read.
 //
 //   shift <= 0: the next 393216 + shift stream bytes land in buffer[0 .. 393216 + shift); the tail keeps whatever
-//               earlier reads left there (sdr_fifo.c:56-59).
+//               earlier reads left there (sdr_fifo.c:56-59).  Those last 1536 bytes are carried as BYTES by whoever replays the FIFO
+//               (K1's registers, the host replay's array; device_types.hpp: kTailBytes), the views below describe the rest.
 //   shift >  0: sdr_read_fifo FIRST copies the `shift` skipped bytes to buffer[0 .. shift) and THEN the `len` frame
 //               bytes to buffer[0 .. len) (sdr_fifo.c:49-55).  When the FIFO runs dry (len < shift: a large coarse
 //               correction with little backlog) buffer[len .. shift) therefore holds SKIPPED stream bytes, not the
@@ -28,13 +29,24 @@ struct FifoCall {
   int status;       // 0 = fewer than 1.5 TF queued: nothing read; 1 = a frame was read
   int do_sync;      // the frame is processed (0 for the first frame read: input_sdr.c:51-55, GAIN_SETTLE_TIME 0)
   int fifo_count;   // sdr->fifo.count after the call
+  int fresh;        // leading segments of the new view this read wrote itself: 1, or 2 with the skipped bytes of a dry read
 };
 
-// One sdr_demod call's worth of FIFO work: 262144 bytes appended, at most one frame read with the shift held in `st`.
-__host__ __device__ inline FifoCall fifo_call(StreamState& st)
+// Stream offset of the byte the read described by the first `fresh` segments of `v` leaves at buffer position p, -1 where the read does
+// not reach (the position keeps what it held).  The rule K1 updates a stream's tail bytes by (device_types.hpp: kTailBytes).
+__host__ __device__ __forceinline__ int64_t read_source(const FrameView& v, int fresh, int p)
 {
-  FifoCall out{0, 0, 0};
-  st.fed += kChunkBytes;
+  if (p < v.seg_end[0]) return v.seg_src[0] + p;
+  if (fresh == 2 && p < v.seg_end[1]) return v.seg_src[1] + p;
+  return -1;
+}
+
+// One sdr_demod call's worth of FIFO work: 262144 bytes appended, at most one frame read with the shift held in `st`.
+// chunk: the bytes this call appended (input_buffer_len, input_sdr.c:36-38; 262144 from librtlsdr, dab2eti.c:238).
+__host__ __device__ inline FifoCall fifo_call(StreamState& st, int chunk = kChunkBytes)
+{
+  FifoCall out{0, 0, 0, 0};
+  st.fed += chunk;
   int64_t count = st.fed - st.consumed;
   if (count >= 3 * kTfSamples) {
     const int shift = st.coarse_timeshift + st.fine_timeshift;
@@ -59,14 +71,17 @@ __host__ __device__ inline FifoCall fifo_call(StreamState& st)
       covered = skipped;
       n = 2;
     }
+    out.fresh = n;
+    // older segments that still show below the tail bytes (which are kept as bytes, not as views: device_types.hpp)
     for (int i = 0; i < st.view.nseg; ++i) {
-      if (st.view.seg_end[i] > covered) {
+      if (st.view.seg_end[i] > covered && covered < kTailStart && (i == 0 || st.view.seg_end[i - 1] < kTailStart)) {
         if (n < kMaxSeg) { nv.seg_end[n] = st.view.seg_end[i]; nv.seg_src[n] = st.view.seg_src[i]; ++n; }
         else st.overflow = 1;
       }
     }
     nv.nseg = n;
     for (int i = n; i < kMaxSeg; ++i) { nv.seg_end[i] = kTfBytes; nv.seg_src[i] = -1; }
+    nv.tail = st.view.tail;
     st.view = nv;
     st.consumed += len;
     count -= len;
@@ -87,6 +102,7 @@ __host__ __device__ inline void fifo_reset(StreamState& st)
   st.tuner_hz = 0;
   st.rng = 1;
   st.view.nseg = 1;
+  st.view.tail = nullptr;
   for (int i = 0; i < kMaxSeg; ++i) { st.view.seg_end[i] = kTfBytes; st.view.seg_src[i] = -1; }
 }
 

@@ -23,13 +23,7 @@
 namespace dabhip {
 namespace {
 
-__device__ __forceinline__ int pview_byte(const uint8_t* stream, const FrameView& v, int p)
-{
-  int i = 0;
-  while (i < v.nseg - 1 && p >= v.seg_end[i]) ++i;
-  const int64_t s = v.seg_src[i];
-  return s < 0 ? 0 : stream[s + p];
-}
+__device__ __forceinline__ int pview_byte(const uint8_t* stream, const FrameView& v, int p) { return frame_byte(stream, v, p); }
 __device__ __forceinline__ int prail(int byte) { return static_cast<int>(static_cast<int8_t>(static_cast<uint8_t>(byte - 127))); }
 
 // ---- d(l) for symbols [sym0, sym0 + nsym) of every frame: one wave per symbol -------------------------------------

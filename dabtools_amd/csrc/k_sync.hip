@@ -39,22 +39,13 @@ __device__ volatile int g_sync_call;     // volatile: read back through the vect
 #define SYNC_STAMP(i) do {} while (0)
 #endif
 
-__device__ __forceinline__ int view_byte(const uint8_t* stream, const FrameView& v, int p)
-{
-  int i = 0;
-  while (i < v.nseg - 1 && p >= v.seg_end[i]) ++i;
-  const int64_t s = v.seg_src[i];
-  return s < 0 ? 0 : stream[s + p];
-}
+__device__ __forceinline__ int view_byte(const uint8_t* stream, const FrameView& v, int p) { return frame_byte(stream, v, p); }
 // one IQ sample (I at the even byte p, Q at p + 1): segment boundaries and sources are even, so both bytes
 // come from the same segment and one 2-byte load fetches them
 // nco_hz != 0 (software AFC only): the sample is de-rotated by exp(-2 pi i nco n / fs), n = sample index in the frame
 __device__ __forceinline__ double2 view_sample(const uint8_t* stream, const FrameView& v, int p, int nco_hz)
 {
-  int i = 0;
-  while (i < v.nseg - 1 && p >= v.seg_end[i]) ++i;
-  const int64_t s = v.seg_src[i];
-  const unsigned w = s < 0 ? 0u : *reinterpret_cast<const uint16_t*>(stream + s + p);
+  const unsigned w = frame_u16(stream, v, p);
   const double2 x = make_double2(static_cast<int8_t>(static_cast<uint8_t>((w & 0xff) - 127)), static_cast<int8_t>(static_cast<uint8_t>((w >> 8) - 127)));
   if (nco_hz == 0) return x;
   double sn, cs;
@@ -209,7 +200,7 @@ __device__ __forceinline__ double2 mul_conj_prs(double2 x, int q)
 struct Shared {
   StreamState st;
   Red red;
-  int status, do_sync, fifo_count;
+  int status, do_sync, fifo_count, fresh;
   int coarse_fs;
   double fine_fs;
 };
@@ -223,8 +214,10 @@ constexpr int kSpecBins = 128 + 28;                        // spectrum bins touc
 // ---- the estimators of sdr_sync.c, each run by the whole workgroup on LDS buffers ---------------------------------------
 // A: 2048 points; Bf: kBatchPoints; tw: exp(2 pi i k / 2048), k < 1024.  All return the same value in every thread.
 
-// dab_coarse_time_sync (sdr_sync.c:34-68) -> byte shift, 0 = the null symbol is where it should be
-__device__ int coarse_time_sync(const uint8_t* stream, const FrameView& view, int force, Red& red, uint8_t* env)
+// dab_coarse_time_sync (sdr_sync.c:34-68) -> byte shift, 0 = the null symbol is where it should be.  In two parts, so that the caller can
+// put the stream's tail bytes in place between them (the search reads the whole frame buffer, the test only its first 5320 bytes):
+// the null-symbol energy test (sdr_sync.c:40-46) ...
+__device__ int null_symbol_energy(const uint8_t* stream, const FrameView& view, Red& red)
 {
   const int tid = threadIdx.x;
   int e = 0;
@@ -233,8 +226,12 @@ __device__ int coarse_time_sync(const uint8_t* stream, const FrameView& view, in
   } else {
     for (int n = tid; n < 266; n += kThreads) e += abs(rail(view_byte(stream, view, 20 * n)));
   }
-  e = block_sum_int(red, e);
-  if (e < 5000 && force == 0) return 0;
+  return block_sum_int(red, e);
+}
+// ... and the search for the null symbol (sdr_sync.c:47-68)
+__device__ int coarse_time_search(const uint8_t* stream, const FrameView& view, Red& red, uint8_t* env)
+{
+  const int tid = threadIdx.x;
   // envelope a[n] = |real[10 n]|, window sums of 266 taps, first minimum
   constexpr int kEnv = (kTfSamples - kNullSamples) / 10 + 266;   // 19661
   constexpr int kWin = (kTfSamples - kNullSamples) / 10;        // 19395 windows examined
@@ -488,13 +485,14 @@ __device__ __forceinline__ SyncLds sync_lds(unsigned char* smem, const double2* 
 // state, building the new view through a dynamically indexed local copy, took well over a microsecond of every call of the chain (tools/sync_times.py).
 // Same results as fifo_call: the host replay of that function is what the CPU suite holds against the reference's sdr_fifo.c, and every GPU trace test
 // compares fifo_count and the views' effects call by call.
-__device__ __forceinline__ void fifo_call_wave(Shared& sh)
+// chunk: bytes this call appended; tail_slot: where this call's copy of the stream's tail bytes goes (device_types.hpp: kTailBytes), or null
+__device__ __forceinline__ void fifo_call_wave(Shared& sh, int chunk, const uint8_t* tail_slot)
 {
   const int lane = threadIdx.x;                          // caller: threadIdx.x < 64
   StreamState& st = sh.st;
-  const int64_t fed = st.fed + kChunkBytes;
+  const int64_t fed = st.fed + chunk;
   int64_t consumed = st.consumed, count = fed - consumed;
-  int status = 0, do_sync = 0;
+  int status = 0, do_sync = 0, fresh = 0;
   int startup = st.startup_delay;
   if (count >= 3 * kTfSamples) {
     const int shift = st.coarse_timeshift + st.fine_timeshift;
@@ -513,8 +511,11 @@ __device__ __forceinline__ void fifo_call_wave(Shared& sh)
     // old entries, one per lane (read before anything is written: one instruction stream)
     const int old_n = st.view.nseg;
     const int old_end = lane < kMaxSeg ? st.view.seg_end[lane] : 0;
+    const int prev_end = lane > 0 && lane < kMaxSeg ? st.view.seg_end[lane - 1] : 0;
     const int64_t old_src = lane < kMaxSeg ? st.view.seg_src[lane] : -1;
-    const bool keep = lane < old_n && lane < kMaxSeg && old_end > covered;
+    // (only what still shows BELOW the tail bytes: those travel as bytes, fifo_view.hpp)
+    const bool keep = lane < old_n && lane < kMaxSeg && old_end > covered && covered < kTailStart && prev_end < kTailStart;
+    fresh = n0;
     const unsigned long long mask = __ballot(keep);
     const int pos = n0 + __popcll(mask & ((1ull << lane) - 1ull));
     const int total = n0 + __popcll(mask);
@@ -526,6 +527,7 @@ __device__ __forceinline__ void fifo_call_wave(Shared& sh)
       st.view.seg_src[0] = consumed;
       if (extra) { st.view.seg_end[1] = skipped; st.view.seg_src[1] = consumed0; }   // buffer[p] = stream[consumed0 + p] for p < shift
       st.view.nseg = n;
+      st.view.tail = tail_slot;
       if (total > kMaxSeg) st.overflow = 1;
     }
     consumed += len;
@@ -541,6 +543,7 @@ __device__ __forceinline__ void fifo_call_wave(Shared& sh)
     sh.status = status;
     sh.do_sync = do_sync;
     sh.fifo_count = static_cast<int>(count);
+    sh.fresh = fresh;
     sh.coarse_fs = 0;
   }
 }
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
                                                              CallDesc* __restrict__ descs, int2* __restrict__ info, int max_calls, int call_begin,
                                                              int call_end, const double2* __restrict__ tw2048,
                                                              const double2* __restrict__ tw1536,
-                                                             const uint8_t* __restrict__ prs_q, int afc)
+                                                             const uint8_t* __restrict__ prs_q, int afc, SyncTails tails)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const SyncLds lds = sync_lds(smem, tw2048);
@@ -578,6 +581,11 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
   const int kdesc0 = call_begin >= 0 ? 0 : kfirst;
   if (tid == 0) { sh.st = states_in[b]; sh.fine_fs = sh.st.fine_freq_shift; }
   const FineTimeTables fine_tab = fine_time_tables(tw1536, prs_q);
+  // The stream's tail bytes -- the last kTailBytes of the reference's frame buffer, which a short read leaves as they were (sdr_fifo.c:56-59) --
+  // travel in registers: thread t < 384 holds bytes 4 t .. 4 t + 3.  (tails.state_in == nullptr: a caller without tail state, stage tests)
+  constexpr int kTailWords = kTailBytes / 4;
+  uint32_t tail_word = 0;
+  if (tails.state_in && tid < kTailWords) tail_word = reinterpret_cast<const uint32_t*>(tails.state_in + static_cast<size_t>(b) * kTailBytes)[tid];
   __syncthreads();
 
   for (int k = kfirst; k < kend; ++k) {
@@ -586,15 +594,42 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
 #endif
     SYNC_STAMP(0);
     // ---- FIFO bookkeeping: input_sdr.c:36-55 over sdr_fifo.c:43-61 (fifo_view.hpp) -------
-    if (tid < 64) fifo_call_wave(sh);
+    uint8_t* const tail_slot = tails.images ? tails.images + (static_cast<size_t>(b) * max_calls + (k - kdesc0)) * kTailBytes : nullptr;
+    if (tid < 64) fifo_call_wave(sh, tails.chunk, tail_slot);
     __syncthreads();
+
+    // what this call's read leaves in the tail bytes: loads issued here, taken up (and the frame's copy written) behind the first wait below
+    unsigned tail_lo = 0, tail_hi = 0;
+    bool take_lo = false, take_hi = false;
+    const bool frame_read = sh.status != 0;
+    if (frame_read && tid < kTailWords) {
+      const int64_t s0 = read_source(sh.st.view, sh.fresh, kTailStart + 4 * tid), s1 = read_source(sh.st.view, sh.fresh, kTailStart + 4 * tid + 2);
+      take_lo = s0 >= 0;
+      take_hi = s1 >= 0;
+      if (take_lo) tail_lo = *reinterpret_cast<const uint16_t*>(stream + s0);
+      if (take_hi) tail_hi = *reinterpret_cast<const uint16_t*>(stream + s1);
+    }
+    auto commit_tail = [&]() {
+      if (frame_read && tid < kTailWords) {
+        if (take_lo) tail_word = (tail_word & 0xffff0000u) | tail_lo;
+        if (take_hi) tail_word = (tail_word & 0x0000ffffu) | (tail_hi << 16);
+        if (tail_slot) reinterpret_cast<uint32_t*>(tail_slot)[tid] = tail_word;
+      }
+    };
 
     const int nco = afc ? sh.st.tuner_hz : 0;
     if (sh.do_sync) {
       const FrameView& view = sh.st.view;
       const Prefetched<2048> pf = prefetch_samples<2048>(stream, view, 2 * (kNullSamples + kCpSamples), nco);   // for the fine time search
       SYNC_STAMP(1);
-      const int coarse = coarse_time_sync(stream, view, sh.st.force_timesync, sh.red, env);      // input_sdr.c:64-74
+      const int force = sh.st.force_timesync;
+      const int energy = null_symbol_energy(stream, view, sh.red);                               // input_sdr.c:64-74
+      commit_tail();
+      int coarse = 0;
+      if (energy >= 5000 || force != 0) {
+        __syncthreads();                                  // the search reads the whole frame buffer, tail bytes included
+        coarse = coarse_time_search(stream, view, sh.red, env);
+      }
       if (tid == 0) { sh.st.coarse_timeshift = coarse; sh.st.force_timesync = 0; }
       __syncthreads();
       SYNC_STAMP(2);
@@ -617,6 +652,8 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
           }
         }
       }
+    } else {
+      commit_tail();                                      // a frame that is read and dropped (input_sdr.c:51-55) still overwrites the buffer
     }
     __syncthreads();
     if (tid >= 64 && tid < 64 + static_cast<int>(sizeof(FrameView) / 4)) {     // the view, word by word, by the second wave (one thread copying 152 bytes out of LDS was a microsecond)
@@ -654,6 +691,7 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
     SYNC_STAMP(9);
   }
   if (tid == 0) { sh.st.fine_freq_shift = sh.fine_fs; states[b] = sh.st; }
+  if (tails.state_out && tid < kTailWords) reinterpret_cast<uint32_t*>(tails.state_out + static_cast<size_t>(b) * kTailBytes)[tid] = tail_word;
 }
 
 // The estimators the chain-only scan left out, for every call it assumed demodulated: grid (max_calls, nstreams).
@@ -806,6 +844,16 @@ __global__ __launch_bounds__(256) void scan_setup_kernel(ScanSetupArgs a)
     if (a.h_states) reinterpret_cast<uint32_t*>(a.states)[i] = w;
     if (a.states_prev) reinterpret_cast<uint32_t*>(a.states_prev)[i] = w;
   }
+  // the streams' tail bytes (device_types.hpp: kTailBytes): all zero at the start of a capture (sdr_init callocs the frame buffer, input_sdr.c:167-186);
+  // the incoming ones kept for a rescan like the states
+  if (a.tail_state) {
+    const size_t ntail_words = static_cast<size_t>(a.nstreams) * (kTailBytes / 4);
+    for (size_t i = tid; i < ntail_words; i += step) {
+      const uint32_t w = a.h_states ? 0u : reinterpret_cast<const uint32_t*>(a.tail_state)[i];
+      if (a.h_states) reinterpret_cast<uint32_t*>(a.tail_state)[i] = 0u;
+      if (a.tail_state_prev) reinterpret_cast<uint32_t*>(a.tail_state_prev)[i] = w;
+    }
+  }
   for (size_t b = tid; b < static_cast<size_t>(a.nstreams); b += step) {
     a.iq_ptrs[b] = a.h_ptrs[b];
     a.nbytes[b] = a.h_nbytes[b];
@@ -848,8 +896,9 @@ hipError_t launch_scan_setup(const ScanSetupArgs& a, hipStream_t stream)
 hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, StreamState* states, CallDesc* descs, int2* info,
                             int nstreams, int max_calls, int call_begin, int call_end, const double2* tw2048,
                             const double2* tw1536, const uint8_t* prs_q, int afc, hipStream_t stream, bool chain_only,
-                            const StreamState* states_in, const int* stream_list)
+                            const StreamState* states_in, const int* stream_list, SyncTails tails)
 {
+  if (tails.chunk <= 0) tails.chunk = kChunkBytes;
   if (nstreams <= 0) return hipSuccess;
   hipError_t e = sync_attr();
   if (e != hipSuccess) return e;
@@ -857,10 +906,10 @@ hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, Str
   if (!states_in) states_in = states;
   if (chain_only)
     hipLaunchKernelGGL(sync_scan_kernel<true>, dim3(nstreams), dim3(kThreads), lds, stream, iq, nbytes, states_in, states, stream_list, descs, info,
-                       max_calls, call_begin, call_end, tw2048, tw1536, prs_q, afc);
+                       max_calls, call_begin, call_end, tw2048, tw1536, prs_q, afc, tails);
   else
     hipLaunchKernelGGL(sync_scan_kernel<false>, dim3(nstreams), dim3(kThreads), lds, stream, iq, nbytes, states_in, states, stream_list, descs, info,
-                       max_calls, call_begin, call_end, tw2048, tw1536, prs_q, afc);
+                       max_calls, call_begin, call_end, tw2048, tw1536, prs_q, afc, tails);
   return hipGetLastError();
 }
 

@@ -168,8 +168,10 @@ int synth_generate_device(const dabhip_synth_cfg* cfgs, int nstreams, int ntf, u
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device: the device modulator needs a GPU"); return -1; }
   if (!cfgs || !iq || nstreams <= 0 || ntf <= 0 || device < 0 || device >= ndev) { set_error("synth_generate_device: bad arguments"); return -1; }
-  for (int i = 0; i < nstreams; ++i)
+  for (int i = 0; i < nstreams; ++i) {
     if (!synth_validate(cfgs[i])) return -1;
+    if (synth_channel_active(cfgs[i])) { set_error("synth_generate_device: the channel stages (dabhip_channel_cfg) exist in the host generator only"); return -1; }
+  }
   if (!ok(hipSetDevice(device), "hipSetDevice")) return -1;
 
   std::vector<float2> twf(2048);

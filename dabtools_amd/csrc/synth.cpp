@@ -50,12 +50,25 @@ SubChannel to_subchannel(const dabhip_subch_cfg& c)
   return sc;
 }
 
-bool validate(const dabhip_synth_cfg& cfg)
+// the multiplex in force at logical CIF `cif`: in the MSC (lead = 0) or as announced by the FIC (lead = the entry's fic_lead)
+struct Multiplex {
+  int nsub;
+  const dabhip_subch_cfg* sub;
+};
+Multiplex multiplex_at(const dabhip_synth_cfg& cfg, int cif, bool fic)
 {
-  if (cfg.nsub < 0 || cfg.nsub > 64) { set_error("synth: nsub out of range"); return false; }
+  Multiplex m{cfg.nsub, cfg.sub};
+  for (const dabhip_reconf_cfg& r : cfg.reconf)
+    if (r.at_cif > 0 && cif >= r.at_cif - (fic ? r.fic_lead : 0)) m = Multiplex{r.nsub, r.sub};
+  return m;
+}
+
+bool validate_multiplex(int nsub, const dabhip_subch_cfg* sub)
+{
+  if (nsub < 0 || nsub > 64) { set_error("synth: nsub out of range"); return false; }
   std::vector<char> used(864, 0);
-  for (int k = 0; k < cfg.nsub; ++k) {
-    const SubChannel sc = to_subchannel(cfg.sub[k]);
+  for (int k = 0; k < nsub; ++k) {
+    const SubChannel sc = to_subchannel(sub[k]);
     if (sc.id < 0 || sc.id > 63 || sc.bitrate <= 0 || sc.start_cu < 0 || sc.start_cu + sc.size_cu > 864) {
       set_error("synth: sub-channel " + std::to_string(k) + " does not fit the CIF");
       return false;
@@ -66,7 +79,29 @@ bool validate(const dabhip_synth_cfg& cfg)
       used[cu] = 1;
     }
   }
+  return true;
+}
+
+bool channel_active(const dabhip_channel_cfg& c)
+{
+  return c.sro_ppm != 0.0 || c.echo_delay[0] || c.echo_delay[1] || c.fade_depth != 0.0 || c.iq_gain_db != 0.0 || c.iq_phase_deg != 0.0;
+}
+
+bool validate(const dabhip_synth_cfg& cfg)
+{
+  if (!validate_multiplex(cfg.nsub, cfg.sub)) return false;
+  int prev = 0;
+  for (const dabhip_reconf_cfg& r : cfg.reconf) {
+    if (r.at_cif == 0) continue;
+    if (r.at_cif <= prev || r.fic_lead < 0) { set_error("synth: reconfigurations must be at ascending CIFs > 0 with fic_lead >= 0"); return false; }
+    prev = r.at_cif;
+    if (!validate_multiplex(r.nsub, r.sub)) return false;
+  }
   if (cfg.skip_samples < 0 || cfg.skip_samples >= kTfSamples) { set_error("synth: skip_samples out of range"); return false; }
+  const dabhip_channel_cfg& c = cfg.channel;
+  for (int e = 0; e < 2; ++e)
+    if (c.echo_delay[e] < 0 || c.echo_delay[e] > 2047) { set_error("synth: echo delay out of range (0 .. 2047 samples)"); return false; }
+  if (c.fade_depth < 0.0 || c.fade_depth >= 1.0 || std::fabs(c.sro_ppm) > 1000.0) { set_error("synth: channel parameters out of range"); return false; }
   return true;
 }
 
@@ -84,8 +119,9 @@ void build_fibs(const dabhip_synth_cfg& cfg, int cif, uint8_t* out96)
 {
   const int count = ((cfg.cif_count0 + cif) % 5000 + 5000) % 5000;
   std::vector<std::vector<uint8_t>> entries;
-  for (int k = 0; k < cfg.nsub; ++k) {
-    const SubChannel sc = to_subchannel(cfg.sub[k]);
+  const Multiplex mux = multiplex_at(cfg, cif, true);
+  for (int k = 0; k < mux.nsub; ++k) {
+    const SubChannel sc = to_subchannel(mux.sub[k]);
     std::vector<uint8_t> e;
     e.push_back(static_cast<uint8_t>((sc.id << 2) | ((sc.start_cu >> 8) & 3)));
     e.push_back(static_cast<uint8_t>(sc.start_cu & 0xff));
@@ -155,8 +191,9 @@ void logical_cif(const dabhip_synth_cfg& cfg, int r, uint8_t* bits)
   }
   if (r < 0) return;   // before the start of the transmission: filler only
   std::vector<uint8_t> data, coded;
-  for (int k = 0; k < cfg.nsub; ++k) {
-    const SubChannel sc = to_subchannel(cfg.sub[k]);
+  const Multiplex mux = multiplex_at(cfg, r, false);
+  for (int k = 0; k < mux.nsub; ++k) {
+    const SubChannel sc = to_subchannel(mux.sub[k]);
     const int nbytes = sc.bitrate * 3;
     data.resize(static_cast<size_t>(nbytes));
     payload_bytes(cfg, r, k, data.data(), nbytes);
@@ -229,7 +266,112 @@ struct Gauss {
   }
 };
 
+// The channel between modulator and receiver (dabhip_channel_cfg): a chain of sample-by-sample stages, each of which is skipped when its parameters
+// are zero, so that an ideal channel hands the modulator's samples through untouched (the captures of rounds 1-4, byte for byte).
+// Not part of the receive path and of no parity claim: whatever IQ it makes, the reference, the oracle and the GPU get the same bytes.
+class Channel {
+ public:
+  explicit Channel(const dabhip_synth_cfg& cfg)
+      : c_(cfg.channel), cfo_turns_(cfg.cfo_hz / 2048000.0), echo_(c_.echo_delay[0] || c_.echo_delay[1]), hist_r_(kHist, 0.0), hist_i_(kHist, 0.0),
+        ring_r_(kRing, 0.0), ring_i_(kRing, 0.0)
+  {
+    rate_ = 1.0 + c_.sro_ppm * 1e-6;
+    iq_g_ = std::pow(10.0, c_.iq_gain_db / 20.0);
+    iq_c_ = std::cos(c_.iq_phase_deg * M_PI / 180.0);
+    iq_s_ = std::sin(c_.iq_phase_deg * M_PI / 180.0);
+    iq_ = c_.iq_gain_db != 0.0 || c_.iq_phase_deg != 0.0;
+    for (int k = 0; k < 2 * kHalf; ++k) {
+      tab_c_[k] = std::cos(M_PI * (k - kHalf + 1) / kHalf);
+      tab_s_[k] = std::sin(M_PI * (k - kHalf + 1) / kHalf);
+    }
+  }
+  // modulator sample n (in order); out(re, im) receives the receiver-side samples, in order
+  template <class Out>
+  void push(double xr, double xi, Out&& out)
+  {
+    const long long n = n_++;
+    if (echo_) {
+      hist_r_[n & (kHist - 1)] = xr;
+      hist_i_[n & (kHist - 1)] = xi;
+      double yr = xr, yi = xi;
+      for (int e = 0; e < 2; ++e) {
+        const int d = c_.echo_delay[e];
+        if (!d || n < d) continue;
+        const double ph = 2 * M_PI * std::fmod(c_.echo_phase[e] + c_.echo_doppler_hz[e] / 2048000.0 * static_cast<double>(n), 1.0);
+        const double gr = c_.echo_gain[e] * std::cos(ph), gi = c_.echo_gain[e] * std::sin(ph);
+        const double pr = hist_r_[(n - d) & (kHist - 1)], pi = hist_i_[(n - d) & (kHist - 1)];
+        yr += gr * pr - gi * pi;
+        yi += gr * pi + gi * pr;
+      }
+      xr = yr;
+      xi = yi;
+    }
+    if (c_.fade_depth != 0.0) {
+      const double a = 1.0 - c_.fade_depth * 0.5 * (1.0 - std::cos(2 * M_PI * std::fmod(c_.fade_hz / 2048000.0 * static_cast<double>(n), 1.0)));
+      xr *= a;
+      xi *= a;
+    }
+    if (cfo_turns_ != 0.0) {
+      const double ph = 2 * M_PI * std::fmod(cfo_turns_ * static_cast<double>(n), 1.0);
+      const double c = std::cos(ph), s = std::sin(ph), r = xr * c - xi * s;
+      xi = xr * s + xi * c;
+      xr = r;
+    }
+    if (c_.sro_ppm == 0.0) { receiver(xr, xi, out); return; }
+    ring_r_[n & (kRing - 1)] = xr;
+    ring_i_[n & (kRing - 1)] = xi;
+    // every output whose 2 kHalf taps end at or before sample n: output m sits at input position m * rate_
+    for (;;) {
+      const double pos = static_cast<double>(m_) * rate_;
+      const long long i0 = static_cast<long long>(std::floor(pos));
+      if (i0 + kHalf > n) break;
+      const double f = pos - static_cast<double>(i0);
+      double yr = 0, yi = 0;
+      if (f == 0.0) {
+        yr = ring_r_[i0 & (kRing - 1)];
+        yi = ring_i_[i0 & (kRing - 1)];
+      } else {
+        // taps k = -kHalf+1 .. kHalf at distance t = k - f: sinc(t) = -(-1)^k sin(pi f) / (pi t), Hann window 0.5 (1 + cos(pi t / kHalf))
+        const double sf = std::sin(M_PI * f), cw = std::cos(M_PI * f / kHalf), sw = std::sin(M_PI * f / kHalf);
+        double sum = 0;
+        for (int j = 0; j < 2 * kHalf; ++j) {
+          const int k = j - kHalf + 1;
+          const long long idx = i0 + k;
+          const double t = static_cast<double>(k) - f;
+          const double w = 0.5 * (1.0 + tab_c_[j] * cw + tab_s_[j] * sw);
+          const double h = ((k & 1) ? sf : -sf) / (M_PI * t) * w;
+          sum += h;
+          if (idx < 0) continue;
+          yr += h * ring_r_[idx & (kRing - 1)];
+          yi += h * ring_i_[idx & (kRing - 1)];
+        }
+        yr /= sum;
+        yi /= sum;
+      }
+      ++m_;
+      receiver(yr, yi, out);
+    }
+  }
+
+ private:
+  template <class Out>
+  void receiver(double xr, double xi, Out&& out)
+  {
+    if (iq_) xi = iq_g_ * (xi * iq_c_ + xr * iq_s_);
+    out(xr, xi);
+  }
+  static constexpr int kHist = 2048, kRing = 64, kHalf = 8;
+  dabhip_channel_cfg c_;
+  double cfo_turns_, rate_ = 1.0, iq_g_ = 1.0, iq_c_ = 1.0, iq_s_ = 0.0;
+  bool echo_, iq_ = false;
+  long long n_ = 0, m_ = 0;
+  std::vector<double> hist_r_, hist_i_, ring_r_, ring_i_;
+  double tab_c_[2 * kHalf], tab_s_[2 * kHalf];
+};
+
 }  // namespace
+
+bool synth_channel_active(const dabhip_synth_cfg& cfg) { return channel_active(cfg.channel); }
 
 uint64_t synth_noise_key(uint64_t seed, uint64_t ctr, uint64_t which) { return key(seed, kDomNoise, ctr, which); }
 
@@ -293,13 +435,17 @@ extern "C" int dabhip_synth_preset(int preset, dabhip_synth_cfg* cfg)
 extern "C" size_t dabhip_synth_bytes(const dabhip_synth_cfg* cfg, int ntf)
 {
   if (!cfg || ntf <= 0) return 0;
-  return (static_cast<size_t>(ntf) * kTfSamples - static_cast<size_t>(cfg->skip_samples)) * 2;
+  const size_t n = static_cast<size_t>(ntf) * kTfSamples;
+  if (cfg->channel.sro_ppm == 0.0) return (n - static_cast<size_t>(cfg->skip_samples)) * 2;
+  return (static_cast<size_t>(static_cast<double>(n) / (1.0 + cfg->channel.sro_ppm * 1e-6)) + 16 - static_cast<size_t>(cfg->skip_samples)) * 2;   // upper bound
 }
 
 extern "C" int dabhip_synth_payload(const dabhip_synth_cfg* cfg, int cif_index, int slot, uint8_t* out, int cap)
 {
-  if (!cfg || slot < 0 || slot >= cfg->nsub) { set_error("synth_payload: bad slot"); return -1; }
-  const int n = to_subchannel(cfg->sub[slot]).bitrate * 3;
+  if (!cfg) { set_error("synth_payload: bad slot"); return -1; }
+  const Multiplex mux = multiplex_at(*cfg, cif_index, false);
+  if (slot < 0 || slot >= mux.nsub) { set_error("synth_payload: bad slot"); return -1; }
+  const int n = to_subchannel(mux.sub[slot]).bitrate * 3;
   if (cap < n) { set_error("synth_payload: buffer too small"); return -1; }
   payload_bytes(*cfg, cif_index, slot, out, n);
   return n;
@@ -330,16 +476,11 @@ extern "C" int64_t dabhip_synth_generate(const dabhip_synth_cfg* cfg, int ntf, u
   static const double c8[8] = {1, M_SQRT1_2, 0, -M_SQRT1_2, -1, -M_SQRT1_2, 0, M_SQRT1_2};
   static const double s8[8] = {0, M_SQRT1_2, 1, M_SQRT1_2, 0, -M_SQRT1_2, -1, -M_SQRT1_2};
   size_t outpos = 0;
-  long long sample_index = 0;
-  const double cfo_turns = cfg->cfo_hz / 2048000.0;       // turns per sample
-  auto emit = [&](double xr, double xi) {
-    if (cfo_turns != 0.0) {
-      const double ph = 2 * M_PI * std::fmod(cfo_turns * static_cast<double>(sample_index), 1.0);
-      const double c = std::cos(ph), s = std::sin(ph), r = xr * c - xi * s;
-      xi = xr * s + xi * c;
-      xr = r;
-    }
+  long long sample_index = 0;                             // receiver-side sample count
+  Channel channel(*cfg);                                  // echoes, fading, carrier offset, sample-rate offset, I/Q imbalance
+  auto quantise = [&](double xr, double xi) {
     if (sample_index++ < cfg->skip_samples) return;
+    if (outpos + 2 > cap) return;
     if (noise_rms_rail > 0) { xr += noise_rms_rail * gauss.next(); xi += noise_rms_rail * gauss.next(); }
     double a = std::floor(127.0 + xr + 0.5), b = std::floor(127.0 + xi + 0.5);
     a = a < 1 ? 1 : (a > 254 ? 254 : a);
@@ -347,6 +488,7 @@ extern "C" int64_t dabhip_synth_generate(const dabhip_synth_cfg* cfg, int ntf, u
     iq[outpos++] = static_cast<uint8_t>(a);
     iq[outpos++] = static_cast<uint8_t>(b);
   };
+  auto emit = [&](double xr, double xi) { channel.push(xr, xi, quantise); };
 
   for (int tf = 0; tf < ntf; ++tf) {
     bits.next_tf(symbits.data());

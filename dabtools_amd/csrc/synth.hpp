@@ -23,6 +23,7 @@ class SymbolBits {
 };
 
 bool synth_validate(const dabhip_synth_cfg& cfg);
+bool synth_channel_active(const dabhip_synth_cfg& cfg);             // any stage of dabhip_channel_cfg switched on
 double synth_noise_rms(const dabhip_synth_cfg& cfg);                 // per rail, in LSB
 uint64_t synth_noise_key(uint64_t seed, uint64_t ctr, uint64_t which);
 

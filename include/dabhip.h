@@ -344,16 +344,18 @@ int dabhip_host_placement_plan(const int32_t *slice_node, int nslices, const cha
 int dabhip_host_table(int which, int32_t *out, int cap);
 
 /* The FIFO of sdr_demod (cbWrite / sdr_read_fifo, sdr_fifo.c:26-61; input_sdr.c:36-55) as the sync-scan kernel keeps it:
- * in closed form over the resident stream.  One call = one 262144-byte sdr_demod call entered with the timing
- * corrections the previous processed frame left in sdr->coarse_timeshift / fine_timeshift.  Returns 0 = nothing read
+ * in closed form over the resident stream.  One call = one sdr_demod call that appends chunk_bytes (input_buffer_len; 262144 from librtlsdr),
+ * entered with the timing corrections the previous processed frame left in sdr->coarse_timeshift / fine_timeshift.  Returns 0 = nothing read
  * (fewer than 1.5 TF queued), 1 = the first frame, read and discarded (input_sdr.c:51-55), 2 = a frame read for
- * processing; <0 = error.  The view says what sdr->buffer holds afterwards: buffer positions [seg_end[i-1], seg_end[i])
- * hold stream bytes seg_src[i] + position (seg_src < 0: the calloc'ed zero bytes); 12 entries each. */
+ * processing; <0 = error.  What sdr->buffer (393216 bytes) holds afterwards comes back in two parts.  Its last 1536 bytes -- the most a
+ * negative time shift leaves unread (sdr_sync.c:197-201, sdr_fifo.c:56-59) -- as BYTES in tail[1536] (needs stream: the bytes fed so far;
+ * null = not tracked).  Everything below as a view: buffer positions [seg_end[i-1], seg_end[i]) hold stream bytes seg_src[i] + position
+ * (seg_src < 0: the calloc'ed zero bytes); 12 entries each. */
 typedef struct dabhip_fifo dabhip_fifo;
 dabhip_fifo *dabhip_host_fifo_new(void);
 void dabhip_host_fifo_free(dabhip_fifo *f);
-int dabhip_host_fifo_call(dabhip_fifo *f, int32_t coarse_timeshift, int32_t fine_timeshift, int32_t *nseg,
-                          int32_t *seg_end, int64_t *seg_src, int32_t *fifo_count);
+int dabhip_host_fifo_call(dabhip_fifo *f, int32_t coarse_timeshift, int32_t fine_timeshift, int32_t chunk_bytes, const uint8_t *stream,
+                          int32_t *nseg, int32_t *seg_end, int64_t *seg_src, int32_t *fifo_count, uint8_t *tail);
 
 /* ---- synthetic Mode-I modulator (host only) --------------------------------------------- */
 typedef struct dabhip_subch_cfg {
@@ -364,6 +366,29 @@ typedef struct dabhip_subch_cfg {
   int32_t eep_protlev; /* option<<2 | level: 0..3 = 1-A..4-A, 4..7 = 1-B..4-B */
   int32_t size_cu;     /* EEP only */
 } dabhip_subch_cfg;
+
+typedef struct dabhip_reconf_cfg {
+  int32_t at_cif;        /* logical CIF index from which the MSC carries this multiplex; 0 = entry unused */
+  int32_t fic_lead;      /* the FIC signals it this many CIFs earlier (>= 0) */
+  int32_t nsub;
+  int32_t pad;
+  dabhip_subch_cfg sub[64];
+} dabhip_reconf_cfg;
+
+/* Order of application to the modulator's complex samples x[n] (n counts from the capture's first sample, skipped ones included):
+ * echoes, fading, carrier offset (cfo_hz above), sample-rate offset, I/Q imbalance; then skip_samples, noise and the cu8 quantisation as before. */
+typedef struct dabhip_channel_cfg {
+  double sro_ppm;          /* the receiver's sample clock against the transmitter's: output sample m is the signal at input position m (1 + ppm 1e-6)
+                              (windowed-sinc interpolation, 16 taps): > 0 = frames arrive SHORTER than 196,608 samples (negative time shifts) */
+  int32_t echo_delay[2];   /* two-ray / three-ray multipath: x[n] += gain e^(2 pi i (phase + doppler n / 2.048e6)) x[n - delay]; delay in samples, 0 = no echo, <= 2047 */
+  double echo_gain[2];     /* linear, relative to the direct path */
+  double echo_phase[2];    /* turns */
+  double echo_doppler_hz[2];
+  double fade_depth;       /* slow flat fading: amplitude 1 - depth (1 - cos(2 pi fade_hz t)) / 2, 0 <= depth < 1 */
+  double fade_hz;
+  double iq_gain_db;       /* receiver imbalance: Q rail gain over I rail */
+  double iq_phase_deg;     /* quadrature error: Q' = g (Q cos phi + I sin phi) */
+} dabhip_channel_cfg;
 
 typedef struct dabhip_synth_cfg {
   uint32_t eid;
@@ -381,10 +406,21 @@ typedef struct dabhip_synth_cfg {
   int32_t fib_patch_len;  /* 0..30 */
   int32_t fib_patch_from_cif;
   uint8_t fib_patch[32];
+  /* Multiplex reconfigurations (round 5): from logical CIF reconf[k].at_cif on (counted from the capture's first CIF; 0 = unused; ascending) the MSC
+   * carries the sub-channels reconf[k].sub[0..nsub) instead, and the FIG 0/1 entries of the FIC announce them from CIF at_cif - fic_lead on.  The
+   * reference knows nothing of ETSI's reconfiguration signalling: merge_info (misc.c:14-27) overwrites the slots of the SubChIds it hears and never
+   * removes one, on every locked TF BEFORE the oldest CIFs of the ring are emitted (dab.c:64-97) -- frames already in the ring are laid out by the new
+   * FIG 0/1.  Whatever that yields is the parity target.  dabhip_synth_payload's slot then indexes the multiplex in force at that CIF. */
+  dabhip_reconf_cfg reconf[2];
+  /* Channel between modulator and receiver (round 5; all zero = the ideal channel of rounds 1-4, byte-identical captures).  Host generator only:
+   * dabhip_synth_generate_device refuses a configuration with any of these set. */
+  dabhip_channel_cfg channel;
 } dabhip_synth_cfg;
 
 /* preset 0: 12 sub-channels, 1136 kbit/s, 862 CU (the benchmark mix); 1: 4 light sub-channels. */
 int dabhip_synth_preset(int preset, dabhip_synth_cfg *cfg);
+/* Bytes dabhip_synth_generate writes for ntf transmission frames -- exactly that with channel.sro_ppm == 0; with a sample-rate offset an upper
+ * bound (the capacity to pass), the call's return value being the count. */
 size_t dabhip_synth_bytes(const dabhip_synth_cfg *cfg, int ntf);
 /* Generate ntf transmission frames of cu8 IQ into iq (capacity cap bytes). Returns bytes written or <0. */
 int64_t dabhip_synth_generate(const dabhip_synth_cfg *cfg, int ntf, uint8_t *iq, size_t cap);

@@ -10,21 +10,22 @@
 #include "dab.h"
 #include "dabhip.h"
 
-static dabhip_dab *hip_dab;
-
 void init_dab_state(struct dab_state_t **dab, void *device_state, void (*eti_callback)(uint8_t *eti))   /* dab.h:91 */
 {
   *dab = calloc(sizeof(struct dab_state_t), 1);
   (*dab)->device_state = device_state;
   (*dab)->eti_callback = eti_callback;
-  hip_dab = dabhip_dab_init(0, eti_callback);          /* the callback type is identical: dab.h:88 */
+  /* the handle lives where the reference keeps its decoder's (dab->v, dab.c:29): one GPU back end per dab_state_t */
+  (*dab)->v = dabhip_dab_init(0, eti_callback);        /* the callback type is identical: dab.h:88 */
 }
 
 void dab_process_frame(struct dab_state_t *dab)                                                         /* dab.h:92 */
 {
+  dabhip_dab *h = (dabhip_dab *)dab->v;
   struct demapped_transmission_frame_t *tf = &dab->tfs[dab->tfidx];   /* tfidx stays 0: one staging buffer */
-  memcpy(dabhip_dab_tf_fic(hip_dab), tf->fic_symbols_demapped, 9216);
-  memcpy(dabhip_dab_tf_msc(hip_dab), tf->msc_symbols_demapped, 221184);
-  dabhip_dab_process_frame(hip_dab);                   /* calls eti_callback 0 or 4 times, synchronously */
-  dab->locked = dabhip_dab_locked(hip_dab);
+  if (!h) return;                                      /* no GPU: no output, like every failure of the reference's back end */
+  memcpy(dabhip_dab_tf_fic(h), tf->fic_symbols_demapped, 9216);
+  memcpy(dabhip_dab_tf_msc(h), tf->msc_symbols_demapped, 221184);
+  dabhip_dab_process_frame(h);                         /* calls eti_callback 0 or 4 times, synchronously */
+  dab->locked = dabhip_dab_locked(h);
 }

@@ -11,20 +11,44 @@
 #include "input_sdr.h"
 #include "dabhip.h"
 
-static dabhip_sdr *hip_sdr;
+/* One GPU front end per struct sdr_state_t: a small side table keyed by the state's address (the reference's struct has no field to spare,
+ * input_sdr.h:12-41).  dab2eti.c has one state; a caller with several gets one handle each.  Not thread-safe across states being initialised at
+ * the same time -- neither is the reference's sdr_init (FFTW's planner, sdr_sync.c). */
+#define HIP_SDR_MAX 64
+static struct { const struct sdr_state_t *key; dabhip_sdr *h; } hip_sdr_tab[HIP_SDR_MAX];
 
-void sdr_init(struct sdr_state_t *sdr) { (void)sdr; hip_sdr = dabhip_sdr_init(0); }                     /* input_sdr.h:44 */
+static dabhip_sdr **hip_sdr_slot(const struct sdr_state_t *sdr, int create)
+{
+  int i;
+  for (i = 0; i < HIP_SDR_MAX; i++)
+    if (hip_sdr_tab[i].key == sdr) return &hip_sdr_tab[i].h;
+  if (create)
+    for (i = 0; i < HIP_SDR_MAX; i++)
+      if (!hip_sdr_tab[i].key) { hip_sdr_tab[i].key = sdr; return &hip_sdr_tab[i].h; }
+  return 0;
+}
+
+void sdr_init(struct sdr_state_t *sdr)                                                                  /* input_sdr.h:44 */
+{
+  dabhip_sdr **slot = hip_sdr_slot(sdr, 1);
+  if (!slot) return;
+  if (*slot) dabhip_sdr_free(*slot);                   /* the same state initialised again: a fresh front end, like the reference's memsets */
+  *slot = dabhip_sdr_init(0);
+}
 
 int sdr_demod(struct demapped_transmission_frame_t *tf, struct sdr_state_t *sdr)                        /* input_sdr.h:43 */
 {
+  dabhip_sdr **slot = hip_sdr_slot(sdr, 0);
+  dabhip_sdr *h = slot ? *slot : 0;
   int ok;
   tf->has_fic = 0;
-  ok = dabhip_sdr_demod(hip_sdr, sdr->input_buffer, sdr->input_buffer_len,   /* 262144 = DEFAULT_BUF_LENGTH, dab2eti.c:238 */
+  if (!h) return 0;                                    /* sdr_init was not called (or failed: no GPU) -- "no frame", the only failure the seam has */
+  ok = dabhip_sdr_demod(h, sdr->input_buffer, sdr->input_buffer_len,         /* whatever the callback left (dab2eti.c:125-126), 262144 from librtlsdr */
                         tf->fic_symbols_demapped[0], tf->msc_symbols_demapped[0]);
-  sdr->coarse_timeshift = dabhip_sdr_coarse_timeshift(hip_sdr);
-  sdr->fine_timeshift = dabhip_sdr_fine_timeshift(hip_sdr);
-  sdr->coarse_freq_shift = dabhip_sdr_coarse_freq_shift(hip_sdr);            /* read by the tuner AFC, dab2eti.c:76-103 */
-  sdr->fine_freq_shift = dabhip_sdr_fine_freq_shift(hip_sdr);
+  sdr->coarse_timeshift = dabhip_sdr_coarse_timeshift(h);
+  sdr->fine_timeshift = dabhip_sdr_fine_timeshift(h);
+  sdr->coarse_freq_shift = dabhip_sdr_coarse_freq_shift(h);                  /* read by the tuner AFC, dab2eti.c:76-103 */
+  sdr->fine_freq_shift = dabhip_sdr_fine_freq_shift(h);
   if (ok == 1) tf->has_fic = 1;
   return ok == 1;
 }

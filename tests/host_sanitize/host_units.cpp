@@ -237,20 +237,25 @@ static void test_fifo_views()
     std::memset(&st, 0, sizeof st);
     fifo_reset(st);
     std::vector<int64_t> buffer(kTfBytes, -1);            // stream offset held at each buffer position (-1: calloc'ed zero)
+    std::vector<int64_t> tail(kTailBytes, -1);            // the last kTailBytes as K1 carries them (here: tags instead of bytes), updated by read_source
     int64_t rd = 0, fed = 0;
-    bool overflowed = false;
-    for (int call = 0; call < 120 && !overflowed; ++call) {
+    int most_segments = 0;
+    for (int call = 0; call < 160; ++call) {
       const int r = static_cast<int>(rng() % 10);
       st.coarse_timeshift = r == 0 ? static_cast<int>(rng() % 380000) : 0;               // a coarse resync now and then
-      st.fine_timeshift = r < 7 ? static_cast<int>(rng() % 61) - 30 : -static_cast<int>(rng() % 3000);
+      // trial >= 15: a receiver clock that runs fast -- ever larger negative shifts for a long stretch, then ever smaller ones: every read short,
+      // each shorter (or longer) than the one before.  As views these nested once per read (more than kMaxSeg: the engine used to give up).
+      if (trial >= 15) st.fine_timeshift = -2 * (call < 70 ? call + 1 : 161 - call) - (r < 2 ? 2 * static_cast<int>(rng() % 5) : 0);
+      else st.fine_timeshift = r < 7 ? static_cast<int>(rng() % 61) - 30 : -2 * static_cast<int>(rng() % 768);      // >= (768 - 1536) * 2, sdr_sync.c:197-201
+      const int chunk = trial % 3 == 2 ? 2 * static_cast<int>(rng() % (kChunkBytes / 2 + 1)) : kChunkBytes;   // input_buffer_len: any even length
       const int shift = st.coarse_timeshift + st.fine_timeshift;
-      fed += kChunkBytes;
+      fed += chunk;
       int64_t count = fed - rd;
       bool read = false;
       if (count >= 3 * kTfSamples) {
         read = true;
         if (shift > 0) {
-          for (int p = 0; p < shift && p < kTfBytes; ++p) buffer[static_cast<size_t>(p)] = rd + p;      // the skipped bytes pass through the buffer
+          for (int p = 0; p < shift && p < kTfBytes && p < count; ++p) buffer[static_cast<size_t>(p)] = rd + p;      // the skipped bytes pass through the buffer
           rd += shift;
           count -= shift;
           const int len = count < kTfBytes ? static_cast<int>(count) : kTfBytes;
@@ -262,26 +267,37 @@ static void test_fifo_views()
           rd += len;
         }
       }
-      const FifoCall c = fifo_call(st);
-      if (st.overflow) { overflowed = true; break; }       // more than kMaxSeg nested short reads: the engine reports it
+      const FifoCall c = fifo_call(st, chunk);
+      CHECK(!st.overflow);
       CHECK((c.status != 0) == read);
       CHECK(c.fifo_count == static_cast<int>(fed - rd));
       CHECK(st.consumed == rd && st.fed == fed);
       if (!read) continue;
-      CHECK(st.view.nseg >= 1 && st.view.nseg <= kMaxSeg);
-      int lo = 0;
-      for (int i = 0; i < st.view.nseg; ++i) {
+      CHECK(st.view.nseg >= 1 && st.view.nseg <= kMaxSeg && (c.fresh == 1 || c.fresh == 2));
+      most_segments = std::max(most_segments, st.view.nseg);
+      for (int p = kTailStart; p < kTfBytes; ++p) {                                       // the tail bytes by the kernel's rule ...
+        const int64_t src = read_source(st.view, c.fresh, p);
+        if (src >= 0) tail[static_cast<size_t>(p - kTailStart)] = src;
+        CHECK(buffer[static_cast<size_t>(p)] == tail[static_cast<size_t>(p - kTailStart)]);
+      }
+      int lo = 0;                                                                          // ... the views everything below them
+      for (int i = 0; i < st.view.nseg && lo < kTailStart; ++i) {
         CHECK(st.view.seg_end[i] > lo || (i == 0 && st.view.seg_end[0] >= 0));
-        for (int p = lo; p < st.view.seg_end[i]; p += 997)                                // sampled positions plus both ends
+        const int hi = std::min(st.view.seg_end[i], kTailStart);
+        for (int p = lo; p < hi; p += 997)                                                // sampled positions plus both ends
           CHECK(buffer[static_cast<size_t>(p)] == (st.view.seg_src[i] < 0 ? -1 : st.view.seg_src[i] + p));
-        if (st.view.seg_end[i] > lo) {
-          const int p = st.view.seg_end[i] - 1;
+        if (hi > lo) {
+          const int p = hi - 1;
           CHECK(buffer[static_cast<size_t>(p)] == (st.view.seg_src[i] < 0 ? -1 : st.view.seg_src[i] + p));
         }
         lo = st.view.seg_end[i];
       }
-      CHECK(lo == kTfBytes);
+      CHECK(lo >= kTailStart);
+      // whatever the views still refer to is recent: nothing pins the stream's past (Engine::stream_need_from)
+      if (shift <= 0 && shift >= -kTailBytes)
+        for (int i = 0; i < st.view.nseg; ++i) CHECK(st.view.seg_src[i] < 0 || i == 0);
     }
+    CHECK(most_segments <= 6);
   }
 }
 

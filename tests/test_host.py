@@ -201,12 +201,12 @@ def _fifo_view_matches_oracle(iq):
     for off in range(0, iq.size - dab.CHUNK_BYTES + 1, dab.CHUNK_BYTES):
         O.or_sdr_demod(S, ol._ptr(iq[off:off + dab.CHUNK_BYTES]), dab.CHUNK_BYTES, ol._ptr(fic), ol._ptr(msc))
         O.or_sdr_get_trace(S, C.byref(tr))
-        status, view, count = fifo.call(coarse, fine)
+        status, view, count = fifo.call(coarse, fine, iq)
         assert (status > 0) == bool(tr.read_frame) and count == tr.fifo_count, off
         if status:
             reads += 1
             want = np.ctypeslib.as_array(O.or_sdr_buffer(S), (dab.TF_BYTES,))
-            got = dab.HostFifo.materialise(iq, view)
+            got = dab.HostFifo.materialise(iq, view, fifo.tail)
             assert np.array_equal(got, want), "call at byte %d: view %r" % (off, view)
             short_after_skip += int(len(view) > 1 and coarse + fine > view[0][0])
         coarse, fine = tr.coarse_timeshift, tr.fine_timeshift
@@ -232,6 +232,36 @@ def test_fifo_view_resync_while_locked_short_read_after_large_skip():
     assert reads >= 30 and short_after_skip >= 1
 
 
+def test_fifo_view_receiver_clock_fast_every_read_is_short():
+    """A receiver whose sample clock runs fast against the transmitter's (+80 ppm here) gets a negative time shift on EVERY call: every read is
+    short and the end of sdr->buffer is never rewritten in full (sdr_fifo.c:56-59).  As views into the stream that history nested without bound
+    and pinned the stream's first bytes for ever (rounds 1-4: a decode of such a stream failed with 'more than kMaxSeg nested short reads', a live
+    session kept the whole stream); the last 1536 bytes now travel as bytes, and the views stay at ONE segment."""
+    cfg = dab.synth_preset(1, seed=9)
+    cfg.channel.sro_ppm = 80.0
+    iq = dab.synth_generate(cfg, 60)
+    O = ol.oracle()
+    S = O.or_sdr_new()
+    fifo = dab.HostFifo()
+    fic = np.zeros(dab.FIC_BITS, np.uint8)
+    msc = np.zeros(dab.MSC_BITS, np.uint8)
+    tr = ol.SdrTrace()
+    coarse = fine = shorts = 0
+    for off in range(0, iq.size - dab.CHUNK_BYTES + 1, dab.CHUNK_BYTES):
+        O.or_sdr_demod(S, ol._ptr(iq[off:off + dab.CHUNK_BYTES]), dab.CHUNK_BYTES, ol._ptr(fic), ol._ptr(msc))
+        O.or_sdr_get_trace(S, C.byref(tr))
+        status, view, count = fifo.call(coarse, fine, iq)
+        if status:
+            assert np.array_equal(dab.HostFifo.materialise(iq, view, fifo.tail), np.ctypeslib.as_array(O.or_sdr_buffer(S), (dab.TF_BYTES,))), off
+            shorts += int(coarse + fine < 0)
+            if off > 30 * dab.CHUNK_BYTES:                            # settled: nothing older than this call's own read is referenced
+                assert len(view) == 1 and view[0][1] > off - 3 * dab.TF_BYTES, view
+        coarse, fine = tr.coarse_timeshift, tr.fine_timeshift
+    O.or_sdr_free(S)
+    fifo.close()
+    assert shorts >= 50
+
+
 def test_fifo_shifted_read_against_reference_fifo():
     """The same bookkeeping against the REAL sdr_fifo.c (oracle/_ref): shift sequences including positive shifts
     larger than what remains queued afterwards."""
@@ -239,25 +269,48 @@ def test_fifo_shifted_read_against_reference_fifo():
     if R is None:
         pytest.skip("oracle/_ref not built")
     rng = np.random.default_rng(11)
-    stream = rng.integers(1, 255, 70 * dab.CHUNK_BYTES, dtype=np.uint8)
+    stream = rng.integers(1, 255, 150 * dab.CHUNK_BYTES, dtype=np.uint8)
     F = R.refh_fifo_new(C.c_uint32(196608 * 2 * 4))                 # input_sdr.c:184
     fifo = dab.HostFifo()
     buf = np.zeros(dab.TF_BYTES, np.uint8)
     shifts = [0, 0, -300, 40, 380000, -1500, 250000, 16, 389000, 389000, -2, 0, 120000, 300000, -766, 389430]
     k = nshort = 0
-    for c in range(stream.size // dab.CHUNK_BYTES):
+    for c in range(70):
         R.refh_fifo_write(F, ol._ptr(stream[c * dab.CHUNK_BYTES:(c + 1) * dab.CHUNK_BYTES]), dab.CHUNK_BYTES)
         shift = shifts[k % len(shifts)]
         if R.refh_fifo_count(F) >= 196608 * 3:                      # input_sdr.c:41-47
             R.refh_fifo_read(F, dab.TF_BYTES, shift, ol._ptr(buf))
-            status, view, count = fifo.call(shift, 0)
+            status, view, count = fifo.call(shift, 0, stream)
             assert status > 0 and count == R.refh_fifo_count(F)
-            assert np.array_equal(dab.HostFifo.materialise(stream, view), buf), (c, shift, view)
+            assert np.array_equal(dab.HostFifo.materialise(stream, view, fifo.tail), buf), (c, shift, view)
             nshort += int(shift > view[0][0])
             k += 1
         else:
-            assert fifo.call(shift, 0)[0] == 0
+            assert fifo.call(shift, 0, stream)[0] == 0
     assert k > 20 and nshort >= 2
+    fifo.close()
+    # the same with calls of every length (input_buffer_len is whatever the callback left, input_sdr.c:36-38): long runs of ever larger negative
+    # shifts (each read shorter than the one before: the old views nested once per read), dry reads in between
+    F = R.refh_fifo_new(C.c_uint32(196608 * 2 * 4))
+    fifo = dab.HostFifo()
+    buf[:] = 0
+    shifts = [0] + [-2 * i for i in range(1, 40)] + [300000, -1536, -1534, 16, -4, -800, 389000, -6, -10, -20]
+    fed = k = 0
+    while fed + dab.CHUNK_BYTES <= stream.size and k < 3 * len(shifts):
+        n = int(rng.choice([dab.CHUNK_BYTES, dab.CHUNK_BYTES, 131072, 65536, 2 * int(rng.integers(0, 131073))]))
+        R.refh_fifo_write(F, ol._ptr(stream[fed:fed + max(n, 1)]), n)
+        fed += n
+        shift = shifts[k % len(shifts)]
+        if R.refh_fifo_count(F) >= 196608 * 3:
+            R.refh_fifo_read(F, dab.TF_BYTES, shift, ol._ptr(buf))
+            status, view, count = fifo.call(shift, 0, stream, n)
+            assert status > 0 and count == R.refh_fifo_count(F), (k, shift)
+            assert np.array_equal(dab.HostFifo.materialise(stream, view, fifo.tail), buf), (k, shift, view)
+            assert len(view) <= 3, view
+            k += 1
+        else:
+            assert fifo.call(shift, 0, stream, n)[0] == 0
+    assert k >= 60
 
 
 def test_product_tables_match_reference_arrays():
