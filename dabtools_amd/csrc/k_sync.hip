@@ -31,6 +31,11 @@ constexpr int kThreads = kFft64Threads;   // 512; one workgroup per stream: more
 #ifndef DABHIP_SYNC_TIMES
 #define DABHIP_SYNC_TIMES 0
 #endif
+// measurement build only (tools/build_variant_sync.sh notail "-DDABHIP_K1_TAIL=0"): the chain without its tail-byte work (wrong results after any short
+// read) -- what carrying the frame buffer's last 1536 bytes costs per call
+#ifndef DABHIP_K1_TAIL
+#define DABHIP_K1_TAIL 1
+#endif
 #if DABHIP_SYNC_TIMES
 __device__ unsigned long long g_sync_times[96 * 16];
 __device__ volatile int g_sync_call;     // volatile: read back through the vector path (a scalar load may be served a stale line)
@@ -217,7 +222,8 @@ constexpr int kSpecBins = 128 + 28;                        // spectrum bins touc
 // dab_coarse_time_sync (sdr_sync.c:34-68) -> byte shift, 0 = the null symbol is where it should be.  In two parts, so that the caller can
 // put the stream's tail bytes in place between them (the search reads the whole frame buffer, the test only its first 5320 bytes):
 // the null-symbol energy test (sdr_sync.c:40-46) ...
-__device__ int null_symbol_energy(const uint8_t* stream, const FrameView& view, Red& red)
+// (this thread's share, to be summed over the workgroup: the caller issues other loads between the two)
+__device__ __forceinline__ int null_symbol_energy_part(const uint8_t* stream, const FrameView& view)
 {
   const int tid = threadIdx.x;
   int e = 0;
@@ -226,7 +232,7 @@ __device__ int null_symbol_energy(const uint8_t* stream, const FrameView& view, 
   } else {
     for (int n = tid; n < 266; n += kThreads) e += abs(rail(view_byte(stream, view, 20 * n)));
   }
-  return block_sum_int(red, e);
+  return e;
 }
 // ... and the search for the null symbol (sdr_sync.c:47-68)
 __device__ int coarse_time_search(const uint8_t* stream, const FrameView& view, Red& red, uint8_t* env)
@@ -598,17 +604,20 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
     if (tid < 64) fifo_call_wave(sh, tails.chunk, tail_slot);
     __syncthreads();
 
-    // what this call's read leaves in the tail bytes: loads issued here, taken up (and the frame's copy written) behind the first wait below
+    // what this call's read leaves in the tail bytes: the loads are issued behind those the chain waits for first (below), taken up -- and the frame's
+    // copy written -- behind that wait
     unsigned tail_lo = 0, tail_hi = 0;
     bool take_lo = false, take_hi = false;
-    const bool frame_read = sh.status != 0;
-    if (frame_read && tid < kTailWords) {
-      const int64_t s0 = read_source(sh.st.view, sh.fresh, kTailStart + 4 * tid), s1 = read_source(sh.st.view, sh.fresh, kTailStart + 4 * tid + 2);
-      take_lo = s0 >= 0;
-      take_hi = s1 >= 0;
-      if (take_lo) tail_lo = *reinterpret_cast<const uint16_t*>(stream + s0);
-      if (take_hi) tail_hi = *reinterpret_cast<const uint16_t*>(stream + s1);
-    }
+    const bool frame_read = DABHIP_K1_TAIL && sh.status != 0;
+    auto load_tail = [&]() {
+      if (frame_read && tid < kTailWords) {
+        const int64_t s0 = read_source(sh.st.view, sh.fresh, kTailStart + 4 * tid), s1 = read_source(sh.st.view, sh.fresh, kTailStart + 4 * tid + 2);
+        take_lo = s0 >= 0;
+        take_hi = s1 >= 0;
+        if (take_lo) tail_lo = *reinterpret_cast<const uint16_t*>(stream + s0);
+        if (take_hi) tail_hi = *reinterpret_cast<const uint16_t*>(stream + s1);
+      }
+    };
     auto commit_tail = [&]() {
       if (frame_read && tid < kTailWords) {
         if (take_lo) tail_word = (tail_word & 0xffff0000u) | tail_lo;
@@ -623,7 +632,9 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
       const Prefetched<2048> pf = prefetch_samples<2048>(stream, view, 2 * (kNullSamples + kCpSamples), nco);   // for the fine time search
       SYNC_STAMP(1);
       const int force = sh.st.force_timesync;
-      const int energy = null_symbol_energy(stream, view, sh.red);                               // input_sdr.c:64-74
+      const int energy_part = null_symbol_energy_part(stream, view);                             // input_sdr.c:64-74
+      load_tail();
+      const int energy = block_sum_int(sh.red, energy_part);
       commit_tail();
       int coarse = 0;
       if (energy >= 5000 || force != 0) {
@@ -653,6 +664,7 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
         }
       }
     } else {
+      load_tail();
       commit_tail();                                      // a frame that is read and dropped (input_sdr.c:51-55) still overwrites the buffer
     }
     __syncthreads();
@@ -898,7 +910,7 @@ hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, Str
                             const double2* tw1536, const uint8_t* prs_q, int afc, hipStream_t stream, bool chain_only,
                             const StreamState* states_in, const int* stream_list, SyncTails tails)
 {
-  if (tails.chunk <= 0) tails.chunk = kChunkBytes;
+  if (tails.chunk < 0) tails.chunk = kChunkBytes;
   if (nstreams <= 0) return hipSuccess;
   hipError_t e = sync_attr();
   if (e != hipSuccess) return e;

@@ -60,7 +60,7 @@ hipError_t launch_host_words(const HostWordsArgs& a, hipStream_t stream);
 // of each stream that breaks the assumption.  states_in (default: states): where the incoming state is read from;
 // stream_list (default: all, block b = stream b): the streams to scan.
 // tails: the streams' tail bytes (device_types.hpp: kTailBytes) -- carried in from state_in, out to state_out, one copy per call that reads a frame
-// into images[(stream * max_calls + call) * kTailBytes] (FrameView::tail of that call's view points there); chunk: bytes appended per call (0 = 262144)
+// into images[(stream * max_calls + call) * kTailBytes] (FrameView::tail of that call's view points there); chunk: bytes appended per call (< 0: 262144)
 struct SyncTails {
   const uint8_t* state_in;
   uint8_t* state_out;
@@ -70,7 +70,7 @@ struct SyncTails {
 hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, StreamState* states, CallDesc* descs, int2* info,
                             int nstreams, int max_calls, int call_begin, int call_end, const double2* tw2048,
                             const double2* tw1536, const uint8_t* prs_q, int afc, hipStream_t stream, bool chain_only = false,
-                            const StreamState* states_in = nullptr, const int* stream_list = nullptr, SyncTails tails = SyncTails{nullptr, nullptr, nullptr, 0});
+                            const StreamState* states_in = nullptr, const int* stream_list = nullptr, SyncTails tails = SyncTails{nullptr, nullptr, nullptr, -1});
 // carry_only = false: the verification pass (violation[b] = first offending call, untouched otherwise);
 // carry_only = true: fine_freq_shift carried through the calls that did not demodulate, for the streams without a violation
 hipError_t launch_sync_verify(const uint8_t* const* iq, const int64_t* nbytes, const int* calls_before, StreamState* states, CallDesc* descs,

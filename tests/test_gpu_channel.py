@@ -90,7 +90,7 @@ def test_channel_impairments_engine_equals_oracle(chan):
     eng = dab.Engine(0)
     total = eng.decode(caps)
     frames = _check_engine(eng, caps, oracle, "fused OFDM stage")
-    assert frames == total and frames >= 400
+    assert frames == total and frames >= 180
     # the receiver paths these captures are there for did occur: every read short (all shifts negative) over a whole capture, and time shifts
     # far from the ideal channel's limit cycle
     sro = oracle[0][1]
@@ -113,7 +113,7 @@ def test_channel_impairments_engine_equals_the_reference(chan):
         want.append((eti, [tuple(c[:5]) for c in calls], [c[5] for c in calls]))
     eng = dab.Engine(0)
     eng.decode(caps)
-    assert _check_engine(eng, caps, want, "against the reference") >= 400
+    assert _check_engine(eng, caps, want, "against the reference") >= 180
     eng.close()
 
 
@@ -404,5 +404,5 @@ def test_bindings_s2_s3_with_two_states_interleaved():
     for i in (0, 1):
         n = L.refh_neti(backs[i])
         got = np.ctypeslib.as_array(L.refh_eti(backs[i]), (n, 6144)).copy() if n else np.zeros((0, 6144), np.uint8)
-        assert got.shape == want[i][0].shape and np.array_equal(got, want[i][0]) and n >= 16, i
+        assert got.shape == want[i][0].shape and np.array_equal(got, want[i][0]) and n >= 8, i
         F.reff_free(fronts[i])

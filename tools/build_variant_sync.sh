@@ -5,5 +5,5 @@ cd "$(dirname "$0")/../dabtools_amd/csrc"
 NAME=$1; FLAGS=$2
 OUT=../../variants; mkdir -p $OUT/obj_$NAME
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w $FLAGS -c k_sync.hip -o $OUT/obj_$NAME/k_sync.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $OUT/libdabhip_$NAME.so $OUT/obj_$NAME/k_sync.o build/k_fft.o build/k_fused.o build/k_fused_plain.o build/k_fused_soft.o build/k_decode.o build/k_synth.o build/k_parity.o build/k_probe.o build/engine.o build/capi.o build/multi.o build/synth.o build/error.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $OUT/libdabhip_$NAME.so $OUT/obj_$NAME/k_sync.o $(ls build/*.o | grep -v '/k_sync.o$')
 echo built $OUT/libdabhip_$NAME.so
