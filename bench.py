@@ -117,12 +117,25 @@ def launch_ranks(args, argv):
     """`bench.py --gpus N` without a launcher: N rank processes, this process their barrier and reducer.  Nothing in this
     process has touched torch or HIP."""
     n = args.gpus
-    cores = os.cpu_count() or 8
+    from dabtools_amd import shard                      # (pure Python: nothing here loads the library or touches the GPU)
+    # each rank's host pool: its share of the CPUs this container really has (affinity mask and CFS quota, not os.cpu_count(): shard.cpu_budget)
+    threads = shard.host_threads_per_rank(n)
+    # Each rank sees ONLY its GPU (ROCR_VISIBLE_DEVICES, set here, before the child exists, so before anything of it touches a GPU): no context on
+    # the other seven devices, no way to land on the wrong one.  The r-th entry of the list this launcher was given, or r.  Not when the caller
+    # selects devices through HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (those index the ROCR list: combining them would select twice), and not
+    # in the one-GPU rehearsal (DABHIP_BENCH_ONE_DEVICE=1); then the rank picks device LOCAL_RANK as before.
+    pin = not any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")) and os.environ.get("DABHIP_BENCH_ONE_DEVICE") != "1"
+    visible = [x for x in os.environ.get("ROCR_VISIBLE_DEVICES", "").split(",") if x.strip()]
+    if visible and len(visible) < n:
+        pin = False
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), DABHIP_BENCH_PIPES="1",
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        env.setdefault("DABHIP_HOST_THREADS", str(max(2, min(24, cores // (2 * n)))))
+        env.setdefault("DABHIP_HOST_THREADS", str(threads))
+        if pin:
+            env["ROCR_VISIBLE_DEVICES"] = visible[r].strip() if visible else str(r)
+            env["DABHIP_BENCH_DEVICE"] = "0"             # the one device the rank sees
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdin=subprocess.PIPE,
                                       stdout=subprocess.PIPE, text=True, bufsize=1))
     lock = threading.Condition()
@@ -549,13 +562,17 @@ def run_rank(args, coord):
     from dabtools_amd import shard
     mine = shard.shard_streams(world * args.streams, world, rank)          # global stream indices of this rank
     rank_info = {"rank": rank, "first_stream": mine[0], "last_stream": mine[-1], "streams": len(mine),
-                 "first_seed": shard.stream_seed(2, mine[0]), "host_threads": os.environ.get("DABHIP_HOST_THREADS", "auto")}
+                 "first_seed": shard.stream_seed(2, mine[0]), "host_threads": os.environ.get("DABHIP_HOST_THREADS", "auto"),
+                 "visible_devices": os.environ.get("ROCR_VISIBLE_DEVICES"), "cpu_budget": dict(zip(("affinity", "cfs_quota"), shard.cpu_budget()))}
     prof = None
     if rank == 0 and not args.dry_run and not args.profile_pass:
         prof = load_profile()                                              # fails loudly BEFORE any GPU time is spent
 
     ntf_rank = 0
     if args.dry_run:
+        if os.environ.get("DABHIP_BENCH_DIE_RANK") == str(rank):           # test knob: this rank dies before the first barrier
+            sys.stderr.write("rank %d: dying on request\n" % rank)
+            os._exit(7)
         coord.barrier()
         t0 = time.perf_counter()
         time.sleep(0.01 * args.steps * (1 + rank))                         # ranks finish at different times: MAX is what counts
@@ -569,6 +586,8 @@ def run_rank(args, coord):
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if os.environ.get("DABHIP_BENCH_ONE_DEVICE") == "1":
             local_rank = 0                                                 # test knob: all ranks share GPU 0 (exercises the N-rank path on a 1-GPU box)
+        if os.environ.get("DABHIP_BENCH_DEVICE", "").isdigit():
+            local_rank = int(os.environ["DABHIP_BENCH_DEVICE"])            # launch_ranks made this rank's GPU the only visible one
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         t_gen = time.perf_counter()
@@ -830,8 +849,8 @@ def main():
     if os.environ.get("DABHIP_BENCH_PIPES") == "1" and world_env > 1:
         coord = Pipes(int(os.environ["RANK"]), world_env)
     elif world_env > 1:
-        cores = os.cpu_count() or 8
-        os.environ.setdefault("DABHIP_HOST_THREADS", str(max(2, min(24, cores // (2 * world_env)))))
+        from dabtools_amd import shard
+        os.environ.setdefault("DABHIP_HOST_THREADS", str(shard.host_threads_per_rank(world_env)))
         coord = Gloo()
     else:
         coord = Single()

@@ -172,6 +172,7 @@ _SIGNATURES = {
     "dabhip_engine_create_on_cpus": (C.c_void_p, [C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int]),
     "dabhip_engine_host_cpus": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int)]),
     "dabhip_host_placement_plan": (C.c_int, [C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_int32), C.c_int]),
+    "dabhip_host_cpu_budget": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dabhip_engine_stream_status": (C.c_uint32, [C.c_void_p, C.c_int]),
     "dabhip_multi_stream_status": (C.c_uint32, [C.c_void_p, C.c_int]),
     "dabhip_stream_status": (C.c_uint32, [C.c_void_p, C.c_int]),
@@ -379,6 +380,13 @@ def host_placement_plan(slice_node, node_cpulist, ncpu):
     n = lib().dabhip_host_placement_plan(nodes, len(slice_node), lists, len(node_cpulist), out, ncpu)
     _need(n >= 0, "host_placement_plan")
     return n, list(out)
+
+
+def host_cpu_budget():
+    """(usable CPUs, CPUs in the affinity mask, CFS quota in CPUs or 0) as the library sizes its host pools (csrc/placement.hpp)."""
+    a, q = C.c_int(0), C.c_int(0)
+    n = lib().dabhip_host_cpu_budget(C.byref(a), C.byref(q))
+    return n, a.value, q.value
 
 
 def host_table(which):

@@ -132,6 +132,12 @@ int dabhip_engine_host_cpus(const dabhip_engine* e, int32_t* cpus, int cap, int*
   for (int i = 0; cpus && i < cap && i < static_cast<int>(c.size()); ++i) cpus[i] = c[static_cast<size_t>(i)];
   return static_cast<int>(c.size());
 }
+int dabhip_host_cpu_budget(int* affinity_cpus, int* cfs_quota_cpus)
+{
+  if (affinity_cpus) *affinity_cpus = static_cast<int>(dabhip::allowed_cpus().size());
+  if (cfs_quota_cpus) *cfs_quota_cpus = dabhip::cfs_quota_cpus();
+  return dabhip::usable_cpus();
+}
 int dabhip_host_placement_plan(const int32_t* slice_node, int nslices, const char* const* node_cpulist, int nnodes, int32_t* cpu_slice, int ncpu)
 {
   if (!slice_node || !node_cpulist || !cpu_slice || nslices <= 0 || nnodes <= 0 || ncpu <= 0) { set_error("placement_plan: bad argument"); return -1; }
@@ -907,6 +913,7 @@ extern "C" int64_t dabhip_stream_feed(dabhip_stream* s, const uint8_t* const* iq
       at = kept;
     }
     // stream byte x of the bytes still held lives at from + org + (x - base); all streams' moves go in one launch behind the loop
+    if (kept >= (size_t(1) << 32)) return broken("stream_feed: more than 4 GiB of a stream's past still referenced");   // (CopyDesc sizes are 32-bit)
     if (kept) {
       moves.push_back(CopyDesc{from.get() + s->org[b] + (need - s->base[b]), to->get() + at - kept, static_cast<uint32_t>(kept), 0});
       longest_move = std::max(longest_move, static_cast<uint32_t>(kept));

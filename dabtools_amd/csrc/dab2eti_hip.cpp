@@ -314,9 +314,14 @@ int main(int argc, char** argv)
   // all frames, file by file in emission order, in ONE download into page-locked memory and one run of large writes
   if (n > 0) {
     uint8_t* host = static_cast<uint8_t*>(dabhip_host_alloc(static_cast<size_t>(n) * DABHIP_ETI_BYTES));
-    if (!host || dabhip_engine_eti_fetch(e, host, n) != n || dabhip_engine_eti_fetch_wait(e) != 0) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); return 2; }
-    write_all(host, static_cast<size_t>(n) * DABHIP_ETI_BYTES);
-    dabhip_host_free(host);
+    if (host && dabhip_engine_eti_fetch(e, host, n) == n && dabhip_engine_eti_fetch_wait(e) == 0) {
+      write_all(host, static_cast<size_t>(n) * DABHIP_ETI_BYTES);
+    } else {
+      // the one-download path serves one decode lane (DABHIP_LANES=1, the default); an engine of several lanes hands its frames over stream by stream
+      if (dabhip_engine_eti_drain(e, to_stdout, nullptr) != n) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); return 2; }
+      flush_stdout();
+    }
+    if (host) dabhip_host_free(host);
   }
   if (g_stats)
     std::fprintf(stderr, "{\"mode\": \"batch\", \"streams\": %zu, \"setup_s\": %.4f, \"upload_decode_s\": %.4f, \"download_write_s\": %.4f, \"eti_frames\": %lld}\n", files.size(),

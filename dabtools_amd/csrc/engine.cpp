@@ -94,7 +94,8 @@ Engine::Engine(int device, int host_threads, std::vector<int> cpus) : device_(de
   for (auto& e : stage_ev_)
     if (!check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) return;
   if (!check(hipStreamCreateWithFlags(&d2h_stream_, hipStreamNonBlocking), "hipStreamCreate") ||
-      !check(hipEventCreateWithFlags(&ev_eti_fetch_, hipEventDisableTiming), "hipEventCreate"))
+      !check(hipEventCreateWithFlags(&ev_eti_fetch_[0], hipEventDisableTiming), "hipEventCreate") ||
+      !check(hipEventCreateWithFlags(&ev_eti_fetch_[1], hipEventDisableTiming), "hipEventCreate"))
     return;
 
   std::vector<double2> tw2048(2048), tw1536(1536);
@@ -141,10 +142,11 @@ Engine::Engine(int device, int host_threads, std::vector<int> cpus) : device_(de
       !d_prbs_.upload(prbs, stream_) || !d_zero_words_.upload(zeros, stream_))
     return;
   if (!check(hipStreamSynchronize(stream_), "table upload")) return;
-  // host threads for the per-stream control plane: half the cores, at most 24; DABHIP_HOST_THREADS overrides it (bench.py
-  // gives each of N ranks on a node cores / N, so that 8 ranks do not start 8 x 24 busy threads)
-  const int hw = static_cast<int>(std::thread::hardware_concurrency());
-  int nthreads = host_threads > 0 ? std::min(host_threads, 64) : std::min(hw / 2, 24);
+  // host threads for the per-stream control plane: half the CPUs this process may use (its affinity mask capped by the cgroup's CFS quota:
+  // placement.hpp usable_cpus(); the machine's thread count says nothing in a container), at most 24, at least 2; DABHIP_HOST_THREADS overrides it
+  // (bench.py gives each of N ranks on a node its share, so that 8 ranks do not start 8 full pools)
+  const int hw = usable_cpus();
+  int nthreads = host_threads > 0 ? std::min(host_threads, 64) : std::max(2, std::min(hw / 2, 24));
   if (const char* env = std::getenv("DABHIP_HOST_THREADS")) nthreads = std::max(1, std::min(64, std::atoi(env)));
   // host placement (placement.hpp): the device's NUMA node; without an explicit CPU list the host threads go to that node's CPUs when the machine
   // has more than one node with CPUs (on a single-socket box there is nothing to choose)
@@ -153,7 +155,7 @@ Engine::Engine(int device, int host_threads, std::vector<int> cpus) : device_(de
     if (numa_enabled() && hipDeviceGetPCIBusId(bdf, sizeof bdf, device) == hipSuccess) numa_node_ = numa_node_of_pci(bdf);
     else (void)hipGetLastError();
     if (host_cpus_.empty() && numa_enabled() && numa_node_ >= 0) {
-      const std::vector<std::vector<int>> nodes = system_node_cpus();
+      const std::vector<std::vector<int>> nodes = allowed_node_cpus();       // (a process pinned to one socket sees one populated node: nothing to choose)
       int populated = 0;
       for (const auto& n : nodes) populated += n.empty() ? 0 : 1;
       if (populated > 1 && numa_node_ < static_cast<int>(nodes.size())) host_cpus_ = nodes[static_cast<size_t>(numa_node_)];
@@ -185,7 +187,8 @@ Engine::~Engine()
   for (auto& e : stage_ev_)
     if (e) (void)hipEventDestroy(e);
   if (d2h_stream_) { (void)hipStreamSynchronize(d2h_stream_); (void)hipStreamDestroy(d2h_stream_); }
-  if (ev_eti_fetch_) (void)hipEventDestroy(ev_eti_fetch_);
+  for (hipEvent_t ev : ev_eti_fetch_)
+    if (ev) (void)hipEventDestroy(ev);
   if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -415,7 +418,8 @@ bool Engine::msc_launch_async(const MscWork& w)
   msc_queued_ = false;
   if (nf == 0) return true;
   // a fetch of the previous decode's frames may still be reading the ETI buffer these launches rewrite (eti_fetch_async)
-  if (eti_fetch_pending_ && !check(hipStreamWaitEvent(stream_, ev_eti_fetch_, 0), "eti fetch wait")) return false;
+  if (const uint64_t issued = eti_fetch_issued_.load())     // (the newest fetch's event: the copies run in order on one stream)
+    if (!check(hipStreamWaitEvent(stream_, ev_eti_fetch_[(issued - 1) & 1], 0), "eti fetch wait")) return false;
   if (!launch_decode_batch(w.batch, d_msc_bits_.get(), d_stream_cif_base_.get(), d_prbs_.get(), d_eti_.get(), kEtiBytes)) return false;
   if (!check(launch_eti_finish(d_meta_.get(), static_cast<int>(nf), d_headers_.get(), w.header_stride, d_fibs_.get(), d_crc_tab_.get(), d_crc_shift_.get(), d_eti_.get(), stream_), "eti finish launch"))
     return false;
@@ -1131,23 +1135,30 @@ int64_t Engine::eti_read(int stream, uint8_t* dst, int64_t cap_frames)
   return read_eti(eti_base_[stream], n, dst) ? n : -1;
 }
 
+// Up to TWO fetches may be outstanding (the CLI's pipeline: its writer thread still waits for fetch k while the decode thread, through with decode
+// k + 1, issues fetch k + 1 into the other output buffer): each has its own event, eti_fetch_wait() waits for the OLDEST one not yet waited for.  A
+// third fetch without a wait is refused -- its destination would be a buffer somebody is still reading.  The copies run in order on one stream.
 int64_t Engine::eti_fetch_async(uint8_t* dst, int64_t cap_frames)
 {
   if (!dst) { set_error("eti_fetch: null destination"); return -1; }
   if (!check(hipSetDevice(device_), "hipSetDevice")) return -1;
+  const uint64_t issued = eti_fetch_issued_.load(), waited = eti_fetch_waited_.load();
+  if (issued - waited >= 2) { set_error("eti_fetch: two fetches are outstanding -- eti_fetch_wait first"); return -1; }
   const int64_t n = std::min(cap_frames, total_eti_);
-  // (decode() has returned: the frames are complete; the copy is ordered before the next decode's K4 by ev_eti_fetch_)
+  // (decode() has returned: the frames are complete; the copy is ordered before the next decode's K4 by the newest fetch event)
   if (n > 0 && !check(hipMemcpyAsync(dst, d_eti_.get(), static_cast<size_t>(n) * kEtiBytes, hipMemcpyDeviceToHost, d2h_stream_), "eti fetch")) return -1;
-  if (!check(hipEventRecord(ev_eti_fetch_, d2h_stream_), "eti fetch event")) return -1;
-  eti_fetch_pending_ = true;
+  if (!check(hipEventRecord(ev_eti_fetch_[issued & 1], d2h_stream_), "eti fetch event")) return -1;
+  eti_fetch_issued_.store(issued + 1);
   return n;
 }
 
 bool Engine::eti_fetch_wait()
 {
-  if (!eti_fetch_pending_) return true;
-  eti_fetch_pending_ = false;
-  return check(hipSetDevice(device_), "hipSetDevice") && check(hipEventSynchronize(ev_eti_fetch_), "eti fetch");
+  const uint64_t waited = eti_fetch_waited_.load();
+  if (waited == eti_fetch_issued_.load()) return true;
+  const bool ok = check(hipSetDevice(device_), "hipSetDevice") && check(hipEventSynchronize(ev_eti_fetch_[waited & 1]), "eti fetch");
+  eti_fetch_waited_.store(waited + 1);
+  return ok;
 }
 
 const uint8_t* Engine::eti_device(int64_t* nframes) const

@@ -287,8 +287,8 @@ class Engine {
   hipEvent_t ev_msc_[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_h2d_[2] = {nullptr, nullptr};
   hipStream_t d2h_stream_ = nullptr;           // eti_fetch_async
-  hipEvent_t ev_eti_fetch_ = nullptr;
-  std::atomic<bool> eti_fetch_pending_{false};   // (cleared by whichever thread waits for the copy: the CLI's writer thread)
+  hipEvent_t ev_eti_fetch_[2] = {nullptr, nullptr};              // one per outstanding fetch (at most two)
+  std::atomic<uint64_t> eti_fetch_issued_{0}, eti_fetch_waited_{0};   // (issued: the decoding thread; waited: whichever thread waits -- the CLI's writer)
   // page-locked staging ring for uploads from pageable memory: the host pool copies piece n + 1 into one buffer while the DMA of
   // piece n drains another
   static constexpr int kStageBufs = 4;

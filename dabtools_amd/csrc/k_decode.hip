@@ -999,12 +999,12 @@ __global__ __launch_bounds__(256) void host_gather_kernel(const CopyDesc* __rest
   uint32_t piece0 = 0;                                     // index of the first piece of descriptor i in the global piece order
   for (int i = 0; i < ndesc; ++i) {
     const CopyDesc d = descs[i];
-    const uint32_t npieces = (d.nbytes + kPiece - 1) / kPiece;
+    const uint32_t npieces = static_cast<uint32_t>((static_cast<uint64_t>(d.nbytes) + kPiece - 1) / kPiece);   // (64-bit sum: sizes close to 2^32)
     // pieces of this descriptor that belong to this workgroup: global index = piece0 + p, taken when (piece0 + p) % gridDim.x == blockIdx.x
     uint32_t p = (blockIdx.x + gridDim.x - piece0 % gridDim.x) % gridDim.x;
     for (; p < npieces; p += gridDim.x) {
-      const uint32_t off = p * kPiece;
-      copy_piece(d.src + off, d.dst + off, min(kPiece, d.nbytes - off));
+      const uint64_t off = static_cast<uint64_t>(p) * kPiece;
+      copy_piece(d.src + off, d.dst + off, static_cast<uint32_t>(min(static_cast<uint64_t>(kPiece), d.nbytes - off)));
     }
     piece0 += npieces;
   }
@@ -1016,7 +1016,9 @@ __global__ __launch_bounds__(256) void device_gather_kernel(const CopyDesc* __re
 {
   constexpr uint32_t kPiece = 64u << 10;
   const CopyDesc d = descs[blockIdx.y];
-  for (uint32_t off = blockIdx.x * kPiece; off < d.nbytes; off += gridDim.x * kPiece) copy_piece(d.src + off, d.dst + off, min(kPiece, d.nbytes - off));
+  // (64-bit offset: with nbytes close to 2^32 a 32-bit one wraps below nbytes again and the loop never ends)
+  for (uint64_t off = static_cast<uint64_t>(blockIdx.x) * kPiece; off < d.nbytes; off += static_cast<uint64_t>(gridDim.x) * kPiece)
+    copy_piece(d.src + off, d.dst + off, static_cast<uint32_t>(min(static_cast<uint64_t>(kPiece), d.nbytes - off)));
 }
 
 hipError_t launch_host_gather(const CopyDesc* descs, int n, int workgroups, hipStream_t stream)
@@ -1029,7 +1031,7 @@ hipError_t launch_host_gather(const CopyDesc* descs, int n, int workgroups, hipS
 hipError_t launch_device_gather(const CopyDesc* descs, int n, uint32_t max_bytes, hipStream_t stream)
 {
   if (n <= 0) return hipSuccess;
-  const uint32_t pieces = (max_bytes + (64u << 10) - 1) / (64u << 10);
+  const uint32_t pieces = static_cast<uint32_t>((static_cast<uint64_t>(max_bytes) + (64u << 10) - 1) >> 16);   // (no wrap for sizes close to 2^32)
   for (int i = 0; i < n; i += 65535)          // (grid.y holds 65,535 descriptors)
     hipLaunchKernelGGL(device_gather_kernel, dim3(std::max(1u, std::min(pieces, 64u)), std::min(n - i, 65535)), dim3(256), 0, stream, descs + i);
   return hipGetLastError();

@@ -70,7 +70,8 @@ dabhip_multi* dabhip_multi_create(const int* devices, int n)
   std::unique_ptr<dabhip_multi> m(new (std::nothrow) dabhip_multi);
   if (!m) return nullptr;
   // host threads per slice: the slices share the host, so that eight of them do not start 8 x 24 busy threads
-  const int hw = static_cast<int>(std::thread::hardware_concurrency());
+  // (of the CPUs this process may use -- affinity mask and CFS quota, placement.hpp --, not of the machine's)
+  const int hw = dabhip::usable_cpus();
   const int host_threads = std::max(2, std::min(24, hw / (2 * n)));
   m->slices.resize(n);
   // host placement (placement.hpp): every slice's threads -- its decode thread here, the engine's control-plane pool and host lane -- on the NUMA
@@ -82,7 +83,7 @@ dabhip_multi* dabhip_multi_create(const int* devices, int n)
       if (hipDeviceGetPCIBusId(bdf, sizeof bdf, devices[i]) == hipSuccess) nodes[static_cast<size_t>(i)] = dabhip::numa_node_of_pci(bdf);
       else (void)hipGetLastError();
     }
-  const std::vector<std::vector<int>> node_cpus = dabhip::system_node_cpus();
+  const std::vector<std::vector<int>> node_cpus = dabhip::allowed_node_cpus();
   int populated = 0;
   for (const auto& c : node_cpus) populated += c.empty() ? 0 : 1;
   std::vector<std::vector<int>> plan(static_cast<size_t>(n));

@@ -7,7 +7,8 @@
 // /sys/devices/system/node/node<N>/cpulist, the CPUs of a node dealt to the slices on it in contiguous, disjoint chunks, and every host
 // thread of a slice bound to its chunk (sched_setaffinity) BEFORE it allocates anything: page-locked buffers are then first touched -- and
 // pinned -- on that node.  A device without a known node (-1: single-socket machines, containers without sysfs) gets no binding at all.
-// DABHIP_NUMA=0 switches it off.  Unmeasured on hardware: the boxes of this pool have one GPU.
+// DABHIP_NUMA=0 switches it off.  Unmeasured on hardware: the boxes of this pool have one GPU.  Round 5: every list is cut down to the CPUs the
+// process is allowed on, and pool sizes come from usable_cpus() below, not from the machine's thread count.
 #pragma once
 
 #include <pthread.h>
@@ -98,6 +99,7 @@ inline int numa_node_of_pci(const std::string& bdf)
   return std::atoi(s.c_str());
 }
 
+// (the machine's lists as sysfs gives them; allowed_node_cpus() below is what placement works with)
 inline std::vector<std::vector<int>> system_node_cpus()
 {
   std::vector<std::vector<int>> nodes;
@@ -113,13 +115,112 @@ inline std::vector<std::vector<int>> system_node_cpus()
   return nodes;
 }
 
-// bind the CALLING thread; an empty list leaves it alone.  Returns false when the kernel refuses (a cpuset that excludes the list, ...)
+// ---- how many CPUs this process may really use (round 5) ----------------------------------------------------------------
+// std::thread::hardware_concurrency() counts the machine's hardware threads -- 256 on the GPU boxes of this pool, whose containers are granted
+// 16 CPUs' worth of time (CFS quota) -- and a launcher's taskset / numactl shrinks the affinity mask further.  Host pools sized from the machine
+// oversubscribe the grant: eight ranks x 24 pool threads burn the quota of a 100 ms period early and the cgroup freezes EVERY thread until the
+// next one.  So pools are sized from min(|affinity mask|, quota), and CPU lists are intersected with the mask before anything is bound to them.
+
+// the CPUs of the calling process's affinity mask (what a launcher's taskset / numactl / cpuset left), ascending
+inline std::vector<int> allowed_cpus()
+{
+  std::vector<int> out;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof set, &set) != 0) return out;
+  for (int c = 0; c < CPU_SETSIZE; ++c)
+    if (CPU_ISSET(c, &set)) out.push_back(c);
+  return out;
+}
+
+// "max 100000" / "1600000 100000" (cgroup v2 cpu.max) -> CPUs' worth of time, rounded up; 0 = no limit or not readable
+inline int parse_cpu_max(const std::string& text)
+{
+  if (text.empty() || text.compare(0, 3, "max") == 0) return 0;
+  char* end = nullptr;
+  const long long quota = std::strtoll(text.c_str(), &end, 10);
+  const long long period = end ? std::strtoll(end, nullptr, 10) : 0;
+  if (quota <= 0 || period <= 0) return 0;
+  return static_cast<int>((quota + period - 1) / period);
+}
+
+// the tightest CFS quota on the way from this process's cgroup to the root, in CPUs (0 = none): cgroup v2 cpu.max, else v1 cfs_quota_us / cfs_period_us
+inline int cfs_quota_cpus()
+{
+  int best = 0;
+  auto take = [&](int q) { if (q > 0 && (best == 0 || q < best)) best = q; };
+  std::string rel;                                         // "0::/some/path" in /proc/self/cgroup (v2)
+  {
+    const std::string cg = read_small_file("/proc/self/cgroup");
+    size_t pos = 0;
+    while (pos < cg.size()) {
+      const size_t eol = cg.find('\n', pos);
+      const std::string line = cg.substr(pos, eol == std::string::npos ? std::string::npos : eol - pos);
+      if (line.compare(0, 3, "0::") == 0) rel = line.substr(3);
+      if (eol == std::string::npos) break;
+      pos = eol + 1;
+    }
+  }
+  while (!rel.empty() && rel.back() == '/') rel.pop_back();
+  std::string path = "/sys/fs/cgroup" + rel;
+  for (int depth = 0; depth < 32; ++depth) {               // the process's own group, then every ancestor (a container usually sees its own as the root)
+    take(parse_cpu_max(read_small_file(path + "/cpu.max")));
+    if (path.size() <= std::string("/sys/fs/cgroup").size()) break;
+    const size_t slash = path.find_last_of('/');
+    if (slash == std::string::npos) break;
+    path.resize(slash);
+  }
+  if (best == 0) {                                         // cgroup v1
+    const long long q = std::atoll(read_small_file("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").c_str());
+    const long long per = std::atoll(read_small_file("/sys/fs/cgroup/cpu/cpu.cfs_period_us").c_str());
+    if (q > 0 && per > 0) take(static_cast<int>((q + per - 1) / per));
+  }
+  return best;
+}
+
+// what host pools are sized from: min(CPUs in the affinity mask, CFS quota), at least 1.  DABHIP_CPUS=n overrides it (tests, odd containers).
+inline int usable_cpus()
+{
+  if (const char* e = std::getenv("DABHIP_CPUS")) {
+    const int v = std::atoi(e);
+    if (v > 0) return v;
+  }
+  int n = static_cast<int>(allowed_cpus().size());
+  if (n <= 0) n = 1;
+  const int q = cfs_quota_cpus();
+  return q > 0 && q < n ? q : n;
+}
+
+// cpus without those outside `allowed` (order kept)
+inline std::vector<int> intersect_cpus(const std::vector<int>& cpus, const std::vector<int>& allowed)
+{
+  std::vector<int> out;
+  for (int c : cpus)
+    for (int a : allowed)
+      if (a == c) { out.push_back(c); break; }
+  return out;
+}
+
+// every node's CPUs this process is allowed on (a launcher that pinned the process to one socket leaves the other node's list empty)
+inline std::vector<std::vector<int>> allowed_node_cpus()
+{
+  std::vector<std::vector<int>> nodes = system_node_cpus();
+  const std::vector<int> allowed = allowed_cpus();
+  if (!allowed.empty())
+    for (auto& n : nodes) n = intersect_cpus(n, allowed);
+  return nodes;
+}
+
+// bind the CALLING thread to the part of `cpus` the process is allowed on; an empty list -- or an empty intersection: the launcher put this process
+// somewhere else, and that stands -- leaves it alone.  Returns false when the kernel refuses.
 inline bool bind_this_thread(const std::vector<int>& cpus)
 {
   if (cpus.empty()) return true;
+  const std::vector<int> use = intersect_cpus(cpus, allowed_cpus());
+  if (use.empty()) return true;
   cpu_set_t set;
   CPU_ZERO(&set);
-  for (int c : cpus)
+  for (int c : use)
     if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
   return pthread_setaffinity_np(pthread_self(), sizeof set, &set) == 0;
 }

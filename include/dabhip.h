@@ -132,7 +132,9 @@ const void *dabhip_engine_eti_device_ptr(const dabhip_engine *e, int64_t *nframe
  * stream by stream in emission order (the order dabhip_engine_eti_drain delivers them in), copied to dst -- page-locked memory from
  * dabhip_host_alloc for a true asynchronous DMA -- on a stream of their own.  Returns at once with the number of frames on their way (<= cap_frames);
  * the copy runs beside the NEXT decode (only that decode's ETI-writing launches wait for it); dabhip_engine_eti_fetch_wait returns when the
- * bytes have arrived.  dst must stay untouched in between. */
+ * bytes have arrived.  dst must stay untouched in between.  At most TWO fetches may be outstanding (two output buffers: one being written out
+ * while the next fills); each dabhip_engine_eti_fetch_wait waits for the OLDEST fetch not yet waited for, and a third fetch without a wait is
+ * refused (-1).  The waiting thread may be another one than the decoding thread (the CLI's writer thread). */
 int64_t dabhip_engine_eti_fetch(dabhip_engine *e, uint8_t *dst, int64_t cap_frames);
 int dabhip_engine_eti_fetch_wait(dabhip_engine *e);
 
@@ -335,6 +337,10 @@ int dabhip_host_control_replay(const uint8_t *fibs, const uint8_t *crc_ok, int n
  * the kernel's notation ("0-63,128-191").  cpu_slice[c] = the slice CPU c is given to, -1 = none; the slices of a node get disjoint contiguous
  * chunks of its list.  Returns the number of slices that got CPUs. */
 int dabhip_host_placement_plan(const int32_t *slice_node, int nslices, const char *const *node_cpulist, int nnodes, int32_t *cpu_slice, int ncpu);
+/* What the host pools are sized from (round 5): returns min(CPUs in the process's affinity mask, CFS quota of its cgroup), at least 1 -- NOT the
+ * machine's thread count, which says nothing inside a container (DABHIP_CPUS=n overrides it); the two inputs come back in *affinity_cpus and
+ * *cfs_quota_cpus (0 = no quota).  No GPU call.  dab2eti.c:237 has one demod thread and no pool to size. */
+int dabhip_host_cpu_budget(int *affinity_cpus, int *cfs_quota_cpus);
 
 /* The constant tables the kernels are built from (dab_tables.hpp generates them from the ETSI rules), so that tests can
  * hold them against the reference's literal arrays: which = 0: the 64 UEP profiles of ueptable (dab_tables.c:16-81) as rows

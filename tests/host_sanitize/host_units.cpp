@@ -98,6 +98,26 @@ static void test_pool_and_lane()
     on_cpu.wait();
     CHECK(where == cpu0);
   }
+  // a CPU list that reaches beyond what the process is allowed on (a launcher's taskset): bound to the part inside; a list wholly outside: left alone
+  {
+    const int outside = CPU_SETSIZE - 1;                               // (no box has 1024 hardware threads in its cpuset)
+    CHECK(!CPU_ISSET(outside, &allowed));
+    AsyncLane partly(std::vector<int>{outside, cpu0});
+    int where = -1;
+    partly.post([&]() { where = sched_getcpu(); });
+    partly.wait();
+    CHECK(where == cpu0);
+    AsyncLane none(std::vector<int>{outside});
+    cpu_set_t got;
+    CPU_ZERO(&got);
+    none.post([&]() { CHECK(sched_getaffinity(0, sizeof got, &got) == 0); });
+    none.wait();
+    CHECK(CPU_EQUAL(&got, &allowed));
+    CHECK(intersect_cpus({5, 1, 9}, {1, 2, 5}) == (std::vector<int>{5, 1}));
+  }
+  // the quota rule: cgroup v2's cpu.max
+  CHECK(parse_cpu_max("max 100000") == 0 && parse_cpu_max("1600000 100000") == 16 && parse_cpu_max("150000 100000") == 2 && parse_cpu_max("") == 0);
+  CHECK(usable_cpus() >= 1 && usable_cpus() <= static_cast<int>(allowed_cpus().size()));
   // two callers of one pool (the engine's decode thread and its host lane never overlap, but nothing must break if they did)
   {
     ThreadPool shared(4);

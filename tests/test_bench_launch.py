@@ -44,6 +44,51 @@ def test_self_launch_two_and_four_ranks():
         _check(_one_json_line(out), n, 3)
 
 
+def test_self_launch_eight_ranks_each_sees_its_own_gpu_and_its_share_of_the_cpus():
+    """configs[3]'s launch (8 ranks x 256 streams) without a GPU: every rank is started with ROCR_VISIBLE_DEVICES = its GPU before it exists
+    (and uses device 0 of that view), and with a host pool that is its share of the CPUs the container really has -- affinity mask and CFS
+    quota, not os.cpu_count() (the GPU boxes report 256 hardware threads and grant 16 CPUs)."""
+    sys.path.insert(0, ROOT)
+    from dabtools_amd import shard
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES",
+                                                             "CUDA_VISIBLE_DEVICES", "DABHIP_HOST_THREADS", "DABHIP_CPUS", "DABHIP_BENCH_ONE_DEVICE")}
+
+    def run(extra):
+        out = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--dry-run", "--steps", "2"], env=dict(base, **extra), stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True, timeout=180, check=True).stdout
+        res = _one_json_line(out)
+        _check(res, 8, 2)
+        return res["ranks"]
+
+    ranks = run({})
+    assert [r["visible_devices"] for r in ranks] == [str(i) for i in range(8)]
+    assert all(r["host_threads"] == str(shard.host_threads_per_rank(8)) for r in ranks)
+    ranks = run({"DABHIP_CPUS": "16"})                               # the GPU boxes' grant: 16 CPUs for 8 ranks -> the floor of 2 threads each
+    assert all(r["host_threads"] == "2" for r in ranks)
+    ranks = run({"DABHIP_CPUS": "256"})
+    assert all(r["host_threads"] == "16" for r in ranks)
+    ranks = run({"ROCR_VISIBLE_DEVICES": "4,5,6,7,0,1,2,3"})         # the launcher was itself given a list: rank r takes its r-th entry
+    assert [r["visible_devices"] for r in ranks] == ["4", "5", "6", "7", "0", "1", "2", "3"]
+    ranks = run({"HIP_VISIBLE_DEVICES": "0,1,2,3,4,5,6,7"})          # the caller selects through HIP's own list: not combined with ROCR's
+    assert all(r["visible_devices"] is None for r in ranks)
+    a, q = shard.cpu_budget()
+    assert 1 <= shard.usable_cpus() <= a and (q is None or q >= 1)
+    if hasattr(os, "sched_setaffinity"):                             # a launcher's taskset shrinks the budget
+        code = "import os,sys; sys.path.insert(0, %r); os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]}); from dabtools_amd import shard; print(shard.usable_cpus())" % ROOT
+        assert subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True, check=True, env=base).stdout.strip() == "1"
+
+
+def test_a_dying_rank_ends_the_launch_with_an_error():
+    """One of four ranks exits before the first barrier (test knob DABHIP_BENCH_DIE_RANK): the launcher must not hang at that barrier -- it ends the
+    other ranks and returns non-zero, without a result line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["DABHIP_BENCH_DIE_RANK"] = "2"
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--dry-run", "--steps", "3"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=120)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")], p.stdout
+
+
 def test_single_rank_unchanged():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--dry-run", "--steps", "2", "--warmup", "0"], env=env, stdout=subprocess.PIPE,

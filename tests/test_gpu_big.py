@@ -17,4 +17,5 @@ def test_one_stream_beyond_four_gib():
     assert out["ok"], out
     assert out["one_shot"]["eti_frames"] == 4 * (11200 - 15) and out["session"]["equal_to_one_shot"]
     assert out["session"]["largest_segment_bytes"] > 2 ** 31
+    assert out["session_segment_just_below_4gib"]["equal_to_one_shot"] and 2 ** 32 - (4 << 20) < out["session_segment_just_below_4gib"]["segment_bytes"] < 2 ** 32
     assert out["oracle_tail"]["first_byte_offset"] > 2 ** 32

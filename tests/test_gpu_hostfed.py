@@ -197,6 +197,21 @@ def test_eti_fetch_is_the_drain_order_and_overlaps_the_next_segment():
     got = np.array(hb.array[:total * 6144]).reshape(total, 6144)
     want = np.concatenate([eng.eti(b) for b in range(3)])
     assert np.array_equal(got, want)
+    # two fetches outstanding (fetch k + 1 issued before fetch k has been waited for: the CLI's decode thread and writer thread), each wait takes the
+    # oldest; a third without a wait is refused, and the ETI buffer growing between the two (a larger decode) does not disturb the first
+    hb2 = dab.HostBuffer(4 * total * 6144)
+    assert eng.eti_fetch(hb.ptr, total) == total
+    big = [dab.synth_generate(c, 30) for c in cfgs] + streams
+    total2 = eng.decode(big)
+    assert total2 > total and eng.eti_fetch(hb2.ptr, total2) == total2
+    with pytest.raises(dab.DabhipError):
+        eng.eti_fetch(hb.ptr, 1)
+    eng.eti_fetch_wait()
+    assert np.array_equal(np.array(hb.array[:total * 6144]).reshape(total, 6144), want)
+    eng.eti_fetch_wait()
+    assert np.array_equal(np.array(hb2.array[:total2 * 6144]).reshape(total2, 6144), np.concatenate([eng.eti(b) for b in range(6)]))
+    eng.eti_fetch_wait()                              # nothing outstanding: returns at once
+    hb2.free()
     eng.close()
     # session: the download of segment k is waited for only AFTER segment k + 1 has been fed (it overlaps that segment's upload and decode;
     # only the K4 of segment k + 1, which rewrites the ETI buffer, is ordered behind it)

@@ -65,6 +65,21 @@ def run(tfs=11200, oracle_tfs=400):
                       "seconds": round(time.time() - t0, 3), "equal_to_one_shot": bool(sess.shape == whole.shape and np.array_equal(sess, whole)), "stream_status": st.status(0)}
     ok = ok and out["session"]["equal_to_one_shot"]
     st.close()
+    # (c) one segment just below 4 GiB: the copy kernel's 64 KB pieces were counted in 32 bits, and for sizes within 4 MiB of 2^32 its loop offset
+    # wrapped below the size again -- a kernel that never ended.  The first feed is such a segment, the second the rest.
+    if nbytes > (1 << 32):
+        st = dab.Stream(1, device=0)
+        first = (1 << 32) - 70000
+        t0 = time.time()
+        got = []
+        for a, z in ((0, first), (first, nbytes)):
+            st.feed_ptrs([buf.ptr + a], [z - a], on_device=True)
+            got.append(st.eti(0))
+        sess = np.concatenate(got)
+        out["session_segment_just_below_4gib"] = {"segment_bytes": first, "seconds": round(time.time() - t0, 3),
+                                                  "equal_to_one_shot": bool(sess.shape == whole.shape and np.array_equal(sess, whole))}
+        ok = ok and out["session_segment_just_below_4gib"]["equal_to_one_shot"]
+        st.close()
     if args.oracle_tfs > 0:
         import oracle_lib as ol
         m = min(args.oracle_tfs, args.tfs)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B at 256 and 512 streams: in-tree library against variants/libdabhip_k1lb4.so (tools/build_variant_k1lb4.sh), then the trace / end-to-end parity tests on the variant
-cd $GRAFT_REPO_ROOT
+set -u
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}; export GRAFT_REPO_ROOT; cd "$GRAFT_REPO_ROOT"
 for n in 256 512; do for lib in "" variants/libdabhip_k1lb4.so; do
   DABHIP_LIB=${lib:+$GRAFT_REPO_ROOT/$lib} python bench.py --streams $n --steps 5 --warmup 2 --no-cpu-baseline --no-variants --no-h2d 2>/dev/null | python -c "
 import sys,json
