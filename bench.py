@@ -554,6 +554,21 @@ def rooflines(prof, args, world, frames_rank, ntf_rank, stage, fft, stream_ceili
                     "from": prof.ref("write", FUSED, "WRITE_SIZE") + " x 1024 / (28,800 B x TFs of the profiled run)",
                     "note": "NOT the bound of this kernel (it never writes the spectra): stated so that nobody reads it as one"},
             "transforms_per_step": transforms, "avg_ms": stage["fft"], "profile_matches_this_workload": same}
+    # `roofline` is SURVEY 8(d)'s number -- K2 by itself -- and K2 is not a kernel of the timed step.  So that a reader of `roofline` alone (the driver's
+    # record keeps that object) sees what the step's own dominant kernels achieve, their summaries ride inside it.
+    if "roofline" in out:
+        inside = {}
+        for key, name in (("roofline_ofdm_fused", "ofdm_demap_kernel"), ("roofline_viterbi", "viterbi_fused_kernel")):
+            if key in out:
+                r = out[key]
+                inside[name] = {"bound": r["bound"], "frac": r["frac"], "frac_from_counters": r["frac_from_counters"]["value"], "avg_ms_per_step": r["avg_ms"] if "avg_ms" in r else r["inputs"]["avg_ms"],
+                                "details": key}
+        if "roofline_ofdm_fused" in out:
+            inside["ofdm_demap_kernel"]["hbm_frac"] = out["roofline_ofdm_fused"]["hbm"]["frac"]
+        if "roofline_viterbi" in out:
+            inside["viterbi_fused_kernel"]["survivor_traffic_frac_of_hbm_peak"] = out["roofline_viterbi"]["survivor_traffic"]["frac_of_hbm_peak"]
+        out["roofline"]["in_timed_step"] = dict(inside, note="the kernels the timed step DOES run (K2's work is done inside ofdm_demap_kernel, which never writes the spectra): "
+                                                             "VALU-issue-bound both; `frac` above is K2 alone against the HBM peak")
     return out
 
 

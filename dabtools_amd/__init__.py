@@ -147,6 +147,7 @@ _SIGNATURES = {
     "dabhip_engine_set_guard_list_cap": (C.c_int, [C.c_void_p, C.c_uint32]),
     "dabhip_stream_set_parity_guard": (C.c_int, [C.c_void_p, C.c_int]),
     "dabhip_stage_decision_audit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "dabhip_stage_decision_audit_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "dabhip_engine_set_subchannels": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
     "dabhip_stream_set_subchannels": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
     "dabhip_stream_create": (C.c_void_p, [C.c_int, C.c_int]),
@@ -579,17 +580,24 @@ class Engine:
         """Test knob: capacity of the guard's list per launch (0 = automatic)."""
         _need(lib().dabhip_engine_set_guard_list_cap(self._h, cap) == 0, "set_guard_list_cap")
 
-    def decision_audit(self, frames=None, device_ptr=None, nframes=None, guard=False):
-        """fp32 OFDM stage vs fp64 on contiguous cu8 frames -> dict (see dabhip_stage_decision_audit)."""
+    def decision_audit(self, frames=None, device_ptr=None, nframes=None, guard=False, fused=False):
+        """fp32 OFDM stage vs fp64 on contiguous cu8 frames -> dict (see dabhip_stage_decision_audit); fused: the default decode's one-kernel stage
+        (dabhip_stage_decision_audit_fused) instead of K2 + K2b."""
         if device_ptr is None:
             frames = np.ascontiguousarray(frames, dtype=np.uint8)
             nframes = frames.size // TF_BYTES
             src, on_dev = frames.ctypes.data, 0
         else:
             src, on_dev = device_ptr, 1
+        keys = ("decisions", "disagree", "disagree_outside_guard", "flagged_by_rule", "max_bin_err", "max_dec_err", "max_prod_err", "listed")
+        if fused:
+            out = (C.c_double * 10)()
+            _need(lib().dabhip_stage_decision_audit_fused(self._h, src, nframes, on_dev, 1 if guard else 0, out) == nframes, "stage_decision_audit_fused")
+            d = dict(zip(keys, list(out)[:8]))
+            d["shipping_kernel_same_bits"], d["shipping_kernel_same_list_count"] = out[8], out[9]
+            return d
         out = (C.c_double * 8)()
         _need(lib().dabhip_stage_decision_audit(self._h, src, nframes, on_dev, 1 if guard else 0, out) == nframes, "stage_decision_audit")
-        keys = ("decisions", "disagree", "disagree_outside_guard", "flagged_by_rule", "max_bin_err", "max_dec_err", "max_prod_err", "listed")
         return dict(zip(keys, list(out)))
 
     def decode(self, streams):

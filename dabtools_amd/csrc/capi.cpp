@@ -388,6 +388,11 @@ int dabhip_stage_decision_audit(dabhip_engine* e, const uint8_t* frames, int nfr
   if (!e || !frames || !out8) { set_error("stage_decision_audit: null argument"); return -1; }
   return e->first().stage_decision_audit(frames, nframes, on_device != 0, guard_on != 0, out8);
 }
+int dabhip_stage_decision_audit_fused(dabhip_engine* e, const uint8_t* frames, int nframes, int on_device, int guard_on, double* out10)
+{
+  if (!e || !frames || !out10) { set_error("stage_decision_audit_fused: null argument"); return -1; }
+  return e->first().stage_decision_audit(frames, nframes, on_device != 0, guard_on != 0, out10, true, out10 + 8);
+}
 int dabhip_stage_fic_decode(dabhip_engine* e, const uint8_t* fic, int nframes, uint8_t* fibs, uint8_t* crc_ok)
 {
   if (!e || !fic || !fibs || !crc_ok) { set_error("stage_fic_decode: null argument"); return -1; }

@@ -1302,11 +1302,16 @@ int Engine::stage_fic_decode(const uint8_t* fic, int nframes, uint8_t* fibs, uin
 // out8 = {decisions, disagreements with fp64, disagreements on carriers the guard rule does NOT flag, decisions the rule flags,
 //         max |X32 - X64| / sqrt(symbol energy), max product error / (|cur|_1 s(l-1) + |prev|_1 s(l)), max residual product
 //         error / (|cur|_1 |prev|_1), entries the demapper listed (guard on)}
-int Engine::stage_decision_audit(const uint8_t* frames, int nframes, bool on_device, bool guard_on, double* out8)
+// fused = true (round 5): the same audit of the kernel the DEFAULT decode runs -- ofdm_demap_kernel's guarded build, through its audit build (the same source
+// lines plus stores of its bins and products; k_fused.hip) -- with the frames laid out as a decode lays them out (FIC slot j, logical CIF rows from kRowLead +
+// 4 j).  out8[7] = entries that kernel listed.  out_extra (2 values, may be null): {1 when the SHIPPING build (launch_ofdm_demap_fused_guarded) run on the
+// same frames leaves exactly the bits the audit build left, before any re-decision; 1 when it lists the same number of decisions}.
+int Engine::stage_decision_audit(const uint8_t* frames, int nframes, bool on_device, bool guard_on, double* out8, bool fused, double* out_extra)
 {
   if (!ok_) { set_error("engine not initialised (no GPU?)"); return -1; }
   if (!hard_only("stage_decision_audit")) return -1;
   if (nframes <= 0 || !out8) return 0;
+  if (fused) return stage_decision_audit_fused(frames, nframes, on_device, guard_on, out8, out_extra);
   struct AuditOut { unsigned long long decisions, disagree, outside, flagged; unsigned bin_bits, dec_bits, prod_bits, pad; };
   DeviceBuffer<uint8_t> d_out;
   if (!d_out.reserve(sizeof(AuditOut)) || !check(hipMemsetAsync(d_out.get(), 0, sizeof(AuditOut), stream_), "audit memset")) return -1;
@@ -1359,6 +1364,99 @@ int Engine::stage_decision_audit(const uint8_t* frames, int nframes, bool on_dev
   auto f = [](unsigned bits) { float v; std::memcpy(&v, &bits, 4); return static_cast<double>(v); };
   out8[0] = static_cast<double>(h.decisions); out8[1] = static_cast<double>(h.disagree); out8[2] = static_cast<double>(h.outside);
   out8[3] = static_cast<double>(h.flagged); out8[4] = f(h.bin_bits); out8[5] = f(h.dec_bits); out8[6] = f(h.prod_bits); out8[7] = static_cast<double>(listed);
+  return nframes;
+}
+
+int Engine::stage_decision_audit_fused(const uint8_t* frames, int nframes, bool on_device, bool guard_on, double* out8, double* out_extra)
+{
+  struct AuditOut { unsigned long long decisions, disagree, outside, flagged; unsigned bin_bits, dec_bits, prod_bits, pad; };
+  DeviceBuffer<uint8_t> d_out;
+  DeviceBuffer<float2> d_bins, d_prod;
+  if (!d_out.reserve(sizeof(AuditOut)) || !check(hipMemsetAsync(d_out.get(), 0, sizeof(AuditOut), stream_), "audit memset")) return -1;
+  const int chunk = 128;
+  uint64_t listed = 0;
+  bool bits_equal = true, list_equal = true;
+  const uint8_t* d_in = frames;
+  if (!on_device) {
+    if (!d_iq_own_.reserve(static_cast<size_t>(nframes) * kTfBytes) ||
+        !check(hipMemcpy(d_iq_own_.get(), frames, static_cast<size_t>(nframes) * kTfBytes, hipMemcpyHostToDevice), "frame upload"))
+      return -1;
+    d_in = d_iq_own_.get();
+  }
+  const size_t per_frame = static_cast<size_t>(kSymbolsPerTf) * 2048;
+  if (!d_bins.reserve(per_frame * chunk) || !d_prod.reserve(per_frame * chunk)) return -1;
+  std::vector<uint32_t> bits_a, bits_b;
+  for (int first = 0; first < nframes; first += chunk) {
+    const int n = std::min(chunk, nframes - first);
+    std::vector<CallDesc> descs(n);
+    std::vector<int2> list(n);
+    std::vector<int> slots(n), rows(n);
+    for (int j = 0; j < n; ++j) {
+      std::memset(&descs[j], 0, sizeof(CallDesc));
+      descs[j].status = 2;
+      descs[j].ordinal = j;
+      descs[j].view = initial_state().view;
+      descs[j].view.seg_src[0] = static_cast<int64_t>(first + j) * kTfBytes;
+      list[j] = make_int2(0, j);
+      slots[j] = j;
+      rows[j] = kRowLead + 4 * j;                         // where a decode puts the frame's first CIF: the scatter reaches kRowLead rows back
+    }
+    std::vector<const uint8_t*> ptrs = {d_in};
+    max_calls_ = n;
+    if (!reserve_tf_slots(n) || !d_iq_ptrs_.upload(ptrs, stream_) || !d_descs_.upload(descs, stream_) || !d_frames_.upload(list, stream_) ||
+        !d_frame_slot_.upload(slots, stream_) || !d_frame_cif_row_.upload(rows, stream_) || !d_delta_.reserve(static_cast<size_t>(n) * kSymbolsPerTf))
+      return -1;
+    const size_t fic_words = static_cast<size_t>(n) * kFicWords, msc_words = static_cast<size_t>(4 * n + kRowLead + 1) * kCifWords;
+    // two passes: the shipping build first (its raw bits and its list count kept), then the audit build, whose output the audit kernel reads
+    uint32_t counts[2] = {0, 0};
+    for (int pass = 0; pass < 2; ++pass) {
+      GuardArgs ga{};
+      guard_launches_ = 0;
+      guard_counters_clear_ = false;
+      guard_flagged_ = 0;
+      if (!check(hipMemsetAsync(d_msc_bits_.get(), 0, msc_words * 4, stream_), "row clear")) return -1;     // (the rows before the first frame's are never written)
+      for (int part = 0; part < 2; ++part) {              // the decode's own two launches: FIC symbols, then MSC symbols, one workgroup per frame each
+        const int sym_a = part ? 4 : 1, sym_b = part ? kSymbolsPerTf : 4;
+        if (!guard_begin(n, &ga)) return -1;
+        const hipError_t e = pass == 0
+            ? launch_ofdm_demap_fused_guarded(d_iq_ptrs_.get(), d_descs_.get(), n, d_frames_.get(), 0, n, d_twf_.get(), d_frame_slot_.get(), d_frame_cif_row_.get(),
+                                              d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_, sym_a, sym_b, 1)
+            : launch_ofdm_demap_fused_audit(d_iq_ptrs_.get(), d_descs_.get(), n, d_frames_.get(), 0, n, d_twf_.get(), d_frame_slot_.get(), d_frame_cif_row_.get(),
+                                            d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_, sym_a, sym_b, 1, d_bins.get(), d_prod.get());
+        if (!check(e, "fused audit launch")) return -1;
+        if (pass == 1 && guard_on) {
+          if (!guard_finish(true, 0, n, sym_a, sym_b, false)) return -1;
+        } else {
+          ++guard_launches_;                              // (guard_finish counts the launch; without it the list is only counted, never acted on)
+        }
+      }
+      std::vector<uint32_t>& keep = pass == 0 ? bits_a : bits_b;
+      keep.resize(fic_words + msc_words);
+      const bool raw = !(pass == 1 && guard_on);          // bits as the kernel left them
+      if (raw && (!check(hipMemcpyAsync(keep.data(), d_fic_bits_.get(), fic_words * 4, hipMemcpyDeviceToHost, stream_), "bits download") ||
+                  !check(hipMemcpyAsync(keep.data() + fic_words, d_msc_bits_.get(), msc_words * 4, hipMemcpyDeviceToHost, stream_), "bits download")))
+        return -1;
+      if (pass == 1 &&
+          !check(launch_decision_audit(d_in + static_cast<size_t>(first) * kTfBytes, n, d_bins.get(), d_fic_bits_.get(), d_msc_bits_.get(), d_tw2048_.get(), d_qpsk_.get(),
+                                       d_out.get(), stream_, d_prod.get(), kRowLead),
+                 "audit launch"))
+        return -1;
+      if (!guard_download() || !check(hipStreamSynchronize(stream_), "audit") || !guard_check()) return -1;
+      counts[pass] = static_cast<uint32_t>(guard_flagged_);
+    }
+    listed += counts[1];
+    list_equal = list_equal && counts[0] == counts[1];
+    if (!guard_on) bits_equal = bits_equal && bits_a == bits_b;
+  }
+  AuditOut h;
+  if (!check(hipMemcpy(&h, d_out.get(), sizeof h, hipMemcpyDeviceToHost), "audit download")) return -1;
+  auto f = [](unsigned bits) { float v; std::memcpy(&v, &bits, 4); return static_cast<double>(v); };
+  out8[0] = static_cast<double>(h.decisions); out8[1] = static_cast<double>(h.disagree); out8[2] = static_cast<double>(h.outside);
+  out8[3] = static_cast<double>(h.flagged); out8[4] = f(h.bin_bits); out8[5] = f(h.dec_bits); out8[6] = f(h.prod_bits); out8[7] = static_cast<double>(listed);
+  if (out_extra) {
+    out_extra[0] = guard_on ? -1.0 : (bits_equal ? 1.0 : 0.0);      // (compared on the raw bits only: with the guard on the audit pass's bits are the re-decided ones)
+    out_extra[1] = list_equal ? 1.0 : 0.0;
+  }
   return nframes;
 }
 

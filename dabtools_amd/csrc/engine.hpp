@@ -203,7 +203,8 @@ class Engine {
   int stage_ofdm_fft(const uint8_t* frames, int nframes, float* spectra, bool on_device, int reps, float* kernel_ms);
   int stage_demap(const float* spectra, int nframes, uint8_t* fic, uint8_t* msc);
   int stage_fic_decode(const uint8_t* fic, int nframes, uint8_t* fibs, uint8_t* crc_ok);
-  int stage_decision_audit(const uint8_t* frames, int nframes, bool on_device, bool guard_on, double* out8);
+  int stage_decision_audit(const uint8_t* frames, int nframes, bool on_device, bool guard_on, double* out8, bool fused = false, double* out_extra = nullptr);
+  int stage_decision_audit_fused(const uint8_t* frames, int nframes, bool on_device, bool guard_on, double* out8, double* out_extra);
   int viterbi_batch(const uint8_t* symbols, uint8_t* data, int framebits, int n);
 
   // -- building blocks shared with the streaming seams (capi.cpp) ------------------------------

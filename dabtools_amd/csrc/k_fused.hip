@@ -12,6 +12,12 @@
 #ifndef DABHIP_FUSED_SOFT
 #define DABHIP_FUSED_SOFT 0          // third build: 4-bit soft decisions (launch_ofdm_demap_fused_soft), no guard
 #endif
+// Fourth build (round 5, test / calibration only): the guarded kernel as it ships -- the same source lines do the arithmetic -- that ALSO leaves every
+// bin it holds and every differential product it decides on in global memory (launch_ofdm_demap_fused_audit), so that dabhip_stage_decision_audit can
+// hold the kernel the default decode runs against fp64 transforms: error of its bins, error of its products, every decision, every list entry.
+#ifndef DABHIP_FUSED_AUDIT
+#define DABHIP_FUSED_AUDIT 0
+#endif
 #ifndef DABHIP_FUSED_GUARD
 #define DABHIP_FUSED_GUARD (!DABHIP_FUSED_SOFT)
 #endif
@@ -132,6 +138,16 @@ struct FusedGuard {
   GuardArgs g;
   unsigned frame;        // index of this TF in the frame list
 };
+#if DABHIP_FUSED_AUDIT
+__device__ float2* g_audit_bins;     // [frame][76][2048] by raw bin
+__device__ float2* g_audit_prod;     // [frame][76][2048] by raw bin: (re, im) of cur conj(prev) as the kernel computed them (symbol 0: unused)
+__device__ __forceinline__ void audit_dump_bins(const float2 (&x)[4], const float2 (&y)[4], unsigned frame, int sym)
+{
+  float2* dst = g_audit_bins + (static_cast<size_t>(frame) * kSymbolsPerTf + sym) * 2048;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) dst[fused_bin(threadIdx.x, m)] = (m & 1) ? y[m >> 1] : x[m >> 1];
+}
+#endif
 #if DABHIP_FUSED_GUARD
 __device__ __forceinline__ float l1norm(const float2 v)
 {
@@ -171,6 +187,9 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
     const float re = cur.x * prev.x + cur.y * prev.y;     // Re(cur conj(prev))
     const float im = cur.x * prev.y - cur.y * prev.x;     // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
     if (m == 0 && ak[0] < 0) continue;                      // the DC bin (thread 0)
+#if DABHIP_FUSED_AUDIT
+    g_audit_prod[(static_cast<size_t>(guard.frame) * kSymbolsPerTf + sym) * 2048 + fused_bin(threadIdx.x, m)] = make_float2(re, im);
+#endif
     dec[ak[m]] = static_cast<uint8_t>(__builtin_bit_cast(unsigned, re) >> 31);        // 1 = "not re > 0" (input_sdr.c:157), zeros aside
     dec[ak[m] + 96] = static_cast<uint8_t>(__builtin_bit_cast(unsigned, im) >> 31);   // 0 = "im > 0" (input_sdr.c:158): inverted by the flush
     asm("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(lo) : "v"(re), "v"(im));
@@ -426,6 +445,9 @@ __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t*
         // the wait for the NEXT prefetch (issued above) never has to drain a store issued right before it
         if (have_out) flush_symbol(h ? decA : decB, s - 1, out);
         fft2048_rest(v, exA, exB, tw, x, y);
+#if DABHIP_FUSED_AUDIT
+        audit_dump_bins(x, y, guard.frame, s);
+#endif
 #if DABHIP_FUSED_SOFT
         if (have_prev) decide(x, y, px, py, qk, h ? decB : decA, soft_scale(dcur, dprev));
 #else
@@ -546,6 +568,20 @@ hipError_t launch_ofdm_demap_fused_soft(bool afc, const uint8_t* const* iq, cons
   else
     hipLaunchKernelGGL(ofdm_demap_kernel<false>, dim3(nparts * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
                        frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard, sym_a, sym_b, nparts);
+  return hipGetLastError();
+}
+#elif DABHIP_FUSED_AUDIT
+hipError_t launch_ofdm_demap_fused_audit(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
+                                         const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
+                                         uint32_t* fic_bits, uint32_t* msc_bits, const GuardArgs& guard, hipStream_t stream, int sym_a, int sym_b, int nparts,
+                                         float2* dump_bins, float2* dump_prod)
+{
+  if (nframes <= 0 || nparts <= 0) return hipSuccess;
+  hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_audit_bins), &dump_bins, sizeof dump_bins, 0, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_audit_prod), &dump_prod, sizeof dump_prod, 0, hipMemcpyHostToDevice, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(ofdm_demap_kernel<false>, dim3(nparts * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, tw, frame_slot,
+                     frame_cif_row, qpsk_of_carrier, fic_bits, msc_bits, guard, sym_a, sym_b, nparts);
   return hipGetLastError();
 }
 #elif DABHIP_FUSED_GUARD

@@ -238,7 +238,12 @@ struct AuditOut {
   unsigned pad;
 };
 
+// kFused = false: the two-kernel stage -- spectra = K2's output (fftshifted), products recomputed as K2b computes them, bits in natural order (frame j: FIC
+// slot j, MSC row 4 j).  kFused = true (round 5): the fused kernel's audit build -- spectra = its bins by RAW bin index, prods = the products it decided
+// on, bits where that kernel puts them: FIC slot j in natural order, MSC scattered over the planar logical CIF rows from row row_lead + 4 j on.
+template <bool kFused>
 __global__ __launch_bounds__(kFft64Threads) void decision_audit_kernel(const uint8_t* __restrict__ frames_iq, const float2* __restrict__ spectra,
+                                                                      const float2* __restrict__ prods, int row_lead,
                                                                       const uint32_t* __restrict__ fic_bits, const uint32_t* __restrict__ msc_bits,
                                                                       const double2* __restrict__ tw2048, const uint16_t* __restrict__ qpsk_of_carrier,
                                                                       AuditOut* __restrict__ out)
@@ -276,21 +281,42 @@ __global__ __launch_bounds__(kFft64Threads) void decision_audit_kernel(const uin
       const int k = c < 768 ? c + 1280 : c - 767;         // raw bin of carrier c
       const int ks = (k + 1024) & 2047;                   // fftshifted index
       const double2 x64 = cur[lds_at(brev(k, 11))];
-      const float2 x32 = spec[l * 2048 + ks];
+      const float2 x32 = spec[l * 2048 + (kFused ? k : ks)];
       if (s_cur > 0) m_bin = fmaxf(m_bin, static_cast<float>(hypot(x32.x - x64.x, x32.y - x64.y)) / s_cur);
       if (l == 0) continue;
       const double2 p64 = prev[lds_at(brev(k, 11))];
-      const float2 p32 = spec[(l - 1) * 2048 + ks];
+      const float2 p32 = spec[(l - 1) * 2048 + (kFused ? k : ks)];
       const double re64 = x64.x * p64.x + x64.y * p64.y, im64 = x64.x * p64.y - x64.y * p64.x;
-      const float re32 = x32.x * p32.x + x32.y * p32.y, im32 = x32.x * p32.y - x32.y * p32.x;
+      float re32 = x32.x * p32.x + x32.y * p32.y, im32 = x32.x * p32.y - x32.y * p32.x;
+      if (kFused) {                                       // what the kernel itself computed (its own instruction sequence, its own roundings)
+        const float2 pr = prods[(static_cast<size_t>(j) * kSymbolsPerTf + l) * 2048 + k];
+        re32 = pr.x;
+        im32 = pr.y;
+      }
       const float n1c = fabsf(x32.x) + fabsf(x32.y), n1p = fabsf(p32.x) + fabsf(p32.y);
       const float unit = n1c * s_prev + n1p * s_cur;
       const float t = guard_threshold(n1c, n1p, kGuardC * s_cur, kGuardC * s_prev);   // the kernels' own test
-      const bool flagged = fminf(fabsf(re32), fabsf(im32)) < t;
+      // (the fused kernel decides by sign bits and therefore also lists every product with an exact zero in it: k_fused.hip, decide)
+      const bool flagged = fminf(fabsf(re32), fabsf(im32)) < t || (kFused && !(fminf(fabsf(re32), fabsf(im32)) > 0.0f));
       n_flag += flagged ? 1 : 0;
       const int q = qpsk_of_carrier[c];
-      const uint32_t* row = l <= 3 ? fic_bits + static_cast<size_t>(j) * 288 + (l - 1) * 96 : msc_bits + static_cast<size_t>(4 * j) * 1728 + (l - 4) * 96;
-      const unsigned got0 = (row[q >> 5] >> (q & 31)) & 1u, got1 = (row[(1536 + q) >> 5] >> ((1536 + q) & 31)) & 1u;
+      unsigned got0, got1;
+      if (!kFused || l <= 3) {
+        const uint32_t* row = l <= 3 ? fic_bits + static_cast<size_t>(j) * 288 + (l - 1) * 96 : msc_bits + static_cast<size_t>(4 * j) * 1728 + (l - 4) * 96;
+        got0 = (row[q >> 5] >> (q & 31)) & 1u;
+        got1 = (row[(1536 + q) >> 5] >> ((1536 + q) & 31)) & 1u;
+      } else {
+        // decision i of the symbol (i = q, 1536 + q): plane r = i & 15 of logical row (first row of the frame + CIF - map[r]), word i >> 9 of the
+        // symbol's six in that plane, bit (i >> 4) & 31 (k_fused.hip: flush_symbol; misc.c:29-39)
+        const int cif = (l - 4) / 18, sidx = (l - 4) % 18;
+        auto bit_of = [&](int i) {
+          const int r = i & 15, delay = static_cast<int>(__brev(static_cast<unsigned>(r)) >> 28);
+          const size_t row = static_cast<size_t>(row_lead + 4 * j + cif - delay);
+          return (msc_bits[row * 1728 + r * 108 + sidx * 6 + (i >> 9)] >> ((i >> 4) & 31)) & 1u;
+        };
+        got0 = bit_of(q);
+        got1 = bit_of(1536 + q);
+      }
       const unsigned want0 = (re64 > 0.0) ? 0u : 1u, want1 = (im64 > 0.0) ? 1u : 0u;
       const int bad = static_cast<int>(got0 != want0) + static_cast<int>(got1 != want1);
       n_dec += 2;
@@ -356,18 +382,24 @@ hipError_t launch_exact_decide_all(const unsigned* counter, unsigned cap, const 
 }
 
 hipError_t launch_decision_audit(const uint8_t* frames_iq, int nframes, const float2* spectra, const uint32_t* fic_bits, const uint32_t* msc_bits,
-                                 const double2* tw2048, const uint16_t* qpsk_of_carrier, void* out, hipStream_t stream)
+                                 const double2* tw2048, const uint16_t* qpsk_of_carrier, void* out, hipStream_t stream, const float2* fused_prods, int row_lead)
 {
   if (nframes <= 0) return hipSuccess;
   static std::once_flag once[64];
   static hipError_t result[64];
   const size_t lds = sizeof(double2) * (2048 + 2048 + 1024);
   const hipError_t attr = once_per_device(once, result, []() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(decision_audit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decision_audit_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(decision_audit_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    return e;
   });
   if (attr != hipSuccess) return attr;
-  hipLaunchKernelGGL(decision_audit_kernel, dim3(nframes), dim3(kFft64Threads), lds, stream, frames_iq, spectra, fic_bits, msc_bits, tw2048,
-                     qpsk_of_carrier, static_cast<AuditOut*>(out));
+  if (fused_prods)
+    hipLaunchKernelGGL(decision_audit_kernel<true>, dim3(nframes), dim3(kFft64Threads), lds, stream, frames_iq, spectra, fused_prods, row_lead, fic_bits, msc_bits,
+                       tw2048, qpsk_of_carrier, static_cast<AuditOut*>(out));
+  else
+    hipLaunchKernelGGL(decision_audit_kernel<false>, dim3(nframes), dim3(kFft64Threads), lds, stream, frames_iq, spectra, nullptr, 0, fic_bits, msc_bits, tw2048,
+                       qpsk_of_carrier, static_cast<AuditOut*>(out));
   return hipGetLastError();
 }
 

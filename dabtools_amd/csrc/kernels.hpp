@@ -120,6 +120,12 @@ hipError_t launch_viterbi_wave(int soft_bits, const WaveGroup* groups, int ngrou
 hipError_t launch_ofdm_demap_fused_guarded(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
                                            const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
                                            uint32_t* fic_bits, uint32_t* msc_bits, const GuardArgs& guard, hipStream_t stream, int sym_a = 1, int sym_b = 76, int nparts = 4);
+// the guarded kernel's audit build (k_fused.hip with -DDABHIP_FUSED_AUDIT=1): also leaves dump_bins[frame][76][2048] (by raw bin) and
+// dump_prod[frame][76][2048] ((re, im) of cur conj(prev) of the data symbols as the kernel computed them)
+hipError_t launch_ofdm_demap_fused_audit(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
+                                         const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
+                                         uint32_t* fic_bits, uint32_t* msc_bits, const GuardArgs& guard, hipStream_t stream, int sym_a, int sym_b, int nparts,
+                                         float2* dump_bins, float2* dump_prod);
 hipError_t launch_ofdm_demap_fused_soft(bool afc, const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
                                         const float2* tw, const int* frame_slot, const int* frame_cif_row, const uint16_t* qpsk_of_carrier,
                                         uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream, int sym_a = 1, int sym_b = 76, int nparts = 4);
@@ -138,7 +144,8 @@ hipError_t launch_exact_decide_all(const unsigned* counter, unsigned cap, const 
                                    const int* frame_slot, const int* frame_cif_row, bool planar, bool skip_fic, uint32_t* fic_bits, uint32_t* msc_bits,
                                    hipStream_t stream);
 hipError_t launch_decision_audit(const uint8_t* frames_iq, int nframes, const float2* spectra, const uint32_t* fic_bits, const uint32_t* msc_bits,
-                                 const double2* tw2048, const uint16_t* qpsk_of_carrier, void* out, hipStream_t stream);
+                                 const double2* tw2048, const uint16_t* qpsk_of_carrier, void* out, hipStream_t stream,
+                                 const float2* fused_prods = nullptr, int row_lead = 0);   // fused_prods != null: the fused kernel's audit (spectra = its bins by raw bin)
 hipError_t launch_batched_copy(const CopyDesc* descs, int n, hipStream_t stream);
 // the descriptors' sources may be page-locked HOST memory (read over PCIe by a small persistent grid); nbytes < 4 GiB each
 hipError_t launch_host_gather(const CopyDesc* descs, int n, int workgroups, hipStream_t stream);

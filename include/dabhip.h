@@ -316,6 +316,11 @@ int dabhip_stage_demap(dabhip_engine *e, const float *spectra, int nframes, uint
  * decisions the rule flags, max |X32 - X64| / sqrt(sum |x|^2), max error of Re/Im(cur conj(prev)) / (|cur|_1 s(l-1) + |prev|_1 s(l)),
  * max residual product error / (|cur|_1 |prev|_1), entries the demapper listed}. */
 int dabhip_stage_decision_audit(dabhip_engine *e, const uint8_t *frames, int nframes, int on_device, int guard_on, double *out8);
+/* The same audit of the kernel the DEFAULT decode runs (round 5): ofdm_demap_kernel's guarded build, through a fourth build of the same source that also
+ * stores the bins it holds and the products it decides on; frames laid out as a decode lays them out.  out10[0..8) as above (the errors are those of the
+ * fused kernel's own bins and products, [7] = entries it listed); out10[8] = 1 when the shipping build, run on the same frames, left exactly the same bits
+ * (guard_on = 0 only; -1 otherwise), out10[9] = 1 when it listed the same number of decisions. */
+int dabhip_stage_decision_audit_fused(dabhip_engine *e, const uint8_t *frames, int nframes, int on_device, int guard_on, double *out10);
 /* FIC decode of nframes TFs (fic.c:160-208): 9216 demapped bytes each -> 12x32 FIB bytes + 12 flags each. */
 int dabhip_stage_fic_decode(dabhip_engine *e, const uint8_t *fic, int nframes, uint8_t *fibs, uint8_t *crc_ok);
 

@@ -152,6 +152,9 @@ def test_roofline_objects_are_computable_from_the_tracked_profile():
     assert abs(v["frac"] - cycles * bench.wave_steps(frames, 0) / 5.0e-3 / (1024 * clock * 1e9)) < 1e-9
     assert v["survivor_traffic"]["x_stage_io"] > 10
     assert v["frac_if_every_instruction_took_2_cycles"] < v["frac"] and 0.3 < v["frac_from_counters"]["value"] < 1.0
+    inside = out["roofline"]["in_timed_step"]               # the kernels the timed step runs, inside the object the driver's record keeps
+    assert inside["ofdm_demap_kernel"]["frac"] == out["roofline_ofdm_fused"]["frac"] and inside["viterbi_fused_kernel"]["frac"] == v["frac"]
+    assert inside["ofdm_demap_kernel"]["bound"] == inside["viterbi_fused_kernel"]["bound"] == "valu issue"
     f = out["roofline_ofdm_fused"]
     assert f["bound"] == "valu issue" and 5 < f["lds"]["bank_conflict_pct"] < 40 and f["hbm"]["frac"] < 0.3
     # ONE number: the instruction mix of the symbol loop priced in issue cycles -- no bracket -- and the counters' own busy

@@ -406,3 +406,35 @@ def test_bindings_s2_s3_with_two_states_interleaved():
         got = np.ctypeslib.as_array(L.refh_eti(backs[i]), (n, 6144)).copy() if n else np.zeros((0, 6144), np.uint8)
         assert got.shape == want[i][0].shape and np.array_equal(got, want[i][0]) and n >= 8, i
         F.reff_free(fronts[i])
+
+
+# ---- the parity guard's ground, measured on the kernel that ships --------------------------------------------------------------------------------
+def test_decision_audit_of_the_fused_kernel():
+    """dabhip_stage_decision_audit_fused: the default decode's one-kernel OFDM stage (ofdm_demap_kernel, guarded build) against fp64 transforms of the same
+    samples, through its audit build -- the same source lines plus stores of the bins and products (k_fused.hip, DABHIP_FUSED_AUDIT).  (a) The shipping
+    build leaves the same bits and lists the same number of decisions on the same frames; (b) the kernel's own list is the per-bin rule's (plus exact
+    zeros); (c) guard off: raw fp32 decisions may disagree with fp64, but only inside the band, and every error stays a factor >= 2 inside the guard's
+    constants; (d) guard on: zero disagreements.  Noisy, weak, clean and channel-impaired input.  tools/decision_audit.py runs it over > 10^10 decisions."""
+    ntf = 20
+    caps = [dab.synth_generate(dab.synth_preset(0, seed=1500 + i, snr_db=snr, amplitude=amp), ntf) for i, (snr, amp) in enumerate(((5.0, 1.0), (5.0, 0.3), (7.0, 1.0), (1000.0, 1.0)))]
+    for name, preset, seed, skip, snr, n, fields in (CHANNELS[0], CHANNELS[7], CHANNELS[10]):
+        iq = dab.synth_generate(apply_channel(dab.synth_preset(preset, seed=seed, snr_db=min(snr, 9.0)), fields), ntf)
+        caps.append(iq[: (iq.size // dab.TF_BYTES) * dab.TF_BYTES])
+    frames = np.concatenate(caps)
+    eng = dab.Engine(0)
+    off = eng.decision_audit(frames=frames, guard=False, fused=True)
+    on = eng.decision_audit(frames=frames, guard=True, fused=True)
+    two = eng.decision_audit(frames=frames, guard=False, fused=False)
+    print("fused audit, guard off:", off, "guard on:", on)
+    nframes = frames.size // dab.TF_BYTES
+    assert off["decisions"] == nframes * 230400 == on["decisions"] == two["decisions"]
+    assert off["shipping_kernel_same_bits"] == 1.0 and off["shipping_kernel_same_list_count"] == 1.0 and on["shipping_kernel_same_list_count"] == 1.0   # (a)
+    assert off["listed"] == off["flagged_by_rule"] == on["listed"] > 0                                                                               # (b)
+    assert off["disagree_outside_guard"] == 0                                                                                                       # (c)
+    assert off["max_bin_err"] < 2.5e-6 and off["max_dec_err"] < 2.5e-6 and off["max_prod_err"] < 2.5e-7
+    assert 0 < off["flagged_by_rule"] < 1e-3 * off["decisions"]
+    assert on["disagree"] == 0                                                                                                                      # (d)
+    # the two OFDM stages run the same butterflies: their errors are of one size, and the fused kernel flags what the two-kernel stage flags (zeros aside)
+    assert 0.3 < off["max_bin_err"] / two["max_bin_err"] < 3.0
+    assert abs(off["flagged_by_rule"] - two["flagged_by_rule"]) <= 0.02 * two["flagged_by_rule"] + 50
+    eng.close()

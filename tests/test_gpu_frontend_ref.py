@@ -136,8 +136,8 @@ def test_randomised_captures_against_the_reference_end_to_end():
     import time
     if ol.ref_frontend() is None or ol.ref() is None:
         pytest.skip("oracle/_ref/libdabref_frontend.so not built")
-    seed = int(time.time()) % 1000003
-    print("seed", seed)
+    from conftest import fresh_seed
+    seed = fresh_seed("test_randomised_captures_against_the_reference_end_to_end") % 1000003     # printed and kept in gpurun_out/test_seeds.txt
     rng = np.random.default_rng(seed)
     caps = []
     for i in range(10):

@@ -23,7 +23,8 @@ def test_randomised_sweep_against_the_oracle():
     sys.path.insert(0, tools)
     os.environ["PYTHONPATH"] = tools + os.pathsep + os.environ.get("PYTHONPATH", "")
     import stress_parity as sp
-    seed = int.from_bytes(os.urandom(4), "little")          # a fresh sweep every run; the seed is in the failure message
+    from conftest import fresh_seed
+    seed = fresh_seed("test_randomised_sweep_against_the_oracle")      # a fresh sweep every run; printed and kept in gpurun_out/test_seeds.txt (DABHIP_TEST_SEED replays)
     res = sp.run(rounds=2, streams=48, tfs=32, workers=min(32, os.cpu_count() or 1), seed=seed)   # (28 TF: 2956 frames in one unlucky draw of noisy captures)
     assert res["differences"] == [], (seed, res["differences"][:5])
     assert res["eti_frames_compared"] >= 3000 and res["calls_compared"] >= 2500, res

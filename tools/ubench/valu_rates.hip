@@ -17,6 +17,7 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, int iters)
   for (int i = 0; i < 8; ++i) { a[i] = v2f{threadIdx.x * 1.0f + i, 0.5f * i}; u[i] = threadIdx.x * 7u + i; }
   const v2f m = v2f{1.0001f, 0.9999f}, c = v2f{0.001f, -0.001f};
   const unsigned k = 0x00030001u;
+  const unsigned kh = 0x3c004000u;                  // two f16: 1.0, 2.0
   if (kOp == 36 || kOp == 37 || kOp == 44 || kOp == 45 || kOp == 53) asm volatile("s_mov_b64 vcc, 0x5555" : : : "vcc");
   if (kOp == 49) asm volatile("s_mov_b64 vcc, exec" : : : "vcc");
   for (int it = 0; it < iters; ++it) {
@@ -82,7 +83,24 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, int iters)
   if (kOp == 56) asm volatile("v_dot4_u32_u8 %0, %0, %1, %0" : "+v"(u[i]) : "v"(k));                              \
   if (kOp == 57) asm volatile("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(a[i].x) : "v"(c.x), "v"(m.x));               \
   if (kOp == 58) asm volatile("v_lshl_or_b32 %0, %0, 8, %1" : "+v"(u[i]) : "v"(k));                               \
-  if (kOp == 59) asm volatile("v_add_lshl_u32 %0, %0, %1, 16" : "+v"(u[i]) : "v"(k));
+  if (kOp == 59) asm volatile("v_add_lshl_u32 %0, %0, %1, 16" : "+v"(u[i]) : "v"(k));                             \
+  if (kOp == 60) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(u[i]) : "v"(kh));                                  \
+  if (kOp == 61) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(u[i]) : "v"(kh));                                  \
+  if (kOp == 62) asm volatile("v_pk_min_f16 %0, %0, %1" : "+v"(u[i]) : "v"(kh));                                  \
+  if (kOp == 63) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(u[i]) : "v"(k));                                   \
+  if (kOp == 64) asm volatile("v_max3_u16 %0, %0, %1, %1" : "+v"(u[i]) : "v"(k));                                 \
+  if (kOp == 65) asm volatile("v_max_u16 %0, %0, %1" : "+v"(u[i]) : "v"(k));                                      \
+  if (kOp == 66) asm volatile("v_max_u16_sdwa %0, %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(u[i]) : "v"(k)); \
+  if (kOp == 67) asm volatile("v_max_f16 %0, %0, %1" : "+v"(u[i]) : "v"(kh));                                     \
+  if (kOp == 68) asm volatile("v_pk_fma_f16 %0, %0, %1, %1" : "+v"(u[i]) : "v"(kh));                              \
+  if (kOp == 69) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(u[i]) : "v"(k));                                   \
+  if (kOp == 70) asm volatile("v_pk_sub_u16 %0, %0, %1" : "+v"(u[i]) : "v"(k));                                   \
+  if (kOp == 71) asm volatile("v_pk_mad_u16 %0, %0, %1, %1" : "+v"(u[i]) : "v"(k));                               \
+  if (kOp == 72) asm volatile("v_add_u16 %0, %0, %1" : "+v"(u[i]) : "v"(k));                                      \
+  if (kOp == 73) asm volatile("v_max_i32 %0, %0, %1" : "+v"(u[i]) : "v"(k));                                      \
+  if (kOp == 74) asm volatile("v_max3_i32 %0, %0, %1, %1" : "+v"(u[i]) : "v"(k));                                 \
+  if (kOp == 75) asm volatile("v_pk_lshrrev_b16 %0, 1, %0" : "+v"(u[i]));                                          \
+  if (kOp == 76) asm volatile("v_pk_maximum3_f16 %0, %0, %1, %1" : "+v"(u[i]) : "v"(kh));
       REP8(OP)
 #undef OP
     }
@@ -116,6 +134,32 @@ int main(int argc, char** argv)
 {
   float* out;
   hipMalloc(&out, 256 * 8 * 256 * sizeof(float));
+  if (argc > 1 && argv[1][0] == 'p') {               // "p16": the packed 16-bit forms an add-compare-select could run on (round 5)
+    run<5>("v_add_u32", out);
+    run<6>("v_pk_add_u16", out);
+    run<7>("v_pk_max_u16", out);
+    run<69>("v_pk_min_u16", out);
+    run<70>("v_pk_sub_u16", out);
+    run<63>("v_pk_max_i16", out);
+    run<60>("v_pk_max_f16", out);
+    run<62>("v_pk_min_f16", out);
+    run<61>("v_pk_add_f16", out);
+    run<68>("v_pk_fma_f16", out);
+    run<76>("v_pk_maximum3_f16", out);
+    run<71>("v_pk_mad_u16", out);
+    run<75>("v_pk_lshrrev_b16", out);
+    run<64>("v_max3_u16", out);
+    run<65>("v_max_u16 (VOP2)", out);
+    run<66>("v_max_u16 sdwa hi", out);
+    run<67>("v_max_f16 (VOP2)", out);
+    run<72>("v_add_u16 (VOP2)", out);
+    run<25>("v_max_u32", out);
+    run<73>("v_max_i32", out);
+    run<74>("v_max3_i32", out);
+    run<38>("v_max_f32", out);
+    run<8>("v_perm_b32", out);
+    return 0;
+  }
   if (argc > 1) {                                    // "lanes": only the cross-lane moves (round 3)
     run<26>("v_mov_b32", out);
     run<50>("permlane32_swap", out);
