@@ -37,9 +37,9 @@ REALTIME_FPS = 1000.0 / 24.0
 SIMDS, XCDS = 256 * 4, 8
 # Every roofline input that cannot be measured from inside this script (PMC counters, the effective clock) is read from the tracked
 # profile of the round, produced by tools/refresh_profiles.sh (rocprofv3 passes over THIS script) -- never baked in here.
-PROFILE_PMC = os.path.join(ROOT, "profiles", "r04_pmc_summary.csv")
+PROFILE_PMC = os.path.join(ROOT, "profiles", "r05_pmc_summary.csv")
 # static instruction mix of the fused OFDM kernel's symbol loop, priced in issue cycles (tools/fused_isa_mix.sh; CPU only)
-PROFILE_FUSED_MIX = os.path.join(ROOT, "profiles", "r04_fused_isa_mix.json")
+PROFILE_FUSED_MIX = os.path.join(ROOT, "profiles", "r05_fused_isa_mix.json")
 # issue cost of a wave64 VALU instruction on gfx950 (MI355X_MICROARCH.md, per-instruction table: v_fma_f32 2 cycles; tools/ubench/valu_rates.hip,
 # profiles/r03_valu_rates.txt: plain 32-bit VOP1/VOP2 2, every VOP3 / VOP3P / DPP / 64-bit form 4)
 CYC_SIMPLE, CYC_VOP3 = 2.0, 4.0

@@ -190,8 +190,14 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
 #if DABHIP_FUSED_AUDIT
     g_audit_prod[(static_cast<size_t>(guard.frame) * kSymbolsPerTf + sym) * 2048 + fused_bin(threadIdx.x, m)] = make_float2(re, im);
 #endif
+#ifndef DABHIP_PROBE_NOSCATTER
     dec[ak[m]] = static_cast<uint8_t>(__builtin_bit_cast(unsigned, re) >> 31);        // 1 = "not re > 0" (input_sdr.c:157), zeros aside
     dec[ak[m] + 96] = static_cast<uint8_t>(__builtin_bit_cast(unsigned, im) >> 31);   // 0 = "im > 0" (input_sdr.c:158): inverted by the flush
+#else
+    // measurement build only (wrong output): the decisions without their 12 one-byte LDS stores per thread and symbol -- the most ANY re-arrangement of
+    // the de-interleaver scatter could save (tools/build_variant.sh noscatter -DDABHIP_PROBE_NOSCATTER; profiles/r05_fused_scatter_probe.txt)
+    asm volatile("" : : "v"(__builtin_bit_cast(unsigned, re) >> 31), "v"(__builtin_bit_cast(unsigned, im) >> 31), "v"(ak[m]));
+#endif
     asm("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(lo) : "v"(re), "v"(im));
     maxc = fmaxf(maxc, l1norm(cur));
   }

@@ -175,7 +175,7 @@ def test_roofline_objects_are_computable_from_the_tracked_profile():
     # the mix file belongs to THIS tree's kernel sources
     import hashlib
     src = b"".join(open(os.path.join(ROOT, "dabtools_amd", "csrc", n), "rb").read() for n in ("k_fused.hip", "fft_core.hpp", "device_types.hpp"))
-    assert mix["source_sha256"] == hashlib.sha256(src).hexdigest(), "profiles/r04_fused_isa_mix.json is stale: run tools/fused_isa_mix.sh"
+    assert mix["source_sha256"] == hashlib.sha256(src).hexdigest(), "profiles/r05_fused_isa_mix.json is stale: run tools/fused_isa_mix.sh"
     # a missing profile, or a missing cell, is an error that says what to do
     import pytest
     with pytest.raises(SystemExit, match="refresh_profiles"):

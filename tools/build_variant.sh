@@ -10,5 +10,5 @@ $H -w -c k_fused.hip -o $OUT/obj_$NAME/k_fused.o &
 $H -w -DDABHIP_FUSED_GUARD=0 -c k_fused.hip -o $OUT/obj_$NAME/k_fused_plain.o &
 $H -w -DDABHIP_FUSED_SOFT=1 -c k_fused.hip -o $OUT/obj_$NAME/k_fused_soft.o &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $OUT/libdabhip_$NAME.so $OUT/obj_$NAME/*.o build/k_sync.o build/k_decode.o build/k_synth.o build/k_parity.o build/k_probe.o build/engine.o build/capi.o build/multi.o build/synth.o build/error.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $OUT/libdabhip_$NAME.so $OUT/obj_$NAME/*.o $(ls build/*.o | grep -v -E '/(k_fft|k_fused|k_fused_plain|k_fused_soft)\.o$')
 echo built $OUT/libdabhip_$NAME.so
