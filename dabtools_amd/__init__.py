@@ -141,6 +141,8 @@ _SIGNATURES = {
     "dabhip_synth_payload": (C.c_int, [C.POINTER(SynthCfg), C.c_int, C.c_int, u8p, C.c_int]),
     "dabhip_synth_fibs": (C.c_int, [C.POINTER(SynthCfg), C.c_int, u8p]),
     "dabhip_engine_set_fused": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_engine_set_sync_speculation": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_stream_set_sync_speculation": (C.c_int, [C.c_void_p, C.c_int]),
     "dabhip_engine_set_parity_guard": (C.c_int, [C.c_void_p, C.c_int]),
     "dabhip_engine_guard_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "dabhip_engine_guard_overflows": (C.c_int, [C.c_void_p]),
@@ -562,6 +564,10 @@ class Engine:
         """True (default): one kernel for OFDM transform + demap (spectra never written); False: K2 + K2b.  Identical output."""
         _need(lib().dabhip_engine_set_fused(self._h, 1 if enable else 0) == 0, "set_fused")
 
+    def set_sync_speculation(self, mode):
+        """K1's chain: 0 = call after call, 1 = speculative rounds, -1 (default) = rounds for small batches.  Identical results."""
+        _need(lib().dabhip_engine_set_sync_speculation(self._h, int(mode)) == 0, "set_sync_speculation")
+
     def set_parity_guard(self, enable):
         """True (default): decisions inside the fp32 error band are re-decided in fp64 -> bits of exact arithmetic."""
         _need(lib().dabhip_engine_set_parity_guard(self._h, 1 if enable else 0) == 0, "set_parity_guard")
@@ -686,9 +692,9 @@ class Engine:
         return out[:n]
 
     def stage_ms(self):
-        names = (C.c_char_p * 16)()
-        ms = (C.c_float * 16)()
-        n = lib().dabhip_engine_stage_ms(self._h, names, ms, 16)
+        names = (C.c_char_p * 24)()
+        ms = (C.c_float * 24)()
+        n = lib().dabhip_engine_stage_ms(self._h, names, ms, 24)
         return {names[i].decode(): ms[i] for i in range(n)}
 
     def fft_stats(self):
@@ -915,6 +921,10 @@ class Stream:
 
     def status(self, stream):
         return int(lib().dabhip_stream_status(self._h, stream))
+
+    def set_sync_speculation(self, mode):
+        """see Engine.set_sync_speculation"""
+        _need(lib().dabhip_stream_set_sync_speculation(self._h, int(mode)) == 0, "stream_set_sync_speculation")
 
     def stage_ms(self):
         names = (C.c_char_p * 16)()

@@ -248,9 +248,9 @@ int dabhip_engine_trace_nco(const dabhip_engine* e, int stream, int32_t* nco_hz,
 int dabhip_engine_stage_ms(const dabhip_engine* e, const char** names, float* ms, int cap)
 {
   if (!e) return -1;
-  constexpr int kN = 16;
+  constexpr int kN = 17;
   static const char* kNames[kN] = {"sync", "fft", "demap", "fic", "control", "gather", "viterbi", "eti", "host_setup", "host_frames", "host_worklist", "wall",
-                                   "h2d", "h2d_mbytes", "h2d_pinned_mbytes", "sync_fp64_calls"};
+                                   "h2d", "h2d_mbytes", "h2d_pinned_mbytes", "sync_fp64_calls", "sync_spec_calls"};
   float v[kN] = {0};
   for (size_t l = 0; l < e->lanes.size(); ++l) {
     if (e->lane_frames.empty() || (l > 0 && e->lane_frames[l] == 0 && e->lane_of.size() < 64)) continue;
@@ -261,6 +261,7 @@ int dabhip_engine_stage_ms(const dabhip_engine* e, const char** names, float* ms
     v[13] += static_cast<float>(t.h2d_bytes * 1e-6);
     v[14] += static_cast<float>(t.h2d_pinned_bytes * 1e-6);
     v[15] += t.sync_fp64_calls;
+    v[16] += t.sync_spec_calls;
   }
   v[11] = e->wall_ms;
   int n = 0;
@@ -334,6 +335,12 @@ int dabhip_engine_set_fused(dabhip_engine* e, int enable)
 {
   if (!e) return -1;
   for (auto& l : e->lanes) l->set_fused(enable != 0);
+  return 0;
+}
+int dabhip_engine_set_sync_speculation(dabhip_engine* e, int mode)
+{
+  if (!e) return -1;
+  for (auto& l : e->lanes) l->set_sync_speculation(mode);
   return 0;
 }
 int dabhip_engine_fft_stats(const dabhip_engine* e, int64_t* launches, int64_t* tfs, double* ms)
@@ -845,6 +852,7 @@ extern "C" int dabhip_stream_set_subchannels(dabhip_stream* s, const int32_t* id
 }
 extern "C" int dabhip_stream_set_afc(dabhip_stream* s, int on) { if (!s) return -1; s->eng.set_afc(on != 0); return 0; }
 extern "C" int dabhip_stream_set_parity_guard(dabhip_stream* s, int on) { if (!s) return -1; s->eng.set_parity_guard(on != 0); return 0; }
+extern "C" int dabhip_stream_set_sync_speculation(dabhip_stream* s, int mode) { if (!s) return -1; s->eng.set_sync_speculation(mode); return 0; }
 extern "C" int dabhip_stream_set_soft(dabhip_stream* s, int on)
 {
   if (!s) return -1;
@@ -978,11 +986,12 @@ extern "C" int64_t dabhip_stream_eti_count(const dabhip_stream* s, int stream) {
 extern "C" int dabhip_stream_stage_ms(const dabhip_stream* s, const char** names, float* ms, int cap)
 {
   if (!s) return -1;
-  static const char* kNames[12] = {"sync", "fft", "demap", "fic", "control", "gather", "viterbi", "eti", "host_setup", "host_frames", "host_worklist", "wall"};
+  static const char* kNames[13] = {"sync", "fft", "demap", "fic", "control", "gather", "viterbi", "eti", "host_setup", "host_frames", "host_worklist", "wall",
+                                   "sync_spec_calls"};
   const StageTimes& t = s->eng.stage_times();
-  const float v[12] = {t.sync, t.fft, t.demap, t.fic, t.control, t.gather, t.viterbi, t.eti, t.setup, t.frames, t.worklist, t.wall};
+  const float v[13] = {t.sync, t.fft, t.demap, t.fic, t.control, t.gather, t.viterbi, t.eti, t.setup, t.frames, t.worklist, t.wall, t.sync_spec_calls};
   int n = 0;
-  for (; n < 12 && n < cap; ++n) {
+  for (; n < 13 && n < cap; ++n) {
     if (names) names[n] = kNames[n];
     if (ms) ms[n] = v[n];
   }

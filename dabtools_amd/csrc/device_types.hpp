@@ -138,6 +138,14 @@ __host__ __device__ inline float soft_scale(float dc, float dp)
   return prod > 0.0f ? kSoftGain * kGuardC * kGuardC / prod : 0.0f;
 }
 
+// The differential product cur conj(prev) of the demapper (input_sdr.c:135-143: re = Re, im = -Im) in fp32, with its roundings FIXED -- one multiply and one
+// fused multiply-add each -- so that every build of every kernel that decides on it rounds alike.  Left to the compiler's contraction, "a b + c d" came
+// out as different pairings of packed multiplies and fused multiply-adds in the shipping and in the audit build of the fused kernel (round 5: the
+// audit's check that both leave the same raw bits failed on 5 .. 8 dB captures; either pairing is within kGuardProd, but an audit has to measure
+// the arithmetic that ships).
+__host__ __device__ __forceinline__ float diff_re(float cx, float cy, float px, float py) { return fmaf(cx, px, cy * py); }
+__host__ __device__ __forceinline__ float diff_im(float cx, float cy, float px, float py) { return fmaf(cx, py, -(cy * px)); }
+
 struct GuardArgs {
   const float* delta;    // nullptr: guard off (the fused OFDM kernel computes its bounds itself and only tests this for null); with soft
                          // decisions: the same array, read for the scale (list == nullptr then)

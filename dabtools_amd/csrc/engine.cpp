@@ -716,6 +716,15 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
       (split_wanted && !d_tail_prev_.reserve(static_cast<size_t>(nstreams) * kTailBytes)))
     return false;
   const SyncTails tails{d_tail_state_.get(), d_tail_state_.get(), d_tail_images_.get(), kChunkBytes};
+  // The look-ahead schedule of the chain (k_sync.hip: sync_ahead_kernel) where the chain would leave most of the device idle: few streams, many calls.
+  // set_sync_speculation(0 / 1): never / always (tests run both); default: up to kAheadMaxStreams streams of at least kAheadMinCalls calls.
+  constexpr int kAheadMaxStreams = 4, kAheadMinCalls = 16, kAheadHypotheses = 33;
+  const bool use_spec = split_wanted && spec_mode_ != 0 && (spec_mode_ > 0 || (nstreams <= kAheadMaxStreams && max_calls_ >= kAheadMinCalls));
+  // calls of a stream per pass: all it has, within a bound on the table (8 bytes per call, start position and stream)
+  const int nspec = std::min(max_calls_, std::min(4096, std::max(64, (1 << 20) / nstreams)));
+  if (use_spec && (!d_spec_table_.reserve(static_cast<size_t>(nstreams) * nspec * kAheadHypotheses) || !d_spec_src0_.reserve(static_cast<size_t>(nstreams) * nspec) ||
+                   !d_spec_ctl_.reserve(nstreams + 1) || !h_spec_hits_.resize(1)))
+    return false;
   if (split_wanted) {
     // d_viol_[0 .. nstreams): first call of a stream that broke the chain's assumption; [nstreams]: calls the fp32 pass of the
     // verification left to the fp64 pass
@@ -769,9 +778,39 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
     // verification beside the next chunk: 1.28 -> 1.30..1.40 ms.  A chain workgroup holds half of a CU's LDS, so the verification
     // beside it runs at half its rate and slows the chain.  Round 3, with the fp32 verification (39.5 KB of LDS, 54 VGPRs): on its own stream beside the FIC
     // symbols' OFDM launch -- step unchanged, 10.4 ms: both are issue-bound, the work only moves.)
-    if (!check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), nstreams, max_calls_, -1, -1,
-                                d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), 0, stream_, true, nullptr, nullptr, tails),
-               "sync chain launch") ||
+    auto chain = [&](const SpecArgs& sp) {
+      return check(launch_sync_scan(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), d_descs_.get(), d_info_.get(), nstreams, max_calls_, -1, -1,
+                                    d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), 0, stream_, true, nullptr, nullptr, tails, sp),
+                   "sync chain launch");
+    };
+    bool chain_ok = true;
+    if (use_spec) {
+      // a short chain to lock on (a fresh capture: the first frame is dropped, the second finds the null symbol, the third the fine shift -- seven calls;
+      // a session's further segment stands where it stands), then passes over all remaining calls at once, each followed by the chain launch that looks
+      // its calls up (a long stream: several passes, each predicting from where the chain really got to)
+      SpecArgs sp;
+      sp.table = d_spec_table_.get();
+      sp.src0 = d_spec_src0_.get();
+      sp.ctl = d_spec_ctl_.get();
+      sp.nspec = nspec;
+      sp.nstreams = nstreams;
+      sp.nhyp = kAheadHypotheses;
+      sp.call_limit = cont ? 0 : 7;
+      sp.record_base = 1;
+      chain_ok = chain(sp);
+      sp.record_base = 0;
+      sp.lookup = 1;
+      const int passes = std::min(16, (max_calls_ + nspec - 1) / nspec);
+      for (int r = 0; r < passes && chain_ok; ++r) {
+        sp.call_limit = r + 1 < passes ? nspec : -1;
+        chain_ok = check(launch_sync_ahead(d_iq_ptrs_.get(), d_nbytes_.get(), d_states_.get(), nstreams, d_tw2048_.get(), d_tw1536_.get(), d_prs_.get(), stream_, sp),
+                         "sync look-ahead launch") &&
+                   chain(sp);
+      }
+    } else {
+      chain_ok = chain(SpecArgs{});
+    }
+    if (!chain_ok ||
         // {status, ordinal} of every call are final once the chain is through (a stream that breaks its assumption is scanned again
         // below): they come back on the side stream while the verification runs, and the caller lays the frames out beside it
         !check(hipEventRecord(ev_chain_, stream_), "chain event") || !check(hipStreamWaitEvent(copy_stream_, ev_chain_, 0), "chain event") ||
@@ -795,6 +834,7 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
   auto fetch = [&]() {
     return check(hipStreamWaitEvent(copy_stream_, ev_[1], 0), "scan event") &&
            (!split_scan || check(hipMemcpyAsync(h_viol_.data(), d_viol_.get(), (nstreams + 1) * sizeof(int), hipMemcpyDeviceToHost, copy_stream_), "violation download")) &&
+           (!(split_scan && use_spec) || check(hipMemcpyAsync(h_spec_hits_.data(), d_spec_ctl_.get() + nstreams, sizeof(int), hipMemcpyDeviceToHost, copy_stream_), "look-ahead hits download")) &&
            check(hipMemcpyAsync(h_info_.data(), d_info_.get(), ndesc * sizeof(int2), hipMemcpyDeviceToHost, copy_stream_), "call info download") &&
            check(hipMemcpyAsync(states, d_states_.get(), nstreams * sizeof(StreamState), hipMemcpyDeviceToHost, copy_stream_), "state download") &&
            check(hipStreamSynchronize(copy_stream_), "sync scan");
@@ -808,6 +848,7 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
       if (h_viol_[b] != 0x7f7f7f7f) redo.push_back(b);
     sync_rescanned_ = static_cast<int>(redo.size());
     times_.sync_fp64_calls = static_cast<float>(h_viol_[nstreams]);
+    times_.sync_spec_calls = use_spec ? static_cast<float>(h_spec_hits_[0]) : 0.0f;
     if (!redo.empty()) {                                   // rare: those streams again, in the reference's order, from their incoming state
       // (what the first layout queued -- its set-up kernel reads the page-locked frame lists when it RUNS -- is through before the lists are rewritten)
       // (the guarded launches of the first layout have run; they are made again for the new frame list: their counters and counts start over --

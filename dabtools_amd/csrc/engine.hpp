@@ -14,6 +14,7 @@
 
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <map>
 #include <functional>
 #include <memory>
@@ -132,6 +133,7 @@ struct StageTimes {
   float sync = 0, fft = 0, demap = 0, fic = 0, control = 0, gather = 0, viterbi = 0, eti = 0;
   float setup = 0, frames = 0, worklist = 0, wall = 0;   // host-side phases (wall clock)
   float sync_fp64_calls = 0;                             // K1 verification: calls whose fp32 arg-max was not clear-cut (decided in fp64)
+  float sync_spec_calls = 0;                             // K1 chain: calls whose estimators came out of the look-ahead pass's table (0: the plain chain ran)
   float h2d = 0;                                         // host-fed decode: upload of the IQ (HIP events; 0 when the IQ was resident)
   double h2d_bytes = 0, h2d_pinned_bytes = 0;            // bytes uploaded, and how many of them came from page-locked memory
 };
@@ -164,6 +166,8 @@ class Engine {
   // kernels K2 (the HBM-roofline stage of SURVEY.md 8(d), always measurable on its own: fft_roofline) and K2b.  The output
   // bits are identical either way.
   void set_fused(bool on) { fused_ = on; }
+  // K1's chain: 0 = call after call, 1 = speculative rounds, -1 = rounds for small batches (include/dabhip.h: dabhip_engine_set_sync_speculation)
+  void set_sync_speculation(int mode) { spec_mode_ = mode < 0 ? -1 : (mode > 0 ? 1 : 0); }
   // sub-channel filter (TODO.md:28-31): bit i = SubChId i is decoded and carried in the ETI frames; takes effect with the next
   // decode() / first segment of a session.  All ones (default) = the reference's frames.
   void set_subchannel_filter(uint64_t keep) { subch_keep_ = keep; }
@@ -314,6 +318,12 @@ class Engine {
   DeviceBuffer<uint8_t> d_tail_state_, d_tail_prev_, d_tail_images_;
   DeviceBuffer<int> d_viol_, d_redo_, d_calls_before_;
   PinnedBuffer<int> h_viol_, h_calls_before_;
+  // the look-ahead schedule of the K1 chain (small batches; k_sync.hip: sync_ahead_kernel): the estimators' table, the predicted start positions, the descriptor base
+  DeviceBuffer<int2> d_spec_table_;
+  DeviceBuffer<int64_t> d_spec_src0_;
+  DeviceBuffer<int> d_spec_ctl_;
+  PinnedBuffer<int> h_spec_hits_;
+  int spec_mode_ = std::getenv("DABHIP_K1_SPEC") ? (std::atoi(std::getenv("DABHIP_K1_SPEC")) > 0 ? 1 : 0) : -1;
   int sync_rescanned_ = 0;            // streams the split scan had to scan again in full (last decode)
   DeviceBuffer<CallDesc> d_descs_;
   DeviceBuffer<int2> d_info_;

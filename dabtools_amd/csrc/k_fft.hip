@@ -280,8 +280,8 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
 #pragma unroll
     for (int m = 0; m < 6; ++m) {
       const float2 cur = tf[l * 2048 + bin[m]];
-      re[m] = cur.x * prev[m].x + cur.y * prev[m].y;     // Re(cur conj(prev))
-      im[m] = cur.x * prev[m].y - cur.y * prev[m].x;     // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
+      re[m] = diff_re(cur.x, cur.y, prev[m].x, prev[m].y);   // Re(cur conj(prev))
+      im[m] = diff_im(cur.x, cur.y, prev[m].x, prev[m].y);   // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
       if (guarded) {
         const float n1c = fabsf(cur.x) + fabsf(cur.y), n1p = fabsf(prev[m].x) + fabsf(prev[m].y);
         if (fminf(fabsf(re[m]), fabsf(im[m])) < guard_threshold(n1c, n1p, dc, dp)) {

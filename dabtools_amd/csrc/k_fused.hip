@@ -184,8 +184,8 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
     if (!bin_in_use(m)) continue;
     if (m == 3 && threadIdx.x != 0) continue;               // y[1]: thread 0 only (wave-uniform everywhere else)
     const float2 cur = (m & 1) ? y[m >> 1] : x[m >> 1], prev = (m & 1) ? py[m >> 1] : px[m >> 1];
-    const float re = cur.x * prev.x + cur.y * prev.y;     // Re(cur conj(prev))
-    const float im = cur.x * prev.y - cur.y * prev.x;     // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
+    const float re = diff_re(cur.x, cur.y, prev.x, prev.y);   // Re(cur conj(prev))
+    const float im = diff_im(cur.x, cur.y, prev.x, prev.y);   // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
     if (m == 0 && ak[0] < 0) continue;                      // the DC bin (thread 0)
 #if DABHIP_FUSED_AUDIT
     g_audit_prod[(static_cast<size_t>(guard.frame) * kSymbolsPerTf + sym) * 2048 + fused_bin(threadIdx.x, m)] = make_float2(re, im);
@@ -213,7 +213,7 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
     for (int m = 0; m < 8; ++m) {
       if (!bin_in_use(m)) continue;
       const float2 cur = (m & 1) ? y[m >> 1] : x[m >> 1], prev = (m & 1) ? py[m >> 1] : px[m >> 1];
-      const float re = cur.x * prev.x + cur.y * prev.y, im = cur.x * prev.y - cur.y * prev.x;
+      const float re = diff_re(cur.x, cur.y, prev.x, prev.y), im = diff_im(cur.x, cur.y, prev.x, prev.y);
       const float least = fminf(fabsf(re), fabsf(im));
       hits |= (ak[m] >= 0 && (least < guard_threshold(l1norm(cur), l1norm(prev), dc, dp) || !(least > 0.0f)) ? 1u : 0u) << m;
     }
@@ -236,8 +236,8 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
   for (int m = 0; m < 8; ++m) {
     if (!bin_in_use(m)) continue;
     const float2 cur = (m & 1) ? y[m >> 1] : x[m >> 1], prev = (m & 1) ? py[m >> 1] : px[m >> 1];
-    const float re = cur.x * prev.x + cur.y * prev.y;     // Re(cur conj(prev))
-    const float im = cur.x * prev.y - cur.y * prev.x;     // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
+    const float re = diff_re(cur.x, cur.y, prev.x, prev.y);   // Re(cur conj(prev))
+    const float im = diff_im(cur.x, cur.y, prev.x, prev.y);   // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
     if (ak[m] >= 0) {                                     // bins without a carrier (DC, guard bands) decide nothing
       dec[ak[m]] = (re > 0.0f) ? 0 : 1;                   // input_sdr.c:157
       dec[ak[m] + 96] = (im > 0.0f) ? 1 : 0;              // input_sdr.c:158
@@ -256,8 +256,8 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
     const float2 cur = (m & 1) ? y[m >> 1] : x[m >> 1], prev = (m & 1) ? py[m >> 1] : px[m >> 1];
-    const float re = cur.x * prev.x + cur.y * prev.y;     // Re(cur conj(prev))
-    const float im = cur.x * prev.y - cur.y * prev.x;     // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
+    const float re = diff_re(cur.x, cur.y, prev.x, prev.y);   // Re(cur conj(prev))
+    const float im = diff_im(cur.x, cur.y, prev.x, prev.y);   // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
     if (ak[m] >= 0) {
       // round-to-nearest-even by the 1.5 x 2^23 trick: the sum's bit pattern is the constant's plus the rounded integer (two's complement), so the clamp to
       // +-7 is ONE v_med3_i32 on the bits and the nibble their low four -- mul, add, med3, and instead of mul, rndne, cvt, med3, and (same values: the sum

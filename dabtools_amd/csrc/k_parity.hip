@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kFft64Threads) void decision_audit_kernel(const uin
       const double2 p64 = prev[lds_at(brev(k, 11))];
       const float2 p32 = spec[(l - 1) * 2048 + (kFused ? k : ks)];
       const double re64 = x64.x * p64.x + x64.y * p64.y, im64 = x64.x * p64.y - x64.y * p64.x;
-      float re32 = x32.x * p32.x + x32.y * p32.y, im32 = x32.x * p32.y - x32.y * p32.x;
+      float re32 = diff_re(x32.x, x32.y, p32.x, p32.y), im32 = diff_im(x32.x, x32.y, p32.x, p32.y);
       if (kFused) {                                       // what the kernel itself computed (its own instruction sequence, its own roundings)
         const float2 pr = prods[(static_cast<size_t>(j) * kSymbolsPerTf + l) * 2048 + k];
         re32 = pr.x;

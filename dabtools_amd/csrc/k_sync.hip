@@ -208,6 +208,7 @@ struct Shared {
   int status, do_sync, fifo_count, fresh;
   int coarse_fs;
   double fine_fs;
+  int2 ahead;            // what the look-ahead pass's table holds for this call's read (sync_call), x < 0: nothing
 };
 
 // LDS: A (2048 points) and the batch buffer Bf lie back to back; the coarse frequency search correlates all 29 offsets in ONE
@@ -474,7 +475,7 @@ struct SyncLds {
   double2* spec;
   Shared* sh;
 };
-__device__ __forceinline__ SyncLds sync_lds(unsigned char* smem, const double2* __restrict__ tw2048)
+__device__ __forceinline__ SyncLds sync_lds(unsigned char* smem, const double2* __restrict__ tw2048, bool fill = true)
 {
   SyncLds l;
   l.A = reinterpret_cast<double2*>(smem);                  // 2048: main DFT buffer
@@ -482,7 +483,8 @@ __device__ __forceinline__ SyncLds sync_lds(unsigned char* smem, const double2* 
   l.tw = l.Bf + kBatchPoints;                               // 1024: LDS copy of the twiddle table
   l.spec = l.tw + 1024;                                     // kSpecBins
   l.sh = reinterpret_cast<Shared*>(l.spec + kSpecBins);
-  for (int i = threadIdx.x; i < 1024; i += kThreads) l.tw[lds_at(i)] = tw2048[i];
+  if (fill)
+    for (int i = threadIdx.x; i < 1024; i += kThreads) l.tw[lds_at(i)] = tw2048[i];
   return l;
 }
 
@@ -554,12 +556,207 @@ __device__ __forceinline__ void fifo_call_wave(Shared& sh, int chunk, const uint
   }
 }
 
+// What one call of sdr_demod needs besides the stream's state: fixed for a workgroup's life
+struct CallEnv {
+  const uint8_t* stream;
+  int b, max_calls, kdesc0, afc;
+  CallDesc* descs;
+  int2* info;
+  SyncTails tails;
+  SyncLds lds;
+  const uint8_t* prs_q;
+  // the look-ahead pass's table (sync_ahead_kernel) -- by value: a pointer to the kernel's argument struct sends every use through scratch memory
+  bool ahead;                // there is one
+  const int2* ahead_table;
+  const int64_t* ahead_src0;
+  int* ahead_hits;
+  int ahead_nspec, ahead_nhyp;
+  int kahead0;               // the call its entry 0 stands for
+};
+// what a call's read leaves in the stream's tail bytes (thread t < 384 holds bytes 4 t .. 4 t + 3 in tail_word): the two halves of the update, so that the
+// caller can issue the loads behind those it waits for first and take them up behind that wait
+struct TailUpdate {
+  unsigned lo = 0, hi = 0;
+  bool take_lo = false, take_hi = false;
+};
+constexpr int kTailWords = kTailBytes / 4;
+__device__ __forceinline__ TailUpdate tail_load(const uint8_t* stream, const Shared& sh, bool frame_read)
+{
+  TailUpdate u;
+  const int tid = threadIdx.x;
+  if (frame_read && tid < kTailWords) {
+    const int64_t s0 = read_source(sh.st.view, sh.fresh, kTailStart + 4 * tid), s1 = read_source(sh.st.view, sh.fresh, kTailStart + 4 * tid + 2);
+    u.take_lo = s0 >= 0;
+    u.take_hi = s1 >= 0;
+    if (u.take_lo) u.lo = *reinterpret_cast<const uint16_t*>(stream + s0);
+    if (u.take_hi) u.hi = *reinterpret_cast<const uint16_t*>(stream + s1);
+  }
+  return u;
+}
+__device__ __forceinline__ void tail_commit(const TailUpdate& u, bool frame_read, uint32_t& tail_word, uint8_t* tail_slot)
+{
+  const int tid = threadIdx.x;
+  if (frame_read && tid < kTailWords) {
+    if (u.take_lo) tail_word = (tail_word & 0xffff0000u) | u.lo;
+    if (u.take_hi) tail_word = (tail_word & 0x0000ffffu) | (u.hi << 16);
+    if (tail_slot) reinterpret_cast<uint32_t*>(tail_slot)[tid] = tail_word;
+  }
+}
+
+// (the look-ahead pass: sync_ahead_kernel below)
+constexpr int kAheadWindowEnd = 2 * (kNullSamples + kCpSamples) + 2 * 2048;   // the estimators read buffer bytes [0, 5320) and [6320, 10416)
+// A call's row of the table and its predicted start position travel one call ahead of their use, in registers of the stream's first wave (lane h holds
+// the entry of start position h): the chain's dependent path then has no global load in it (two in a row cost every call 1.5 us).
+struct AheadRow {
+  int64_t src0 = -1;
+  int2 entry = make_int2(-1, 0);
+};
+__device__ __forceinline__ AheadRow ahead_fetch(const int2* __restrict__ table, const int64_t* __restrict__ src0, int nspec, int nhyp, int b, int j)   // by the first wave
+{
+  AheadRow r;
+  if (j >= 0 && j < nspec) {
+    const size_t slot = static_cast<size_t>(b) * nspec + j;
+    r.src0 = src0[slot];
+    if (static_cast<int>(threadIdx.x) < nhyp) r.entry = table[slot * nhyp + threadIdx.x];
+  }
+  return r;
+}
+// the entry for a read that began where this call's did (the view fifo_call_wave just left), by the first wave; the same value in all its lanes
+__device__ __forceinline__ int2 ahead_lookup(int nhyp, const AheadRow& row, const FrameView& view)
+{
+  const int2 miss = make_int2(-1, 0);
+  const int64_t src = view.seg_src[0];
+  if (row.src0 < 0 || src < 0 || view.seg_end[0] < kAheadWindowEnd) return miss;
+  const int64_t d = src - row.src0;
+  const int half = nhyp / 2;
+  if ((d & 1) != 0 || d < -2 * half || d > 2 * half) return miss;
+  const int h = static_cast<int>(d / 2) + half;
+  return make_int2(__shfl(row.entry.x, h), __shfl(row.entry.y, h));
+}
 // kChainOnly = false: sdr_demod's synchronisation as the reference runs it, call after call.
 // kChainOnly = true : only what the NEXT call depends on -- FIFO bookkeeping, coarse time, fine time.  The coarse frequency
 //   offset is assumed to come out within +-1 carrier (so the frame is demodulated and no resync is forced) and left, with the
 //   fine frequency estimate, to sync_verify_kernel, which runs over all transmission frames in parallel; a stream whose
 //   assumption fails is scanned again in full (Engine::scan_streams).  Not with the software AFC, where the NCO of the next
 //   frame depends on both estimates.
+// ONE call of sdr_demod (input_sdr.c:27-112) on the workgroup's shared state: call k of the stream, descriptor k - kdesc0.  The body of the chain's loop
+// (sync_scan_kernel) and of the speculative pass (sync_spec_kernel).  Ends with a barrier.
+template <bool kChainOnly>
+__device__ __forceinline__ void sync_call(const CallEnv& env, Shared& sh, int k, const FineTimeTables& fine_tab, uint32_t& tail_word, AheadRow& row)
+{
+  const int tid = threadIdx.x;
+  const uint8_t* const stream = env.stream;
+  double2* const A = env.lds.A;
+  double2* const Bf = env.lds.Bf;
+  double2* const tw = env.lds.tw;
+  uint8_t* const env_bytes = reinterpret_cast<uint8_t*>(Bf);     // 19661 bytes, coarse search only
+  SYNC_STAMP(0);
+  // ---- FIFO bookkeeping: input_sdr.c:36-55 over sdr_fifo.c:43-61 (fifo_view.hpp) -------
+  uint8_t* const tail_slot = env.tails.images ? env.tails.images + (static_cast<size_t>(env.b) * env.max_calls + (k - env.kdesc0)) * kTailBytes : nullptr;
+  if (tid < 64) {
+    fifo_call_wave(sh, env.tails.chunk, tail_slot);
+    if (env.ahead) {
+      // what the look-ahead pass (sync_ahead_kernel) holds for a read that began where this one did; then the next call's row on its way
+      const int2 found = sh.do_sync ? ahead_lookup(env.ahead_nhyp, row, sh.st.view) : make_int2(-1, 0);
+      if (tid == 0) sh.ahead = found;
+      row = ahead_fetch(env.ahead_table, env.ahead_src0, env.ahead_nspec, env.ahead_nhyp, env.b, k + 1 - env.kahead0);
+    }
+  }
+  __syncthreads();
+
+  // what this call's read leaves in the tail bytes: the loads are issued behind those the chain waits for first (below), taken up -- and the frame's
+  // copy written -- behind that wait
+  const bool frame_read = DABHIP_K1_TAIL && sh.status != 0;
+  TailUpdate tail_upd;
+
+  const int nco = env.afc ? sh.st.tuner_hz : 0;
+  if (sh.do_sync) {
+    const FrameView& view = sh.st.view;
+    // {null-symbol energy, fine time shift} out of the look-ahead pass's table, x < 0: nothing there (or no pass: never with the software AFC)
+    const int2 ahead = env.ahead ? sh.ahead : make_int2(-1, 0);
+    const bool hit = ahead.x >= 0;                        // (the same in every thread)
+    if (hit && tid == 0) atomicAdd(env.ahead_hits, 1);   // statistics ("sync_spec_calls")
+    Prefetched<2048> pf;
+    pf.ok = false;
+    if (!hit) pf = prefetch_samples<2048>(stream, view, 2 * (kNullSamples + kCpSamples), nco);   // for the fine time search
+    SYNC_STAMP(1);
+    const int force = sh.st.force_timesync;
+    const int energy_part = hit ? 0 : null_symbol_energy_part(stream, view);                   // input_sdr.c:64-74
+    tail_upd = tail_load(stream, sh, frame_read);
+    int energy = ahead.x;
+    if (hit) __syncthreads();                             // (force has been read by everyone before it is cleared below)
+    else energy = block_sum_int(sh.red, energy_part);
+    tail_commit(tail_upd, frame_read, tail_word, tail_slot);
+    int coarse = 0;
+    if (energy >= 5000 || force != 0) {
+      __syncthreads();                                  // the search reads the whole frame buffer, tail bytes included
+      coarse = coarse_time_search(stream, view, sh.red, env_bytes);
+    }
+    if (tid == 0) { sh.st.coarse_timeshift = coarse; sh.st.force_timesync = 0; }
+    __syncthreads();
+    SYNC_STAMP(2);
+    if (coarse == 0) {
+      const int fine = hit ? ahead.y : fine_time_sync(stream, view, nco, A, Bf, tw, fine_tab, sh.red, pf);   // input_sdr.c:84
+      if (tid == 0) sh.st.fine_timeshift = fine;
+      if (kChainOnly) {
+        if (tid == 0) sh.status = 2;                    // assumed; sync_verify_kernel checks it
+      } else {
+        const int cfs = coarse_freq_sync(stream, view, nco, fine, A, env.lds.spec, tw, env.prs_q, sh.red);   // input_sdr.c:90-104
+        if (tid == 0) sh.coarse_fs = cfs;
+        if (abs(cfs) > 1) {
+          if (tid == 0) sh.st.force_timesync = 1;       // input_sdr.c:105-109
+        } else {
+          const double ffs = fine_freq_corr(stream, view, nco, sh.red);                        // input_sdr.c:112
+          if (tid == 0) {
+            sh.fine_fs = ffs;
+            sh.status = 2;
+          }
+        }
+      }
+    }
+  } else {
+    tail_upd = tail_load(stream, sh, frame_read);
+    tail_commit(tail_upd, frame_read, tail_word, tail_slot);   // a frame that is read and dropped (input_sdr.c:51-55) still overwrites the buffer
+  }
+  __syncthreads();
+  if (tid >= 64 && tid < 64 + static_cast<int>(sizeof(FrameView) / 4)) {     // the view, word by word, by the second wave (one thread copying 152 bytes out of LDS was a microsecond)
+    CallDesc& d = env.descs[static_cast<size_t>(env.b) * env.max_calls + (k - env.kdesc0)];
+    reinterpret_cast<uint32_t*>(&d.view)[tid - 64] = reinterpret_cast<const uint32_t*>(&sh.st.view)[tid - 64];
+  }
+  if (tid == 0) {
+    CallDesc& d = env.descs[static_cast<size_t>(env.b) * env.max_calls + (k - env.kdesc0)];
+    d.status = sh.status;
+    d.ordinal = sh.status == 2 ? sh.st.next_ordinal++ : -1;
+    if (env.info) env.info[static_cast<size_t>(env.b) * env.max_calls + (k - env.kdesc0)] = make_int2(d.status, d.ordinal);   // what the host lays the frames out with
+    d.coarse_timeshift = sh.st.coarse_timeshift;
+    d.fine_timeshift = sh.st.fine_timeshift;
+    d.coarse_freq_shift = sh.coarse_fs;
+    d.fifo_count = sh.fifo_count;
+    d.fine_freq_shift = sh.fine_fs;
+    d.nco_hz = nco;
+    if (env.afc) {
+      // the tuner feedback of demod_thread_fn (dab2eti.c:76-103), applied to the NCO instead of the tuner; it runs
+      // after EVERY call, also those that produced no frame (coarse 0, fine estimate stale), exactly as there
+      StreamState& st = sh.st;
+      const int c = sh.coarse_fs;
+      if (abs(c) > 1) st.tuner_hz += c < 0 ? -1000 : 1000;
+      if (abs(c) == 1) {
+        st.rng = st.rng * 1103515245u + 12345u;
+        const int step = static_cast<int>((st.rng >> 16) % 1000u);
+        st.tuner_hz += c < 0 ? -step : step;
+      }
+      // dab2eti.c:97-98 in its integer semantics: abs() is the int one (the double is truncated first: |ffs| >= 51), and
+      // "frequency = frequency + ffs/3" stores a double into the unsigned tuner frequency, i.e. floors the sum
+      if (c == 0 && abs(static_cast<int>(sh.fine_fs)) > 50) st.tuner_hz += static_cast<int>(floor(sh.fine_fs / 3));
+    }
+  }
+  __syncthreads();
+  SYNC_STAMP(9);
+}
+
+// spec (the look-ahead schedule, Engine::scan_streams): call_limit >= 0: at most that many calls in this launch; ctl != nullptr: the descriptor numbering
+// of a scan made of several launches -- the launch with record_base set writes its first call there, the others read it; lookup: the look-ahead pass's table
+// stands for the calls from where the stream stands at this launch
 template <bool kChainOnly>
 __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* const* __restrict__ iq,
                                                              const int64_t* __restrict__ nbytes,
@@ -568,142 +765,142 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
                                                              CallDesc* __restrict__ descs, int2* __restrict__ info, int max_calls, int call_begin,
                                                              int call_end, const double2* __restrict__ tw2048,
                                                              const double2* __restrict__ tw1536,
-                                                             const uint8_t* __restrict__ prs_q, int afc, SyncTails tails)
+                                                             const uint8_t* __restrict__ prs_q, int afc, SyncTails tails, SpecArgs spec)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const SyncLds lds = sync_lds(smem, tw2048);
-  double2* A = lds.A;
-  double2* Bf = lds.Bf;
-  double2* tw = lds.tw;
-  Shared& sh = *lds.sh;
-  uint8_t* env = reinterpret_cast<uint8_t*>(Bf);     // 19661 bytes, coarse search only
-
   const int b = stream_list ? stream_list[blockIdx.x] : blockIdx.x, tid = threadIdx.x;
-  const uint8_t* stream = iq[b];
   const int64_t total_calls = nbytes[b] / kChunkBytes;
-  const int kend = call_end < 0 ? static_cast<int>(total_calls) : min(call_end, static_cast<int>(total_calls));
+  int kend = call_end < 0 ? static_cast<int>(total_calls) : min(call_end, static_cast<int>(total_calls));
   // call_begin < 0: continue where the stream's state stands (calls already fed), descriptors numbered from there
   const int kfirst = call_begin >= 0 ? call_begin : static_cast<int>(states_in[b].fed / kChunkBytes);
-  const int kdesc0 = call_begin >= 0 ? 0 : kfirst;
+  int kdesc0 = call_begin >= 0 ? 0 : kfirst;
+  if (spec.ctl) {                                          // a scan made of several launches: the first one records the numbering, the others read it
+    if (spec.record_base) { if (tid == 0) { spec.ctl[b] = kdesc0; if (blockIdx.x == 0) spec.ctl[gridDim.x] = 0; } }   // (and the count of table hits cleared)
+    else kdesc0 = spec.ctl[b];
+  }
+  if (spec.call_limit >= 0) kend = min(kend, kfirst + spec.call_limit);
+  if (spec.call_limit >= 0 && kfirst >= kend) return;     // a short chain with nothing to do: states and tails stay as they are
+  const SyncLds lds = sync_lds(smem, tw2048);
+  Shared& sh = *lds.sh;
+  const CallEnv env{iq[b], b, max_calls, kdesc0, afc, descs, info, tails, lds, prs_q, spec.lookup != 0, spec.table, spec.src0, spec.ctl + spec.nstreams, spec.nspec, spec.nhyp, kfirst};
   if (tid == 0) { sh.st = states_in[b]; sh.fine_fs = sh.st.fine_freq_shift; }
   const FineTimeTables fine_tab = fine_time_tables(tw1536, prs_q);
   // The stream's tail bytes -- the last kTailBytes of the reference's frame buffer, which a short read leaves as they were (sdr_fifo.c:56-59) --
   // travel in registers: thread t < 384 holds bytes 4 t .. 4 t + 3.  (tails.state_in == nullptr: a caller without tail state, stage tests)
-  constexpr int kTailWords = kTailBytes / 4;
   uint32_t tail_word = 0;
   if (tails.state_in && tid < kTailWords) tail_word = reinterpret_cast<const uint32_t*>(tails.state_in + static_cast<size_t>(b) * kTailBytes)[tid];
   __syncthreads();
 
+  AheadRow row;
+  if (env.ahead && tid < 64) row = ahead_fetch(env.ahead_table, env.ahead_src0, env.ahead_nspec, env.ahead_nhyp, b, 0);
   for (int k = kfirst; k < kend; ++k) {
 #if DABHIP_SYNC_TIMES
     if (blockIdx.x == 0 && tid == 0) g_sync_call = k - kfirst;
 #endif
-    SYNC_STAMP(0);
-    // ---- FIFO bookkeeping: input_sdr.c:36-55 over sdr_fifo.c:43-61 (fifo_view.hpp) -------
-    uint8_t* const tail_slot = tails.images ? tails.images + (static_cast<size_t>(b) * max_calls + (k - kdesc0)) * kTailBytes : nullptr;
-    if (tid < 64) fifo_call_wave(sh, tails.chunk, tail_slot);
-    __syncthreads();
-
-    // what this call's read leaves in the tail bytes: the loads are issued behind those the chain waits for first (below), taken up -- and the frame's
-    // copy written -- behind that wait
-    unsigned tail_lo = 0, tail_hi = 0;
-    bool take_lo = false, take_hi = false;
-    const bool frame_read = DABHIP_K1_TAIL && sh.status != 0;
-    auto load_tail = [&]() {
-      if (frame_read && tid < kTailWords) {
-        const int64_t s0 = read_source(sh.st.view, sh.fresh, kTailStart + 4 * tid), s1 = read_source(sh.st.view, sh.fresh, kTailStart + 4 * tid + 2);
-        take_lo = s0 >= 0;
-        take_hi = s1 >= 0;
-        if (take_lo) tail_lo = *reinterpret_cast<const uint16_t*>(stream + s0);
-        if (take_hi) tail_hi = *reinterpret_cast<const uint16_t*>(stream + s1);
-      }
-    };
-    auto commit_tail = [&]() {
-      if (frame_read && tid < kTailWords) {
-        if (take_lo) tail_word = (tail_word & 0xffff0000u) | tail_lo;
-        if (take_hi) tail_word = (tail_word & 0x0000ffffu) | (tail_hi << 16);
-        if (tail_slot) reinterpret_cast<uint32_t*>(tail_slot)[tid] = tail_word;
-      }
-    };
-
-    const int nco = afc ? sh.st.tuner_hz : 0;
-    if (sh.do_sync) {
-      const FrameView& view = sh.st.view;
-      const Prefetched<2048> pf = prefetch_samples<2048>(stream, view, 2 * (kNullSamples + kCpSamples), nco);   // for the fine time search
-      SYNC_STAMP(1);
-      const int force = sh.st.force_timesync;
-      const int energy_part = null_symbol_energy_part(stream, view);                             // input_sdr.c:64-74
-      load_tail();
-      const int energy = block_sum_int(sh.red, energy_part);
-      commit_tail();
-      int coarse = 0;
-      if (energy >= 5000 || force != 0) {
-        __syncthreads();                                  // the search reads the whole frame buffer, tail bytes included
-        coarse = coarse_time_search(stream, view, sh.red, env);
-      }
-      if (tid == 0) { sh.st.coarse_timeshift = coarse; sh.st.force_timesync = 0; }
-      __syncthreads();
-      SYNC_STAMP(2);
-      if (coarse == 0) {
-        const int fine = fine_time_sync(stream, view, nco, A, Bf, tw, fine_tab, sh.red, pf);   // input_sdr.c:84
-        if (tid == 0) sh.st.fine_timeshift = fine;
-        if (kChainOnly) {
-          if (tid == 0) sh.status = 2;                    // assumed; sync_verify_kernel checks it
-        } else {
-          const int cfs = coarse_freq_sync(stream, view, nco, fine, A, lds.spec, tw, prs_q, sh.red);   // input_sdr.c:90-104
-          if (tid == 0) sh.coarse_fs = cfs;
-          if (abs(cfs) > 1) {
-            if (tid == 0) sh.st.force_timesync = 1;       // input_sdr.c:105-109
-          } else {
-            const double ffs = fine_freq_corr(stream, view, nco, sh.red);                        // input_sdr.c:112
-            if (tid == 0) {
-              sh.fine_fs = ffs;
-              sh.status = 2;
-            }
-          }
-        }
-      }
-    } else {
-      load_tail();
-      commit_tail();                                      // a frame that is read and dropped (input_sdr.c:51-55) still overwrites the buffer
-    }
-    __syncthreads();
-    if (tid >= 64 && tid < 64 + static_cast<int>(sizeof(FrameView) / 4)) {     // the view, word by word, by the second wave (one thread copying 152 bytes out of LDS was a microsecond)
-      CallDesc& d = descs[static_cast<size_t>(b) * max_calls + (k - kdesc0)];
-      reinterpret_cast<uint32_t*>(&d.view)[tid - 64] = reinterpret_cast<const uint32_t*>(&sh.st.view)[tid - 64];
-    }
-    if (tid == 0) {
-      CallDesc& d = descs[static_cast<size_t>(b) * max_calls + (k - kdesc0)];
-      d.status = sh.status;
-      d.ordinal = sh.status == 2 ? sh.st.next_ordinal++ : -1;
-      if (info) info[static_cast<size_t>(b) * max_calls + (k - kdesc0)] = make_int2(d.status, d.ordinal);   // what the host lays the frames out with
-      d.coarse_timeshift = sh.st.coarse_timeshift;
-      d.fine_timeshift = sh.st.fine_timeshift;
-      d.coarse_freq_shift = sh.coarse_fs;
-      d.fifo_count = sh.fifo_count;
-      d.fine_freq_shift = sh.fine_fs;
-      d.nco_hz = nco;
-      if (afc) {
-        // the tuner feedback of demod_thread_fn (dab2eti.c:76-103), applied to the NCO instead of the tuner; it runs
-        // after EVERY call, also those that produced no frame (coarse 0, fine estimate stale), exactly as there
-        StreamState& st = sh.st;
-        const int c = sh.coarse_fs;
-        if (abs(c) > 1) st.tuner_hz += c < 0 ? -1000 : 1000;
-        if (abs(c) == 1) {
-          st.rng = st.rng * 1103515245u + 12345u;
-          const int step = static_cast<int>((st.rng >> 16) % 1000u);
-          st.tuner_hz += c < 0 ? -step : step;
-        }
-        // dab2eti.c:97-98 in its integer semantics: abs() is the int one (the double is truncated first: |ffs| >= 51), and
-        // "frequency = frequency + ffs/3" stores a double into the unsigned tuner frequency, i.e. floors the sum
-        if (c == 0 && abs(static_cast<int>(sh.fine_fs)) > 50) st.tuner_hz += static_cast<int>(floor(sh.fine_fs / 3));
-      }
-    }
-    __syncthreads();
-    SYNC_STAMP(9);
+    sync_call<kChainOnly>(env, sh, k, fine_tab, tail_word, row);
   }
   if (tid == 0) { sh.st.fine_freq_shift = sh.fine_fs; states[b] = sh.st; }
   if (tails.state_out && tid < kTailWords) reinterpret_cast<uint32_t*>(tails.state_out + static_cast<size_t>(b) * kTailBytes)[tid] = tail_word;
+}
+
+// ---- the look-ahead pass -------------------------------------------------------------------------------------------------------------------
+// The chain is sequential because a call's time shifts position the NEXT read -- but what a call computes from its frame (the null-symbol energy and the
+// fine time search: all that the chain-only scan needs) is a function of the samples at the START of the frame buffer, i.e. of the stream position the
+// read began at, and a locked receiver's reads begin within a few samples of where a receiver that never corrected anything would begin them (the
+// reference's fine time search settles into a limit cycle of +20, -8, -8, -2 bytes on an ideal channel; it never returns "0, 0, 0").  So this pass runs,
+// for every call the stream has left and every start position within +-(nhyp / 2) samples of the predicted one, the two estimators at once -- grid (nhyp,
+// nspec, nstreams), all on the device together -- and leaves them in a table keyed by (call, start position); the chain launch behind it (sync_call) looks
+// its call's start position up and skips the estimators on a hit.  The table holds what the chain would have computed, bit for bit (same code, same
+// samples, same order of operations), so the results are the chain's in every case; a call whose read begins outside the window (a coarse correction,
+// a drifting sample clock), that reads short of the estimators' samples, or that the prediction did not expect to read at all, is computed by the chain
+// as before.  Worth it where the chain leaves most of the device idle (Engine::scan_streams: small batches): one ensemble of 64 TF 0.52 -> 0.2 ms.
+// The predicted start positions: the stream's calls replayed from where it stands with every time shift 0 (the pending one applied first).  Getting to
+// "the state before call j" is bookkeeping only: calls up to the first predicted-zero shift go through the chain's own FIFO code (fifo_call_wave: a
+// pending shift, a first frame still to be dropped), from there on a read is a full frame at the read pointer (fifo_view.hpp with shift 0), the counters
+// repeat every three calls (3 x 262144 = 2 x 393216) and whole periods are skipped in one step.
+__global__ __launch_bounds__(kThreads) void sync_ahead_kernel(const uint8_t* const* __restrict__ iq, const int64_t* __restrict__ nbytes,
+                                                              const StreamState* __restrict__ states, const double2* __restrict__ tw2048,
+                                                              const double2* __restrict__ tw1536, const uint8_t* __restrict__ prs_q, int chunk, SpecArgs spec)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.z, j = blockIdx.y, h = blockIdx.x, tid = threadIdx.x;
+  const int total_calls = static_cast<int>(nbytes[b] / kChunkBytes);
+  const int kcur = static_cast<int>(states[b].fed / kChunkBytes);
+  if (j >= min(spec.nspec, total_calls - kcur)) return;
+  const SyncLds lds = sync_lds(smem, tw2048, false);       // (the twiddle table only once the call turns out to have work: a third of the calls read no frame)
+  Shared& sh = *lds.sh;
+  static_assert(sizeof(StreamState) % 4 == 0 && sizeof(StreamState) / 4 <= kThreads, "copied word by word");
+  if (tid < static_cast<int>(sizeof(StreamState) / 4)) reinterpret_cast<uint32_t*>(&sh.st)[tid] = reinterpret_cast<const uint32_t*>(states + b)[tid];
+  __syncthreads();
+
+  // ---- the j calls before this one, as predicted: every frame demodulated, no time shift ----
+  int i = 0;
+  while (i < j) {
+    const bool lean = sh.st.coarse_timeshift + sh.st.fine_timeshift == 0 && sh.st.startup_delay > 0 && chunk == kChunkBytes;
+    __syncthreads();                                       // every thread has read the state before it changes
+    if (!lean) {
+      // the chain's own bookkeeping for this call (a pending shift: short, skipping or dry read; the first frame, which is dropped), then the predicted outcome
+      if (tid < 64) fifo_call_wave(sh, chunk, nullptr);
+      __syncthreads();
+      if (tid == 0 && sh.do_sync) {
+        sh.st.coarse_timeshift = sh.st.fine_timeshift = sh.st.force_timesync = 0;
+        ++sh.st.next_ordinal;
+      }
+      __syncthreads();
+      ++i;
+      continue;
+    }
+    // from here to call j: fifo_call with shift 0 -- a full frame from the read pointer once 1.5 frames are queued
+    int64_t fed = sh.st.fed, consumed = sh.st.consumed;
+    auto step = [&]() {
+      fed += kChunkBytes;
+      if (fed - consumed >= 3 * kTfSamples) consumed += kTfBytes;
+      ++i;
+    };
+    if (j - i >= 9) {
+      const int64_t queued = fed - consumed;
+      step(); step(); step();
+      if (fed - consumed == queued) {                      // two reads in three calls: the period; whole periods in one step
+        const int q = (j - i) / 3;
+        fed += static_cast<int64_t>(q) * 3 * kChunkBytes;
+        consumed += static_cast<int64_t>(q) * 2 * kTfBytes;
+        i += 3 * q;
+      }
+    }
+    while (i < j) step();
+    if (tid == 0) { sh.st.fed = fed; sh.st.consumed = consumed; }   // (the view a full read leaves shows through nothing: this call's read rewrites the buffer)
+    __syncthreads();
+  }
+
+  // ---- this call's read, and the estimators at start position (predicted + 2 (h - nhyp / 2)) ----
+  // (one start position per workgroup: as a loop over several of them the kernel takes 200 registers instead of 105 and loses its second workgroup per CU)
+  if (tid < 64) fifo_call_wave(sh, chunk, nullptr);
+  __syncthreads();
+  const bool expected = sh.do_sync && sh.st.view.seg_src[0] >= 0 && sh.st.view.seg_end[0] >= kAheadWindowEnd;
+  const int64_t src0 = expected ? sh.st.view.seg_src[0] : -1;
+  const size_t slot = static_cast<size_t>(b) * spec.nspec + j;
+  if (h == 0 && tid == 0) spec.src0[slot] = src0;
+  if (!expected) return;
+  const int64_t src = src0 + 2 * (h - spec.nhyp / 2);
+  int2 out = make_int2(-1, 0);
+  if (src >= 0 && src + kAheadWindowEnd <= nbytes[b]) {   // (workgroup-uniform)
+    const FineTimeTables fine_tab = fine_time_tables(tw1536, prs_q);
+    for (int n = tid; n < 1024; n += kThreads) lds.tw[lds_at(n)] = tw2048[n];
+    __syncthreads();                                       // the view has been read by everyone
+    if (tid == 0) {
+      sh.st.view.nseg = 1;
+      sh.st.view.seg_end[0] = kTfBytes;
+      sh.st.view.seg_src[0] = src;
+      sh.st.view.tail = nullptr;
+    }
+    __syncthreads();
+    const FrameView& view = sh.st.view;
+    const Prefetched<2048> pf = prefetch_samples<2048>(iq[b], view, 2 * (kNullSamples + kCpSamples), 0);
+    const int energy = block_sum_int(sh.red, null_symbol_energy_part(iq[b], view));                 // input_sdr.c:64-74
+    const int fine = fine_time_sync(iq[b], view, 0, lds.A, lds.Bf, lds.tw, fine_tab, sh.red, pf);   // input_sdr.c:84
+    out = make_int2(energy, fine);
+  }
+  if (tid == 0) spec.table[slot * spec.nhyp + h] = out;
 }
 
 // The estimators the chain-only scan left out, for every call it assumed demodulated: grid (max_calls, nstreams).
@@ -832,6 +1029,7 @@ static hipError_t sync_attr()
     const int lds = static_cast<int>(sync_scan_lds_bytes());
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_scan_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_scan_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_ahead_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_verify_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sync_verify32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sync_verify32_lds_bytes()));
     return e;
@@ -908,7 +1106,7 @@ hipError_t launch_scan_setup(const ScanSetupArgs& a, hipStream_t stream)
 hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, StreamState* states, CallDesc* descs, int2* info,
                             int nstreams, int max_calls, int call_begin, int call_end, const double2* tw2048,
                             const double2* tw1536, const uint8_t* prs_q, int afc, hipStream_t stream, bool chain_only,
-                            const StreamState* states_in, const int* stream_list, SyncTails tails)
+                            const StreamState* states_in, const int* stream_list, SyncTails tails, SpecArgs spec)
 {
   if (tails.chunk < 0) tails.chunk = kChunkBytes;
   if (nstreams <= 0) return hipSuccess;
@@ -918,10 +1116,21 @@ hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, Str
   if (!states_in) states_in = states;
   if (chain_only)
     hipLaunchKernelGGL(sync_scan_kernel<true>, dim3(nstreams), dim3(kThreads), lds, stream, iq, nbytes, states_in, states, stream_list, descs, info,
-                       max_calls, call_begin, call_end, tw2048, tw1536, prs_q, afc, tails);
+                       max_calls, call_begin, call_end, tw2048, tw1536, prs_q, afc, tails, spec);
   else
     hipLaunchKernelGGL(sync_scan_kernel<false>, dim3(nstreams), dim3(kThreads), lds, stream, iq, nbytes, states_in, states, stream_list, descs, info,
-                       max_calls, call_begin, call_end, tw2048, tw1536, prs_q, afc, tails);
+                       max_calls, call_begin, call_end, tw2048, tw1536, prs_q, afc, tails, spec);
+  return hipGetLastError();
+}
+
+hipError_t launch_sync_ahead(const uint8_t* const* iq, const int64_t* nbytes, const StreamState* states, int nstreams, const double2* tw2048, const double2* tw1536,
+                             const uint8_t* prs_q, hipStream_t stream, const SpecArgs& spec)
+{
+  if (nstreams <= 0 || spec.nspec <= 0 || spec.nhyp <= 0) return hipSuccess;
+  hipError_t e = sync_attr();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(sync_ahead_kernel, dim3(spec.nhyp, spec.nspec, nstreams), dim3(kThreads), sync_scan_lds_bytes(), stream, iq, nbytes, states, tw2048, tw1536, prs_q,
+                     kChunkBytes, spec);
   return hipGetLastError();
 }
 

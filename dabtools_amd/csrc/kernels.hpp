@@ -67,10 +67,26 @@ struct SyncTails {
   uint8_t* images;
   int chunk;
 };
+// The look-ahead schedule of a chain-only scan (small batches; k_sync.hip: sync_ahead_kernel): a pass that computes the chain's estimators for every call a
+// stream has left, at every start position near the predicted one, all at once; the chain launch behind it looks them up.
+struct SpecArgs {
+  int2* table = nullptr;                // [nstreams][nspec][nhyp]: {null-symbol energy, fine time shift} of a read beginning at src0 + 2 (h - nhyp / 2); x < 0: none
+  int64_t* src0 = nullptr;              // [nstreams][nspec]: predicted start position (stream offset) of the call's read, -1: no demodulating read expected
+  int* ctl = nullptr;                   // [nstreams]: descriptor numbering of the scan (its first call), recorded by the launch with record_base; [nstreams]: table hits
+  int nstreams = 0;
+  int nspec = 0, nhyp = 0;
+  int lookup = 0;                       // chain launches: the table stands for the calls from where the stream stands now
+  int call_limit = -1;                  // chain launches: at most this many calls per stream (< 0: to the end)
+  int record_base = 0;
+};
 hipError_t launch_sync_scan(const uint8_t* const* iq, const int64_t* nbytes, StreamState* states, CallDesc* descs, int2* info,
                             int nstreams, int max_calls, int call_begin, int call_end, const double2* tw2048,
                             const double2* tw1536, const uint8_t* prs_q, int afc, hipStream_t stream, bool chain_only = false,
-                            const StreamState* states_in = nullptr, const int* stream_list = nullptr, SyncTails tails = SyncTails{nullptr, nullptr, nullptr, -1});
+                            const StreamState* states_in = nullptr, const int* stream_list = nullptr, SyncTails tails = SyncTails{nullptr, nullptr, nullptr, -1},
+                            SpecArgs spec = SpecArgs{});
+// the look-ahead pass over the calls every stream has left from where it stands (at most spec.nspec of them)
+hipError_t launch_sync_ahead(const uint8_t* const* iq, const int64_t* nbytes, const StreamState* states, int nstreams, const double2* tw2048, const double2* tw1536,
+                             const uint8_t* prs_q, hipStream_t stream, const SpecArgs& spec);
 // carry_only = false: the verification pass (violation[b] = first offending call, untouched otherwise);
 // carry_only = true: fine_freq_shift carried through the calls that did not demodulate, for the streams without a violation
 hipError_t launch_sync_verify(const uint8_t* const* iq, const int64_t* nbytes, const int* calls_before, StreamState* states, CallDesc* descs,

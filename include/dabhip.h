@@ -180,6 +180,15 @@ int dabhip_engine_set_subchannels(dabhip_engine *e, const int32_t *ids, int n);
  * dabhip_engine_fft_stats describes whichever kernel ran; dabhip_engine_fft_roofline measures K2 by itself. */
 int dabhip_engine_set_fused(dabhip_engine *e, int enable);
 
+/* Schedule of K1's per-stream chain (sdr_demod's FIFO + time synchronisation, input_sdr.c:36-84, where call n + 1 is positioned by what call n
+ * found).  mode 0: the chain, call after call.  mode 1: with a look-ahead pass -- what a call computes from its frame (null-symbol energy,
+ * fine time search) depends only on where in the stream its read began, and a locked receiver's reads begin within a few samples of a predictable
+ * place: one pass computes both for every remaining call and every start position near the predicted one, all at once, and the chain looks them up
+ * (and computes them itself where a read began elsewhere).  Same results in every case, call for call.  mode -1 (default): the pass for small
+ * batches (where the chain leaves most of the device idle), the plain chain for large ones; DABHIP_K1_SPEC in the environment sets the default.
+ * dabhip_engine_stage_ms reports the calls served from the pass's table as "sync_spec_calls". */
+int dabhip_engine_set_sync_speculation(dabhip_engine *e, int mode);
+
 /* ---- several devices of one node (BASELINE configs[3]: 2048 streams = 256 per GPU x 8) --------------
  * dab2eti.c:237,279-302 drives ONE device from one demod thread.  A batch of independent ensembles shards by stream with no
  * data exchange at all: the streams of a decode are dealt to the listed devices in contiguous slices (slice i of n takes B / n
@@ -255,6 +264,7 @@ int dabhip_stream_set_afc(dabhip_stream *s, int enable);
 int dabhip_stream_set_subchannels(dabhip_stream *s, const int32_t *ids, int n);   /* before the first segment only */
 int dabhip_stream_set_soft(dabhip_stream *s, int enable);   /* before the first segment only */
 int dabhip_stream_set_parity_guard(dabhip_stream *s, int enable);   /* default on, see dabhip_engine_set_parity_guard */
+int dabhip_stream_set_sync_speculation(dabhip_stream *s, int mode);   /* default -1, see dabhip_engine_set_sync_speculation */
 /* Page-locked host memory for segments: fill the next one while the current one decodes (double buffering). */
 void *dabhip_host_alloc(size_t nbytes);
 void dabhip_host_free(void *p);
@@ -288,7 +298,8 @@ int dabhip_engine_trace_nco(const dabhip_engine *e, int stream, int32_t *nco_hz,
  * phases "host_setup", "host_frames", "host_worklist" and the total "wall"; then, for a host-fed decode (on_device == 0),
  * "h2d" (ms of the IQ upload, HIP events), "h2d_mbytes" (10^6 bytes uploaded) and "h2d_pinned_mbytes" (how much of that came
  * straight from page-locked memory; the rest went through the engine's staging ring); and "sync_fp64_calls": calls whose coarse
- * frequency arg-max the single-precision first pass of K1's verification left to the fp64 pass (a count, not a time).
+ * frequency arg-max the single-precision first pass of K1's verification left to the fp64 pass (a count, not a time); "sync_spec_calls": calls of
+ * K1's chain whose estimators came out of the look-ahead pass's table (dabhip_engine_set_sync_speculation; 0 when the plain chain ran).
  * Returns number of entries written. */
 int dabhip_engine_stage_ms(const dabhip_engine *e, const char **names, float *ms, int cap);
 /* Per-launch statistics of the OFDM FFT kernel in the last decode: number of launches,

@@ -180,3 +180,23 @@ def test_roofline_objects_are_computable_from_the_tracked_profile():
     import pytest
     with pytest.raises(SystemExit, match="refresh_profiles"):
         prof.cell("clk", "no_such_kernel", "SQ_INSTS_VALU")
+
+
+def test_decision_audit_profile_belongs_to_this_trees_kernels():
+    """profiles/r05_decision_audit.json -- the measured ground the parity guard's constants stand on -- names the
+    kernel the default decode runs, was measured on THIS tree's sources (tools/decision_audit.py hashes them; re-run it on a GPU box after touching any),
+    covers >= 10^10 decisions with no disagreement outside the guard's band and none with the guard on, keeps a margin of >= 4 on both constants, and the
+    shipping build left the audit build's bits and list counts in every case."""
+    import hashlib
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import decision_audit
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_decision_audit.json")))
+    assert "ofdm_demap_kernel" in d["kernel"] and d["sources"] == list(decision_audit.AUDITED_SOURCES)
+    assert d["source_sha256"] == decision_audit.source_sha(), "profiles/r05_decision_audit.json is stale: run tools/decision_audit.py --channels 300 on a GPU box"
+    assert d["total_decisions"] >= 1e10 and d["total_disagree_outside_band"] == 0 and d["total_disagree_guard_on"] == 0
+    assert d["margin_kGuardC_over_worst"] >= 4 and d["margin_kGuardProd_over_worst"] >= 4
+    assert d["shipping_kernel_same_bits_in_every_case"] and d["shipping_kernel_same_list_count_in_every_case"]
+    assert d["worst_max_bin_err_over_sqrt_energy"] < d["a_priori_worst_case_bin_err_over_sqrt_energy"]      # the a-priori bound is NOT what the constants rest on
+    assert any(c["channel"] != "ideal" for c in d["cases"])

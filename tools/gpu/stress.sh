@@ -4,7 +4,9 @@ set -u
 GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}; export GRAFT_REPO_ROOT; cd "$GRAFT_REPO_ROOT"
 N=${NAME:-stress_parity}
 mkdir -p gpurun_out/stress
-PYTHONPATH=tools timeout ${LIMIT:-3000} python tools/stress_parity.py --rounds ${ROUNDS:-16} --streams ${STREAMS:-64} --tfs ${TFS:-28} --seed ${SEED:-40404} ${STRESS_ARGS:-} > gpurun_out/stress/$N.json 2> gpurun_out/stress/$N.err; echo "rc=$?"
+PYTHONPATH=tools timeout ${LIMIT:-3000} python tools/stress_parity.py --rounds ${ROUNDS:-16} --streams ${STREAMS:-64} --tfs ${TFS:-28} --seed ${SEED:-40404} --checkpoint gpurun_out/stress/$N.partial.json ${STRESS_ARGS:-} > gpurun_out/stress/$N.json 2> gpurun_out/stress/$N.err; echo "rc=$?"
+# a run that was cut off leaves the rounds it finished ("rounds_finished" in the record)
+[ -s gpurun_out/stress/$N.json ] || cp gpurun_out/stress/$N.partial.json gpurun_out/stress/$N.json 2>/dev/null
 python - <<PY
 import json
 d = json.loads(open("gpurun_out/stress/$N.json").read().strip().splitlines()[-1])

@@ -184,8 +184,9 @@ def random_channel(cfg, rng):
     return rec
 
 
-def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None, reference=False, harsh=False, layouts=False, channel=False, reconf=False):
-    """The sweep itself -> result dict (one record per capture under "cases")."""
+def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None, reference=False, harsh=False, layouts=False, channel=False, reconf=False, checkpoint=None):
+    """The sweep itself -> result dict (one record per capture under "cases").  checkpoint: a path the result so far is written to after every round
+    (a run that is cut off -- the reference as checker takes minutes per round -- then leaves the rounds it finished, "rounds_finished" says how many)."""
     import dabtools_amd as dab
     workers = workers or min(32, os.cpu_count() or 1)
     job = reference_job if reference else oracle_job
@@ -196,6 +197,17 @@ def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None, ref
     total_frames = total_calls = 0
     bad, cases = [], []
     t0 = time.time()
+
+    def summary(done):
+        return {"layouts": "random multiplexes (1 .. 16 sub-channels, any UEP row / EEP level and size)" if layouts else "the two presets",
+                "reconfiguration": "one or two assemblable changes of the multiplex mid-stream (add / move / re-protect / resize / drop from the FIC), FIC leading by 0 .. 10 CIFs" if reconf else "none",
+                "channel": "one to three of: sample-rate offset (+-20, +-50, +-100, uniform +-110 ppm), one or two echoes (50 / 400 / 600 / random < 900 samples, gain 0.1 .. 1.4, Doppler), "
+                           "slow fading (depth 0.3 .. 0.9, 0.3 .. 9 Hz), I/Q imbalance (+-2.5 dB, +-12 deg)" if channel else "ideal",
+                "mix": "harsh (5 dB ... clean, up to 1.4 carriers off tune, amplitudes 0.08 ... 2.5)" if harsh else "default",
+                "checker": "the reference itself: real front end over hipFFTW + real back end (oracle/_ref)" if reference else "oracle/or_replay",
+                "rounds": rounds, "rounds_finished": done, "streams_per_round": streams, "eti_frames_compared": total_frames, "calls_compared": total_calls,
+                "differences": bad, "seconds": round(time.time() - t0, 1), "seed": seed, "cases": cases}
+
     with mp.get_context("spawn").Pool(workers) as pool:
         for r in range(rounds):
             cfgs, paths, iqs, ragged, extras = [], [], [], [], []
@@ -249,18 +261,15 @@ def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None, ref
                                 "trace_equal": gtrace == wtrace})
             if log:
                 print("round %d: %d streams, %d ETI frames so far, %d differences" % (r, len(iqs), total_frames, len(bad)), file=log, flush=True)
+            if checkpoint:
+                with open(checkpoint + ".tmp", "w") as f:
+                    f.write(json.dumps(summary(r + 1)) + "\n")
+                os.replace(checkpoint + ".tmp", checkpoint)
     eng.close()
     for f in os.listdir(tmp):
         os.remove(os.path.join(tmp, f))
     os.rmdir(tmp)
-    return {"layouts": "random multiplexes (1 .. 16 sub-channels, any UEP row / EEP level and size)" if layouts else "the two presets",
-            "reconfiguration": "one or two assemblable changes of the multiplex mid-stream (add / move / re-protect / resize / drop from the FIC), FIC leading by 0 .. 10 CIFs" if reconf else "none",
-            "channel": "one to three of: sample-rate offset (+-20, +-50, +-100, uniform +-110 ppm), one or two echoes (50 / 400 / 600 / random < 900 samples, gain 0.1 .. 1.4, Doppler), "
-                       "slow fading (depth 0.3 .. 0.9, 0.3 .. 9 Hz), I/Q imbalance (+-2.5 dB, +-12 deg)" if channel else "ideal",
-            "mix": "harsh (5 dB ... clean, up to 1.4 carriers off tune, amplitudes 0.08 ... 2.5)" if harsh else "default",
-            "checker": "the reference itself: real front end over hipFFTW + real back end (oracle/_ref)" if reference else "oracle/or_replay",
-            "rounds": rounds, "streams_per_round": streams, "eti_frames_compared": total_frames, "calls_compared": total_calls,
-            "differences": bad, "seconds": round(time.time() - t0, 1), "seed": seed, "cases": cases}
+    return summary(rounds)
 
 
 def main():
@@ -276,8 +285,10 @@ def main():
     ap.add_argument("--layouts", action="store_true", help="every capture its own random multiplex instead of one of the two presets")
     ap.add_argument("--channel", action="store_true", help="every capture through a random impaired channel (sample-rate offset, echoes, fading, I/Q imbalance)")
     ap.add_argument("--reconf", action="store_true", help="every capture reconfigures its multiplex once or twice mid-stream")
+    ap.add_argument("--checkpoint", type=str, default=None, help="write the result so far to this file after every round")
     args = ap.parse_args()
-    res = run(args.rounds, args.streams, args.tfs, args.workers, args.seed, log=sys.stderr, reference=args.reference, harsh=args.harsh, layouts=args.layouts, channel=args.channel, reconf=args.reconf)
+    res = run(args.rounds, args.streams, args.tfs, args.workers, args.seed, log=sys.stderr, reference=args.reference, harsh=args.harsh, layouts=args.layouts, channel=args.channel,
+              reconf=args.reconf, checkpoint=args.checkpoint)
     print(json.dumps(res))
     sys.exit(1 if res["differences"] else 0)
 
