@@ -439,7 +439,9 @@ def single_ensemble(dab, torch, dev, eng, tensors, args):
            "value": frames / dt, "unit": "ETI frames/s", "x_realtime": frames / dt / REALTIME_FPS, "ms_per_decode": 1e3 * dt, "eti_frames_per_decode": frames,
            "stage_ms": {k: round(v / reps, 4) for k, v in stage.items() if not k.startswith("h2d")},
            "decoder_form": "one wave per code word (k_vitwave.hip) for the %d MSC code words and %d FIC blocks of this decode" % (12 * frames, 4 * (args.tfs - 1)),
-           "batch_curve": "profiles/r04_batch_curve.json (B = 1 .. 256, tools/batch_curve.py)"}
+           "sync_schedule": "K1 with the look-ahead pass (k_sync.hip: sync_ahead_kernel; default for <= 4 streams): %d of the chain's calls per decode took their estimators from "
+                            "its table; with the plain chain this decode's sync stage is 0.58 ms (profiles/r05_batch_curve_plain_chain.json)" % round(stage.get("sync_spec_calls", 0.0) / reps),
+           "batch_curve": "profiles/r05_batch_curve.json (B = 1 .. 64, tools/batch_curve.py; plain chain beside it: r05_batch_curve_plain_chain.json)"}
     ntf = min(args.tfs, 40)
     hb = dab.HostBuffer(ntf * dab.TF_BYTES)
     assert dab.lib().dabhip_device_copy(hb.ptr, tensors[0].data_ptr(), ntf * dab.TF_BYTES, 0) == 0

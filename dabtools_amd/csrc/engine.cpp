@@ -194,6 +194,45 @@ Engine::~Engine()
 }
 
 // ---------------------------------------------------------------------------------------------
+bool Engine::upload_small(const SmallUpload* items, int n, hipStream_t s, PinnedBuffer<uint32_t>& staging)
+{
+  size_t total = 0, staged = 0;
+  bool words = true;
+  for (int i = 0; i < n; ++i) {
+    total += items[i].bytes;
+    if (!items[i].pinned) staged += (items[i].bytes + 3) / 4;
+    words = words && items[i].bytes % 4 == 0 && reinterpret_cast<uintptr_t>(items[i].src) % 4 == 0;
+  }
+  if (!words || total > kSmallUploadBytes) {
+    for (int i = 0; i < n; ++i)
+      if (items[i].bytes && !check(hipMemcpyAsync(items[i].dst, items[i].src, items[i].bytes, hipMemcpyHostToDevice, s), "work list upload")) return false;
+    return true;
+  }
+  if (staging.size() < kSmallUploadBytes / 4 && !staging.resize(kSmallUploadBytes / 4)) return false;   // once: the buffer never moves while a kernel may read it
+  size_t at = 0;
+  HostWordsArgs hw{};
+  int k = 0;
+  for (int i = 0; i < n; ++i) {
+    if (items[i].bytes == 0) continue;
+    const uint32_t* src = static_cast<const uint32_t*>(items[i].src);
+    if (!items[i].pinned) {
+      std::memcpy(staging.data() + at, items[i].src, items[i].bytes);
+      src = staging.data() + at;
+      at += items[i].bytes / 4;
+    }
+    hw.src[k] = src;
+    hw.dst[k] = static_cast<uint32_t*>(items[i].dst);
+    hw.nwords[k] = static_cast<uint32_t>(items[i].bytes / 4);
+    if (++k == 4) {
+      if (!check(launch_host_words(hw, s), "work list upload")) return false;
+      hw = HostWordsArgs{};
+      k = 0;
+    }
+  }
+  (void)staged;
+  return k == 0 || check(launch_host_words(hw, s), "work list upload");
+}
+
 // work lists of a batch to the device (any stream: only the launches below consume them)
 bool Engine::upload_decode_batch(const DecodeBatch& b, const HostList<DecodeJob>& jobs, hipStream_t s)
 {
@@ -371,9 +410,16 @@ bool Engine::fic_decode_slots_async(int first, int n, uint8_t* fibs_host, uint8_
   // (ev_upload_ in decode_impl, the synchronising callers elsewhere).
   hipStream_t ks = copy;
   if (ks != stream_ && (!check(hipEventRecord(ev_fic_, stream_), "fic event") || !check(hipStreamWaitEvent(ks, ev_fic_, 0), "fic event"))) return false;
-  if (!d_plans_.upload(plan_table_.plans(), ks) || !d_groups_.upload(groups, ks) || !d_job_ids_.upload(ids, ks) ||
-      !d_grouped_.reserve(static_cast<size_t>(ntiles) * block_words * 64) || !d_decisions_.reserve(static_cast<size_t>(ntiles) * dr * 64))
-    return false;
+  {
+    const std::vector<CodewordPlan>& plans = plan_table_.plans();
+    if (!d_plans_.reserve(plans.size()) || !d_groups_.reserve(groups.size()) || !d_job_ids_.reserve(ids.size()) ||
+        !d_grouped_.reserve(static_cast<size_t>(ntiles) * block_words * 64) || !d_decisions_.reserve(static_cast<size_t>(ntiles) * dr * 64))
+      return false;
+    const SmallUpload items[3] = {{plans.data(), d_plans_.get(), plans.size() * sizeof(CodewordPlan), false},
+                                  {groups.data(), d_groups_.get(), groups.size() * sizeof(WaveGroup), false},
+                                  {ids.data(), d_job_ids_.get(), ids.size() * sizeof(int), false}};
+    if (!upload_small(items, 3, ks, h_small_fic_)) return false;
+  }
   if (!check(launch_fic_group(d_fic_bits_.get(), 4 * first, nblocks, block_words, d_grouped_.get(), ks), "fic group launch") ||
       !check(wave_form
                  ? launch_viterbi_wave(soft_bits_, d_groups_.get(), ntiles, d_job_ids_.get(), d_plans_.get(), d_grouped_.get(), block_words,
@@ -407,8 +453,26 @@ bool Engine::msc_prepare(const std::vector<const JobList*>& stream_jobs, const s
 bool Engine::msc_upload(const MscWork& w, hipStream_t s)
 {
   if (w.nframes == 0) return true;
-  return d_eti_.reserve(w.nframes * kEtiBytes) && d_meta_.upload(w.meta, s) && d_headers_.upload(w.headers, s) &&
-         d_stream_cif_base_.upload(w.stream_row_base, s) && upload_decode_batch(w.batch, w.jobs, s);
+  if (!d_eti_.reserve(w.nframes * kEtiBytes)) return false;
+  const DecodeBatch& b = w.batch;
+  if (b.groups.empty())
+    return d_meta_.upload(w.meta, s) && d_headers_.upload(w.headers, s) && d_stream_cif_base_.upload(w.stream_row_base, s);
+  const std::vector<CodewordPlan>& plans = plan_table_.plans();
+  const int row_words = kCifWords * (soft_bits_ ? 4 : 1);
+  const size_t ntiles = b.job_ids.size() / 64;
+  if (!d_meta_.reserve(w.meta.size()) || !d_headers_.reserve(w.headers.size()) || !d_stream_cif_base_.reserve(w.stream_row_base.size()) ||
+      !d_plans_.reserve(plans.size()) || !d_groups_.reserve(b.groups.size()) || !d_job_ids_.reserve(b.job_ids.size()) || !d_jobs_.reserve(w.jobs.size()) ||
+      !d_decisions_.reserve(static_cast<size_t>(b.max_dec_rows) * 64) || !d_grouped_.reserve(ntiles * row_words * 64))
+    return false;
+  // (the work lists are page-locked vectors -- MscWork --, the plan table and the row bases plain ones)
+  const SmallUpload items[7] = {{w.meta.data(), d_meta_.get(), w.meta.size() * sizeof(EtiFrameMeta), true},
+                                {w.headers.data(), d_headers_.get(), w.headers.size(), true},
+                                {w.stream_row_base.data(), d_stream_cif_base_.get(), w.stream_row_base.size() * sizeof(int), false},
+                                {plans.data(), d_plans_.get(), plans.size() * sizeof(CodewordPlan), false},
+                                {b.groups.data(), d_groups_.get(), b.groups.size() * sizeof(WaveGroup), true},
+                                {b.job_ids.data(), d_job_ids_.get(), b.job_ids.size() * sizeof(int), true},
+                                {w.jobs.data(), d_jobs_.get(), w.jobs.size() * sizeof(DecodeJob), true}};
+  return upload_small(items, 7, s, h_small_msc_);
 }
 
 // K4 + K5 queued on the main stream (nothing is awaited: the caller does that once, then msc_collect() reads the events)

@@ -259,6 +259,18 @@ class Engine {
   bool carry_and_reserve(const std::vector<int>& tf_base, const std::vector<int>& row_base, int nslots, int nrows);
   // MSC decode batch: work lists to the device, regroup + fused Viterbi launches
   bool upload_decode_batch(const DecodeBatch& b, const HostList<DecodeJob>& jobs, hipStream_t s);
+  // Several small host arrays to the device in one launch per four of them (launch_host_words: the kernel reads page-locked host memory itself) instead
+  // of one copy-engine command each -- a small decode is made of those commands and the 5 .. 10 us of idle GPU between two of them.  Arrays that are
+  // not page-locked are staged in `staging` first (which must not be in use by an earlier, still queued call: one buffer per call site).  Large lists
+  // (more than kSmallUploadBytes in all) go as plain asynchronous copies, as before.  dst: device memory, reserved by the caller.
+  struct SmallUpload {
+    const void* src;
+    void* dst;
+    size_t bytes;
+    bool pinned;
+  };
+  static constexpr size_t kSmallUploadBytes = 256 * 1024;
+  bool upload_small(const SmallUpload* items, int n, hipStream_t s, PinnedBuffer<uint32_t>& staging);
   bool launch_decode_batch(const DecodeBatch& b, const uint32_t* bits, const int* d_stream_cif_base, const uint32_t* prbs, uint8_t* out,
                            int record_stride);
   bool msc_launch_async(const MscWork& w);   // K4 + K5 queued, nothing awaited
@@ -318,6 +330,7 @@ class Engine {
   DeviceBuffer<uint8_t> d_tail_state_, d_tail_prev_, d_tail_images_;
   DeviceBuffer<int> d_viol_, d_redo_, d_calls_before_;
   PinnedBuffer<int> h_viol_, h_calls_before_;
+  PinnedBuffer<uint32_t> h_small_fic_, h_small_msc_;   // staging of upload_small, one per call site
   // the look-ahead schedule of the K1 chain (small batches; k_sync.hip: sync_ahead_kernel): the estimators' table, the predicted start positions, the descriptor base
   DeviceBuffer<int2> d_spec_table_;
   DeviceBuffer<int64_t> d_spec_src0_;
