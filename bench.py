@@ -359,6 +359,8 @@ def h2d_inclusive(dab, device, tensors, sizes, frames_resident, args):
             if k + 1 < len(segs):
                 st.prefetch_ptrs(*segs[k + 1])
             n = st.feed_ptrs(*segs[k])                      # (its K4 waits for the download of segment k - 1, issued below one iteration ago)
+            if k >= 1:
+                st.eti_fetch_wait()                         # segment k - 1's frames have had this whole feed to arrive (at most two fetches may be outstanding)
             st.eti_fetch(eti_host[k & 1].ptr, n)            # segment k's frames on their way while segment k + 1 uploads and decodes
             per_seg.append((n, time.perf_counter() - tk))
         st.eti_fetch_wait()

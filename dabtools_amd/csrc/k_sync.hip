@@ -641,10 +641,20 @@ __device__ __forceinline__ int2 ahead_lookup(int nhyp, const AheadRow& row, cons
 //   frame depends on both estimates.
 // ONE call of sdr_demod (input_sdr.c:27-112) on the workgroup's shared state: call k of the stream, descriptor k - kdesc0.  The body of the chain's loop
 // (sync_scan_kernel) and of the speculative pass (sync_spec_kernel).  Ends with a barrier.
+// a call's update of the tail bytes whose loads are still in flight: taken up at the start of the next call (TailPending below)
+struct TailPending {
+  TailUpdate upd;
+  uint8_t* slot = nullptr;
+  bool valid = false;
+};
 template <bool kChainOnly>
-__device__ __forceinline__ void sync_call(const CallEnv& env, Shared& sh, int k, const FineTimeTables& fine_tab, uint32_t& tail_word, AheadRow& row)
+__device__ __forceinline__ void sync_call(const CallEnv& env, Shared& sh, int k, const FineTimeTables& fine_tab, uint32_t& tail_word, AheadRow& row, TailPending& pend)
 {
   const int tid = threadIdx.x;
+  if (pend.valid) {                                       // (the same in every thread) the previous call's tail bytes: their loads have had a whole call's time
+    tail_commit(pend.upd, true, tail_word, pend.slot);
+    pend.valid = false;
+  }
   const uint8_t* const stream = env.stream;
   double2* const A = env.lds.A;
   double2* const Bf = env.lds.Bf;
@@ -686,7 +696,15 @@ __device__ __forceinline__ void sync_call(const CallEnv& env, Shared& sh, int k,
     int energy = ahead.x;
     if (hit) __syncthreads();                             // (force has been read by everyone before it is cleared below)
     else energy = block_sum_int(sh.red, energy_part);
-    tail_commit(tail_upd, frame_read, tail_word, tail_slot);
+    // With the estimators out of the table nothing in this call waits for memory but the tail bytes' loads, and nothing in it reads the tail bytes unless the
+    // coarse search runs: the update is then taken up at the start of the next call (or behind the loop) instead of stalling this one for a memory latency.
+    if (hit && frame_read && energy < 5000 && force == 0) {
+      pend.upd = tail_upd;
+      pend.slot = tail_slot;
+      pend.valid = true;
+    } else {
+      tail_commit(tail_upd, frame_read, tail_word, tail_slot);
+    }
     int coarse = 0;
     if (energy >= 5000 || force != 0) {
       __syncthreads();                                  // the search reads the whole frame buffer, tail bytes included
@@ -792,13 +810,15 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
   __syncthreads();
 
   AheadRow row;
+  TailPending pend;
   if (env.ahead && tid < 64) row = ahead_fetch(env.ahead_table, env.ahead_src0, env.ahead_nspec, env.ahead_nhyp, b, 0);
   for (int k = kfirst; k < kend; ++k) {
 #if DABHIP_SYNC_TIMES
     if (blockIdx.x == 0 && tid == 0) g_sync_call = k - kfirst;
 #endif
-    sync_call<kChainOnly>(env, sh, k, fine_tab, tail_word, row);
+    sync_call<kChainOnly>(env, sh, k, fine_tab, tail_word, row, pend);
   }
+  if (pend.valid) tail_commit(pend.upd, true, tail_word, pend.slot);
   if (tid == 0) { sh.st.fine_freq_shift = sh.fine_fs; states[b] = sh.st; }
   if (tails.state_out && tid < kTailWords) reinterpret_cast<uint32_t*>(tails.state_out + static_cast<size_t>(b) * kTailBytes)[tid] = tail_word;
 }
