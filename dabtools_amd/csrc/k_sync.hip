@@ -833,7 +833,7 @@ __global__ __launch_bounds__(kThreads) void sync_scan_kernel(const uint8_t* cons
 // its call's start position up and skips the estimators on a hit.  The table holds what the chain would have computed, bit for bit (same code, same
 // samples, same order of operations), so the results are the chain's in every case; a call whose read begins outside the window (a coarse correction,
 // a drifting sample clock), that reads short of the estimators' samples, or that the prediction did not expect to read at all, is computed by the chain
-// as before.  Worth it where the chain leaves most of the device idle (Engine::scan_streams: small batches): one ensemble of 64 TF 0.52 -> 0.2 ms.
+// as before.  Worth it where the chain leaves most of the device idle (Engine::scan_streams: small batches): one ensemble of 64 TF: sync stage 0.58 -> 0.29 ms (profiles/r05_batch_curve*.json).
 // The predicted start positions: the stream's calls replayed from where it stands with every time shift 0 (the pending one applied first).  Getting to
 // "the state before call j" is bookkeeping only: calls up to the first predicted-zero shift go through the chain's own FIFO code (fifo_call_wave: a
 // pending shift, a first frame still to be dropped), from there on a read is a full frame at the read pointer (fifo_view.hpp with shift 0), the counters
