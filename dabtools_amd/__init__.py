@@ -135,6 +135,7 @@ _SIGNATURES = {
     "dabhip_host_fifo_free": (None, [C.c_void_p]),
     "dabhip_host_fifo_call": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, u8p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                         C.POINTER(C.c_int32), u8p]),
+    "dabhip_host_fifo_skip_unshifted": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "dabhip_synth_preset": (C.c_int, [C.c_int, C.POINTER(SynthCfg)]),
     "dabhip_synth_bytes": (C.c_size_t, [C.POINTER(SynthCfg), C.c_int]),
     "dabhip_synth_generate": (C.c_int64, [C.POINTER(SynthCfg), C.c_int, u8p, C.c_size_t]),
@@ -421,6 +422,12 @@ class HostFifo:
                                         _p(self.tail) if stream is not None else None)
         _need(r >= 0, "host_fifo_call")
         return r, [(int(ends[i]), int(srcs[i])) for i in range(nseg.value)], cnt.value
+
+    def skip_unshifted(self, ncalls):
+        """ncalls further 262144-byte calls without any time shift, counters only (dabhip_host_fifo_skip_unshifted) -> (fed, consumed)"""
+        fed, consumed = C.c_int64(0), C.c_int64(0)
+        _need(lib().dabhip_host_fifo_skip_unshifted(self._h, ncalls, C.byref(fed), C.byref(consumed)) == 0, "host_fifo_skip_unshifted")
+        return fed.value, consumed.value
 
     @staticmethod
     def materialise(stream, view, tail=None):

@@ -702,6 +702,16 @@ extern "C" int dabhip_host_fifo_call(dabhip_fifo* f, int32_t coarse_timeshift, i
   return c.status ? (c.do_sync ? 2 : 1) : 0;
 }
 
+extern "C" int dabhip_host_fifo_skip_unshifted(dabhip_fifo* f, int32_t ncalls, int64_t* fed, int64_t* consumed)
+{
+  if (!f || ncalls < 0) { set_error("host_fifo_skip_unshifted: bad argument"); return -1; }
+  if (f->st.coarse_timeshift + f->st.fine_timeshift != 0 || f->st.startup_delay <= 0) { set_error("host_fifo_skip_unshifted: a shift is pending or the first frame is still to be dropped"); return -1; }
+  fifo_skip_unshifted(f->st.fed, f->st.consumed, ncalls);
+  if (fed) *fed = f->st.fed;
+  if (consumed) *consumed = f->st.consumed;
+  return 0;
+}
+
 // ---- device-side modulator (k_synth.hip) ------------------------------------------------------
 namespace dabhip { int synth_generate_device(const dabhip_synth_cfg* cfgs, int nstreams, int ntf, uint8_t* const* iq, int device); }
 extern "C" int dabhip_synth_generate_device(const dabhip_synth_cfg* cfgs, int nstreams, int ntf, uint8_t* const* iq, int device)

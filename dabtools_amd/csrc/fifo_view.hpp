@@ -93,6 +93,31 @@ __host__ __device__ inline FifoCall fifo_call(StreamState& st, int chunk = kChun
   return out;
 }
 
+// n further calls of fifo_call(st) for a stream that reads without any time shift (the look-ahead pass's prediction, k_sync.hip: sync_ahead_kernel), as far
+// as the FIFO's two counters go: fed += n chunks, and a full frame leaves the read pointer whenever 1.5 frames are queued (the branch "shift <= 0" above
+// with shift = 0).  Preconditions (the caller's): no shift pending, the first frame already dropped, chunk = 262144.  The counters repeat every three calls
+// (3 x 262144 = 2 x 393216, two reads): whole periods are skipped in one step, so the cost does not grow with n.
+__host__ __device__ inline void fifo_skip_unshifted(int64_t& fed, int64_t& consumed, int n)
+{
+  int i = 0;
+  auto step = [&]() {
+    fed += kChunkBytes;
+    if (fed - consumed >= 3 * kTfSamples) consumed += kTfBytes;
+    ++i;
+  };
+  if (n >= 9) {
+    const int64_t queued = fed - consumed;
+    step(); step(); step();
+    if (fed - consumed == queued) {                        // two reads in three calls: the period
+      const int q = (n - i) / 3;
+      fed += static_cast<int64_t>(q) * 3 * kChunkBytes;
+      consumed += static_cast<int64_t>(q) * 2 * kTfBytes;
+      i += 3 * q;
+    }
+  }
+  while (i < n) step();
+}
+
 // the state sdr_init leaves (input_sdr.c:167-186): empty FIFO, calloc'ed (all-zero) frame buffer
 __host__ __device__ inline void fifo_reset(StreamState& st)
 {

@@ -870,24 +870,10 @@ __global__ __launch_bounds__(kThreads) void sync_ahead_kernel(const uint8_t* con
       ++i;
       continue;
     }
-    // from here to call j: fifo_call with shift 0 -- a full frame from the read pointer once 1.5 frames are queued
+    // from here to call j: fifo_call with shift 0 -- a full frame from the read pointer once 1.5 frames are queued (fifo_view.hpp)
     int64_t fed = sh.st.fed, consumed = sh.st.consumed;
-    auto step = [&]() {
-      fed += kChunkBytes;
-      if (fed - consumed >= 3 * kTfSamples) consumed += kTfBytes;
-      ++i;
-    };
-    if (j - i >= 9) {
-      const int64_t queued = fed - consumed;
-      step(); step(); step();
-      if (fed - consumed == queued) {                      // two reads in three calls: the period; whole periods in one step
-        const int q = (j - i) / 3;
-        fed += static_cast<int64_t>(q) * 3 * kChunkBytes;
-        consumed += static_cast<int64_t>(q) * 2 * kTfBytes;
-        i += 3 * q;
-      }
-    }
-    while (i < j) step();
+    fifo_skip_unshifted(fed, consumed, j - i);
+    i = j;
     if (tid == 0) { sh.st.fed = fed; sh.st.consumed = consumed; }   // (the view a full read leaves shows through nothing: this call's read rewrites the buffer)
     __syncthreads();
   }

@@ -379,6 +379,12 @@ void dabhip_host_fifo_free(dabhip_fifo *f);
 int dabhip_host_fifo_call(dabhip_fifo *f, int32_t coarse_timeshift, int32_t fine_timeshift, int32_t chunk_bytes, const uint8_t *stream,
                           int32_t *nseg, int32_t *seg_end, int64_t *seg_src, int32_t *fifo_count, uint8_t *tail);
 
+/* ncalls further calls of 262144 bytes for a FIFO that reads without any time shift, counters only: what K1's look-ahead pass (sync_ahead_kernel)
+ * predicts the stream's read pointer with, in closed form (the counters repeat every three calls).  Equals ncalls x dabhip_host_fifo_call(f, 0, 0,
+ * 262144, ...) in `fed` (bytes appended so far) and `consumed` (stream offset of the read pointer); the frame-buffer view is left as it was.
+ * Refused (-1) while a shift is pending or the first frame has not been dropped yet. */
+int dabhip_host_fifo_skip_unshifted(dabhip_fifo *f, int32_t ncalls, int64_t *fed, int64_t *consumed);
+
 /* ---- synthetic Mode-I modulator (host only) --------------------------------------------- */
 typedef struct dabhip_subch_cfg {
   int32_t id;          /* SubChId 0..63 */

@@ -408,3 +408,59 @@ def test_host_placement_plan_masks_are_numa_local_and_disjoint():
     # more slices than CPUs on a node: nobody goes unbound
     n, _ = dab.host_placement_plan([0, 0, 0], ["5-6"], 8)
     assert n == 3
+
+
+def test_look_ahead_prediction_of_the_read_pointer_equals_the_fifo_call_by_call():
+    """K1's look-ahead pass (k_sync.hip: sync_ahead_kernel) predicts where a stream's reads will begin by advancing the FIFO's counters over n calls in
+    closed form (fifo_view.hpp: fifo_skip_unshifted -- whole periods of three calls in one step).  Held here against n single calls of the FIFO itself
+    (dabhip_host_fifo_call, which the suite holds against the reference's sdr_fifo.c), from every phase of the period and after shifted reads, for
+    n from 0 to a stream of hours."""
+    import dabtools_amd as dab
+
+    def walk(prefix):                                  # a FIFO taken through `prefix` = [(coarse, fine), ...] calls -> (fifo, fed, consumed)
+        f = dab.HostFifo()
+        fed = consumed = 0
+        for cts, fts in prefix:
+            status, view, count = f.call(cts, fts)
+            fed += 262144
+            consumed = fed - count
+        f.call  # (the last call's shifts stay pending in the state: the prefixes below end with (0, 0))
+        return f, fed, consumed
+
+    prefixes = [[(0, 0)] * k for k in range(4, 10)]                                              # every phase of the three-call period
+    prefixes += [[(0, 0)] * 4 + [(293220, 0)] + [(0, -2)] + [(0, 0)] * k for k in range(1, 5)]    # behind a coarse correction and a negative fine shift
+    prefixes += [[(0, 0)] * 5 + [(0, 1236)] + [(0, -234)] + [(0, 0)] * k for k in range(2, 6)]    # behind a skipping and a short read
+    checked = 0
+    for prefix in prefixes:
+        for n in (0, 1, 2, 3, 7, 8, 9, 10, 11, 12, 13, 59, 60, 61, 1000, 16785, 100003):
+            a, fed, consumed = walk(prefix)
+            want_fed, want_consumed = fed, consumed
+            b, _, _ = walk(prefix)
+            for _ in range(min(n, 70)):                # call by call (the closed form is linear in whole periods beyond that: checked by arithmetic below)
+                status, view, count = b.call(0, 0)
+                want_fed += 262144
+                want_consumed = want_fed - count
+            got_fed, got_consumed = a.skip_unshifted(min(n, 70))
+            assert (got_fed, got_consumed) == (want_fed, want_consumed), (prefix, n)
+            if n > 70:                                 # n calls = 70 + whole periods + a remainder: the same counters as stepping the remainder after the periods
+                c, _, _ = walk(prefix)
+                big_fed, big_consumed = c.skip_unshifted(n)
+                periods = (n - 70) // 3
+                d, _, _ = walk(prefix)
+                d.skip_unshifted(70)
+                step_fed, step_consumed = d.skip_unshifted((n - 70) % 3)
+                assert (big_fed, big_consumed) == (step_fed + periods * 3 * 262144, step_consumed + periods * 2 * 393216), (prefix, n)
+            checked += 1
+            for h in (a, b):
+                h.close()
+    assert checked == len(prefixes) * 17
+    # refused while a shift is pending or before the first frame has been dropped
+    f = dab.HostFifo()
+    f.call(0, 0)
+    with pytest.raises(dab.DabhipError):
+        f.skip_unshifted(5)
+    f.close()
+    g, _, _ = walk([(0, 0)] * 5 + [(0, 16)])
+    with pytest.raises(dab.DabhipError):
+        g.skip_unshifted(5)
+    g.close()
