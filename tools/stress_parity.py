@@ -184,7 +184,7 @@ def random_channel(cfg, rng):
     return rec
 
 
-def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None, reference=False, harsh=False, layouts=False, channel=False, reconf=False, checkpoint=None):
+def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None, reference=False, harsh=False, layouts=False, channel=False, reconf=False, checkpoint=None, audit_tfs=2):
     """The sweep itself -> result dict (one record per capture under "cases").  checkpoint: a path the result so far is written to after every round
     (a run that is cut off -- the reference as checker takes minutes per round -- then leaves the rounds it finished, "rounds_finished" says how many)."""
     import dabtools_amd as dab
@@ -194,6 +194,8 @@ def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None, ref
     tmp = "/tmp/stress_parity_%d" % os.getpid()
     os.makedirs(tmp, exist_ok=True)
     eng = dab.Engine(0)
+    audit_eng = dab.Engine(0) if audit_tfs > 0 else None
+    audit = {"tfs_per_capture": audit_tfs, "decisions": 0, "disagree_guard_off": 0, "disagree_outside_band": 0, "listed_by_the_kernel": 0, "worst_bin_err_over_sqrt_energy": 0.0}
     total_frames = total_calls = 0
     bad, cases = [], []
     t0 = time.time()
@@ -206,7 +208,7 @@ def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None, ref
                 "mix": "harsh (5 dB ... clean, up to 1.4 carriers off tune, amplitudes 0.08 ... 2.5)" if harsh else "default",
                 "checker": "the reference itself: real front end over hipFFTW + real back end (oracle/_ref)" if reference else "oracle/or_replay",
                 "rounds": rounds, "rounds_finished": done, "streams_per_round": streams, "eti_frames_compared": total_frames, "calls_compared": total_calls,
-                "differences": bad, "seconds": round(time.time() - t0, 1), "seed": seed, "cases": cases}
+                "differences": bad, "decision_audit_of_the_fused_ofdm_kernel": audit, "seconds": round(time.time() - t0, 1), "seed": seed, "cases": cases}
 
     with mp.get_context("spawn").Pool(workers) as pool:
         for r in range(rounds):
@@ -241,6 +243,17 @@ def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None, ref
             pending = pool.map_async(job, [(p,) for p in paths], chunksize=1)
             eng.decode(iqs)
             got = [(eng.eti(b), eng.trace(b, iqs[b].size // 262144)[0]) for b in range(len(iqs))]
+            # the parity guard's ground, on these very captures: the one-kernel OFDM stage the decode just ran against fp64 transforms of the
+            # same samples, guard off -- how many raw fp32 decisions differ, and how many of those lie OUTSIDE the band the guard re-decides (must be 0).
+            # Any 393216 bytes serve a numerical audit: `audit_tfs` consecutive frame-sized pieces from the middle of every capture.
+            if audit_tfs > 0:
+                pieces = [iq[(iq.size // 2) // 393216 * 393216:][: audit_tfs * 393216] for iq in iqs]
+                pieces = [x[: x.size // 393216 * 393216] for x in pieces if x.size >= 393216]
+                if pieces:
+                    a = audit_eng.decision_audit(frames=np.concatenate(pieces), guard=False, fused=True)
+                    audit["decisions"] += int(a["decisions"]); audit["disagree_guard_off"] += int(a["disagree"]); audit["disagree_outside_band"] += int(a["disagree_outside_guard"])
+                    audit["listed_by_the_kernel"] += int(a["listed"])
+                    audit["worst_bin_err_over_sqrt_energy"] = max(audit["worst_bin_err_over_sqrt_energy"], float(a["max_bin_err"]))
             want = pending.get()
             for b in range(len(iqs)):
                 eti, trace = got[b]
@@ -266,6 +279,8 @@ def run(rounds=6, streams=48, tfs=24, workers=None, seed=20261002, log=None, ref
                     f.write(json.dumps(summary(r + 1)) + "\n")
                 os.replace(checkpoint + ".tmp", checkpoint)
     eng.close()
+    if audit_eng:
+        audit_eng.close()
     for f in os.listdir(tmp):
         os.remove(os.path.join(tmp, f))
     os.rmdir(tmp)
@@ -286,11 +301,12 @@ def main():
     ap.add_argument("--channel", action="store_true", help="every capture through a random impaired channel (sample-rate offset, echoes, fading, I/Q imbalance)")
     ap.add_argument("--reconf", action="store_true", help="every capture reconfigures its multiplex once or twice mid-stream")
     ap.add_argument("--checkpoint", type=str, default=None, help="write the result so far to this file after every round")
+    ap.add_argument("--audit-tfs", type=int, default=2, help="frame-sized pieces of every capture put through the decision audit of the fused OFDM kernel (0: none)")
     args = ap.parse_args()
     res = run(args.rounds, args.streams, args.tfs, args.workers, args.seed, log=sys.stderr, reference=args.reference, harsh=args.harsh, layouts=args.layouts, channel=args.channel,
-              reconf=args.reconf, checkpoint=args.checkpoint)
+              reconf=args.reconf, checkpoint=args.checkpoint, audit_tfs=args.audit_tfs)
     print(json.dumps(res))
-    sys.exit(1 if res["differences"] else 0)
+    sys.exit(1 if res["differences"] or res["decision_audit_of_the_fused_ofdm_kernel"]["disagree_outside_band"] else 0)
 
 
 if __name__ == "__main__":
