@@ -430,6 +430,17 @@ bool Engine::fic_decode_slots_async(int first, int n, uint8_t* fibs_host, uint8_
     return false;
   if (!check(launch_fib_crc(d_fibs_.get() + static_cast<size_t>(first) * 384, n * 12, d_crc_tab_.get(), d_fib_ok_.get() + static_cast<size_t>(first) * 12, ks), "fib crc launch")) return false;
   if (!check(hipEventRecord(ev_fic_done_, ks), "fic event")) return false;
+  // (few frames, page-locked destinations -- the engine's own: both downloads as one kernel that writes the host arrays itself, see scan_streams' fetch)
+  if (n <= 512 && fibs_host == h_fibs_.data() && ok_host == h_fib_ok_.data()) {
+    HostWordsArgs hw{};
+    hw.src[0] = reinterpret_cast<const uint32_t*>(d_fibs_.get() + static_cast<size_t>(first) * 384);
+    hw.dst[0] = reinterpret_cast<uint32_t*>(fibs_host);
+    hw.nwords[0] = static_cast<uint32_t>(n) * 96;
+    hw.src[1] = reinterpret_cast<const uint32_t*>(d_fib_ok_.get() + static_cast<size_t>(first) * 12);
+    hw.dst[1] = reinterpret_cast<uint32_t*>(ok_host);
+    hw.nwords[1] = static_cast<uint32_t>(n) * 3;
+    return check(launch_host_words(hw, copy), "fib download") && check(hipEventRecord(ev_fibs_, copy), "fib download event");
+  }
   return check(hipMemcpyAsync(fibs_host, d_fibs_.get() + static_cast<size_t>(first) * 384, static_cast<size_t>(n) * 384, hipMemcpyDeviceToHost, copy), "fib download") &&
          check(hipMemcpyAsync(ok_host, d_fib_ok_.get() + static_cast<size_t>(first) * 12, static_cast<size_t>(n) * 12, hipMemcpyDeviceToHost, copy), "fib flag download") &&
          check(hipEventRecord(ev_fibs_, copy), "fib download event");
@@ -896,6 +907,24 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
   // (on the side stream, behind the scan's last kernel: what the layout callback may have queued on the main stream meanwhile -- the
   // first OFDM launch -- is not waited for)
   auto fetch = [&]() {
+    // Small scans: the four downloads as ONE kernel that writes the page-locked host arrays itself (launch_host_words works in either direction: both
+    // sides are addresses the device can reach) instead of four copy-engine commands in a row, each some microseconds of the host waiting.
+    const size_t words = (split_scan ? nstreams + 1 : 0) + (split_scan && use_spec ? 1 : 0) + ndesc * 2 + static_cast<size_t>(nstreams) * (sizeof(StreamState) / 4);
+    if (words <= (size_t(1) << 18)) {
+      HostWordsArgs hw{};
+      int k = 0;
+      auto add = [&](const void* src, void* dst, size_t n) {
+        hw.src[k] = static_cast<const uint32_t*>(src);
+        hw.dst[k] = static_cast<uint32_t*>(dst);
+        hw.nwords[k++] = static_cast<uint32_t>(n);
+      };
+      if (split_scan) add(d_viol_.get(), h_viol_.data(), nstreams + 1);
+      if (split_scan && use_spec) add(d_spec_ctl_.get() + nstreams, h_spec_hits_.data(), 1);
+      add(d_info_.get(), h_info_.data(), ndesc * 2);
+      add(d_states_.get(), states, static_cast<size_t>(nstreams) * (sizeof(StreamState) / 4));
+      return check(hipStreamWaitEvent(copy_stream_, ev_[1], 0), "scan event") && check(launch_host_words(hw, copy_stream_), "scan results download") &&
+             check(hipStreamSynchronize(copy_stream_), "sync scan");
+    }
     return check(hipStreamWaitEvent(copy_stream_, ev_[1], 0), "scan event") &&
            (!split_scan || check(hipMemcpyAsync(h_viol_.data(), d_viol_.get(), (nstreams + 1) * sizeof(int), hipMemcpyDeviceToHost, copy_stream_), "violation download")) &&
            (!(split_scan && use_spec) || check(hipMemcpyAsync(h_spec_hits_.data(), d_spec_ctl_.get() + nstreams, sizeof(int), hipMemcpyDeviceToHost, copy_stream_), "look-ahead hits download")) &&
