@@ -6,10 +6,14 @@
 // dab_coarse_freq_sync_2 (:205-258) and dab_fine_freq_corr (:259-302).
 //
 // The chain is sequential per stream (the timing correction found in TF n positions TF
-// n+1) and independent across streams, so one 256-thread workgroup owns one stream for
+// n+1) and independent across streams, so one 512-thread workgroup owns one stream for
 // the whole scan: no inter-workgroup traffic, B workgroups in flight.  Arithmetic is fp64
 // like the reference's FFTW calls (two 2048-point DFTs, one 1536-point and 29 128-point
 // inverse DFTs per TF); arg-max decisions use the reference's float compare, first hit wins.
+// Kernels: sync_scan_kernel (the chain; <true> = only what the next call depends on, the rest left to
+// sync_verify32_kernel / sync_verify_kernel / sync_carry_kernel, which run over all calls at once),
+// sync_ahead_kernel (small batches: the chain's estimators for every remaining call at every start
+// position near the predicted one, so that the chain only looks them up).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -640,7 +644,7 @@ __device__ __forceinline__ int2 ahead_lookup(int nhyp, const AheadRow& row, cons
 //   assumption fails is scanned again in full (Engine::scan_streams).  Not with the software AFC, where the NCO of the next
 //   frame depends on both estimates.
 // ONE call of sdr_demod (input_sdr.c:27-112) on the workgroup's shared state: call k of the stream, descriptor k - kdesc0.  The body of the chain's loop
-// (sync_scan_kernel) and of the speculative pass (sync_spec_kernel).  Ends with a barrier.
+// (sync_scan_kernel).  Ends with a barrier.
 // a call's update of the tail bytes whose loads are still in flight: taken up at the start of the next call (TailPending below)
 struct TailPending {
   TailUpdate upd;
