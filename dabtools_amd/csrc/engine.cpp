@@ -196,11 +196,10 @@ Engine::~Engine()
 // ---------------------------------------------------------------------------------------------
 bool Engine::upload_small(const SmallUpload* items, int n, hipStream_t s, PinnedBuffer<uint32_t>& staging)
 {
-  size_t total = 0, staged = 0;
+  size_t total = 0;
   bool words = true;
   for (int i = 0; i < n; ++i) {
     total += items[i].bytes;
-    if (!items[i].pinned) staged += (items[i].bytes + 3) / 4;
     words = words && items[i].bytes % 4 == 0 && reinterpret_cast<uintptr_t>(items[i].src) % 4 == 0;
   }
   if (!words || total > kSmallUploadBytes) {
@@ -229,7 +228,6 @@ bool Engine::upload_small(const SmallUpload* items, int n, hipStream_t s, Pinned
       k = 0;
     }
   }
-  (void)staged;
   return k == 0 || check(launch_host_words(hw, s), "work list upload");
 }
 
