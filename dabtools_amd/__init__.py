@@ -572,7 +572,7 @@ class Engine:
         _need(lib().dabhip_engine_set_fused(self._h, 1 if enable else 0) == 0, "set_fused")
 
     def set_sync_speculation(self, mode):
-        """K1's chain: 0 = call after call, 1 = speculative rounds, -1 (default) = rounds for small batches.  Identical results."""
+        """K1's chain: 0 = call after call, 1 = with the look-ahead pass, -1 (default) = the pass for small batches.  Identical results."""
         _need(lib().dabhip_engine_set_sync_speculation(self._h, int(mode)) == 0, "set_sync_speculation")
 
     def set_parity_guard(self, enable):

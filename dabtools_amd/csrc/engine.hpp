@@ -166,7 +166,7 @@ class Engine {
   // kernels K2 (the HBM-roofline stage of SURVEY.md 8(d), always measurable on its own: fft_roofline) and K2b.  The output
   // bits are identical either way.
   void set_fused(bool on) { fused_ = on; }
-  // K1's chain: 0 = call after call, 1 = speculative rounds, -1 = rounds for small batches (include/dabhip.h: dabhip_engine_set_sync_speculation)
+  // K1's chain: 0 = call after call, 1 = with the look-ahead pass, -1 = the pass for small batches (include/dabhip.h: dabhip_engine_set_sync_speculation)
   void set_sync_speculation(int mode) { spec_mode_ = mode < 0 ? -1 : (mode > 0 ? 1 : 0); }
   // sub-channel filter (TODO.md:28-31): bit i = SubChId i is decoded and carried in the ETI frames; takes effect with the next
   // decode() / first segment of a session.  All ones (default) = the reference's frames.
