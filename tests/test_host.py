@@ -464,3 +464,18 @@ def test_look_ahead_prediction_of_the_read_pointer_equals_the_fifo_call_by_call(
     with pytest.raises(dab.DabhipError):
         g.skip_unshifted(5)
     g.close()
+
+
+def test_documents_name_profile_files_that_exist_and_hold_no_placeholders():
+    """README / DESIGN / COVERAGE / INTEGRATION / profiles/README quote measurements by file: every profiles/rNN_* they name is in the tree, and no
+    unfilled placeholder is left in them."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    missing = []
+    for doc in ("README.md", "DESIGN.md", "COVERAGE.md", "INTEGRATION.md", os.path.join("profiles", "README.md")):
+        text = open(os.path.join(root, doc)).read()
+        names = set(re.findall(r"profiles/(r0\d_[A-Za-z0-9_.\-]+\.(?:json|txt|csv))", text))
+        if doc.endswith(os.path.join("profiles", "README.md")):
+            names |= set(re.findall(r"`(r0\d_[A-Za-z0-9_.\-]+\.(?:json|txt|csv))`", text))
+        missing += [(doc, n) for n in sorted(names) if not os.path.exists(os.path.join(root, "profiles", n))]
+        assert not re.search(r"\bR\d_[A-Z]+\b|TODO|TBD|XXX", text), doc
+    assert not missing, missing
