@@ -39,7 +39,7 @@ SIMDS, XCDS = 256 * 4, 8
 # profile of the round, produced by tools/refresh_profiles.sh (rocprofv3 passes over THIS script) -- never baked in here.
 PROFILE_PMC = os.path.join(ROOT, "profiles", "r05_pmc_summary.csv")
 # static instruction mix of the fused OFDM kernel's symbol loop, priced in issue cycles (tools/fused_isa_mix.sh; CPU only)
-PROFILE_FUSED_MIX = os.path.join(ROOT, "profiles", "r05_fused_isa_mix.json")
+PROFILE_FUSED_MIX = os.path.join(ROOT, "profiles", "r06_fused_isa_mix.json")
 # issue cost of a wave64 VALU instruction on gfx950 (MI355X_MICROARCH.md, per-instruction table: v_fma_f32 2 cycles; tools/ubench/valu_rates.hip,
 # profiles/r03_valu_rates.txt: plain 32-bit VOP1/VOP2 2, every VOP3 / VOP3P / DPP / 64-bit form 4)
 CYC_SIMPLE, CYC_VOP3 = 2.0, 4.0
@@ -599,6 +599,10 @@ def run_rank(args, coord):
         coord.barrier()
         frames = 4 * (args.tfs - 15) * len(mine)
         stage, fft, fused_off, extra = {}, None, None, {}
+        # (no GPU: a stand-in identity, so that the distinct-devices check below runs in the CPU suite too)
+        rank_info["device"] = {"index": 0 if os.environ.get("DABHIP_BENCH_ONE_DEVICE") == "1" else rank,
+                               "pci_bus_id": os.environ.get("DABHIP_BENCH_DRY_BUS_ID") or "dry-run:%02d" % (0 if os.environ.get("DABHIP_BENCH_ONE_DEVICE") == "1" else rank),
+                               "name": "none (dry run)"}                   # (DABHIP_BENCH_DRY_BUS_ID: test knob -- every rank claims this device)
     else:
         import torch
         import dabtools_amd as dab
@@ -609,6 +613,8 @@ def run_rank(args, coord):
             local_rank = int(os.environ["DABHIP_BENCH_DEVICE"])            # launch_ranks made this rank's GPU the only visible one
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
+        bus_id, dev_name = dab.device_identity(local_rank)                 # which physical GPU this rank decodes on (checked across ranks by rank 0)
+        rank_info["device"] = {"index": local_rank, "pci_bus_id": bus_id, "name": dev_name}
         t_gen = time.perf_counter()
         tensors, ndistinct = make_streams(torch, dev, args.streams, args.tfs, min(args.distinct, args.streams), rank, args.snr, args.host_synth)
         torch.cuda.synchronize()
@@ -737,6 +743,16 @@ def run_rank(args, coord):
     rank_info["host_ms_per_step"] = {k: round(stage[k], 4) for k in ("control", "host_worklist", "host_setup", "host_frames", "wall") if k in stage}
     rows = coord.gather({"info": rank_info, "elapsed": elapsed, "frames": frames})
     if rank == 0:
+        # N ranks must have sat on N distinct GPUs, or the aggregate is not an N-GPU figure: shown by the PCI bus ids, refused otherwise -- except in
+        # the declared one-GPU rehearsal (DABHIP_BENCH_ONE_DEVICE=1), which the line then says of itself
+        bus_ids = [r["info"].get("device", {}).get("pci_bus_id") for r in rows]
+        distinct = len(set(bus_ids))
+        rehearsal = os.environ.get("DABHIP_BENCH_ONE_DEVICE") == "1"
+        if distinct != world and not rehearsal:
+            sys.stderr.write("bench.py: %d ranks decoded on %d distinct devices (%s): not a %d-GPU measurement -- no line printed "
+                             "(DABHIP_BENCH_ONE_DEVICE=1 declares a one-GPU rehearsal)\n" % (world, distinct, ", ".join(map(str, bus_ids)), world))
+            coord.close()
+            sys.exit(3)
         elapsed_max = max(r["elapsed"] for r in rows)
         frames_step = sum(r["frames"] for r in rows)
         value = frames_step * args.steps / elapsed_max
@@ -758,7 +774,11 @@ def run_rank(args, coord):
                        "eti_frames_per_step": frames_step, "ofdm_stage": ofdm_stage,
                        "sharding": "independent ensembles, %d per GPU, stream s on rank s // %d, no collective" % (args.streams, args.streams)},
             "ranks": [dict(r["info"], elapsed_s=r["elapsed"], eti_frames_per_step=r["frames"]) for r in rows],
+            "devices": {"distinct_pci_bus_ids": distinct, "pci_bus_ids": bus_ids, "names": sorted(set(r["info"].get("device", {}).get("name") for r in rows)),
+                        "rehearsal_on_one_device": rehearsal and world > 1},
         }
+        if rehearsal and world > 1:
+            out["devices"]["note"] = "DABHIP_BENCH_ONE_DEVICE=1: all %d ranks share one GPU -- a rehearsal of the %d-rank path, NOT a %d-GPU figure" % (world, world, world)
         if args.dry_run:
             out["dry_run"] = True
         if stage:
@@ -825,6 +845,9 @@ def run_in_process(args):
         st = multi.engine(i).stage_ms()
         per_slice.append({"slice": i, "device": devices[i], "wall_ms": round(multi.wall_ms(i), 3), "control_ms": round(st["control"], 3),
                           "host_worklist_ms": round(st["host_worklist"], 3), "eti_frames": sum(multi.eti_count(b) for b in range(i * args.streams, (i + 1) * args.streams))})
+    ids = [dab.device_identity(d)[0] for d in devices]
+    if len(set(ids)) != n and not one_device:
+        sys.exit("bench.py: %d slices on %d distinct devices: not a %d-GPU measurement" % (n, len(set(ids)), n))
     print(json.dumps({
         "metric": "ETI frames/s (24 ms each), Mode-I batch, synthetic IQ resident in HBM", "value": value, "unit": "ETI frames/s", "x_realtime": value / REALTIME_FPS,
         "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -832,7 +855,8 @@ def run_in_process(args):
         "config": {"workload": workload_text(args), "streams_per_gpu": args.streams, "tf_per_stream": args.tfs, "eti_frames_per_step": frames,
                    "launch": "in-process: dabhip_multi over devices %s (one engine + host thread per entry)" % devices,
                    "sharding": "independent ensembles, %d per slice, stream s on slice s // %d, no collective" % (args.streams, args.streams)},
-        "slices": per_slice}))
+        "slices": per_slice,
+        "devices": {"distinct_pci_bus_ids": len(set(ids)), "pci_bus_ids": ids, "rehearsal_on_one_device": one_device and n > 1}}))
 
 
 def main():

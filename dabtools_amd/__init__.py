@@ -76,6 +76,7 @@ ETI_CALLBACK = C.CFUNCTYPE(None, u8p)
 _SIGNATURES = {
     "dabhip_last_error": (C.c_char_p, []),
     "dabhip_device_count": (C.c_int, []),
+    "dabhip_device_identity": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int]),
     "dabhip_create_viterbi": (C.c_void_p, [C.c_int]),
     "dabhip_init_viterbi": (C.c_int, []),
     "dabhip_viterbi": (None, [C.c_void_p, u8p, u8p, C.c_int]),
@@ -130,6 +131,34 @@ _SIGNATURES = {
     "dabhip_host_parse_fibs": (C.c_int, [u8p, u8p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "dabhip_host_eti_header": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), u8p, C.c_int]),
     "dabhip_host_control_replay": (C.c_int, [u8p, u8p, C.c_int, C.POINTER(C.c_int32), u8p, C.POINTER(C.c_int32), C.c_int]),
+    "dabhip_host_control_replay_log": (C.c_int64, [C.c_char_p, C.c_int64]),
+    "dabhip_engine_stream_log": (C.c_int64, [C.c_void_p, C.c_int, C.c_char_p, C.c_int64]),
+    "dabhip_stream_log": (C.c_int64, [C.c_void_p, C.c_int, C.c_char_p, C.c_int64]),
+    "dabhip_multi_stream_log": (C.c_int64, [C.c_void_p, C.c_int, C.c_char_p, C.c_int64]),
+    "dabhip_multi_stream_log_of": (C.c_int64, [C.c_void_p, C.c_int, C.c_char_p, C.c_int64]),
+    "dabhip_dab_take_log": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "dabhip_stream_create_on_cpus": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int]),
+    "dabhip_multi_stream_create": (C.c_void_p, [C.POINTER(C.c_int), C.c_int, C.c_int]),
+    "dabhip_multi_stream_destroy": (None, [C.c_void_p]),
+    "dabhip_multi_stream_slices": (C.c_int, [C.c_void_p]),
+    "dabhip_multi_stream_streams": (C.c_int, [C.c_void_p]),
+    "dabhip_multi_stream_slice_of": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dabhip_multi_stream_session": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "dabhip_multi_stream_prefetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int]),
+    "dabhip_multi_stream_feed": (C.c_int64, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int]),
+    "dabhip_multi_stream_feed_resident": (C.c_int64, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "dabhip_multi_stream_need_from": (C.c_int64, [C.c_void_p, C.c_int]),
+    "dabhip_multi_stream_eti_count": (C.c_int64, [C.c_void_p, C.c_int]),
+    "dabhip_multi_stream_status_of": (C.c_uint32, [C.c_void_p, C.c_int]),
+    "dabhip_multi_stream_eti_read": (C.c_int64, [C.c_void_p, C.c_int, u8p, C.c_int64]),
+    "dabhip_multi_stream_eti_drain": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dabhip_multi_stream_eti_fetch": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "dabhip_multi_stream_eti_fetch_wait": (C.c_int, [C.c_void_p]),
+    "dabhip_multi_stream_set_afc": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_multi_stream_set_soft": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_multi_stream_set_parity_guard": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_multi_stream_set_sync_speculation": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_multi_stream_set_subchannels": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
     "dabhip_host_table": (C.c_int, [C.c_int, C.POINTER(C.c_int32), C.c_int]),
     "dabhip_host_fifo_new": (C.c_void_p, []),
     "dabhip_host_fifo_free": (None, [C.c_void_p]),
@@ -145,6 +174,9 @@ _SIGNATURES = {
     "dabhip_engine_set_sync_speculation": (C.c_int, [C.c_void_p, C.c_int]),
     "dabhip_stream_set_sync_speculation": (C.c_int, [C.c_void_p, C.c_int]),
     "dabhip_engine_set_parity_guard": (C.c_int, [C.c_void_p, C.c_int]),
+    "dabhip_engine_parity_guard_level": (C.c_int, [C.c_void_p]),
+    "dabhip_parity_guard_default_level": (C.c_int, []),
+    "dabhip_parity_guard_constants": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dabhip_engine_guard_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "dabhip_engine_guard_overflows": (C.c_int, [C.c_void_p]),
     "dabhip_engine_set_guard_list_cap": (C.c_int, [C.c_void_p, C.c_uint32]),
@@ -233,6 +265,33 @@ def _p(a):
 def _need(cond, what):
     if not cond:
         raise DabhipError("%s: %s" % (what, last_error()))
+
+
+def device_identity(device):
+    """(PCI bus id, name) of a device index (dabhip_device_identity)."""
+    bus, name = C.create_string_buffer(64), C.create_string_buffer(256)
+    _need(lib().dabhip_device_identity(int(device), bus, len(bus), name, len(name)) == 0, "device_identity")
+    return bus.value.decode(), name.value.decode()
+
+
+def _guard_level(level):
+    """False / 0 -> off, True -> the library's default level (-1), 1 / 2 -> that level (dabhip.h: DABHIP_GUARD_*)."""
+    if level is True:
+        return -1
+    if level is False or level is None:
+        return 0
+    return int(level)
+
+
+def guard_constants(level):
+    """(bound on a bin's error relative to |x|_2, bound on the product's rounding relative to |cur|_1 |prev|_1) of guard level 1 or 2."""
+    a, b = C.c_double(0), C.c_double(0)
+    _need(lib().dabhip_parity_guard_constants(int(level), C.byref(a), C.byref(b)) == 0, "parity_guard_constants")
+    return a.value, b.value
+
+
+def guard_default_level():
+    return lib().dabhip_parity_guard_default_level()
 
 
 # ---- synthetic modulator --------------------------------------------------------------------
@@ -374,6 +433,13 @@ def host_control_replay(fibs, crc_ok):
                                          hlen.ctypes.data_as(C.POINTER(C.c_int32)), cap)
     _need(n >= 0, "host_control_replay")
     return first[:n], [hdrs[i, :hlen[i]].copy() for i in range(n)]
+
+
+def host_control_replay_log():
+    """The operator messages (dab.c:51,57,78-82) of this thread's last host_control_replay, as text."""
+    buf = C.create_string_buffer(1 << 16)
+    _need(lib().dabhip_host_control_replay_log(buf, len(buf)) >= 0, "host_control_replay_log")
+    return buf.value.decode("ascii")
 
 
 def host_placement_plan(slice_node, node_cpulist, ncpu):
@@ -523,6 +589,12 @@ class Dab:
     def locked(self):
         return bool(lib().dabhip_dab_locked(self._h))
 
+    def take_log(self):
+        """What the reference's dab_process_frame would have printed on stderr since the last call (dabhip_dab_take_log)."""
+        buf = C.create_string_buffer(1 << 16)
+        _need(lib().dabhip_dab_take_log(self._h, buf, len(buf)) >= 0, "dab_take_log")
+        return buf.value.decode("ascii")
+
     @property
     def status(self):
         return int(lib().dabhip_dab_status(self._h))
@@ -575,9 +647,13 @@ class Engine:
         """K1's chain: 0 = call after call, 1 = with the look-ahead pass, -1 (default) = the pass for small batches.  Identical results."""
         _need(lib().dabhip_engine_set_sync_speculation(self._h, int(mode)) == 0, "set_sync_speculation")
 
-    def set_parity_guard(self, enable):
-        """True (default): decisions inside the fp32 error band are re-decided in fp64 -> bits of exact arithmetic."""
-        _need(lib().dabhip_engine_set_parity_guard(self._h, 1 if enable else 0) == 0, "set_parity_guard")
+    def set_parity_guard(self, level=True):
+        """Decisions inside the fp32 error band are re-decided in fp64 -> bits of exact arithmetic.  level: False / 0 = off, 1 = the measured
+        band, 2 = the proven band, True = the library's default level (dabhip.h: DABHIP_GUARD_*)."""
+        _need(lib().dabhip_engine_set_parity_guard(self._h, _guard_level(level)) == 0, "set_parity_guard")
+
+    def parity_guard_level(self):
+        return lib().dabhip_engine_parity_guard_level(self._h)
 
     def guard_stats(self):
         """(decisions re-decided by the parity guard, hard decisions taken) of the last decode."""
@@ -662,6 +738,13 @@ class Engine:
     def stream_status(self, stream):
         """dabhip_engine_stream_status: 0 = fine, else STREAM_* fault bits (the stream emitted no frames while its multiplex was un-assemblable)."""
         return int(lib().dabhip_engine_stream_status(self._h, stream))
+
+    def log(self, stream):
+        """The reference's operator messages for one stream of the last decode, cleared by the call (dabhip_engine_stream_log): 'Locked' (dab.c:51),
+        'Lock lost, resetting ringbuffer' (dab.c:57), the one-time ensemble dump (dab.c:78-82, misc.c:316-328)."""
+        buf = C.create_string_buffer(1 << 16)
+        _need(lib().dabhip_engine_stream_log(self._h, stream, buf, len(buf)) >= 0, "engine_stream_log")
+        return buf.value.decode("ascii")
 
     def eti_fetch(self, dst_ptr, cap_frames):
         """dabhip_engine_eti_fetch: all frames of the last decode (stream-major) on their way to (page-locked) host memory."""
@@ -778,8 +861,8 @@ class Multi:
     def set_soft(self, enable):
         self._set(lib().dabhip_multi_set_soft, enable)
 
-    def set_parity_guard(self, enable):
-        self._set(lib().dabhip_multi_set_parity_guard, enable)
+    def set_parity_guard(self, level=True):
+        _need(lib().dabhip_multi_set_parity_guard(self._h, _guard_level(level)) == 0, "multi_set_parity_guard")
 
     def set_fused(self, enable):
         self._set(lib().dabhip_multi_set_fused, enable)
@@ -830,6 +913,11 @@ class Multi:
     def eti_count(self, stream):
         return lib().dabhip_multi_eti_count(self._h, stream)
 
+    def log(self, stream):
+        buf = C.create_string_buffer(1 << 16)
+        _need(lib().dabhip_multi_stream_log(self._h, stream, buf, len(buf)) >= 0, "multi_stream_log")
+        return buf.value.decode("ascii")
+
     def eti(self, stream):
         n = lib().dabhip_multi_eti_count(self._h, stream)
         _need(n >= 0, "multi_eti_count")
@@ -878,17 +966,39 @@ class Stream:
     """Streaming session (dabhip_stream_*): B unbounded captures decoded segment by segment; the concatenated ETI
     frames equal one Engine.decode of the whole captures."""
 
-    def __init__(self, nstreams, device=0, afc=False, soft=False, subchannels=None):
+    _PREFIX = "dabhip_stream_"
+    _RENAMED = {}
+
+    def _f(self, name):
+        return getattr(lib(), self._PREFIX + self._RENAMED.get(name, name))
+
+    def __init__(self, nstreams, device=0, afc=False, soft=False, subchannels=None, guard=None):
         self._h = lib().dabhip_stream_create(device, nstreams)
         _need(self._h, "stream_create")
         self.nstreams = nstreams
+        self._configure(afc, soft, subchannels, guard)
+
+    def _configure(self, afc, soft, subchannels, guard):
         if subchannels:
             ids = list(subchannels)
-            _need(lib().dabhip_stream_set_subchannels(self._h, (C.c_int32 * len(ids))(*ids), len(ids)) == 0, "stream_set_subchannels")
+            _need(self._f("set_subchannels")(self._h, (C.c_int32 * len(ids))(*ids), len(ids)) == 0, "stream_set_subchannels")
         if afc:
-            _need(lib().dabhip_stream_set_afc(self._h, 1) == 0, "stream_set_afc")
+            _need(self._f("set_afc")(self._h, 1) == 0, "stream_set_afc")
         if soft:
-            _need(lib().dabhip_stream_set_soft(self._h, 1) == 0, "stream_set_soft")
+            _need(self._f("set_soft")(self._h, 1) == 0, "stream_set_soft")
+        if guard is not None:
+            self.set_parity_guard(guard)
+
+    def set_parity_guard(self, level=True):
+        """see Engine.set_parity_guard"""
+        _need(self._f("set_parity_guard")(self._h, _guard_level(level)) == 0, "stream_set_parity_guard")
+
+    def log(self, stream):
+        """The reference's operator messages for one stream since the last call (dabhip_stream_log): 'Locked', 'Lock lost, resetting ringbuffer', ensemble dump."""
+        buf = C.create_string_buffer(1 << 16)
+        n = self._f("log")(self._h, stream, buf, len(buf))
+        _need(n >= 0, "stream_log")
+        return buf.value.decode("ascii")
 
     def feed(self, segments):
         """segments: one numpy uint8 array (possibly empty) per stream -> ETI frames produced by this segment."""
@@ -896,7 +1006,7 @@ class Stream:
         _need(len(arrs) == self.nstreams, "stream_feed: one segment per stream")
         ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
         sizes = (C.c_size_t * len(arrs))(*[a.size for a in arrs])
-        n = lib().dabhip_stream_feed(self._h, ptrs, sizes, 0)
+        n = self._f("feed")(self._h, ptrs, sizes, 0)
         _need(n >= 0, "stream_feed")
         return n
 
@@ -904,7 +1014,7 @@ class Stream:
         """feed() over raw addresses (page-locked host memory from host_alloc(), or device memory)."""
         p = (C.c_void_p * len(ptrs))(*ptrs)
         s = (C.c_size_t * len(sizes))(*sizes)
-        n = lib().dabhip_stream_feed(self._h, p, s, 1 if on_device else 0)
+        n = self._f("feed")(self._h, p, s, 1 if on_device else 0)
         _need(n >= 0, "stream_feed")
         return n
 
@@ -913,25 +1023,25 @@ class Stream:
         avail[b] = bytes there now."""
         p = (C.c_void_p * len(base_ptrs))(*base_ptrs)
         a = (C.c_size_t * len(avail))(*avail)
-        n = lib().dabhip_stream_feed_resident(self._h, p, a)
+        n = self._f("feed_resident")(self._h, p, a)
         _need(n >= 0, "stream_feed_resident")
         return n
 
     def need_from(self, stream):
-        return int(lib().dabhip_stream_need_from(self._h, stream))
+        return int(self._f("need_from")(self._h, stream))
 
     def prefetch_ptrs(self, ptrs, sizes, on_device=False):
         """dabhip_stream_prefetch: start uploading the segment a later feed_ptrs() with the same arguments will consume."""
         p = (C.c_void_p * len(ptrs))(*ptrs)
         s = (C.c_size_t * len(sizes))(*sizes)
-        _need(lib().dabhip_stream_prefetch(self._h, p, s, 1 if on_device else 0) == 0, "stream_prefetch")
+        _need(self._f("prefetch")(self._h, p, s, 1 if on_device else 0) == 0, "stream_prefetch")
 
     def status(self, stream):
-        return int(lib().dabhip_stream_status(self._h, stream))
+        return int(self._f("status")(self._h, stream))
 
     def set_sync_speculation(self, mode):
         """see Engine.set_sync_speculation"""
-        _need(lib().dabhip_stream_set_sync_speculation(self._h, int(mode)) == 0, "stream_set_sync_speculation")
+        _need(self._f("set_sync_speculation")(self._h, int(mode)) == 0, "stream_set_sync_speculation")
 
     def stage_ms(self):
         names = (C.c_char_p * 16)()
@@ -941,24 +1051,27 @@ class Stream:
 
     def eti_fetch(self, dst_ptr, cap_frames):
         """dabhip_stream_eti_fetch: all frames of the segment fed last on their way to (page-locked) host memory; returns their number."""
-        n = lib().dabhip_stream_eti_fetch(self._h, dst_ptr, cap_frames)
+        n = self._f("eti_fetch")(self._h, dst_ptr, cap_frames)
         _need(n >= 0, "stream_eti_fetch")
         return n
 
     def eti_fetch_wait(self):
-        _need(lib().dabhip_stream_eti_fetch_wait(self._h) == 0, "stream_eti_fetch_wait")
+        _need(self._f("eti_fetch_wait")(self._h) == 0, "stream_eti_fetch_wait")
+
+    def eti_count(self, stream):
+        return int(self._f("eti_count")(self._h, stream))
 
     def eti(self, stream):
-        n = lib().dabhip_stream_eti_count(self._h, stream)
+        n = self._f("eti_count")(self._h, stream)
         _need(n >= 0, "stream_eti_count")
         out = np.zeros((n, ETI_BYTES), dtype=np.uint8)
         if n:
-            _need(lib().dabhip_stream_eti_read(self._h, stream, _p(out), n) == n, "stream_eti_read")
+            _need(self._f("eti_read")(self._h, stream, _p(out), n) == n, "stream_eti_read")
         return out
 
     def close(self):
         if self._h:
-            lib().dabhip_stream_destroy(self._h)
+            self._f("destroy")(self._h)
             self._h = None
 
     def __del__(self):
@@ -966,3 +1079,34 @@ class Stream:
             self.close()
         except Exception:
             pass
+
+
+class MultiStream(Stream):
+    """Sessions over several devices (dabhip_multi_stream_*): nstreams unbounded captures dealt ONCE to the listed devices in contiguous slices (the rule
+    of Multi.plan), every slice a complete Stream session on its device; every call is made on all slices at once.  Frames per segment and in total are
+    those of one Stream over all captures.  A device may be listed several times (every entry is its own slice)."""
+    _PREFIX = "dabhip_multi_stream_"
+    _RENAMED = {"status": "status_of", "log": "log_of"}
+
+    def __init__(self, nstreams, devices, afc=False, soft=False, subchannels=None, guard=None):
+        devs = list(devices)
+        self._h = lib().dabhip_multi_stream_create((C.c_int * len(devs))(*devs), len(devs), nstreams)
+        _need(self._h, "multi_stream_create")
+        self.nstreams = nstreams
+        self.devices = devs
+        self._configure(afc, soft, subchannels, guard)
+
+    def slice_of(self, stream):
+        """(slice, device, first stream of the slice, streams in the slice)"""
+        dev, first, count = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        sl = lib().dabhip_multi_stream_slice_of(self._h, stream, C.byref(dev), C.byref(first), C.byref(count))
+        _need(sl >= 0, "multi_stream_slice_of")
+        return sl, dev.value, first.value, count.value
+
+    def stage_ms(self, slice_index=0):
+        h = lib().dabhip_multi_stream_session(self._h, slice_index)
+        _need(h, "multi_stream_session")
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = lib().dabhip_stream_stage_ms(h, names, ms, 16)
+        return {names[i].decode(): ms[i] for i in range(n)}

@@ -178,6 +178,21 @@ int64_t dabhip_engine_eti_read(dabhip_engine* e, int stream, uint8_t* dst, int64
   if (stream < 0 || stream >= static_cast<int>(e->lane_of.size())) { set_error("eti_read: bad stream"); return -1; }
   return e->lanes[e->lane_of[stream]]->eti_read(e->local_of[stream], dst, cap_frames);
 }
+// copy `text` into buf (NUL-terminated, cut at cap - 1 bytes); returns the length of the whole text
+static int64_t hand_over_text(const std::string& text, char* buf, int64_t cap)
+{
+  if (buf && cap > 0) {
+    const size_t n = std::min(text.size(), static_cast<size_t>(cap - 1));
+    std::memcpy(buf, text.data(), n);
+    buf[n] = 0;
+  }
+  return static_cast<int64_t>(text.size());
+}
+int64_t dabhip_engine_stream_log(dabhip_engine* e, int stream, char* buf, int64_t cap)
+{
+  if (!e || stream < 0 || stream >= static_cast<int>(e->lane_of.size())) return -1;
+  return hand_over_text(e->lanes[e->lane_of[stream]]->take_stream_log(e->local_of[stream]), buf, cap);
+}
 int64_t dabhip_engine_eti_fetch(dabhip_engine* e, uint8_t* dst, int64_t cap_frames)
 {
   if (!e || !dst) { set_error("eti_fetch: null argument"); return -1; }
@@ -297,10 +312,19 @@ int dabhip_engine_set_subchannels(dabhip_engine* e, const int32_t* ids, int n)
   for (auto& l : e->lanes) l->set_subchannel_filter(subchannel_mask(ids, n));
   return 0;
 }
-int dabhip_engine_set_parity_guard(dabhip_engine* e, int enable)
+int dabhip_engine_set_parity_guard(dabhip_engine* e, int level)
 {
   if (!e) return -1;
-  for (auto& l : e->lanes) l->set_parity_guard(enable != 0);
+  for (auto& l : e->lanes) l->set_parity_guard(level);
+  return 0;
+}
+int dabhip_engine_parity_guard_level(const dabhip_engine* e) { return e ? e->lanes[0]->parity_guard_level() : -1; }
+int dabhip_parity_guard_default_level(void) { return dabhip::kDefaultGuardLevel; }
+int dabhip_parity_guard_constants(int level, double* bin_c, double* prod_c)
+{
+  if (level < 1 || level > 2) return -1;
+  if (bin_c) *bin_c = dabhip::guard_c_of(level);
+  if (prod_c) *prod_c = dabhip::guard_prod_of(level);
   return 0;
 }
 int dabhip_engine_guard_stats(const dabhip_engine* e, int64_t* flagged, int64_t* decisions)
@@ -533,6 +557,7 @@ void dabhip_dab_free(dabhip_dab* d) { delete d; }
 uint8_t* dabhip_dab_tf_fic(dabhip_dab* d) { return d ? d->fic.data() : nullptr; }
 uint8_t* dabhip_dab_tf_msc(dabhip_dab* d) { return d ? d->msc.data() : nullptr; }
 int dabhip_dab_locked(const dabhip_dab* d) { return d && d->plane.locked(); }
+int64_t dabhip_dab_take_log(dabhip_dab* d, char* buf, int64_t cap) { return d ? hand_over_text(d->plane.take_log(), buf, cap) : -1; }
 uint32_t dabhip_dab_status(const dabhip_dab* d) { return d ? d->plane.fault() : 0xffffffffu; }
 int dabhip_dab_set_soft(dabhip_dab* d, int enable)
 {
@@ -614,6 +639,9 @@ int dabhip_host_eti_header(const int32_t* hdr3, const int32_t* sub, uint8_t* out
   return build_eti_header(out, info);
 }
 
+// the operator messages (ControlPlane::take_log) of the calling thread's last dabhip_host_control_replay
+static thread_local std::string g_replay_log;
+int64_t dabhip_host_control_replay_log(char* buf, int64_t cap) { return hand_over_text(g_replay_log, buf, cap); }
 int dabhip_host_control_replay(const uint8_t* fibs, const uint8_t* crc_ok, int ntf, int32_t* first_cif, uint8_t* headers,
                                int32_t* header_len, int cap_frames)
 {
@@ -621,6 +649,7 @@ int dabhip_host_control_replay(const uint8_t* fibs, const uint8_t* crc_ok, int n
   ControlPlane plane;
   JobList jobs;
   for (int t = 0; t < ntf; ++t) plane.on_tf(t, fibs + static_cast<size_t>(t) * 384, crc_ok + static_cast<size_t>(t) * 12, jobs);
+  g_replay_log = plane.take_log();
   const int n = static_cast<int>(jobs.size());
   for (int i = 0; i < n && i < cap_frames; ++i) {
     first_cif[i] = jobs[i].first_cif;
@@ -758,7 +787,8 @@ struct dabhip_stream {
   DeviceBuffer<CopyDesc> d_gather_descs[3];
   struct Pending { std::vector<const uint8_t*> iq; std::vector<size_t> nbytes; };
   Pending pending[3];                          // what was prefetched into window i (checked against the feed that consumes it)
-  dabhip_stream(int device, int nstreams) : eng(device), n(nstreams), base(nstreams, 0), avail(nstreams, 0), org(nstreams, 0)
+  dabhip_stream(int device, int nstreams, int host_threads = 0, std::vector<int> cpus = {})
+      : eng(device, host_threads, std::move(cpus)), n(nstreams), base(nstreams, 0), avail(nstreams, 0), org(nstreams, 0)
   {
     for (int s = 0; s < 3; ++s)
       for (int b = 0; b < nstreams; ++b) win[s].emplace_back(new DeviceBuffer<uint8_t>());
@@ -852,6 +882,16 @@ extern "C" dabhip_stream* dabhip_stream_create(int device, int nstreams)
   if (!s->eng.ok() || !s->streams_ok()) { delete s; return nullptr; }
   return s;
 }
+// the same with the host side chosen by the caller (dabhip_multi_stream_create: one session per device, each on the CPUs of its device's NUMA node)
+extern "C" dabhip_stream* dabhip_stream_create_on_cpus(int device, int nstreams, int host_threads, const int32_t* cpus, int ncpus)
+{
+  if (nstreams <= 0) { set_error("stream_create: no streams"); return nullptr; }
+  std::vector<int> list;
+  for (int i = 0; cpus && i < ncpus; ++i) list.push_back(cpus[i]);
+  dabhip_stream* s = new dabhip_stream(device, nstreams, host_threads, list);
+  if (!s->eng.ok() || !s->streams_ok()) { delete s; return nullptr; }
+  return s;
+}
 extern "C" void dabhip_stream_destroy(dabhip_stream* s) { delete s; }
 extern "C" int dabhip_stream_set_subchannels(dabhip_stream* s, const int32_t* ids, int n)
 {
@@ -861,7 +901,7 @@ extern "C" int dabhip_stream_set_subchannels(dabhip_stream* s, const int32_t* id
   return 0;
 }
 extern "C" int dabhip_stream_set_afc(dabhip_stream* s, int on) { if (!s) return -1; s->eng.set_afc(on != 0); return 0; }
-extern "C" int dabhip_stream_set_parity_guard(dabhip_stream* s, int on) { if (!s) return -1; s->eng.set_parity_guard(on != 0); return 0; }
+extern "C" int dabhip_stream_set_parity_guard(dabhip_stream* s, int on) { if (!s) return -1; s->eng.set_parity_guard(on); return 0; }
 extern "C" int dabhip_stream_set_sync_speculation(dabhip_stream* s, int mode) { if (!s) return -1; s->eng.set_sync_speculation(mode); return 0; }
 extern "C" int dabhip_stream_set_soft(dabhip_stream* s, int on)
 {
@@ -1008,6 +1048,11 @@ extern "C" int dabhip_stream_stage_ms(const dabhip_stream* s, const char** names
   return n;
 }
 extern "C" uint32_t dabhip_stream_status(const dabhip_stream* s, int stream) { return s ? s->eng.stream_status(stream) : 0xffffffffu; }
+extern "C" int64_t dabhip_stream_log(dabhip_stream* s, int stream, char* buf, int64_t cap)
+{
+  if (!s || stream < 0 || stream >= s->n) return -1;
+  return hand_over_text(s->eng.take_stream_log(stream), buf, cap);
+}
 extern "C" int64_t dabhip_stream_eti_read(dabhip_stream* s, int stream, uint8_t* dst, int64_t cap_frames)
 {
   if (!s || !dst) { set_error("stream_eti_read: null argument"); return -1; }
@@ -1042,6 +1087,21 @@ extern "C" int dabhip_stream_ceiling(int device, size_t bytes, int reps, double*
 {
   if (!gbs) { set_error("stream_ceiling: null argument"); return -1; }
   if (dabhip::stream_ceiling(device, bytes, reps, gbs) != 0) { set_error("stream_ceiling: allocation or launch failed"); return -1; }
+  return 0;
+}
+
+// which physical device an index is: PCI bus id ("0000:c1:00.0") and marketing name -- what a multi-rank run records per rank, so that N ranks can be
+// shown to have sat on N distinct GPUs (bench.py: ranks[].device)
+extern "C" int dabhip_device_identity(int device, char* bus_id, int cap_bus, char* name, int cap_name)
+{
+  if (!bus_id || cap_bus < 16 || !name || cap_name < 2) { set_error("device_identity: buffers too small"); return -1; }
+  hipDeviceProp_t prop;
+  if (hipDeviceGetPCIBusId(bus_id, cap_bus, device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("device_identity: no such device: " + std::to_string(device));
+    return -1;
+  }
+  std::snprintf(name, static_cast<size_t>(cap_name), "%s", prop.name);
   return 0;
 }
 

@@ -12,7 +12,9 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "dab_bits.hpp"
@@ -234,11 +236,15 @@ class ControlPlane {
     if (ok_count > 0) decode_fibs(tf_info_, fibs, crc_ok);
     if (ok_count == 12) {
       ++okcount_;
-      if (okcount_ >= 10 && !locked_) locked_ = true;
+      if (okcount_ >= 10 && !locked_) {
+        locked_ = true;
+        note("Locked\n");                                  // dab.c:51
+      }
     } else {
       okcount_ = 0;
       if (locked_) {                 // lock lost: ring is dropped (dab.c:55-61)
         locked_ = false;
+        note("Lock lost, resetting ringbuffer\n");       // dab.c:57
         ncifs_ = 0;
         return 0;
       }
@@ -271,6 +277,10 @@ class ControlPlane {
       if (ncifs_ == 0) ring_first_ = 4 * ordinal;
       ncifs_ += 4;
       return 0;
+    }
+    if (!ens_shown_) {               // the one-time ensemble dump (dab.c:78-82)
+      note_ensemble();
+      ens_shown_ = true;
     }
     for (int i = 0; i < 4; ++i) {    // emit the oldest CIF, then slide (dab.c:85-95)
       // (a multiplex the reference could not assemble inside its arrays: ring and counter move on, no frame is made -- see StreamFault)
@@ -335,11 +345,34 @@ class ControlPlane {
     dst[hdr_len_ - 1] = static_cast<uint8_t>(hcrc & 0xff);
     return hdr_len_;
   }
+  // What the reference prints on stderr for its operator -- "Locked" (dab.c:51), "Lock lost, resetting ringbuffer" (dab.c:57), the one-time ensemble dump
+  // (dab.c:78-82 -> dump_ens_info, misc.c:316-328) -- as text, in order, since the last take_log().  dab2eti-hip puts it on stderr; a batch caller may never
+  // look (the text of one stream is a few hundred bytes per lock event; capped).
+  std::string take_log() { std::string t; t.swap(log_); return t; }
+  const std::string& log() const { return log_; }
   // (tests) the current ensemble, to hold frame_header() against build_eti_header()
   const EnsembleInfo& ensemble() const { return ens_; }
   uint64_t filter() const { return keep_; }
 
  private:
+  void note(const char* text)
+  {
+    if (log_.size() < (size_t(1) << 16)) log_ += text;
+  }
+  void note_ensemble()                       // dump_ens_info (misc.c:316-328), format strings as there
+  {
+    char line[160];
+    std::snprintf(line, sizeof line, "ENSEMBLE_INFO: EId=0x%04x, CIFCount = %d %d\n", ens_.eid, ens_.cif_hi, ens_.cif_lo);
+    note(line);
+    for_each_slot(ens_.present, [&](int i) {
+      const SubChannel& sc = ens_.sub[i];
+      std::snprintf(line, sizeof line, "SubChId=%d, slForm=%d, StartAddress=%d, size=%d, bitrate=%d, ASCTy=0x%02x\n", sc.id, sc.slform, sc.start_cu, sc.size_cu, sc.bitrate,
+                    static_cast<unsigned>(sc.ascty));
+      note(line);
+    });
+  }
+  std::string log_;
+  bool ens_shown_ = false;
   EnsembleInfo tf_info_, ens_;
   bool locked_ = false;
   uint64_t keep_ = ~0ull;

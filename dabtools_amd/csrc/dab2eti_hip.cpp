@@ -6,10 +6,16 @@
 //
 //   rtl_sdr -f 220352000 -s 2048000 - | dab2eti-hip - > ensemble.eti         (streaming: "-" = stdin)
 //   dab2eti-hip --stream [--segment-calls N] huge.cu8 > ensemble.eti
+//   dab2eti-hip --stream --devices 0-7 cap0000.cu8 ... cap2047.cu8 > all.eti  (sessions on several devices: dabhip_multi_stream)
 //
-// Streaming mode (any input "-", or --stream) decodes unbounded input in segments of N 262,144-byte calls (default
-// 64 = 16 MiB) through a dabhip_stream session: a reader thread fills page-locked buffers while the GPU decodes an earlier one and the
-// one in between uploads (dabhip_stream_prefetch), frames leave as soon as their segment is done, memory stays bounded, output bytes are those of the one-shot mode.
+// Streaming mode (any input "-", or --stream) decodes unbounded input in segments of N 262,144-byte calls through a dabhip_stream session (on several
+// devices: a dabhip_multi_stream, the inputs dealt to the devices in contiguous slices): reader threads fill page-locked buffers while the GPU decodes an
+// earlier one and the one in between uploads (dabhip_stream_prefetch), frames leave as soon as their segment is done, memory stays bounded, output bytes are
+// those of the one-shot mode.  N defaults to 64 (16 MiB per input and segment: throughput) when every input is a regular file and to 2 (0.5 MiB = 128 ms of
+// signal: latency) when one of them is a pipe, a FIFO or a terminal -- a live receiver's frames leave within a fraction of a second of their samples.
+//
+// stderr carries what the reference's operator sees (dab.c:51,57,78-82): "Locked", "Lock lost, resetting ringbuffer" and the one-time ensemble dump, per
+// input (prefixed with the input's name when there are several); --quiet turns them off.
 //
 // Each file is one 2.048 Msps cu8 IQ capture (I at even bytes, Q at odd bytes), replayed in
 // 262,144-byte calls exactly as librtlsdr would deliver it (dab2eti.c:117-130,238), without tuner
@@ -81,9 +87,55 @@ bool map_file(const char* name, Mapped* m)
 // segment's decode, and a writer thread puts them on fd 1 in large writes -- the same bytes in the same order as one 6144-byte write per frame
 // (dab2eti.c:132-135), stream by stream within a segment.
 bool g_stats = false;                            // --stats: phase times on stderr (one JSON line), for tools/cli_throughput.py
+bool g_quiet = false;                            // --quiet: no operator messages
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool afc, bool soft, const std::vector<int32_t>& subch, int device)
+// the reference's operator messages of one input (dabhip_*_log text) on stderr: as they are for a single input, every line prefixed otherwise
+void print_log(const char* text, const char* name, bool prefix)
+{
+  if (!*text) return;
+  if (!prefix) { std::fputs(text, stderr); return; }
+  for (const char* p = text; *p;) {
+    const char* nl = std::strchr(p, '\n');
+    const size_t len = nl ? static_cast<size_t>(nl - p) : std::strlen(p);
+    std::fprintf(stderr, "%s: %.*s\n", name, static_cast<int>(len), p);
+    p += len + (nl ? 1 : 0);
+  }
+}
+
+// one session on one device, or one per device behind dabhip_multi_stream: the same calls either way
+struct Session {
+  dabhip_stream* one = nullptr;
+  dabhip_multi_stream* many = nullptr;
+  bool create(const std::vector<int>& devices, int n)
+  {
+    if (devices.size() > 1) many = dabhip_multi_stream_create(devices.data(), static_cast<int>(devices.size()), n);
+    else one = dabhip_stream_create(devices.empty() ? 0 : devices[0], n);
+    return one || many;
+  }
+  void destroy() { if (one) dabhip_stream_destroy(one); if (many) dabhip_multi_stream_destroy(many); one = nullptr; many = nullptr; }
+  void set_afc() { if (one) dabhip_stream_set_afc(one, 1); else dabhip_multi_stream_set_afc(many, 1); }
+  void set_soft() { if (one) dabhip_stream_set_soft(one, 1); else dabhip_multi_stream_set_soft(many, 1); }
+  void set_subchannels(const std::vector<int32_t>& ids)
+  {
+    if (one) dabhip_stream_set_subchannels(one, ids.data(), static_cast<int>(ids.size()));
+    else dabhip_multi_stream_set_subchannels(many, ids.data(), static_cast<int>(ids.size()));
+  }
+  int prefetch(const uint8_t* const* iq, const size_t* nbytes) { return one ? dabhip_stream_prefetch(one, iq, nbytes, 0) : dabhip_multi_stream_prefetch(many, iq, nbytes, 0); }
+  int64_t feed(const uint8_t* const* iq, const size_t* nbytes) { return one ? dabhip_stream_feed(one, iq, nbytes, 0) : dabhip_multi_stream_feed(many, iq, nbytes, 0); }
+  int64_t eti_fetch(uint8_t* dst, int64_t frames) { return one ? dabhip_stream_eti_fetch(one, dst, frames) : dabhip_multi_stream_eti_fetch(many, dst, frames); }
+  int eti_fetch_wait() { return one ? dabhip_stream_eti_fetch_wait(one) : dabhip_multi_stream_eti_fetch_wait(many); }
+  int64_t eti_count(int i) { return one ? dabhip_stream_eti_count(one, i) : dabhip_multi_stream_eti_count(many, i); }
+  int64_t log(int i, char* buf, int64_t cap) { return one ? dabhip_stream_log(one, i, buf, cap) : dabhip_multi_stream_log_of(many, i, buf, cap); }
+  int device_of(int i)
+  {
+    int dev = -1;
+    if (many) dabhip_multi_stream_slice_of(many, i, &dev, nullptr, nullptr);
+    return dev;
+  }
+};
+
+int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool afc, bool soft, const std::vector<int32_t>& subch, const std::vector<int>& devices)
 {
   const double t_start = now_s();
   const int n = static_cast<int>(names.size());
@@ -92,11 +144,12 @@ int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool 
     in[i] = std::strcmp(names[i], "-") == 0 ? stdin : std::fopen(names[i], "rb");
     if (!in[i]) { std::perror(names[i]); return 1; }
   }
-  dabhip_stream* s = dabhip_stream_create(device, n);
-  if (!s) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); return 2; }
-  if (afc) dabhip_stream_set_afc(s, 1);
-  if (soft) dabhip_stream_set_soft(s, 1);
-  if (!subch.empty()) dabhip_stream_set_subchannels(s, subch.data(), static_cast<int>(subch.size()));
+  Session ses;
+  Session* s = &ses;
+  if (!ses.create(devices, n)) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); return 2; }
+  if (afc) ses.set_afc();
+  if (soft) ses.set_soft();
+  if (!subch.empty()) ses.set_subchannels(subch);
   constexpr int kBufs = 3, kOut = 2;
   uint8_t* buf[kBufs];
   // frames a segment can yield per stream: 4 per transmission frame it completes, plus what the backlog of the segment before adds
@@ -161,7 +214,7 @@ int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool 
       OutItem it;
       { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !queue.empty(); }); it = queue.front(); queue.erase(queue.begin()); }
       if (it.frames > 0) {
-        if (dabhip_stream_eti_fetch_wait(s) != 0) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); std::_Exit(2); }
+        if (s->eti_fetch_wait() != 0) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); std::_Exit(2); }
         write_all(out[it.o], static_cast<size_t>(it.frames) * DABHIP_ETI_BYTES);
       }
       { std::lock_guard<std::mutex> lk(mu); out_free[it.o] = true; }
@@ -184,22 +237,27 @@ int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool 
     { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return filled[k] != 0; }); state = filled[k]; next_state = filled[kn]; }
     // segments are handed over in order: this one first (unless it went up during the previous decode already) ...
     if (!prefetched[k]) {
-      if (dabhip_stream_prefetch(s, ptrs[k].data(), got[k].data(), 0) != 0) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); rc = 2; }
+      if (s->prefetch(ptrs[k].data(), got[k].data()) != 0) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); rc = 2; }
       prefetched[k] = true;
     }
     // ... and when the segment after it is already in memory (file replay), its upload runs while this one decodes
     if (!rc && state != 2 && next_state != 0 && !prefetched[kn]) {
-      if (dabhip_stream_prefetch(s, ptrs[kn].data(), got[kn].data(), 0) != 0) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); rc = 2; }
+      if (s->prefetch(ptrs[kn].data(), got[kn].data()) != 0) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); rc = 2; }
       prefetched[kn] = true;
     }
-    const int64_t frames = rc ? -1 : dabhip_stream_feed(s, ptrs[k].data(), got[k].data(), 0);
+    const int64_t frames = rc ? -1 : s->feed(ptrs[k].data(), got[k].data());
     prefetched[k] = false;
     if (frames < 0) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); rc = 2; }
     if (!rc) {
       if (frames > out_frames) { std::fprintf(stderr, "dab2eti-hip: a segment produced more frames than planned for\n"); rc = 2; }
       { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return out_free[o]; }); out_free[o] = false; }
-      if (!rc && frames > 0 && dabhip_stream_eti_fetch(s, out[o], frames) != frames) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); rc = 2; }
-      for (int i = 0; i < n && rc == 0; ++i) total[i] += dabhip_stream_eti_count(s, i);
+      if (!rc && frames > 0 && s->eti_fetch(out[o], frames) != frames) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); rc = 2; }
+      for (int i = 0; i < n && rc == 0; ++i) total[i] += s->eti_count(i);
+      if (!g_quiet) {                            // the reference's operator messages of this segment (dab.c:51,57,78-82)
+        char text[8192];
+        for (int i = 0; i < n; ++i)
+          if (s->log(i, text, sizeof text) > 0) print_log(text, names[i], n > 1);
+      }
       seg_done.push_back(now_s());
       seg_frames.push_back(frames);
     }
@@ -212,7 +270,10 @@ int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool 
   writer.join();
   const double t_written = now_s();
   for (auto& t : readers) t.join();
-  for (int i = 0; i < n; ++i) std::fprintf(stderr, "%s: %lld ETI frames\n", names[i], total[i]);
+  for (int i = 0; i < n; ++i) {
+    if (ses.many) std::fprintf(stderr, "%s: %lld ETI frames (device %d)\n", names[i], total[i], ses.device_of(i));
+    else std::fprintf(stderr, "%s: %lld ETI frames\n", names[i], total[i]);
+  }
   if (g_stats) {
     // steady state: from the first segment that produced frames to the last, the frames of the segments after that first one
     size_t first = 0;
@@ -220,13 +281,13 @@ int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool 
     long long steady_frames = 0, all = 0;
     for (size_t i = 0; i < seg_frames.size(); ++i) { all += seg_frames[i]; if (i > first) steady_frames += seg_frames[i]; }
     const double steady_s = first < seg_done.size() ? t_written - seg_done[first] : 0.0;
-    std::fprintf(stderr, "{\"mode\": \"stream\", \"streams\": %d, \"segments\": %zu, \"segment_bytes_per_stream\": %zu, \"setup_s\": %.4f, \"run_s\": %.4f, \"eti_frames\": %lld, "
+    std::fprintf(stderr, "{\"mode\": \"stream\", \"devices\": %zu, \"streams\": %d, \"segments\": %zu, \"segment_bytes_per_stream\": %zu, \"setup_s\": %.4f, \"run_s\": %.4f, \"eti_frames\": %lld, "
                          "\"steady_frames\": %lld, \"steady_s\": %.4f, \"steady_frames_per_s\": %.1f}\n",
-                 n, seg_frames.size(), seg_bytes, t_ready - t_start, t_written - t_ready, all, steady_frames, steady_s, steady_s > 0 ? steady_frames / steady_s : 0.0);
+                 devices.empty() ? size_t(1) : devices.size(), n, seg_frames.size(), seg_bytes, t_ready - t_start, t_written - t_ready, all, steady_frames, steady_s, steady_s > 0 ? steady_frames / steady_s : 0.0);
   }
   for (auto& b : buf) dabhip_host_free(b);
   for (auto& ob : out) dabhip_host_free(ob);
-  dabhip_stream_destroy(s);
+  ses.destroy();
   return 0;
 }
 }  // namespace
@@ -234,13 +295,14 @@ int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool 
 int main(int argc, char** argv)
 {
   bool streaming = false, afc = false, soft = false;
-  size_t seg_calls = 64;
+  size_t seg_calls = 0;                        // 0 = default: 64 for regular files, 2 when an input is a pipe / FIFO / terminal
   std::vector<int32_t> subch;                  // --subch 3,7: decode and carry only these SubChIds (TODO.md:28-31)
   std::vector<int> devices;                    // --devices 0-7 | 0,2,3 | 0,0 (an entry per slice; repeats allowed): dabhip_multi
   std::vector<const char*> names;
   for (int i = 1; i < argc; ++i) {
     if (std::strcmp(argv[i], "--stream") == 0) streaming = true;
     else if (std::strcmp(argv[i], "--stats") == 0) g_stats = true;
+    else if (std::strcmp(argv[i], "--quiet") == 0) g_quiet = true;
     else if (std::strcmp(argv[i], "--afc") == 0) afc = true;          // software AFC: captures with a carrier offset (no tuner to steer)
     else if (std::strcmp(argv[i], "--soft") == 0) soft = true;        // 4-bit soft decisions (not the reference's hard ones)
     else if (std::strcmp(argv[i], "--subch") == 0 && i + 1 < argc) {
@@ -267,11 +329,20 @@ int main(int argc, char** argv)
     else { names.push_back(argv[i]); streaming = streaming || std::strcmp(argv[i], "-") == 0; }
   }
   if (names.empty()) {
-    std::fprintf(stderr, "Usage: dab2eti-hip [--stream] [--segment-calls N] [--afc] [--soft] [--subch ID[,ID...]] [--devices A-B|A,B,...] capture.cu8|- [more.cu8 ...] > out.eti\n");
+    std::fprintf(stderr, "Usage: dab2eti-hip [--stream] [--segment-calls N] [--afc] [--soft] [--quiet] [--subch ID[,ID...]] [--devices A-B|A,B,...] capture.cu8|- [more.cu8 ...] > out.eti\n");
     return 1;
   }
-  if (streaming && devices.size() > 1) { std::fprintf(stderr, "dab2eti-hip: --devices with several entries applies to the batch mode (files), not to --stream / stdin\n"); return 1; }
-  if (streaming) return run_streaming(names, seg_calls * 262144, afc, soft, subch, devices.empty() ? 0 : devices[0]);
+  if (streaming) {
+    if (seg_calls == 0) {                      // a live source: short segments, so that frames leave as their samples arrive (dab2eti.c:117-130 decodes call by call)
+      bool live = false;
+      for (const char* name : names) {
+        struct stat st;
+        if (std::strcmp(name, "-") == 0 ? fstat(0, &st) != 0 || !S_ISREG(st.st_mode) : stat(name, &st) == 0 && !S_ISREG(st.st_mode)) live = true;
+      }
+      seg_calls = live ? 2 : 64;
+    }
+    return run_streaming(names, seg_calls * 262144, afc, soft, subch, devices);
+  }
   argc = static_cast<int>(names.size()) + 1;
   for (int i = 1; i < argc; ++i) argv[i] = const_cast<char*>(names[i - 1]);
   const double t_start = now_s();
@@ -294,6 +365,8 @@ int main(int argc, char** argv)
       int dev = -1;
       dabhip_multi_slice_of(m, static_cast<int>(b), &dev);
       std::fprintf(stderr, "%s: %lld ETI frames (device %d)\n", argv[b + 1], static_cast<long long>(dabhip_multi_eti_count(m, static_cast<int>(b))), dev);
+      char text[8192];
+      if (!g_quiet && dabhip_multi_stream_log(m, static_cast<int>(b), text, sizeof text) > 0) print_log(text, argv[b + 1], files.size() > 1);
     }
     if (dabhip_multi_eti_drain(m, to_stdout, nullptr) != n) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); return 2; }
     flush_stdout();
@@ -309,8 +382,11 @@ int main(int argc, char** argv)
   const int64_t n = dabhip_engine_decode(e, ptrs.data(), sizes.data(), static_cast<int>(ptrs.size()), 0);
   if (n < 0) { std::fprintf(stderr, "dab2eti-hip: %s\n", dabhip_last_error()); return 2; }
   const double t_decoded = now_s();
-  for (size_t b = 0; b < files.size(); ++b)
+  for (size_t b = 0; b < files.size(); ++b) {
     std::fprintf(stderr, "%s: %lld ETI frames\n", argv[b + 1], static_cast<long long>(dabhip_engine_eti_count(e, static_cast<int>(b))));
+    char text[8192];
+    if (!g_quiet && dabhip_engine_stream_log(e, static_cast<int>(b), text, sizeof text) > 0) print_log(text, argv[b + 1], files.size() > 1);
+  }
   // all frames, file by file in emission order, in ONE download into page-locked memory and one run of large writes
   if (n > 0) {
     uint8_t* host = static_cast<uint8_t*>(dabhip_host_alloc(static_cast<size_t>(n) * DABHIP_ETI_BYTES));

@@ -113,29 +113,44 @@ struct CopyDesc {
 };
 
 // Parity guard of the OFDM stage (k_parity.hip): decisions whose fp32 margin is inside the error band are listed for an fp64
-// re-decision.  delta[frame * delta_stride + symbol] = kGuardC * sqrt(energy of the symbol's 2048 samples).
-// Constants: >= 5 x the worst dabhip_stage_decision_audit measured over > 10^10 decisions (profiles/r02_decision_audit.json).
-constexpr float kGuardC = 5.0e-6f;       // bound on |X32 - X| of any bin, relative to sqrt(sum_n |x_n|^2)   (measured worst: 6.3e-7)
-constexpr float kGuardProd = 5.0e-7f;    // rounding of the fp32 product Re/Im(cur conj(prev)), relative to |cur|_1 |prev|_1   (measured worst: 1.0e-7)
+// re-decision.  delta[frame * delta_stride + symbol] = c * sqrt(energy of the symbol's 2048 samples), c = GuardArgs::c.
+// Two sets of constants (dabhip_engine_set_parity_guard(e, level); DESIGN.md section 3 carries the derivation of the second):
+//   level 1, "measured": >= 4.5 x the worst error dabhip_stage_decision_audit_fused has measured over > 10^10 decisions (profiles/r0N_decision_audit.json);
+//   level 2, "proven": >= a rigorous forward-error bound of THIS transform (radix 8.8.8.4 as fft_core.hpp writes it, round-to-nearest fp32, fused
+//   multiply-adds where the source says so, twiddles = float(cos / sin in double)) and of the differential product (diff_re / diff_im below):
+//     |X32[k] - X[k]| <= 2^-24 sqrt(2048) (6.7072 + 7.7072 + 7.7072 + 2) (1 + 1e-5) |x|_2 = 6.5072e-5 |x|_2      (any bin k; tools/fft_error_bound.py)
+//     |fl(Re / Im(cur conj(prev))) - (the same of the fp32 bins, exactly)| <= 2 (2^-24) (1 + 2^-24) |cur|_2 |prev|_2 = 1.1921e-7 |cur|_2 |prev|_2
+//   both rounded up a little further so that the fp32 evaluation of the threshold itself (sqrtf of the energy, three fused multiply-adds: relative
+//   error < 1e-6) stays on the safe side.
+constexpr float kGuardC = 5.0e-6f;       // level 1: bound on |X32 - X| of any bin, relative to sqrt(sum_n |x_n|^2)   (measured worst: 7.6e-7)
+constexpr float kGuardProd = 5.0e-7f;    // level 1: rounding of the fp32 product Re/Im(cur conj(prev)), relative to |cur|_1 |prev|_1   (measured worst: 1.1e-7)
+constexpr float kGuardCProven = 6.6e-5f;      // level 2 (bound: 6.5072e-5)
+constexpr float kGuardProdProven = 1.25e-7f;  // level 2 (bound: 1.1921e-7; |.|_2 <= |.|_1 gives the test further room)
+constexpr int kDefaultGuardLevel = 2;     // the proven band: exact by construction; price: 13 x the re-decisions on noisy input, none on clean input
+__host__ __device__ constexpr float guard_c_of(int level) { return level >= 2 ? kGuardCProven : kGuardC; }
+__host__ __device__ constexpr float guard_prod_of(int level) { return level >= 2 ? kGuardProdProven : kGuardProd; }
 // the guard's test, the same operations in every kernel that applies it (so that they all list the same decisions):
-// |cur|_1 (dp + kGuardProd |prev|_1) + |prev|_1 dc
-__host__ __device__ __forceinline__ float guard_threshold(float n1c, float n1p, float dc, float dp)
+//   |cur|_1 (dp + prod |prev|_1) + (|prev|_1 + dp) dc
+// = |cur|_1 dp + |prev|_1 dc  (the bins' errors dc, dp carried into the product)  +  prod |cur|_1 |prev|_1  (the product's own roundings)  +  dc dp  (error x error).
+__host__ __device__ __forceinline__ float guard_threshold(float n1c, float n1p, float dc, float dp, float prod)
 {
-  return fmaf(n1c, fmaf(n1p, kGuardProd, dp), n1p * dc);
+  return fmaf(n1c, fmaf(n1p, prod, dp), (n1p + dp) * dc);
 }
 // Soft decisions (extension): value = round(soft_scale x) clamped to +-7, x = Re / Im of cur conj(prev).  The scale is made of
 // the two symbols' sample energies -- on a noise-free Mode-I signal mean |x| = (2048 / 1536) s(l) s(l-1) / sqrt(2), s = sqrt(sum_n
 // |x_n|^2), which the factor below maps to 7.0 (= the clamp: see below) -- so it is known before a symbol is transformed (the one-kernel OFDM stage cannot
-// wait for a mean over its own output) and is the same in every kernel that demaps.  dc, dp = kGuardC s of the two symbols.
+// wait for a mean over its own output) and is the same in every kernel that demaps.  dc, dp = kSoftNormC s of the two symbols (the energies travel
+// in the guard's delta array, scaled by GuardArgs::c = kSoftNormC: soft decisions and the guard never run together).
 // Round 4: the gain was 4.5 until the soft rule got an oracle (oracle/or_soft.c) that can be run in any quantisation: a sweep of the gain on the CPU
 // (tools/soft_quant_loss.py --gain, 14 captures x 24 TF per point) put the optimum of the 4-bit values at 6.5 .. 7 -- a clean value AT the clamp: range is
 // worth less than resolution near zero, where the decisions are made.  Payload BER 4-bit / unquantised at 5, 6, 7 dB: 1.17, 1.14, 1.82 at gain 4.5;
 // 1.06, 1.06, ~1.3 at 7.0 (profiles/r04_soft_quantisation.json, profiles/r04_soft_gain_sweep.txt).
+constexpr float kSoftNormC = 5.0e-6f;
 constexpr float kSoftGain = 7.0f / 0.94280904f;
 __host__ __device__ inline float soft_scale(float dc, float dp)
 {
   const float prod = dc * dp;
-  return prod > 0.0f ? kSoftGain * kGuardC * kGuardC / prod : 0.0f;
+  return prod > 0.0f ? kSoftGain * kSoftNormC * kSoftNormC / prod : 0.0f;
 }
 
 // The differential product cur conj(prev) of the demapper (input_sdr.c:135-143: re = Re, im = -Im) in fp32, with its roundings FIXED -- one multiply and one
@@ -150,8 +165,10 @@ struct GuardArgs {
   const float* delta;    // nullptr: guard off (the fused OFDM kernel computes its bounds itself and only tests this for null); with soft
                          // decisions: the same array, read for the scale (list == nullptr then)
   int32_t delta_stride;
+  float c, prod;         // the level's constants (guard_c_of / guard_prod_of); soft decisions: c = kSoftNormC
   uint32_t cap;          // capacity of list
-  uint2* list;           // {frame index, symbol << 16 | raw bin}
+  uint4* list;           // {frame index, symbol << 16 | raw bin, address of the first byte of the symbol's window in the IQ stream when it and the previous
+                         //  symbol's lie contiguously inside what the call read (low, high word; 0: to be looked up through the frame's view)}
   uint32_t* counter;     // entries appended (may exceed cap: overflow, detected by the host)
 };
 

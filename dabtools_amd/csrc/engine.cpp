@@ -194,8 +194,9 @@ Engine::~Engine()
 }
 
 // ---------------------------------------------------------------------------------------------
-bool Engine::upload_small(const SmallUpload* items, int n, hipStream_t s, PinnedBuffer<uint32_t>& staging)
+bool Engine::upload_small(const SmallUpload* items, int n, hipStream_t s, SmallStage& stage)
 {
+  PinnedBuffer<uint32_t>& staging = stage.words;
   size_t total = 0;
   bool words = true;
   for (int i = 0; i < n; ++i) {
@@ -208,6 +209,10 @@ bool Engine::upload_small(const SmallUpload* items, int n, hipStream_t s, Pinned
     return true;
   }
   if (staging.size() < kSmallUploadBytes / 4 && !staging.resize(kSmallUploadBytes / 4)) return false;   // once: the buffer never moves while a kernel may read it
+  // the stage's previous launch reads these words when it runs: still in flight -> wait for it (see engine.hpp; not reached by today's callers)
+  if (stage.armed && hipEventQuery(stage.done) == hipErrorNotReady && !check(hipEventSynchronize(stage.done), "work list staging")) return false;
+  (void)hipGetLastError();
+  if (!stage.done && !check(hipEventCreateWithFlags(&stage.done, hipEventDisableTiming), "hipEventCreate")) return false;
   size_t at = 0;
   HostWordsArgs hw{};
   int k = 0;
@@ -228,7 +233,9 @@ bool Engine::upload_small(const SmallUpload* items, int n, hipStream_t s, Pinned
       k = 0;
     }
   }
-  return k == 0 || check(launch_host_words(hw, s), "work list upload");
+  if (k != 0 && !check(launch_host_words(hw, s), "work list upload")) return false;
+  stage.armed = check(hipEventRecord(stage.done, s), "work list staging event");
+  return stage.armed;
 }
 
 // work lists of a batch to the device (any stream: only the launches below consume them)
@@ -491,7 +498,9 @@ bool Engine::msc_launch_async(const MscWork& w)
   msc_queued_ = false;
   if (nf == 0) return true;
   // a fetch of the previous decode's frames may still be reading the ETI buffer these launches rewrite (eti_fetch_async)
-  if (const uint64_t issued = eti_fetch_issued_.load())     // (the newest fetch's event: the copies run in order on one stream)
+  // (the newest fetch's event: the copies run in order on one stream.  Only while a fetch is outstanding: one that has been waited for has landed, and
+  // a wait packet costs 10 .. 15 us of idle GPU in front of K4)
+  if (const uint64_t issued = eti_fetch_issued_.load(); issued != eti_fetch_waited_.load())
     if (!check(hipStreamWaitEvent(stream_, ev_eti_fetch_[(issued - 1) & 1], 0), "eti fetch wait")) return false;
   if (!launch_decode_batch(w.batch, d_msc_bits_.get(), d_stream_cif_base_.get(), d_prbs_.get(), d_eti_.get(), kEtiBytes)) return false;
   if (!check(launch_eti_finish(d_meta_.get(), static_cast<int>(nf), d_headers_.get(), w.header_stride, d_fibs_.get(), d_crc_tab_.get(), d_crc_shift_.get(), d_eti_.get(), stream_), "eti finish launch"))
@@ -589,7 +598,9 @@ bool Engine::guard_begin(int ntf_in_launch, GuardArgs* out)
 {
   // the list: flag rates measured on noisy input are a few decisions per TF (7e-6 of 230,400 at 5 dB); 64 entries per TF, at least
   // 256 K, and a launch that overflows it is decided again in full (exact_decide_all_kernel) instead of failing
-  uint32_t cap = static_cast<uint32_t>(std::max<int64_t>(int64_t(1) << 18, static_cast<int64_t>(ntf_in_launch) * 64));
+  // (the proven level's band is 13 x as wide: 16 x the entries)
+  const int level = guard_rule_level();
+  uint32_t cap = static_cast<uint32_t>(std::min<int64_t>(int64_t(1) << 30, std::max<int64_t>(int64_t(1) << (level >= 2 ? 20 : 18), static_cast<int64_t>(ntf_in_launch) * (level >= 2 ? 512 : 64))));
   if (guard_cap_override_) cap = guard_cap_override_;
   if (guard_launches_ == 0 && h_guard_counts_.size() < static_cast<size_t>(kGuardMinLaunches) * kGuardSlotWords && !h_guard_counts_.resize(static_cast<size_t>(kGuardMinLaunches) * kGuardSlotWords)) return false;
   if (static_cast<size_t>(guard_launches_ + 1) * kGuardSlotWords > h_guard_counts_.size()) { set_error("parity guard: more guarded launches than planned for in one decode"); return false; }
@@ -605,7 +616,8 @@ bool Engine::guard_begin(int ntf_in_launch, GuardArgs* out)
   // the capacity THIS launch was given (a later launch of the same decode may find the list re-reserved and larger): guard_check compares with it
   if (guard_caps_.size() <= static_cast<size_t>(guard_launches_)) guard_caps_.resize(static_cast<size_t>(guard_launches_) + 1);
   guard_caps_[static_cast<size_t>(guard_launches_)] = guard_cap_;
-  *out = GuardArgs{d_delta_.get(), kSymbolsPerTf, guard_cap_, d_guard_list_.get(), d_guard_counter_.get() + static_cast<size_t>(guard_launches_) * kGuardSlotWords};
+  *out = GuardArgs{d_delta_.get(), kSymbolsPerTf, guard_c_of(level), guard_prod_of(level), guard_cap_, d_guard_list_.get(),
+                   d_guard_counter_.get() + static_cast<size_t>(guard_launches_) * kGuardSlotWords};
   return true;
 }
 // the counters' host and device arrays for a decode of ntf frames (the layout kernel clears the device side)
@@ -1093,6 +1105,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
     if (guard && guard_launches_ == 0 && !guard_counters_clear_ && !guard_reserve_counters(ntf)) return false;
     soft_args.delta = d_delta_.get();
     soft_args.delta_stride = kSymbolsPerTf;
+    soft_args.c = kSoftNormC;
     if (one_kernel) {
       for (int first = 0; first < ntf; first += chunk)
         if (!fused_parts(first, std::min(chunk, ntf - first), 1, 4, 1)) return false;      // the three FIC symbols (and symbol 0, their reference)
@@ -1101,7 +1114,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
         const int n = std::min(chunk * 19, ntf - first);
         GuardArgs ga = soft ? soft_args : GuardArgs{};   // (hard decisions: a non-null delta switches the guard's listing on)
         if (guard && !guard_begin(n, &ga)) return false;
-        if (energies && !check(launch_symbol_delta(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, 4, d_delta_.get(), kSymbolsPerTf, stream_), "symbol delta launch"))
+        if (energies && !check(launch_symbol_delta(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, 4, d_delta_.get(), kSymbolsPerTf, soft ? kSoftNormC : guard_c_of(guard_rule_level()), stream_), "symbol delta launch"))
           return false;
         if (!check(launch_fic_prepass(soft_bits_, d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(),
                                       d_frame_slot_.get(), d_qpsk_.get(), d_fic_bits_.get(), ga, stream_),
@@ -1149,7 +1162,7 @@ int64_t Engine::decode_impl(const uint8_t* const* iq, const size_t* nbytes, int 
       if (guard && !guard_begin(n, &ga)) { gpu_ok = false; break; }
       // with the guard on (or soft decisions), K2 also leaves the per-symbol sample energies K2b decides with
       gpu_ok = gpu_ok && check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), max_calls_, d_frames_.get(), first, n, d_spectra_.get(), d_twf_.get(), stream_,
-                                               energies ? d_delta_.get() : nullptr),
+                                               energies ? d_delta_.get() : nullptr, soft ? kSoftNormC : guard_c_of(guard_rule_level())),
                                "fft launch");
       gpu_ok = gpu_ok && record(chunk_ev_[3 * c + 1], stream_);
       gpu_ok = gpu_ok && check(launch_demap(true, soft_bits_, d_spectra_.get(), first, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_), "demap launch");
@@ -1481,12 +1494,12 @@ int Engine::stage_decision_audit(const uint8_t* frames, int nframes, bool on_dev
     guard_counters_clear_ = false;
     guard_flagged_ = 0;
     if (guard_on && (!d_delta_.reserve(static_cast<size_t>(n) * kSymbolsPerTf) || !guard_begin(n, &ga) ||
-                     !check(launch_symbol_delta(d_iq_ptrs_.get(), d_descs_.get(), n, d_frames_.get(), 0, n, kSymbolsPerTf, d_delta_.get(), kSymbolsPerTf, stream_), "symbol delta launch")))
+                     !check(launch_symbol_delta(d_iq_ptrs_.get(), d_descs_.get(), n, d_frames_.get(), 0, n, kSymbolsPerTf, d_delta_.get(), kSymbolsPerTf, guard_c_of(guard_rule_level()), stream_), "symbol delta launch")))
       return -1;
     if (!check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), n, d_frames_.get(), 0, n, d_spectra_.get(), d_twf_.get(), stream_), "fft launch") ||
         !check(launch_demap(false, 0, d_spectra_.get(), 0, n, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_), "demap launch") ||
         (guard_on && !guard_finish(false, 0, n, 1, kSymbolsPerTf, false)) ||
-        !check(launch_decision_audit(d_in + static_cast<size_t>(first) * kTfBytes, n, d_spectra_.get(), d_fic_bits_.get(), d_msc_bits_.get(), d_tw2048_.get(), d_qpsk_.get(), d_out.get(), stream_), "audit launch") ||
+        !check(launch_decision_audit(d_in + static_cast<size_t>(first) * kTfBytes, n, d_spectra_.get(), d_fic_bits_.get(), d_msc_bits_.get(), d_tw2048_.get(), d_qpsk_.get(), d_out.get(), stream_, nullptr, 0, guard_rule_level()), "audit launch") ||
         (guard_on && !guard_download()) || !check(hipStreamSynchronize(stream_), "audit") || (guard_on && !guard_check()))
       return -1;
     listed += static_cast<uint64_t>(guard_flagged_);
@@ -1570,7 +1583,7 @@ int Engine::stage_decision_audit_fused(const uint8_t* frames, int nframes, bool 
         return -1;
       if (pass == 1 &&
           !check(launch_decision_audit(d_in + static_cast<size_t>(first) * kTfBytes, n, d_bins.get(), d_fic_bits_.get(), d_msc_bits_.get(), d_tw2048_.get(), d_qpsk_.get(),
-                                       d_out.get(), stream_, d_prod.get(), kRowLead),
+                                       d_out.get(), stream_, d_prod.get(), kRowLead, guard_rule_level()),
                  "audit launch"))
         return -1;
       if (!guard_download() || !check(hipStreamSynchronize(stream_), "audit") || !guard_check()) return -1;
@@ -1674,7 +1687,7 @@ bool Engine::demod_one_frame(const uint8_t* iq_virtual_base, const CallDesc& des
   guard_launches_ = 0;
   guard_counters_clear_ = false;
   if (guard && (!d_delta_.reserve(kSymbolsPerTf) || !guard_begin(1, &ga) ||
-                !check(launch_symbol_delta(d_iq_ptrs_.get(), d_descs_.get(), 1, d_frames_.get(), 0, 1, kSymbolsPerTf, d_delta_.get(), kSymbolsPerTf, stream_), "symbol delta launch")))
+                !check(launch_symbol_delta(d_iq_ptrs_.get(), d_descs_.get(), 1, d_frames_.get(), 0, 1, kSymbolsPerTf, d_delta_.get(), kSymbolsPerTf, guard_c_of(guard_rule_level()), stream_), "symbol delta launch")))
     return false;
   if (!check(launch_ofdm_fft(d_iq_ptrs_.get(), d_descs_.get(), 1, d_frames_.get(), 0, 1, d_spectra_.get(), d_twf_.get(), stream_), "fft launch") ||
       !check(launch_demap(false, 0, d_spectra_.get(), 0, 1, d_frame_slot_.get(), d_frame_cif_row_.get(), d_qpsk_.get(), d_fic_bits_.get(), d_msc_bits_.get(), ga, stream_), "demap launch") ||

@@ -175,8 +175,12 @@ class Engine {
   // parity guard (k_parity.hip; default on): hard decisions whose fp32 margin lies inside the error band of the fp32 OFDM
   // transform are re-decided in fp64 from the int8 samples, so the demapped bits are those of exact arithmetic (what the
   // reference's fp64 FFTW path yields).  Inactive with soft decisions and with the software AFC (no reference semantics there).
-  void set_parity_guard(bool on) { parity_guard_ = on; }
+  // level: 0 = off (raw fp32 decisions), 1 = the measured constants, 2 = the proven ones (device_types.hpp: kGuardC.. / kGuardCProven..)
+  void set_parity_guard(int level) { guard_level_ = level < 0 ? kDefaultGuardLevel : (level > 2 ? 2 : level); }   // < 0: the default level
+  int parity_guard_level() const { return guard_level_; }
   // decisions flagged and re-decided by the guard in the last decode (FIC pre-pass + OFDM stage), and decisions taken
+  // the reference's operator messages of one stream (ControlPlane::take_log): text pending since the last call, cleared by it
+  std::string take_stream_log(int stream) { return (stream >= 0 && stream < static_cast<int>(planes_.size())) ? planes_[static_cast<size_t>(stream)].take_log() : std::string(); }
   void guard_stats(int64_t* flagged, int64_t* decisions) const { if (flagged) *flagged = guard_flagged_; if (decisions) *decisions = guard_decisions_; }
   int guard_overflows() const { return guard_overflows_; }
   void set_guard_list_cap(uint32_t cap) { guard_cap_override_ = cap; }   // test knob: a tiny list makes the overflow path run
@@ -261,7 +265,9 @@ class Engine {
   bool upload_decode_batch(const DecodeBatch& b, const HostList<DecodeJob>& jobs, hipStream_t s);
   // Several small host arrays to the device in one launch per four of them (launch_host_words: the kernel reads page-locked host memory itself) instead
   // of one copy-engine command each -- a small decode is made of those commands and the 5 .. 10 us of idle GPU between two of them.  Arrays that are
-  // not page-locked are staged in `staging` first (which must not be in use by an earlier, still queued call: one buffer per call site).  Large lists
+  // not page-locked are staged in `staging` first.  The staging words and the page-locked sources are read when the launch RUNS, not when it is queued:
+  // every call site has its own SmallStage, whose event marks the end of its last launch -- a call that finds that launch still in flight waits for it
+  // before it overwrites the words (no caller does that today: every one drains its stream in between; the wait turns a silent overwrite into a stall).  Large lists
   // (more than kSmallUploadBytes in all) go as plain asynchronous copies, as before.  dst: device memory, reserved by the caller.
   struct SmallUpload {
     const void* src;
@@ -270,7 +276,13 @@ class Engine {
     bool pinned;
   };
   static constexpr size_t kSmallUploadBytes = 256 * 1024;
-  bool upload_small(const SmallUpload* items, int n, hipStream_t s, PinnedBuffer<uint32_t>& staging);
+  struct SmallStage {
+    PinnedBuffer<uint32_t> words;
+    hipEvent_t done = nullptr;               // recorded behind the stage's last launch
+    bool armed = false;
+    ~SmallStage() { if (done) (void)hipEventDestroy(done); }
+  };
+  bool upload_small(const SmallUpload* items, int n, hipStream_t s, SmallStage& staging);
   bool launch_decode_batch(const DecodeBatch& b, const uint32_t* bits, const int* d_stream_cif_base, const uint32_t* prbs, uint8_t* out,
                            int record_stride);
   bool msc_launch_async(const MscWork& w);   // K4 + K5 queued, nothing awaited
@@ -278,7 +290,8 @@ class Engine {
   bool unpack_tf_slot(int slot, uint8_t* fic_bytes, uint8_t* msc_bytes);
 
   // parity guard plumbing: list + counter for one launch, fix-up after it, entry count to the host (checked at the end)
-  bool guard_active() const { return parity_guard_ && soft_bits_ == 0 && !afc_; }
+  bool guard_active() const { return guard_level_ > 0 && soft_bits_ == 0 && !afc_; }
+  int guard_rule_level() const { return guard_level_ > 0 ? guard_level_ : kDefaultGuardLevel; }   // the rule the audits count with when the guard is off
   bool guard_begin(int ntf_in_launch, GuardArgs* out);
   // the launch just queued covered frames [first, first + n) of the frame list, data symbols [sym_a, sym_b); skip_fic: another launch owns symbols 1..3
   bool guard_finish(bool planar, int first, int n, int sym_a, int sym_b, bool skip_fic);
@@ -287,7 +300,8 @@ class Engine {
   bool guard_check();
 
   bool ok_ = false;
-  bool afc_ = false, fused_ = true, parity_guard_ = true;
+  bool afc_ = false, fused_ = true;
+  int guard_level_ = kDefaultGuardLevel;
   uint64_t subch_keep_ = ~0ull;
   int soft_bits_ = 0;
   // Decodes of at most this many code words (MSC: ETI frames x sub-channels; FIC: 4 per TF) run one WAVE per code word (k_vitwave.hip: latency
@@ -330,7 +344,7 @@ class Engine {
   DeviceBuffer<uint8_t> d_tail_state_, d_tail_prev_, d_tail_images_;
   DeviceBuffer<int> d_viol_, d_redo_, d_calls_before_;
   PinnedBuffer<int> h_viol_, h_calls_before_;
-  PinnedBuffer<uint32_t> h_small_fic_, h_small_msc_;   // staging of upload_small, one per call site
+  SmallStage h_small_fic_, h_small_msc_;   // staging of upload_small, one per call site
   // the look-ahead schedule of the K1 chain (small batches; k_sync.hip: sync_ahead_kernel): the estimators' table, the predicted start positions, the descriptor base
   DeviceBuffer<int2> d_spec_table_;
   DeviceBuffer<int64_t> d_spec_src0_;
@@ -368,7 +382,7 @@ class Engine {
   PinnedBuffer<int> h_frame_slot_, h_frame_cif_row_;
   std::vector<int> carry_keep_, prev_used_, calls_done_, ord_done_, prev_tf_base_, prev_row_base_;
   DeviceBuffer<float> d_delta_;
-  DeviceBuffer<uint2> d_guard_list_;
+  DeviceBuffer<uint4> d_guard_list_;
   DeviceBuffer<uint32_t> d_guard_counter_;
   PinnedBuffer<uint32_t> h_guard_counts_;
   int guard_launches_ = 0;

@@ -85,6 +85,7 @@ __device__ __forceinline__ void fft2048_store(float2 (&v)[8], float2* bufP, floa
 struct EnergyOut {
   float* esum;           // LDS, 2 symbols x 4 waves
   float* delta_tf;       // this frame's 76 bounds
+  float c;               // the guard level's constant (GuardArgs::c)
 };
 __device__ __forceinline__ void energy_part(const float2 (&v)[8], float* esum4)
 {
@@ -95,11 +96,11 @@ __device__ __forceinline__ void energy_part(const float2 (&v)[8], float* esum4)
   for (int sft = 32; sft > 0; sft >>= 1) e += __shfl_xor(e, sft);
   if ((threadIdx.x & 63) == 0) esum4[threadIdx.x >> 6] = e;
 }
-__device__ __forceinline__ void energy_store(const float* esum4, float* delta_tf, int sym)
+__device__ __forceinline__ void energy_store(const float* esum4, float* delta_tf, int sym, float c)
 {
   // the wave parts are exact integers (< 2^24); added up as integers so that every kernel arrives at the very same float
   if (threadIdx.x == 0)
-    delta_tf[sym] = kGuardC * sqrtf(static_cast<float>(static_cast<int>(esum4[0]) + static_cast<int>(esum4[1]) + static_cast<int>(esum4[2]) + static_cast<int>(esum4[3])));
+    delta_tf[sym] = c * sqrtf(static_cast<float>(static_cast<int>(esum4[0]) + static_cast<int>(esum4[1]) + static_cast<int>(esum4[2]) + static_cast<int>(esum4[3])));
 }
 
 template <bool kFast, bool kEnergy>
@@ -119,7 +120,7 @@ __device__ __forceinline__ int transform_symbols(GlobalU16 fast_src, const uint8
     if (kEnergy) energy_part(v, eo.esum + 4 * (sym & 1));
     if (parity) fft2048_store(v, exB, exA, tw, out_tf + static_cast<size_t>(sym) * 2048);
     else fft2048_store(v, exA, exB, tw, out_tf + static_cast<size_t>(sym) * 2048);
-    if (kEnergy) energy_store(eo.esum + 4 * (sym & 1), eo.delta_tf, sym);
+    if (kEnergy) energy_store(eo.esum + 4 * (sym & 1), eo.delta_tf, sym, eo.c);
     parity ^= 1;
   }
   return parity;
@@ -173,7 +174,7 @@ __device__ __forceinline__ void fft_block(const uint8_t* stream, const FrameView
       if (kEnergy) energy_part(v, eo.esum + 4 * ((sym0 + i) & 1));
       if (i & 1) fft2048_store(v, exB, exA, tw, out_tf + static_cast<size_t>(sym0 + i) * 2048);
       else fft2048_store(v, exA, exB, tw, out_tf + static_cast<size_t>(sym0 + i) * 2048);
-      if (kEnergy) energy_store(eo.esum + 4 * ((sym0 + i) & 1), eo.delta_tf, sym0 + i);
+      if (kEnergy) energy_store(eo.esum + 4 * ((sym0 + i) & 1), eo.delta_tf, sym0 + i, eo.c);
     }
     done = sym0 + kFixed;
   }
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(kThreads, 4) void ofdm_fft_kernel(const uint8_t* co
                                                                const CallDesc* __restrict__ descs, int max_calls,
                                                                const int2* __restrict__ frames, int first,
                                                                float2* __restrict__ spectra,
-                                                               const float2* __restrict__ tw_global, float* __restrict__ delta)
+                                                               const float2* __restrict__ tw_global, float* __restrict__ delta, float delta_c)
 {
   __shared__ __attribute__((aligned(16))) float2 exA[kExSize];
   __shared__ __attribute__((aligned(16))) float2 exB[kExSize];
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(kThreads, 4) void ofdm_fft_kernel(const uint8_t* co
   const int2 fr = frames[first + j];
   const CallDesc* desc = descs + static_cast<size_t>(fr.x) * max_calls + fr.y;
   if (threadIdx.x == 0) view = desc->view;
-  const EnergyOut eo{esum, kEnergy ? delta + static_cast<size_t>(first + j) * kSymbolsPerTf : nullptr};
+  const EnergyOut eo{esum, kEnergy ? delta + static_cast<size_t>(first + j) * kSymbolsPerTf : nullptr, delta_c};
   fft_block<kSymPerBlock, kEnergy>(iq[fr.x], view, desc->view.seg_end[0], desc->view.seg_src[0], part * kSymPerBlock,
                                    spectra + static_cast<size_t>(j) * (kSymbolsPerTf * 2048), tw_global, exA, exB, desc->nco_hz, eo);
 }
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(kThreads, 4) void fic_fft_kernel(const uint8_t* con
   const CallDesc* desc = descs + static_cast<size_t>(fr.x) * max_calls + fr.y;
   if (threadIdx.x == 0) view = desc->view;
   fft_block<4, false>(iq[fr.x], view, desc->view.seg_end[0], desc->view.seg_src[0], 0, spectra4 + static_cast<size_t>(j) * (4 * 2048), tw_global,
-                      exA, exB, desc->nco_hz, EnergyOut{nullptr, nullptr});
+                      exA, exB, desc->nco_hz, EnergyOut{nullptr, nullptr, 0.0f});
 }
 
 // ---- K2b ----------------------------------------------------------------------------------
@@ -284,9 +285,9 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
       im[m] = diff_im(cur.x, cur.y, prev[m].x, prev[m].y);   // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
       if (guarded) {
         const float n1c = fabsf(cur.x) + fabsf(cur.y), n1p = fabsf(prev[m].x) + fabsf(prev[m].y);
-        if (fminf(fabsf(re[m]), fabsf(im[m])) < guard_threshold(n1c, n1p, dc, dp)) {
+        if (fminf(fabsf(re[m]), fabsf(im[m])) < guard_threshold(n1c, n1p, dc, dp, guard.prod)) {
           const unsigned at = atomicAdd(guard.counter, 1u);
-          if (at < guard.cap) guard.list[at] = make_uint2(static_cast<unsigned>(first + j), (static_cast<unsigned>(l) << 16) | static_cast<unsigned>((bin[m] + 1024) & 2047));
+          if (at < guard.cap) guard.list[at] = make_uint4(static_cast<unsigned>(first + j), (static_cast<unsigned>(l) << 16) | static_cast<unsigned>((bin[m] + 1024) & 2047), 0u, 0u);
         }
       }
       prev[m] = cur;
@@ -343,13 +344,13 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
 }  // namespace
 
 hipError_t launch_ofdm_fft(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first,
-                           int nframes, float2* spectra, const float2* tw, hipStream_t stream, float* delta)
+                           int nframes, float2* spectra, const float2* tw, hipStream_t stream, float* delta, float delta_c)
 {
   if (nframes <= 0) return hipSuccess;
   if (delta)
-    hipLaunchKernelGGL(ofdm_fft_kernel<true>, dim3(4 * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, spectra, tw, delta);
+    hipLaunchKernelGGL(ofdm_fft_kernel<true>, dim3(4 * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, spectra, tw, delta, delta_c);
   else
-    hipLaunchKernelGGL(ofdm_fft_kernel<false>, dim3(4 * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, spectra, tw, delta);
+    hipLaunchKernelGGL(ofdm_fft_kernel<false>, dim3(4 * nframes), dim3(kThreads), 0, stream, iq, descs, max_calls, frames, first, spectra, tw, delta, delta_c);
   return hipGetLastError();
 }
 

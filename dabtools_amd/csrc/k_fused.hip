@@ -137,6 +137,7 @@ __device__ __forceinline__ void fft2048_rest(float2 (&v)[8], const float2* bufP,
 struct FusedGuard {
   GuardArgs g;
   unsigned frame;        // index of this TF in the frame list
+  uint64_t fast_base;    // address of the frame buffer's byte 0 in the IQ stream for the symbols read in place (fused_symbols<true>); 0 for those read through the view
 };
 #if DABHIP_FUSED_AUDIT
 __device__ float2* g_audit_bins;     // [frame][76][2048] by raw bin
@@ -202,7 +203,7 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
     maxc = fmaxf(maxc, l1norm(cur));
   }
 #ifndef DABHIP_PROBE_NOTEST
-  const bool any = !(lo > guard_threshold(maxc, maxp, dc, dp));
+  const bool any = !(lo > guard_threshold(maxc, maxp, dc, dp, guard.g.prod));
 #else
   const bool any = false;
 #endif
@@ -215,7 +216,7 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
       const float2 cur = (m & 1) ? y[m >> 1] : x[m >> 1], prev = (m & 1) ? py[m >> 1] : px[m >> 1];
       const float re = diff_re(cur.x, cur.y, prev.x, prev.y), im = diff_im(cur.x, cur.y, prev.x, prev.y);
       const float least = fminf(fabsf(re), fabsf(im));
-      hits |= (ak[m] >= 0 && (least < guard_threshold(l1norm(cur), l1norm(prev), dc, dp) || !(least > 0.0f)) ? 1u : 0u) << m;
+      hits |= (ak[m] >= 0 && (least < guard_threshold(l1norm(cur), l1norm(prev), dc, dp, guard.g.prod) || !(least > 0.0f)) ? 1u : 0u) << m;
     }
     while (hits) {
       const unsigned m = __ffs(hits) - 1;
@@ -223,7 +224,9 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
       if (guard.g.delta == nullptr) continue;             // (never in this build: the engine runs the plain kernel when the guard is off)
       const unsigned at = atomicAdd(guard.g.counter, 1u);
       const unsigned k = static_cast<unsigned>(fused_bin(threadIdx.x, static_cast<int>(m)));
-      if (at < guard.g.cap) guard.g.list[at] = make_uint2(guard.frame, (static_cast<unsigned>(sym) << 16) | k);
+      // (the re-decision reads the two symbols' samples: their address goes along, so that it does not have to walk frame list, descriptor and view first)
+      const uint64_t win = guard.fast_base ? guard.fast_base + 2u * static_cast<unsigned>(kNullSamples + kSymSamples * sym + kCpSamples) : 0u;
+      if (at < guard.g.cap) guard.g.list[at] = make_uint4(guard.frame, (static_cast<unsigned>(sym) << 16) | k, static_cast<unsigned>(win), static_cast<unsigned>(win >> 32));
     }
   }
 }
@@ -296,10 +299,10 @@ __device__ __forceinline__ void symbol_energy_part(const float2 (&v)[8], int* es
   const int total = static_cast<int>(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e), 63)));
   esum[threadIdx.x >> 6] = total;                       // every lane writes the same word
 }
-__device__ __forceinline__ float symbol_bound(const int* esum)
+__device__ __forceinline__ float symbol_bound(const int* esum, float c)
 {
   const int4 p = *reinterpret_cast<const int4*>(esum);
-  return kGuardC * sqrtf(static_cast<float>(p.x + p.y + p.z + p.w));
+  return c * sqrtf(static_cast<float>(p.x + p.y + p.z + p.w));
 }
 
 #if !DABHIP_FUSED_SOFT
@@ -443,7 +446,7 @@ __device__ __forceinline__ void fused_symbols(GlobalU16 fast_src, const uint8_t*
 #endif
         fft2048_first(v, exA, tw);
 #ifndef DABHIP_PROBE_NOENERGY
-        const float dcur = guarded ? symbol_bound(esum + 4 * h) : 0.0f;
+        const float dcur = guarded ? symbol_bound(esum + 4 * h, DABHIP_FUSED_SOFT ? kSoftNormC : guard.g.c) : 0.0f;
 #else
         const float dcur = 1.0e-3f;
 #endif
@@ -551,11 +554,13 @@ __global__ __launch_bounds__(kThreads, DABHIP_FUSED_WG_PER_CU) void ofdm_demap_k
   fast_end -= (fast_end - sym_begin) & 1;
   float2 px[4], py[4];                                  // the previous symbol's bins
   // the guard re-decides from the raw samples: with the software AFC's NCO in the path there is no such exact reference
-  FusedGuard guard{gargs, static_cast<unsigned>(first + j)};
+  FusedGuard guard{gargs, static_cast<unsigned>(first + j), 0};
   if (nco_inc) guard.g.delta = nullptr;
   float dprev = 0.0f;                                   // error bound of the previous symbol's bins
   float maxp = 0.0f;                                    // largest |bin|_1 of the previous symbol among this thread's bins (guarded build)
+  guard.fast_base = reinterpret_cast<uintptr_t>(stream + (seg_src0 >= 0 ? seg_src0 : 0));
   fused_symbols<true, kNco>(src, stream, view, sym_begin, fast_end, false, px, py, exA, exB, decA, decB, tw, qk, nco_inc, out, guard, esum, dprev, maxp);
+  guard.fast_base = 0;
   fused_symbols<false, kNco>(src, stream, view, fast_end, sym_end, fast_end > sym_begin, px, py, exA, exB, decA, decB, tw, qk, nco_inc, out, guard, esum, dprev, maxp);
 }
 

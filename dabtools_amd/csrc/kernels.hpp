@@ -92,9 +92,10 @@ hipError_t launch_sync_ahead(const uint8_t* const* iq, const int64_t* nbytes, co
 hipError_t launch_sync_verify(const uint8_t* const* iq, const int64_t* nbytes, const int* calls_before, StreamState* states, CallDesc* descs,
                               int nstreams, int max_calls, const double2* tw2048, const uint8_t* prs_q, int* violation, bool carry_only, hipStream_t stream);
 
-// delta != nullptr: the kernel also leaves the guard's per-symbol error bound kGuardC sqrt(sum |x|^2) at delta[(first + j) * 76 + symbol]
+// delta != nullptr: the kernel also leaves the guard's per-symbol error bound delta_c sqrt(sum |x|^2) at delta[(first + j) * 76 + symbol]
+// (delta_c = GuardArgs::c of the launches that will read it: the guard level's constant, or kSoftNormC for soft decisions)
 hipError_t launch_ofdm_fft(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first,
-                           int nframes, float2* spectra, const float2* tw, hipStream_t stream, float* delta = nullptr);
+                           int nframes, float2* spectra, const float2* tw, hipStream_t stream, float* delta = nullptr, float delta_c = kGuardC);
 
 // K2b: DQPSK + demap + frequency de-interleave -> bit-packed rows.  FIC rows at TF slot frame_slot[first + j];
 // MSC rows start at CIF row frame_cif_row[first + j]: planar = scattered into time-de-interleaved logical rows
@@ -150,8 +151,8 @@ hipError_t launch_ofdm_demap_fused_plain(bool afc, const uint8_t* const* iq, con
                                          uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream, int sym_a = 1, int sym_b = 76, int nparts = 4);
 // parity guard (k_parity.hip): per-symbol error bounds, fp64 re-decision of the flagged carriers, and the audit
 hipError_t launch_symbol_delta(const uint8_t* const* iq, const CallDesc* descs, int max_calls, const int2* frames, int first, int nframes,
-                               int nsym, float* delta, int delta_stride, hipStream_t stream);
-hipError_t launch_exact_decide(const uint2* list, const unsigned* counter, unsigned cap, const uint8_t* const* iq, const CallDesc* descs,
+                               int nsym, float* delta, int delta_stride, float delta_c, hipStream_t stream);
+hipError_t launch_exact_decide(const uint4* list, const unsigned* counter, unsigned cap, const uint8_t* const* iq, const CallDesc* descs,
                                int max_calls, const int2* frames, const double2* tw2048, const uint16_t* qpsk_of_carrier, const uint16_t* carrier_of_qpsk,
                                const int* frame_slot, const int* frame_cif_row, bool planar, uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream);
 // list overflow of a guarded launch: its frames' symbols [sym_a, sym_b) decided again in full from fp64 transforms (returns at once otherwise)
@@ -161,7 +162,7 @@ hipError_t launch_exact_decide_all(const unsigned* counter, unsigned cap, const 
                                    hipStream_t stream);
 hipError_t launch_decision_audit(const uint8_t* frames_iq, int nframes, const float2* spectra, const uint32_t* fic_bits, const uint32_t* msc_bits,
                                  const double2* tw2048, const uint16_t* qpsk_of_carrier, void* out, hipStream_t stream,
-                                 const float2* fused_prods = nullptr, int row_lead = 0);   // fused_prods != null: the fused kernel's audit (spectra = its bins by raw bin)
+                                 const float2* fused_prods = nullptr, int row_lead = 0, int guard_level = 1);   // fused_prods != null: the fused kernel's audit (spectra = its bins by raw bin)
 hipError_t launch_batched_copy(const CopyDesc* descs, int n, hipStream_t stream);
 // the descriptors' sources may be page-locked HOST memory (read over PCIe by a small persistent grid); nbytes < 4 GiB each
 hipError_t launch_host_gather(const CopyDesc* descs, int n, int workgroups, hipStream_t stream);

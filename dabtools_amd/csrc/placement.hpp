@@ -14,9 +14,12 @@
 #include <pthread.h>
 #include <sched.h>
 
+#include <algorithm>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace dabhip {
@@ -121,15 +124,38 @@ inline std::vector<std::vector<int>> system_node_cpus()
 // oversubscribe the grant: eight ranks x 24 pool threads burn the quota of a 100 ms period early and the cgroup freezes EVERY thread until the
 // next one.  So pools are sized from min(|affinity mask|, quota), and CPU lists are intersected with the mask before anything is bound to them.
 
-// the CPUs of the calling process's affinity mask (what a launcher's taskset / numactl / cpuset left), ascending
+// The CPUs this PROCESS may run on (what a launcher's taskset / numactl / cpuset left), ascending: /proc/self/status "Cpus_allowed_list" -- the mask of the
+// thread-group leader, which is what a launcher set -- and not sched_getaffinity(0), which answers for the CALLING thread (a pool thread that has been
+// bound already would report its own chunk) and fails with EINVAL on machines with more than 1024 CPU ids when handed a fixed cpu_set_t.  Falls back to
+// the calling thread's mask read with a set sized for the machine; an unreadable mask is NO restriction (every CPU the machine reports), never "one CPU".
 inline std::vector<int> allowed_cpus()
 {
+  {
+    const std::string st = read_small_file("/proc/self/status");
+    const size_t at = st.find("Cpus_allowed_list:");
+    if (at != std::string::npos) {
+      const size_t from = at + 18, eol = st.find('\n', from);
+      const std::vector<int> list = parse_cpulist(st.substr(from, eol == std::string::npos ? std::string::npos : eol - from));
+      if (!list.empty()) return list;
+    }
+  }
   std::vector<int> out;
-  cpu_set_t set;
-  CPU_ZERO(&set);
-  if (sched_getaffinity(0, sizeof set, &set) != 0) return out;
-  for (int c = 0; c < CPU_SETSIZE; ++c)
-    if (CPU_ISSET(c, &set)) out.push_back(c);
+  for (size_t ncpu = 1024; ncpu <= (size_t(1) << 20); ncpu *= 4) {       // grow the set until the kernel's mask fits (EINVAL: too small)
+    cpu_set_t* set = CPU_ALLOC(ncpu);
+    if (!set) break;
+    const size_t bytes = CPU_ALLOC_SIZE(ncpu);
+    CPU_ZERO_S(bytes, set);
+    const int rc = sched_getaffinity(0, bytes, set);
+    if (rc == 0)
+      for (size_t c = 0; c < ncpu; ++c)
+        if (CPU_ISSET_S(c, bytes, set)) out.push_back(static_cast<int>(c));
+    CPU_FREE(set);
+    if (rc == 0 || errno != EINVAL) break;
+  }
+  if (out.empty()) {                                                      // unreadable: no restriction known
+    const unsigned hw = std::thread::hardware_concurrency();
+    for (unsigned c = 0; c < (hw ? hw : 1u); ++c) out.push_back(static_cast<int>(c));
+  }
   return out;
 }
 
@@ -212,17 +238,22 @@ inline std::vector<std::vector<int>> allowed_node_cpus()
 }
 
 // bind the CALLING thread to the part of `cpus` the process is allowed on; an empty list -- or an empty intersection: the launcher put this process
-// somewhere else, and that stands -- leaves it alone.  Returns false when the kernel refuses.
+// somewhere else, and that stands -- leaves it alone (returns true: nothing was asked of the kernel).  Returns false when the kernel refuses.
 inline bool bind_this_thread(const std::vector<int>& cpus)
 {
   if (cpus.empty()) return true;
   const std::vector<int> use = intersect_cpus(cpus, allowed_cpus());
   if (use.empty()) return true;
-  cpu_set_t set;
-  CPU_ZERO(&set);
+  const size_t ncpu = static_cast<size_t>(*std::max_element(use.begin(), use.end())) + 1;
+  cpu_set_t* set = CPU_ALLOC(ncpu);
+  if (!set) return false;
+  const size_t bytes = CPU_ALLOC_SIZE(ncpu);
+  CPU_ZERO_S(bytes, set);
   for (int c : use)
-    if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
-  return pthread_setaffinity_np(pthread_self(), sizeof set, &set) == 0;
+    if (c >= 0) CPU_SET_S(static_cast<size_t>(c), bytes, set);
+  const bool ok = pthread_setaffinity_np(pthread_self(), bytes, set) == 0;
+  CPU_FREE(set);
+  return ok;
 }
 
 }  // namespace dabhip

@@ -82,6 +82,10 @@ uint8_t *dabhip_dab_tf_msc(dabhip_dab *d);   /* 221184 bytes */
  * times, synchronously, with a pointer to a 6144-byte frame valid during the call. */
 int dabhip_dab_process_frame(dabhip_dab *d);
 int dabhip_dab_locked(const dabhip_dab *d);
+/* What the reference's dab_process_frame prints on stderr for its operator -- "Locked" (dab.c:51), "Lock lost, resetting ringbuffer" (dab.c:57), the one-time
+ * ensemble dump (dab.c:78-82, misc.c:316-328) -- as text: what is pending since the last call is copied to buf (NUL-terminated, cut at cap - 1 bytes) and
+ * cleared; returns the pending text's length (0: nothing happened), < 0: bad handle.  integration/dab_hip.c writes it to stderr. */
+int64_t dabhip_dab_take_log(dabhip_dab *d, char *buf, int64_t cap);
 /* as dabhip_engine_stream_status for this seam: with a flagged multiplex dabhip_dab_process_frame invokes the callback 0 times where
  * dab_process_frame (dab.c:85-95 -> misc.c:218-314) would run off its arrays */
 uint32_t dabhip_dab_status(const dabhip_dab *d);
@@ -123,6 +127,11 @@ int64_t dabhip_engine_eti_count(const dabhip_engine *e, int stream);      /* fra
 #define DABHIP_STREAM_EEP_OPTION 4u         /* EEP protection option > 1: outside ETSI EN 300 401 and past the reference's table */
 #define DABHIP_STREAM_SUBCH_SIZE 8u         /* EEP size below one unit of its level (bit rate 0): the reference's frame carries uninitialised stack bytes there */
 uint32_t dabhip_engine_stream_status(const dabhip_engine *e, int stream);
+/* The reference's operator feedback for one stream of the last decode: what dab_process_frame prints on stderr -- "Locked" (dab.c:51), "Lock lost,
+ * resetting ringbuffer" (dab.c:57), the one-time ensemble dump "ENSEMBLE_INFO: ..." / "SubChId=..." (dab.c:78-82, misc.c:316-328) -- same text, same
+ * order.  The text pending since the last call is copied to buf (NUL-terminated, cut at cap - 1 bytes) and cleared; returns its full length (0: nothing
+ * to report), < 0: no such stream.  dab2eti-hip prints it on stderr. */
+int64_t dabhip_engine_stream_log(dabhip_engine *e, int stream, char *buf, int64_t cap);
 /* Copy the ETI frames of one stream (in emission order) to host memory. */
 int64_t dabhip_engine_eti_read(dabhip_engine *e, int stream, uint8_t *dst, int64_t cap_frames);
 /* Deliver all frames, stream by stream in emission order, to a sink (stdout contract helper). */
@@ -153,14 +162,27 @@ int dabhip_engine_set_soft(dabhip_engine *e, int enable);
 
 /* Parity guard (default ON).  The reference takes its hard decisions as sign tests on fp64 FFTW spectra (input_sdr.c:132-162);
  * the OFDM stage here transforms in fp32.  With the guard on, every decision whose |Re| or |Im| of cur*conj(prev) lies inside
- * the fp32 error band (a few per million at high SNR, ~1e-4 of them at 5 dB) is re-decided in fp64 from the int8 samples, so
- * the demapped bits -- and therefore the ETI bytes -- are those exact arithmetic gives.  Tolerance statement: with the guard
- * off the disagreement rate of the raw fp32 decisions is what dabhip_stage_decision_audit measures.
+ * the fp32 error band is re-decided in fp64 from the int8 samples, so the demapped bits -- and therefore the ETI bytes -- are
+ * those exact arithmetic gives.  `level`:
+ *   DABHIP_GUARD_OFF (0)       raw fp32 decisions; their disagreement rate is what dabhip_stage_decision_audit measures;
+ *   DABHIP_GUARD_MEASURED (1)  the band is >= 4.5 x the worst error measured over > 10^10 audited decisions ("exact with measured margin");
+ *   DABHIP_GUARD_PROVEN (2)    the band is a rigorous forward-error bound of this very transform and product ("exact by construction":
+ *                              DESIGN.md section 3 carries the derivation, tools/fft_error_bound.py the arithmetic); 13 x as wide, i.e. 13 x
+ *                              the re-decisions on noisy input, none on clean input;
+ *   DABHIP_GUARD_DEFAULT (-1)  the library's default level (dabhip_parity_guard_default_level()).
  * Applies to hard decisions without the software AFC (the two configurations that claim reference semantics). */
-int dabhip_engine_set_parity_guard(dabhip_engine *e, int enable);
+#define DABHIP_GUARD_DEFAULT (-1)
+#define DABHIP_GUARD_OFF 0
+#define DABHIP_GUARD_MEASURED 1
+#define DABHIP_GUARD_PROVEN 2
+int dabhip_engine_set_parity_guard(dabhip_engine *e, int level);
+int dabhip_engine_parity_guard_level(const dabhip_engine *e);
+int dabhip_parity_guard_default_level(void);
+/* the two constants of a level: bound on a bin's error relative to sqrt(sum |x_n|^2), bound on the product's rounding relative to |cur|_1 |prev|_1 */
+int dabhip_parity_guard_constants(int level, double *bin_c, double *prod_c);
 /* Decisions the guard re-decided in the last decode, and hard decisions taken in all. */
 int dabhip_engine_guard_stats(const dabhip_engine *e, int64_t *flagged, int64_t *decisions);
-/* The guard lists the decisions to re-decide per kernel launch (64 entries per TF, at least 262,144).  A launch with more of them
+/* The guard lists the decisions to re-decide per kernel launch (64 entries per TF, at least 262,144; the proven level: 1024, 1,048,576).  A launch with more of them
  * -- input that synchronises but has many near-zero products: strongly notched, narrowband or near-DC frames -- does not fail: its
  * frames are decided again in full from fp64 transforms (slow, still the bits of exact arithmetic).  Number of such launches in the
  * last decode; and the list capacity as a test knob (0 = automatic). */
@@ -215,6 +237,7 @@ int64_t dabhip_multi_decode(dabhip_multi *m, const uint8_t *const *iq, const siz
 int64_t dabhip_multi_eti_count(const dabhip_multi *m, int stream);
 uint32_t dabhip_multi_stream_status(const dabhip_multi *m, int stream);   /* as dabhip_engine_stream_status, global stream index */
 int64_t dabhip_multi_eti_read(dabhip_multi *m, int stream, uint8_t *dst, int64_t cap_frames);
+int64_t dabhip_multi_stream_log(dabhip_multi *m, int stream, char *buf, int64_t cap);   /* as dabhip_engine_stream_log, global stream index */
 int64_t dabhip_multi_eti_drain(dabhip_multi *m, dabhip_eti_sink sink, void *user);   /* all frames, global stream order */
 int dabhip_multi_trace(const dabhip_multi *m, int stream, int32_t *ints6, double *ffs, int cap_calls);
 /* The engine of one slice, for the per-engine queries (stage times, guard statistics); owned by the multi object. */
@@ -223,7 +246,7 @@ dabhip_engine *dabhip_multi_engine(dabhip_multi *m, int slice);
 float dabhip_multi_wall_ms(const dabhip_multi *m, int slice);
 int dabhip_multi_set_afc(dabhip_multi *m, int enable);
 int dabhip_multi_set_soft(dabhip_multi *m, int enable);
-int dabhip_multi_set_parity_guard(dabhip_multi *m, int enable);
+int dabhip_multi_set_parity_guard(dabhip_multi *m, int level);
 int dabhip_multi_set_fused(dabhip_multi *m, int enable);
 int dabhip_multi_set_subchannels(dabhip_multi *m, const int32_t *ids, int n);
 
@@ -236,6 +259,8 @@ int dabhip_multi_set_subchannels(dabhip_multi *m, const int32_t *ids, int n);
  * After each feed the frames of THAT segment are read with the eti_* calls below. */
 typedef struct dabhip_stream dabhip_stream;
 dabhip_stream *dabhip_stream_create(int device, int nstreams);
+/* the same with the host side chosen by the caller: host_threads of the control-plane pool (0 = automatic), CPUs to bind them to (ncpus = 0: unbound) */
+dabhip_stream *dabhip_stream_create_on_cpus(int device, int nstreams, int host_threads, const int32_t *cpus, int ncpus);
 void dabhip_stream_destroy(dabhip_stream *s);
 /* Append nbytes[b] bytes to stream b (host pointers, or device pointers when on_device != 0) and decode every
  * 262144-byte call that became complete.  Returns the ETI frames produced by this segment, <0 on error. */
@@ -255,6 +280,7 @@ int64_t dabhip_stream_need_from(const dabhip_stream *s, int stream);   /* oldest
 int64_t dabhip_stream_eti_count(const dabhip_stream *s, int stream);
 int dabhip_stream_stage_ms(const dabhip_stream *s, const char **names, float *ms, int cap);   /* of the segment fed last; names as dabhip_engine_stage_ms */
 uint32_t dabhip_stream_status(const dabhip_stream *s, int stream);        /* as dabhip_engine_stream_status, sticky over the session's segments */
+int64_t dabhip_stream_log(dabhip_stream *s, int stream, char *buf, int64_t cap);   /* as dabhip_engine_stream_log: the operator messages since the last call */
 int64_t dabhip_stream_eti_read(dabhip_stream *s, int stream, uint8_t *dst, int64_t cap_frames);
 int64_t dabhip_stream_eti_drain(dabhip_stream *s, dabhip_eti_sink sink, void *user);
 /* as dabhip_engine_eti_fetch / _wait, for the frames of the segment fed last: its download overlaps the next segment's upload and decode */
@@ -263,8 +289,46 @@ int dabhip_stream_eti_fetch_wait(dabhip_stream *s);
 int dabhip_stream_set_afc(dabhip_stream *s, int enable);
 int dabhip_stream_set_subchannels(dabhip_stream *s, const int32_t *ids, int n);   /* before the first segment only */
 int dabhip_stream_set_soft(dabhip_stream *s, int enable);   /* before the first segment only */
-int dabhip_stream_set_parity_guard(dabhip_stream *s, int enable);   /* default on, see dabhip_engine_set_parity_guard */
+int dabhip_stream_set_parity_guard(dabhip_stream *s, int level);   /* see dabhip_engine_set_parity_guard */
 int dabhip_stream_set_sync_speculation(dabhip_stream *s, int mode);   /* default -1, see dabhip_engine_set_sync_speculation */
+/* ---- sessions over several devices of one node -----------------------------------------------------------------------
+ * dab2eti.c:60-130,237 is a session on ONE device: calls arrive for ever from one demod thread.  B independent unbounded streams shard like a batch
+ * does: the streams are dealt ONCE, at creation, to the listed devices in contiguous slices (the rule of dabhip_multi_plan: slice i of n takes
+ * B / n streams, the first B mod n slices one more), every slice is a complete dabhip_stream session on its device with its own host thread, and
+ * every call below is that call made on all slices at once with each slice's part of the pointer arrays.  No collective, no peer access.  The
+ * frames of a segment are byte-identical to those of ONE dabhip_stream session over all B streams (and, concatenated over the segments, to one
+ * dabhip_engine_decode of the whole captures), in global stream order.  A device may be listed more than once (each entry is its own slice).
+ * iq[b] / base[b]: host pointers (page-locked for asynchronous uploads: dabhip_host_alloc memory is visible to every device), or -- on_device /
+ * feed_resident -- device pointers that live on the device of stream b's slice (dabhip_multi_stream_slice_of).
+ * Call sequence of a host-fed pipeline (what `dab2eti-hip --stream --devices 0-7` does):
+ *     prefetch(seg 0); loop k: prefetch(seg k + 1); n = feed(seg k); eti_fetch(out[k & 1], n); ... a writer thread: eti_fetch_wait(); write(out[k & 1]). */
+typedef struct dabhip_multi_stream dabhip_multi_stream;
+dabhip_multi_stream *dabhip_multi_stream_create(const int *devices, int n, int nstreams);
+void dabhip_multi_stream_destroy(dabhip_multi_stream *m);
+int dabhip_multi_stream_slices(const dabhip_multi_stream *m);
+int dabhip_multi_stream_streams(const dabhip_multi_stream *m);
+/* slice index of `stream` (< 0: bad argument); its device, and the slice's first stream and stream count */
+int dabhip_multi_stream_slice_of(const dabhip_multi_stream *m, int stream, int *device, int *first, int *count);
+/* one slice's session, for the per-session queries (dabhip_stream_stage_ms); owned by the multi object, NULL for an empty slice */
+dabhip_stream *dabhip_multi_stream_session(dabhip_multi_stream *m, int slice);
+int dabhip_multi_stream_prefetch(dabhip_multi_stream *m, const uint8_t *const *iq, const size_t *nbytes, int on_device);
+int64_t dabhip_multi_stream_feed(dabhip_multi_stream *m, const uint8_t *const *iq, const size_t *nbytes, int on_device);
+int64_t dabhip_multi_stream_feed_resident(dabhip_multi_stream *m, const uint8_t *const *base, const size_t *avail);
+int64_t dabhip_multi_stream_need_from(const dabhip_multi_stream *m, int stream);
+int64_t dabhip_multi_stream_eti_count(const dabhip_multi_stream *m, int stream);
+uint32_t dabhip_multi_stream_status_of(const dabhip_multi_stream *m, int stream);   /* as dabhip_stream_status, global stream index (dabhip_multi_stream_status is the batch object's) */
+int64_t dabhip_multi_stream_eti_read(dabhip_multi_stream *m, int stream, uint8_t *dst, int64_t cap_frames);
+int64_t dabhip_multi_stream_log_of(dabhip_multi_stream *m, int stream, char *buf, int64_t cap);   /* as dabhip_stream_log, global stream index */
+int64_t dabhip_multi_stream_eti_drain(dabhip_multi_stream *m, dabhip_eti_sink sink, void *user);   /* frames of the segment fed last, global stream order */
+/* all frames of the segment fed last in global stream order, one asynchronous download per slice into dst (page-locked); _wait: they have landed */
+int64_t dabhip_multi_stream_eti_fetch(dabhip_multi_stream *m, uint8_t *dst, int64_t cap_frames);
+int dabhip_multi_stream_eti_fetch_wait(dabhip_multi_stream *m);
+int dabhip_multi_stream_set_afc(dabhip_multi_stream *m, int enable);
+int dabhip_multi_stream_set_soft(dabhip_multi_stream *m, int enable);                    /* before the first segment only */
+int dabhip_multi_stream_set_parity_guard(dabhip_multi_stream *m, int level);
+int dabhip_multi_stream_set_sync_speculation(dabhip_multi_stream *m, int mode);
+int dabhip_multi_stream_set_subchannels(dabhip_multi_stream *m, const int32_t *ids, int n);   /* before the first segment only */
+
 /* Page-locked host memory for segments: fill the next one while the current one decodes (double buffering). */
 void *dabhip_host_alloc(size_t nbytes);
 void dabhip_host_free(void *p);
@@ -272,6 +336,10 @@ void dabhip_host_free(void *p);
 /* Streaming rates of the device, for reading the K2 roofline figure against what a bare kernel reaches (not on the data path):
  * gbs[0] fill, gbs[1] copy, gbs[2] K2's mix (1 byte read per 4 written), GB/s of bytes moved, over buffers of `bytes` bytes. */
 int dabhip_stream_ceiling(int device, size_t bytes, int reps, double *gbs);
+
+/* Which physical device an index is: its PCI bus id ("0000:c1:00.0", cap_bus >= 16) and name.  bench.py records both per rank and refuses to report
+ * a multi-rank figure whose ranks did not sit on distinct devices.  0, <0: no such device. */
+int dabhip_device_identity(int device, char *bus_id, int cap_bus, char *name, int cap_name);
 
 /* Device memory for callers without a GPU runtime of their own: the batch entries (dabhip_engine_decode with on_device,
  * dabhip_synth_generate_device, the stage entries) take plain device pointers.  copy: to_device != 0: host -> device. */
@@ -348,6 +416,8 @@ int dabhip_host_eti_header(const int32_t *hdr3, const int32_t *sub, uint8_t *out
  * (272-byte rows) + lengths.  Returns the number of ETI frames. */
 int dabhip_host_control_replay(const uint8_t *fibs, const uint8_t *crc_ok, int ntf, int32_t *first_cif,
                                uint8_t *headers, int32_t *header_len, int cap_frames);
+/* the operator messages (see dabhip_engine_stream_log) of the calling thread's last dabhip_host_control_replay */
+int64_t dabhip_host_control_replay_log(char *buf, int64_t cap);
 
 /* The placement rule by itself (no GPU, no sysfs): slice i sits on NUMA node slice_node[i] (< 0: unknown); node_cpulist[n] is node n's CPU list in
  * the kernel's notation ("0-63,128-191").  cpu_slice[c] = the slice CPU c is given to, -1 = none; the slices of a node get disjoint contiguous

@@ -4,6 +4,7 @@
  * stay as they are.  Compiled against the reference's dab.h and tested by oracle/Makefile (_ref/libdabref_hipS3.so) +
  * tests/test_gpu_parity_r2.py::test_reference_callers_over_the_hip_seams.
  */
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -28,4 +29,8 @@ void dab_process_frame(struct dab_state_t *dab)                                 
   memcpy(dabhip_dab_tf_msc(h), tf->msc_symbols_demapped, 221184);
   dabhip_dab_process_frame(h);                         /* calls eti_callback 0 or 4 times, synchronously */
   dab->locked = dabhip_dab_locked(h);
+  {                                                    /* "Locked" / "Lock lost, resetting ringbuffer" / the ensemble dump: dab.c:51,57,78-82 */
+    char text[8192];
+    if (dabhip_dab_take_log(h, text, sizeof text) > 0) fputs(text, stderr);
+  }
 }

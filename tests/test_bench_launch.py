@@ -31,6 +31,10 @@ def _check(res, n, steps):
     slowest = max(r["elapsed_s"] for r in ranks)                 # MAX over ranks, whole-job frames
     assert abs(res["value"] - n * 256 * 196 * steps / slowest) < 1e-6 * res["value"]
     assert abs(res["ms_per_step"] - 1e3 * slowest / steps) < 1e-6
+    # every rank records the device it decoded on; the line says how many distinct ones there were
+    assert [r["device"]["pci_bus_id"] for r in ranks] == res["devices"]["pci_bus_ids"]
+    assert res["devices"]["distinct_pci_bus_ids"] == len(set(res["devices"]["pci_bus_ids"]))
+    assert res["devices"]["distinct_pci_bus_ids"] == n or res["devices"]["rehearsal_on_one_device"]
     if n > 1:
         assert ranks[-1]["elapsed_s"] > ranks[0]["elapsed_s"]   # the dry run makes higher ranks slower on purpose
         assert all(r["host_threads"] != "auto" for r in ranks)  # per-rank host pool capped (cores / ranks)
@@ -76,6 +80,31 @@ def test_self_launch_eight_ranks_each_sees_its_own_gpu_and_its_share_of_the_cpus
     if hasattr(os, "sched_setaffinity"):                             # a launcher's taskset shrinks the budget
         code = "import os,sys; sys.path.insert(0, %r); os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]}); from dabtools_amd import shard; print(shard.usable_cpus())" % ROOT
         assert subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True, check=True, env=base).stdout.strip() == "1"
+
+
+def test_ranks_that_share_a_device_are_refused_unless_declared_a_rehearsal():
+    """An N-rank line is an N-GPU figure only if the N ranks sat on N distinct GPUs: rank 0 compares the PCI bus ids the ranks recorded and prints NO line
+    (exit code non-zero) when they do not differ -- except under DABHIP_BENCH_ONE_DEVICE=1, the declared one-GPU rehearsal, whose line then says so
+    itself.  tools/scale_sweep.py builds the 1/2/4/8 table from such lines and labels every row."""
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DABHIP_BENCH_ONE_DEVICE", "DABHIP_BENCH_DRY_BUS_ID")}
+    cmd = [sys.executable, BENCH, "--gpus", "4", "--dry-run", "--steps", "2"]
+    p = subprocess.run(cmd, env=dict(base, DABHIP_BENCH_DRY_BUS_ID="0000:c1:00.0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode != 0 and "4 ranks decoded on 1 distinct devices" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")], p.stdout
+    p = subprocess.run(cmd, env=dict(base, DABHIP_BENCH_ONE_DEVICE="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, check=True)
+    res = _one_json_line(p.stdout)
+    assert res["devices"]["distinct_pci_bus_ids"] == 1 and res["devices"]["rehearsal_on_one_device"] is True and "NOT a 4-GPU figure" in res["devices"]["note"]
+    # the sweep: 1, 2 and 8 ranks, dry; then the declared rehearsal
+    sweep = [sys.executable, os.path.join(ROOT, "tools", "scale_sweep.py"), "--dry-run", "--gpus", "1,2,8", "--steps", "2", "--streams", "4", "--tfs", "20"]
+    p = subprocess.run(sweep, env=base, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, check=True)
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert [r["n_gpus"] for r in d["rows"]] == [1, 2, 8] and all(r["kind"] == "measured" and r["distinct_devices"] == r["n_gpus"] for r in d["rows"])
+    assert not d["any_rehearsal"] and d["rows"][0]["efficiency_vs_n1"] == 1.0 and d["rows"][2]["efficiency_vs_n1"] is not None
+    assert d["last_driver_bench"] is None or d["last_driver_bench"]["file"].startswith("BENCH_r")
+    p = subprocess.run(sweep + ["--one-device"], env=base, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, check=True)
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["any_rehearsal"] and [r["kind"] for r in d["rows"]] == ["measured", "REHEARSAL (one GPU)", "REHEARSAL (one GPU)"]
+    assert d["rows"][2]["efficiency_vs_n1"] is None and "REHEARSAL" in p.stderr
 
 
 def test_a_dying_rank_ends_the_launch_with_an_error():
@@ -175,7 +204,7 @@ def test_roofline_objects_are_computable_from_the_tracked_profile():
     # the mix file belongs to THIS tree's kernel sources
     import hashlib
     src = b"".join(open(os.path.join(ROOT, "dabtools_amd", "csrc", n), "rb").read() for n in ("k_fused.hip", "fft_core.hpp", "device_types.hpp"))
-    assert mix["source_sha256"] == hashlib.sha256(src).hexdigest(), "profiles/r05_fused_isa_mix.json is stale: run tools/fused_isa_mix.sh"
+    assert mix["source_sha256"] == hashlib.sha256(src).hexdigest(), "profiles/r06_fused_isa_mix.json is stale: run tools/fused_isa_mix.sh"
     # a missing profile, or a missing cell, is an error that says what to do
     import pytest
     with pytest.raises(SystemExit, match="refresh_profiles"):
@@ -183,20 +212,52 @@ def test_roofline_objects_are_computable_from_the_tracked_profile():
 
 
 def test_decision_audit_profile_belongs_to_this_trees_kernels():
-    """profiles/r05_decision_audit.json -- the measured ground the parity guard's constants stand on -- names the
-    kernel the default decode runs, was measured on THIS tree's sources (tools/decision_audit.py hashes them; re-run it on a GPU box after touching any),
-    covers >= 10^10 decisions with no disagreement outside the guard's band and none with the guard on, keeps a margin of >= 4 on both constants, and the
-    shipping build left the audit build's bits and list counts in every case."""
-    import hashlib
+    """profiles/r06_decision_audit.json -- the ground both guard levels stand on -- names the kernel the default
+    decode runs, was measured on THIS tree's sources (tools/decision_audit.py hashes them; re-run it on a GPU box after touching any), covers >= 10^10
+    decisions with no disagreement outside EITHER level's band and none with the guard on at either level; the worst measured errors lie below the proven
+    bound (tools/fft_error_bound.py), the proven level's constants are >= that bound, the measured level keeps a margin of >= 4 over the worst errors, and
+    the shipping build left the audit build's bits and list counts in every case."""
     import json
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import decision_audit
-    d = json.load(open(os.path.join(ROOT, "profiles", "r05_decision_audit.json")))
+    import fft_error_bound
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_decision_audit.json")))
     assert "ofdm_demap_kernel" in d["kernel"] and d["sources"] == list(decision_audit.AUDITED_SOURCES)
-    assert d["source_sha256"] == decision_audit.source_sha(), "profiles/r05_decision_audit.json is stale: run tools/decision_audit.py --channels 300 on a GPU box"
+    assert d["source_sha256"] == decision_audit.source_sha(), "profiles/r06_decision_audit.json is stale: run tools/decision_audit.py --channels 300 on a GPU box"
     assert d["total_decisions"] >= 1e10 and d["total_disagree_outside_band"] == 0 and d["total_disagree_guard_on"] == 0
+    assert d["proven_level"]["total_disagree_outside_band"] == 0 and d["proven_level"]["total_disagree_guard_on"] == 0
     assert d["margin_kGuardC_over_worst"] >= 4 and d["margin_kGuardProd_over_worst"] >= 4
     assert d["shipping_kernel_same_bits_in_every_case"] and d["shipping_kernel_same_list_count_in_every_case"]
-    assert d["worst_max_bin_err_over_sqrt_energy"] < d["a_priori_worst_case_bin_err_over_sqrt_energy"]      # the a-priori bound is NOT what the constants rest on
+    bound = fft_error_bound.constants()
+    assert d["proven_bound"]["bin_err_over_l2"] == bound["bin_bound"] and d["proven_bound"]["product_rounding_over_l2l2"] == bound["prod_bound"]
+    assert d["worst_measured_below_proven_bound"] and d["worst_max_bin_err_over_sqrt_energy"] <= bound["bin_bound"] and d["worst_max_residual_product_err"] <= bound["prod_bound"]
+    assert d["guard_constants"]["proven"]["kGuardCProven"] >= bound["bin_bound"] and d["guard_constants"]["proven"]["kGuardProdProven"] >= bound["prod_bound"]
     assert any(c["channel"] != "ideal" for c in d["cases"])
+
+
+def test_proven_guard_constants_cover_the_rigorous_bound():
+    """device_types.hpp's kGuardCProven / kGuardProdProven (read through the library: no GPU needed) are >= the forward-error bound tools/fft_error_bound.py
+    derives for the transform and product as the kernels write them, and that script's fp32 model of the same operation order stays below the bound on
+    adversarial inputs (single tones, clipped tones, cancelling halves, OFDM symbols) -- while exceeding the MEASURED level's constant on some of them,
+    which is why the proven level exists."""
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import dabtools_amd as dab
+    import fft_error_bound
+    c = fft_error_bound.constants()
+    assert 6.4e-5 < c["bin_bound"] < 6.6e-5 and 1.19e-7 < c["prod_bound"] < 1.2e-7
+    assert dab.guard_constants(2)[0] >= c["bin_bound"] and dab.guard_constants(2)[1] >= c["prod_bound"]
+    assert dab.guard_constants(1)[0] < c["bin_bound"]                       # the measured level does NOT claim the bound
+    assert dab.guard_default_level() in (1, 2)
+    rng = np.random.default_rng(6)
+    worst = 0.0
+    for name, x in fft_error_bound.adversarial_inputs(rng):
+        norm = float(np.sqrt(np.sum(np.abs(x) ** 2)))
+        if norm == 0:
+            continue
+        err = float(np.max(np.abs(fft_error_bound.fft2048_model(x) - np.fft.fft(x)))) / norm
+        assert err <= c["bin_bound"], (name, err)
+        worst = max(worst, err)
+    assert worst > dab.guard_constants(1)[0]                                # a clipped tone: 5.3e-6 |x|_2 > 5e-6

@@ -409,7 +409,8 @@ def test_bindings_s2_s3_with_two_states_interleaved():
 
 
 # ---- the parity guard's ground, measured on the kernel that ships --------------------------------------------------------------------------------
-def test_decision_audit_of_the_fused_kernel():
+@pytest.mark.parametrize("level", [1, 2])
+def test_decision_audit_of_the_fused_kernel(level):
     """dabhip_stage_decision_audit_fused: the default decode's one-kernel OFDM stage (ofdm_demap_kernel, guarded build) against fp64 transforms of the same
     samples, through its audit build -- the same source lines plus stores of the bins and products (k_fused.hip, DABHIP_FUSED_AUDIT).  (a) The shipping
     build leaves the same bits and lists the same number of decisions on the same frames; (b) the kernel's own list is the per-bin rule's (plus exact
@@ -422,10 +423,11 @@ def test_decision_audit_of_the_fused_kernel():
         caps.append(iq[: (iq.size // dab.TF_BYTES) * dab.TF_BYTES])
     frames = np.concatenate(caps)
     eng = dab.Engine(0)
+    eng.set_parity_guard(level)                          # the audit counts with this level's rule (1 = measured band, 2 = proven band)
     off = eng.decision_audit(frames=frames, guard=False, fused=True)
     on = eng.decision_audit(frames=frames, guard=True, fused=True)
     two = eng.decision_audit(frames=frames, guard=False, fused=False)
-    print("fused audit, guard off:", off, "guard on:", on)
+    print("fused audit, level", level, "guard off:", off, "guard on:", on)
     nframes = frames.size // dab.TF_BYTES
     assert off["decisions"] == nframes * 230400 == on["decisions"] == two["decisions"]
     assert off["shipping_kernel_same_bits"] == 1.0 and off["shipping_kernel_same_list_count"] == 1.0 and on["shipping_kernel_same_list_count"] == 1.0   # (a)

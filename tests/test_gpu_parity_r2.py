@@ -275,11 +275,16 @@ def test_reference_callers_over_the_hip_seams(seam):
     assert 0 in locked[12:] and locked[-1] == 1                # the run loses lock and regains it
 
 
-def test_parity_guard_makes_fp32_decisions_exact(engine):
-    """The stated float tolerance of the OFDM stage, and its removal.  K2 + K2b in fp32 against fp64 transforms of the same
-    samples (dabhip_stage_decision_audit) at 5 dB, where decisions sit closest to zero: (a) guard off: the raw fp32 decisions
-    may disagree, but only on carriers the guard rule flags, and every fp32 error stays a factor >= 2 inside the guard
-    constants; (b) guard on: zero disagreements.  tools/decision_audit.py runs the same on > 10^9 decisions per SNR."""
+@pytest.mark.parametrize("level", [1, 2])
+def test_parity_guard_makes_fp32_decisions_exact(engine, level):
+    """The stated float tolerance of the OFDM stage, and its removal, at both guard levels (1 = measured band, 2 = proven band: dabhip.h).  K2 + K2b in
+    fp32 against fp64 transforms of the same samples (dabhip_stage_decision_audit) at 5 dB, where decisions sit closest to zero: (a) guard off: the raw
+    fp32 decisions may disagree, but only on carriers the guard rule flags, and every fp32 error stays a factor >= 2 inside the MEASURED level's
+    constants (a fortiori inside the proven ones, which are >= the rigorous bound of tools/fft_error_bound.py); (b) guard on: zero disagreements.
+    tools/decision_audit.py runs the same on > 10^10 decisions at both levels."""
+    engine.set_parity_guard(level)
+    c_bin, c_prod = dab.guard_constants(level)
+    assert (c_bin, c_prod) == (pytest.approx(5.0e-6), pytest.approx(5.0e-7)) if level == 1 else (c_bin >= 6.5072e-5 and c_prod >= 1.1921e-7)
     ntf = 24
     caps = [dab.synth_generate(dab.synth_preset(0, seed=1200 + i, snr_db=snr, amplitude=amp), ntf) for i, (snr, amp) in enumerate(((5.0, 1.0), (5.0, 0.3), (7.0, 1.0), (1000.0, 1.0)))]
     frames = np.concatenate(caps)
@@ -292,24 +297,33 @@ def test_parity_guard_makes_fp32_decisions_exact(engine):
     assert off["max_prod_err"] < 2.5e-7                                       # kGuardProd = 5e-7
     assert 0 < off["flagged_by_rule"] < 1e-3 * off["decisions"]
     assert on["disagree"] == 0 and on["listed"] == off["flagged_by_rule"]     # (b)
+    engine.set_parity_guard(True)
 
 
 def test_parity_guard_end_to_end_and_off_switch():
-    """Guard on (default) vs off on noisy captures: same frames out; the guard re-decides a small, non-zero number of
-    decisions; with it on, fused and two-kernel OFDM stages and the oracle agree byte for byte."""
+    """Guard on (both levels) vs off on noisy captures: same frames out; the guard re-decides a small, non-zero number of decisions -- the proven level
+    roughly 13 x as many as the measured one; with it on, fused and two-kernel OFDM stages and the oracle agree byte for byte."""
     caps = [dab.synth_generate(dab.synth_preset(1, seed=1300 + i, snr_db=snr), 30) for i, snr in enumerate((5.0, 6.0, 9.0))]
     replays = [ol.or_replay(c) for c in caps]
     wants = [r[0] for r in replays]
     demodulated = sum(t.ok for _, trace in replays for t in trace)            # sdr_demod calls that returned 1: one TF of decisions each
     eng = dab.Engine(0)
-    for fused in (True, False):
-        eng.set_fused(fused)
-        eng.decode(caps)
-        flagged, decisions = eng.guard_stats()
-        assert 0 < flagged < 1e-3 * decisions, (fused, flagged, decisions)
-        assert decisions == demodulated * 230400, (fused, decisions, demodulated)
-        for b, w in enumerate(wants):
-            assert np.array_equal(eng.eti(b), w), (fused, b)
+    assert eng.parity_guard_level() == dab.guard_default_level() in (1, 2)
+    counts = {}
+    for level in (1, 2):
+        eng.set_parity_guard(level)
+        assert eng.parity_guard_level() == level
+        for fused in (True, False):
+            eng.set_fused(fused)
+            eng.decode(caps)
+            flagged, decisions = eng.guard_stats()
+            assert 0 < flagged < 2e-3 * decisions, (level, fused, flagged, decisions)
+            assert decisions == demodulated * 230400, (fused, decisions, demodulated)
+            assert eng.guard_overflows() == 0
+            counts[level, fused] = flagged
+            for b, w in enumerate(wants):
+                assert np.array_equal(eng.eti(b), w), (level, fused, b)
+    assert 6 * counts[1, True] < counts[2, True] < 30 * counts[1, True], counts       # the band is 13.2 x as wide
     eng.set_parity_guard(False)
     eng.decode(caps)
     assert eng.guard_stats()[0] == 0

@@ -6,6 +6,7 @@ import ctypes as C
 import hashlib
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -101,6 +102,31 @@ def test_host_control_plane_vs_reference_eti_sequence():
         # the FIBs that follow the header are those of the oldest CIF in the ring
         tf, q = divmod(int(first[i]), 4)
         assert np.array_equal(eti[i][h.size:h.size + 96], np.array(fibs[tf]).reshape(12, 32)[3 * q:3 * q + 3].reshape(-1)), i
+
+
+def test_operator_messages_match_the_reference_stderr():
+    """What dab_process_frame prints for its operator -- 'Locked' (dab.c:51), 'Lock lost, resetting ringbuffer' (dab.c:57), the one-time ensemble dump
+    (dab.c:78-82 -> misc.c:316-328) -- comes out of the host control plane as the same text in the same order: against the REAL reference's stderr on the
+    golden back-end run (tests/golden/backend_e2e_stderr.txt, made by make_operator_log.py: lock, dump, a lock loss, a re-lock without a second dump)."""
+    g = np.load(os.path.join(G, "backend_e2e.npz"))
+    want = open(os.path.join(G, "backend_e2e_stderr.txt")).read()
+    assert want.count("Locked\n") == 2 and "Lock lost, resetting ringbuffer\n" in want and want.count("ENSEMBLE_INFO") == 1
+    O = ol.oracle()
+    fibs, oks = [], []
+    for row in g["tf_bits"]:
+        bits = np.ascontiguousarray(np.unpackbits(row)[:9216])
+        f = np.zeros((12, 32), np.uint8)
+        o = np.zeros(12, np.uint8)
+        O.or_fic_decode(ol._ptr(bits), ol._ptr(f), ol._ptr(o))
+        fibs.append(f.reshape(-1))
+        oks.append(o)
+    dab.host_control_replay(np.array(fibs), np.array(oks))
+    assert dab.host_control_replay_log() == want
+    if os.path.isdir("/root/reference/src"):       # in the build container: the reference itself, live
+        sys.path.insert(0, G)
+        import make_operator_log
+        live, _ = make_operator_log.reference_stderr(g["tf_bits"])
+        assert live == want
 
 
 def test_synth_is_deterministic_and_wellformed():

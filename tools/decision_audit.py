@@ -10,7 +10,9 @@ product relative to the guard's units, and the margin the guard's constants keep
   --two-kernel: K2 + K2b (rounds 2-4: profiles/r02_decision_audit.json).
   --channels N: besides the noise / amplitude grid, N transmission frames through each of the impaired channels of round 5 (sample-rate
           offset, echoes inside and beyond the prefix, fading, I/Q imbalance; host generator, unaligned frames: any bytes serve a numerical audit).
-Needs a GPU.  Prints one JSON object; profiles/r05_decision_audit.json holds the run DESIGN.md section 3 quotes.  The JSON carries the sha-256 of the
+Round 6: every case is audited at BOTH guard levels (dabhip.h: 1 = measured band, 2 = proven band -- the rigorous forward-error bound of
+tools/fft_error_bound.py); the worst measured errors must lie below the proven bound, and no disagreement may fall outside either band.
+Needs a GPU.  Prints one JSON object; profiles/r06_decision_audit.json holds the run DESIGN.md section 3 quotes.  The JSON carries the sha-256 of the
 kernel sources it was measured on (tests/test_bench_launch.py holds it against the tree)."""
 import argparse
 import hashlib
@@ -59,18 +61,25 @@ def _channel_capture(args):
 
 
 def audit(eng, fused, **kw):
-    off = eng.decision_audit(guard=False, fused=fused, **kw)
-    on = eng.decision_audit(guard=True, fused=fused, **kw)
-    rec = {"decisions": off["decisions"],
-           "guard_off": {"disagree": off["disagree"], "rate": off["disagree"] / off["decisions"],
-                         "disagree_outside_guard_band": off["disagree_outside_guard"], "flagged_by_rule": off["flagged_by_rule"],
-                         "flag_rate": off["flagged_by_rule"] / off["decisions"], "listed_by_the_kernel": off["listed"]},
-           "guard_on": {"disagree": on["disagree"], "listed": on["listed"]},
-           "max_bin_err_over_sqrt_energy": off["max_bin_err"], "max_product_err_over_unit": off["max_dec_err"],
-           "max_residual_product_err": off["max_prod_err"]}
-    if fused:
-        rec["shipping_kernel_same_bits"] = bool(off["shipping_kernel_same_bits"] == 1.0)
-        rec["shipping_kernel_same_list_count"] = bool(off["shipping_kernel_same_list_count"] == 1.0 and on["shipping_kernel_same_list_count"] == 1.0)
+    rec = {}
+    for level in (1, 2):
+        eng.set_parity_guard(level)                       # the rule the audit counts with, and the band the guarded pass re-decides
+        off = eng.decision_audit(guard=False, fused=fused, **kw)
+        on = eng.decision_audit(guard=True, fused=fused, **kw)
+        part = {"guard_off": {"disagree": off["disagree"], "rate": off["disagree"] / off["decisions"],
+                              "disagree_outside_guard_band": off["disagree_outside_guard"], "flagged_by_rule": off["flagged_by_rule"],
+                              "flag_rate": off["flagged_by_rule"] / off["decisions"], "listed_by_the_kernel": off["listed"]},
+                "guard_on": {"disagree": on["disagree"], "listed": on["listed"]}}
+        if fused:
+            part["shipping_kernel_same_bits"] = bool(off["shipping_kernel_same_bits"] == 1.0)
+            part["shipping_kernel_same_list_count"] = bool(off["shipping_kernel_same_list_count"] == 1.0 and on["shipping_kernel_same_list_count"] == 1.0)
+        if level == 1:                                    # (the errors themselves do not depend on the level)
+            rec.update(part)
+            rec.update({"decisions": off["decisions"], "max_bin_err_over_sqrt_energy": off["max_bin_err"], "max_product_err_over_unit": off["max_dec_err"],
+                        "max_residual_product_err": off["max_prod_err"]})
+        else:
+            rec["proven_level"] = part
+    eng.set_parity_guard(True)
     return rec
 
 
@@ -115,6 +124,10 @@ def main():
                 rec["seconds"] = round(time.time() - t0, 2)
                 cases.append(rec)
                 print(json.dumps(rec), file=sys.stderr)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fft_error_bound
+    bound = fft_error_bound.constants()
+    measured_c, proven_c = dab.guard_constants(1), dab.guard_constants(2)
     worst_bin = max(c["max_bin_err_over_sqrt_energy"] for c in cases)
     worst_dec = max(c["max_product_err_over_unit"] for c in cases)
     worst_res = max(c["max_residual_product_err"] for c in cases)
@@ -122,23 +135,33 @@ def main():
                    + " vs fp64 transforms of the same samples, hard decisions",
            "kernel": "ofdm_demap_kernel<false> (k_fused.hip)" if fused else "ofdm_fft_kernel + demap_kernel (k_fft.hip)",
            "source_sha256": source_sha(), "sources": list(AUDITED_SOURCES),
-           "guard_constants": {"kGuardC": 5.0e-6, "kGuardProd": 5.0e-7},
-           # a-priori worst case of a 4-stage fp32 transform (Higham: ~ log2(n) u |x|_2 per bin for the radix-2 chain; with radix-8 stages 4 levels of
-           # rounding and the twiddles' own errors): ~ 4 sqrt(2048) 2^-24 = 1.1e-5 |x|_2 -- ABOVE kGuardC: the guard stands on the measured errors,
-           # which is why they are re-measured on the kernel that ships
-           "a_priori_worst_case_bin_err_over_sqrt_energy": 4 * 2048 ** 0.5 * 2.0 ** -24,
+           "default_guard_level": dab.guard_default_level(),
+           "guard_constants": {"measured": {"kGuardC": measured_c[0], "kGuardProd": measured_c[1]}, "proven": {"kGuardCProven": proven_c[0], "kGuardProdProven": proven_c[1]}},
+           # the rigorous forward-error bound of this transform and product (tools/fft_error_bound.py): the proven level's constants are >= it,
+           # the measured level's are below it and stand on the worst errors measured here
+           "proven_bound": {"bin_err_over_l2": bound["bin_bound"], "product_rounding_over_l2l2": bound["prod_bound"], "from": "tools/fft_error_bound.py"},
            "worst_max_bin_err_over_sqrt_energy": worst_bin, "worst_max_product_err_over_unit": worst_dec, "worst_max_residual_product_err": worst_res,
-           "margin_kGuardC_over_worst": 5.0e-6 / max(worst_bin, worst_dec, 1e-30), "margin_kGuardProd_over_worst": 5.0e-7 / max(worst_res, 1e-30),
+           "worst_measured_below_proven_bound": bool(worst_bin <= bound["bin_bound"] and worst_res <= bound["prod_bound"]),
+           "proven_constants_cover_the_bound": bool(proven_c[0] >= bound["bin_bound"] and proven_c[1] >= bound["prod_bound"]),
+           "margin_kGuardC_over_worst": measured_c[0] / max(worst_bin, worst_dec, 1e-30), "margin_kGuardProd_over_worst": measured_c[1] / max(worst_res, 1e-30),
+           "margin_proven_bound_over_worst_bin": bound["bin_bound"] / max(worst_bin, 1e-30), "margin_proven_bound_over_worst_product": bound["prod_bound"] / max(worst_res, 1e-30),
            "total_decisions": sum(c["decisions"] for c in cases),
            "total_disagree_guard_off": sum(c["guard_off"]["disagree"] for c in cases),
            "total_disagree_outside_band": sum(c["guard_off"]["disagree_outside_guard_band"] for c in cases),
            "total_disagree_guard_on": sum(c["guard_on"]["disagree"] for c in cases),
+           "proven_level": {"total_disagree_outside_band": sum(c["proven_level"]["guard_off"]["disagree_outside_guard_band"] for c in cases),
+                            "total_disagree_guard_on": sum(c["proven_level"]["guard_on"]["disagree"] for c in cases),
+                            "total_flagged_by_rule": sum(c["proven_level"]["guard_off"]["flagged_by_rule"] for c in cases)},
+           "total_flagged_by_rule": sum(c["guard_off"]["flagged_by_rule"] for c in cases),
            "cases": cases}
     if fused:
-        out["shipping_kernel_same_bits_in_every_case"] = all(c["shipping_kernel_same_bits"] for c in cases)
-        out["shipping_kernel_same_list_count_in_every_case"] = all(c["shipping_kernel_same_list_count"] for c in cases)
+        out["shipping_kernel_same_bits_in_every_case"] = all(c["shipping_kernel_same_bits"] and c["proven_level"]["shipping_kernel_same_bits"] for c in cases)
+        out["shipping_kernel_same_list_count_in_every_case"] = all(c["shipping_kernel_same_list_count"] and c["proven_level"]["shipping_kernel_same_list_count"] for c in cases)
     print(json.dumps(out))
-    sys.exit(0 if out["total_disagree_outside_band"] == 0 and out["total_disagree_guard_on"] == 0 and out.get("shipping_kernel_same_bits_in_every_case", True) else 1)
+    ok = (out["total_disagree_outside_band"] == 0 and out["total_disagree_guard_on"] == 0 and out["proven_level"]["total_disagree_outside_band"] == 0 and
+          out["proven_level"]["total_disagree_guard_on"] == 0 and out["worst_measured_below_proven_bound"] and out["proven_constants_cover_the_bound"] and
+          out.get("shipping_kernel_same_bits_in_every_case", True))
+    sys.exit(0 if ok else 1)
 
 
 if __name__ == "__main__":

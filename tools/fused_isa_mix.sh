@@ -1,6 +1,6 @@
 #!/bin/bash
 # The static instruction mix of the default OFDM stage's symbol loop (ofdm_demap_kernel<false>, guarded build of k_fused.hip), priced in issue
-# cycles: profiles/r05_fused_isa_mix.{txt,json} (bench.py reads the JSON; tests/test_bench_launch.py holds its source hash against the tree).
+# cycles: profiles/r06_fused_isa_mix.{txt,json} (bench.py reads the JSON; tests/test_bench_launch.py holds its source hash against the tree).
 # CPU only: hipcc cross-compiles.  Re-run after every change of k_fused.hip / fft_core.hpp / device_types.hpp -- the block labels move.
 set -euo pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -15,7 +15,7 @@ SHA=$(cat "$S/k_fused.hip" "$S/fft_core.hpp" "$S/device_types.hpp" | sha256sum |
 #        not priced by weight -- their mix prices the instructions the measured count per transform has beyond the weighted static count
 W="${FUSED_WEIGHTS:-BB0_27=0,BB0_29=0,BB0_64=0,BB0_66=0,BB0_41=0.5,BB0_43=0.5,BB0_45=0.5,BB0_70=0.5,BB0_72=0.5,BB0_48=0,BB0_50=0,BB0_52=0,BB0_56=0,BB0_75=0,BB0_77=0,BB0_79=0,BB0_83=0,BB0_40=0,BB0_61=0}"
 RM="${FUSED_REMAINDER:-BB0_48,BB0_50,BB0_52,BB0_75,BB0_77,BB0_79}"
-python3 "$R/tools/isa_mix.py" --asm "$A" --kernel ofdm_demap_kernelILb0 --per-iteration 0.5 --weights "$W" --remainder "$RM" --source-sha "$SHA" > "$R/profiles/r05_fused_isa_mix.txt"
-tail -n 1 "$R/profiles/r05_fused_isa_mix.txt" > "$R/profiles/r05_fused_isa_mix.json"
+python3 "$R/tools/isa_mix.py" --asm "$A" --kernel ofdm_demap_kernelILb0 --per-iteration 0.5 --weights "$W" --remainder "$RM" --source-sha "$SHA" > "$R/profiles/r06_fused_isa_mix.txt"
+tail -n 1 "$R/profiles/r06_fused_isa_mix.txt" > "$R/profiles/r06_fused_isa_mix.json"
 rm -f "$A"
-cat "$R/profiles/r05_fused_isa_mix.txt" | cut -c1-200
+cat "$R/profiles/r06_fused_isa_mix.txt" | cut -c1-200
