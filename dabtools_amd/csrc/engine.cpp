@@ -103,6 +103,10 @@ Engine::Engine(int device, int host_threads, std::vector<int> cpus) : device_(de
   for (int k = 0; k < 2048; ++k) {
     const double a = 2 * M_PI * k / 2048;
     tw2048[k] = make_double2(std::cos(a), std::sin(a));
+    // the quarter points exactly (libm's cos(pi / 2) is 6.1e-17): bins 512 and 1536 of an int8 symbol are Gaussian integers, their differential products can
+    // be EXACTLY zero (at low signal levels they are, every few thousand frames), and the fp64 re-decision of such a product must come out as the exact
+    // integer arithmetic does -- as the sample-by-sample form happened to, and as any transform with trivial quarter turns (FFTW's codelets) does
+    if (k % 512 == 0) tw2048[k] = make_double2(k == 0 ? 1.0 : k == 1024 ? -1.0 : 0.0, k == 512 ? 1.0 : k == 1536 ? -1.0 : 0.0);
     twf[k] = make_float2(static_cast<float>(std::cos(a)), static_cast<float>(-std::sin(a)));   // forward kernel
   }
   for (int k = 0; k < 1536; ++k) tw1536[k] = make_double2(std::cos(2 * M_PI * k / 1536), std::sin(2 * M_PI * k / 1536));
@@ -803,8 +807,11 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
   const SyncTails tails{d_tail_state_.get(), d_tail_state_.get(), d_tail_images_.get(), kChunkBytes};
   // The look-ahead schedule of the chain (k_sync.hip: sync_ahead_kernel) where the chain would leave most of the device idle: few streams, many calls.
   // set_sync_speculation(0 / 1): never / always (tests run both); default: up to kAheadMaxStreams streams of at least kAheadMinCalls calls.
-  constexpr int kAheadMaxStreams = 4, kAheadMinCalls = 16, kAheadHypotheses = 33;
-  const bool use_spec = split_wanted && spec_mode_ != 0 && (spec_mode_ > 0 || (nstreams <= kAheadMaxStreams && max_calls_ >= kAheadMinCalls));
+  // (forced on, the pass is still bounded: beyond kAheadForcedMaxStreams streams -- where it cannot help and its table, nstreams x nspec x 33 x 8 bytes
+  // with nspec >= 64, would run to tens of megabytes and 33 x nspec x nstreams workgroups -- the plain chain runs whatever the mode says)
+  constexpr int kAheadMaxStreams = 4, kAheadMinCalls = 16, kAheadHypotheses = 33, kAheadForcedMaxStreams = 512;
+  const bool use_spec = split_wanted && spec_mode_ != 0 &&
+                        (spec_mode_ > 0 ? nstreams <= kAheadForcedMaxStreams : (nstreams <= kAheadMaxStreams && max_calls_ >= kAheadMinCalls));
   // calls of a stream per pass: all it has, within a bound on the table (8 bytes per call, start position and stream)
   const int nspec = std::min(max_calls_, std::min(4096, std::max(64, (1 << 20) / nstreams)));
   if (use_spec && (!d_spec_table_.reserve(static_cast<size_t>(nstreams) * nspec * kAheadHypotheses) || !d_spec_src0_.reserve(static_cast<size_t>(nstreams) * nspec) ||

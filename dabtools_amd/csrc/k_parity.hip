@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "dab_tables.hpp"
 #include "device_types.hpp"
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256, 8) void exact_decide_kernel(const uint4* __res
                                                               const uint16_t* __restrict__ qpsk_of_carrier,
                                                               const int* __restrict__ frame_slot,
                                                               const int* __restrict__ frame_cif_row, int planar, uint32_t* __restrict__ fic_bits,
-                                                              uint32_t* __restrict__ msc_bits)
+                                                              uint32_t* __restrict__ msc_bits, int sample_by_sample)
 {
   const unsigned n = min(counter[0], cap);
   const int lane = threadIdx.x & 63;
@@ -193,8 +194,9 @@ __global__ __launch_bounds__(256, 8) void exact_decide_kernel(const uint4* __res
     const uint4 next = e + stride < n ? list[e + stride] : ent;            // in flight while this entry is summed
     const int f = __builtin_amdgcn_readfirstlane(static_cast<int>(ent.x)), l = __builtin_amdgcn_readfirstlane(static_cast<int>(ent.y >> 16));
     const int k = __builtin_amdgcn_readfirstlane(static_cast<int>(ent.y & 0x7ffu));     // raw bin
-    const uint64_t win = (static_cast<uint64_t>(static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(ent.w)))) << 32) |
-                         static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(ent.z)));
+    uint64_t win = (static_cast<uint64_t>(static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(ent.w)))) << 32) |
+                   static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(ent.z)));
+    if (sample_by_sample) win = 0;                        // test knob (DABHIP_EXACT_SAMPLEWISE=1): every entry through the general form
     ent = next;
     // where the two bits go (independent of the sums: these loads fly beside the samples')
     const int c = (k >= 1 && k <= 768) ? k + 767 : k - 1280;
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256, 8) void exact_decide_kernel(const uint4* __res
       const CallDesc* desc = descs + static_cast<size_t>(fr.x) * max_calls + fr.y;
       const uint8_t* stream = iq[fr.x];
       const int start = 2 * (kNullSamples + kSymSamples * l + kCpSamples);
-      if (desc->view.seg_src[0] >= 0 && start + 4096 <= desc->view.seg_end[0]) {
+      if (!sample_by_sample && desc->view.seg_src[0] >= 0 && start + 4096 <= desc->view.seg_end[0]) {
         const uint8_t* cur = stream + desc->view.seg_src[0] + start;
         const uint8_t* prev = cur - 2 * kSymSamples;
         double xr, xi;
@@ -241,6 +243,21 @@ __global__ __launch_bounds__(256, 8) void exact_decide_kernel(const uint4* __res
         exact_bin(stream, desc->view, l - 1, k, tw2048, &pr, &pi);
       }
     }
+#ifdef DABHIP_EXACT_DEBUG
+    {
+      const int2 fr = frames[f];
+      const CallDesc* desc = descs + static_cast<size_t>(fr.x) * max_calls + fr.y;
+      double a0, a1, a2, a3;
+      exact_bin(iq[fr.x], desc->view, l, k, tw2048, &a0, &a1);
+      exact_bin(iq[fr.x], desc->view, l - 1, k, tw2048, &a2, &a3);
+      if (lane == 0) {
+        const double re1 = cr * pr + ci * pi, im1 = cr * pi - ci * pr, re2 = a0 * a2 + a1 * a3, im2 = a0 * a3 - a1 * a2;
+        if ((re1 > 0.0) != (re2 > 0.0) || (im1 > 0.0) != (im2 > 0.0))
+          printf("MISMATCH f=%d l=%d k=%d pair: c=(%.17g,%.17g) p=(%.17g,%.17g) re=%.6g im=%.6g | samplewise: c=(%.17g,%.17g) p=(%.17g,%.17g) re=%.6g im=%.6g\n", f, l, k, cr, ci, pr,
+                 pi, re1, im1, a0, a1, a2, a3, re2, im2);
+      }
+    }
+#endif
     if (lane != 0) continue;
     const double re = cr * pr + ci * pi;                  // Re(cur conj(prev)); the reference divides by |prev|^2 > 0 (input_sdr.c:135-143)
     const double im = cr * pi - ci * pr;                  // the imaginary part as stored there
@@ -470,8 +487,9 @@ hipError_t launch_exact_decide(const uint4* list, const unsigned* counter, unsig
                                int max_calls, const int2* frames, const double2* tw2048, const uint16_t* qpsk_of_carrier, const uint16_t* /*carrier_of_qpsk*/,
                                const int* frame_slot, const int* frame_cif_row, bool planar, uint32_t* fic_bits, uint32_t* msc_bits, hipStream_t stream)
 {
+  static const int samplewise = std::getenv("DABHIP_EXACT_SAMPLEWISE") ? std::atoi(std::getenv("DABHIP_EXACT_SAMPLEWISE")) : 0;
   hipLaunchKernelGGL(exact_decide_kernel, dim3(2048), dim3(256), 0, stream, list, counter, cap, iq, descs, max_calls, frames, tw2048,
-                     qpsk_of_carrier, frame_slot, frame_cif_row, planar ? 1 : 0, fic_bits, msc_bits);
+                     qpsk_of_carrier, frame_slot, frame_cif_row, planar ? 1 : 0, fic_bits, msc_bits, samplewise);
   return hipGetLastError();
 }
 

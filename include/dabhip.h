@@ -208,6 +208,7 @@ int dabhip_engine_set_fused(dabhip_engine *e, int enable);
  * place: one pass computes both for every remaining call and every start position near the predicted one, all at once, and the chain looks them up
  * (and computes them itself where a read began elsewhere).  Same results in every case, call for call.  mode -1 (default): the pass for small
  * batches (where the chain leaves most of the device idle), the plain chain for large ones; DABHIP_K1_SPEC in the environment sets the default.
+ * Mode 1 is a test / measurement knob: it is honoured up to 512 streams (beyond that the pass cannot help and its table would run to tens of megabytes).
  * dabhip_engine_stage_ms reports the calls served from the pass's table as "sync_spec_calls". */
 int dabhip_engine_set_sync_speculation(dabhip_engine *e, int mode);
 

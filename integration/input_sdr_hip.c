@@ -7,6 +7,8 @@
  * FFTW3-API header the image's ROCm ships, hipfft/hipfftw.h -- for the types of struct sdr_state_t only: nothing here calls an FFT) and run under the
  * same harness as the reference's real front end: tests/test_gpu_frontend_ref.py::test_seam_s2_binding_under_the_reference_harness.
  */
+#include <stdio.h>
+
 #include "dab.h"
 #include "input_sdr.h"
 #include "dabhip.h"
@@ -23,17 +25,21 @@ static dabhip_sdr **hip_sdr_slot(const struct sdr_state_t *sdr, int create)
   for (i = 0; i < HIP_SDR_MAX; i++)
     if (hip_sdr_tab[i].key == sdr) return &hip_sdr_tab[i].h;
   if (create)
-    for (i = 0; i < HIP_SDR_MAX; i++)
-      if (!hip_sdr_tab[i].key) { hip_sdr_tab[i].key = sdr; return &hip_sdr_tab[i].h; }
+    for (i = 0; i < HIP_SDR_MAX; i++)        /* a free slot, or one whose front end could not be made (failed init: no GPU at the time) */
+      if (!hip_sdr_tab[i].key || !hip_sdr_tab[i].h) { hip_sdr_tab[i].key = sdr; return &hip_sdr_tab[i].h; }
   return 0;
 }
 
 void sdr_init(struct sdr_state_t *sdr)                                                                  /* input_sdr.h:44 */
 {
   dabhip_sdr **slot = hip_sdr_slot(sdr, 1);
-  if (!slot) return;
+  if (!slot) {                                         /* the reference's API has no sdr_free: states are never released, and the table is finite */
+    fprintf(stderr, "input_sdr_hip: more than %d sdr_state_t initialised: this one gets no GPU front end (sdr_demod will report no frames)\n", HIP_SDR_MAX);
+    return;
+  }
   if (*slot) dabhip_sdr_free(*slot);                   /* the same state initialised again: a fresh front end, like the reference's memsets */
   *slot = dabhip_sdr_init(0);
+  if (!*slot) fprintf(stderr, "input_sdr_hip: %s\n", dabhip_last_error());      /* no GPU: there is no CPU fallback; sdr_demod reports no frames */
 }
 
 int sdr_demod(struct demapped_transmission_frame_t *tf, struct sdr_state_t *sdr)                        /* input_sdr.h:43 */
