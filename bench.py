@@ -37,7 +37,7 @@ REALTIME_FPS = 1000.0 / 24.0
 SIMDS, XCDS = 256 * 4, 8
 # Every roofline input that cannot be measured from inside this script (PMC counters, the effective clock) is read from the tracked
 # profile of the round, produced by tools/refresh_profiles.sh (rocprofv3 passes over THIS script) -- never baked in here.
-PROFILE_PMC = os.path.join(ROOT, "profiles", "r05_pmc_summary.csv")
+PROFILE_PMC = os.path.join(ROOT, "profiles", "r06_pmc_summary.csv")
 # static instruction mix of the fused OFDM kernel's symbol loop, priced in issue cycles (tools/fused_isa_mix.sh; CPU only)
 PROFILE_FUSED_MIX = os.path.join(ROOT, "profiles", "r06_fused_isa_mix.json")
 # issue cost of a wave64 VALU instruction on gfx950 (MI355X_MICROARCH.md, per-instruction table: v_fma_f32 2 cycles; tools/ubench/valu_rates.hip,
@@ -289,6 +289,9 @@ def cli_leg(streams, tfs):
             "value_is": "steady state inside the process: frames of all segments after the first productive one / time until the last byte is written",
             "whole_process": {"seconds": sp["seconds"], "eti_frames_per_s": sp["eti_frames_per_s"], "setup_s": sp["inside_the_process"]["setup_s"],
                               "note": "process start, HIP initialisation, page-locking the five segment buffers and lock-in included"},
+            "two_sessions_on_one_gpu": {"command": "dab2eti-hip --stream --devices 0,0 ...   (dabhip_multi_stream: the inputs dealt to two sessions, both on GPU 0 here)",
+                                        "value": r["stream_pipeline_two_sessions_on_one_gpu"]["inside_the_process"]["steady_frames_per_s"],
+                                        "whole_process_eti_frames_per_s": r["stream_pipeline_two_sessions_on_one_gpu"]["eti_frames_per_s"]},
             "one_batch": r["one_batch"], "one_stream_from_stdin": r["one_stream_from_stdin"],
             "stdout_bytes_equal_library_frames": bool(r["batch_stdout_equals_library_frames"] and r["stream_stdout_equals_library_frames"] and r["stdin_stdout_equals_library_frames"]),
             "streams": streams, "tf_per_stream": tfs, "full_size": "profiles/r04_cli_throughput.json (256 streams x 256 TF = 25.8 GB of captures: 567 k ETI frames/s steady state)"}
@@ -659,9 +662,12 @@ def run_rank(args, coord):
         extra = {}
         if rank == 0:
             flagged, decisions = eng.guard_stats()
-            extra["parity_guard"] = {"on": not args.no_parity_guard and not args.soft, "decisions_per_step": decisions, "redecided_in_fp64_per_step": flagged,
+            level = 0 if (args.no_parity_guard or args.soft) else eng.parity_guard_level()
+            extra["parity_guard"] = {"on": level > 0, "level": level, "level_is": {0: "off", 1: "measured band", 2: "proven band (rigorous forward-error bound: DESIGN.md section 3)"}[level],
+                                     "constants": dict(zip(("bin_error_over_l2", "product_rounding_over_l1l1"), dab.guard_constants(level))) if level else None,
+                                     "decisions_per_step": decisions, "redecided_in_fp64_per_step": flagged,
                                      "note": "hard decisions whose fp32 margin lies inside the error band are re-decided in fp64 from the int8 samples "
-                                             "(k_parity.hip); raw fp32 disagreement rate without it: profiles/r02_decision_audit.json"}
+                                             "(k_parity.hip); both levels audited on the shipping kernel: profiles/r06_decision_audit.json; price by level: profiles/r06_guard_levels.jsonl"}
             # K2 = ofdm_fft_kernel by itself, on the same resident IQ and the frame list of the step just timed
             fft = eng.fft_roofline(max(3, min(args.steps, 10)))
             try:
@@ -691,6 +697,19 @@ def run_rank(args, coord):
                                                      "stage_ms_per_step": {k: v for k, v in eng.stage_ms().items() if k in ("fft", "demap")},
                                                      "note": "dabhip_engine_set_parity_guard(0): raw fp32 decisions (disagreement with exact arithmetic: 0 on this "
                                                              "clean workload, 2.6e-8 of the decisions at 5 dB); this rank only"}
+                if args.snr < 100.0:                                           # noisy input: what the OTHER guard level costs (on clean input nothing is listed at either)
+                    other = 1 if level == 2 else 2
+                    eng.set_parity_guard(other)
+                    eng.decode_device(ptrs, sizes)
+                    torch.cuda.synchronize(dev)
+                    t1 = time.perf_counter()
+                    for _ in range(args.steps):
+                        f4 = eng.decode_device(ptrs, sizes)
+                    torch.cuda.synchronize(dev)
+                    e4 = time.perf_counter() - t1
+                    extra["parity_guard_other_level_variant"] = {"level": other, "value": f4 * args.steps / e4, "unit": "ETI frames/s", "ms_per_step": 1e3 * e4 / args.steps,
+                                                                 "redecided_in_fp64_per_step": eng.guard_stats()[0],
+                                                                 "stage_ms_per_step": {k: v for k, v in eng.stage_ms().items() if k in ("fft", "demap")}}
                 eng.set_parity_guard(True)
             if not args.soft and not args.two_kernel_ofdm and not args.no_variants:
                 # the same job with the two-kernel OFDM stage (K2 writes the spectra, K2b reads them back), for comparison
@@ -798,7 +817,7 @@ def run_rank(args, coord):
         if args.snr < 100.0:
             out["config"]["snr_db"] = args.snr
             out["config"]["decisions"] = "soft (4-bit)" if args.soft else "hard"
-        for k in ("parity_guard", "parity_guard_off_variant", "single_ensemble", "steady_state_session", "payload", "h2d_inclusive", "cpu_baseline", "profile_meta"):
+        for k in ("parity_guard", "parity_guard_off_variant", "parity_guard_other_level_variant", "single_ensemble", "steady_state_session", "payload", "h2d_inclusive", "cpu_baseline", "profile_meta"):
             if k in extra:
                 out[k] = extra[k]
         print(json.dumps(out))

@@ -87,7 +87,10 @@ def main():
         _, _, blob2 = run([CLI, "-"], stdin=f, capture=True)
     out["stdin_stdout_equals_library_frames"] = bool(np.array_equal(np.frombuffer(blob2, dtype=np.uint8).reshape(-1, 6144), want[0]))
     out["stdout_sha256_first_stream"] = hashlib.sha256(blob1).hexdigest()
-    for name, cmd in (("stream_pipeline", [CLI, "--stats", "--stream", "--segment-calls", str(args.segment_calls)] + files), ("one_batch", [CLI, "--stats"] + files)):
+    # (--devices 0,0: the same inputs as TWO sessions -- dabhip_multi_stream, one per listed device -- sharing GPU 0: the path `--devices 0-7` takes on a node)
+    for name, cmd in (("stream_pipeline", [CLI, "--stats", "--quiet", "--stream", "--segment-calls", str(args.segment_calls)] + files),
+                      ("stream_pipeline_two_sessions_on_one_gpu", [CLI, "--stats", "--quiet", "--stream", "--devices", "0,0", "--segment-calls", str(args.segment_calls)] + files),
+                      ("one_batch", [CLI, "--stats", "--quiet"] + files)):
         best = None
         for _ in range(2):
             dt, frames, _ = run(cmd)

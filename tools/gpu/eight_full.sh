@@ -13,3 +13,6 @@ for n in ("eight_1", "eight_2", "one"):
     d = json.loads(open("gpurun_out/eight_full/%s.json" % n).read().strip().splitlines()[-1])
     print(n, round(d["value"]), round(d["ms_per_step"], 2), [(r["host_ms_per_step"]["control"], r["host_ms_per_step"]["host_worklist"]) for r in d["ranks"]])
 PY
+# the 1 / 2 / 4 / 8 table on this one GPU: every multi-rank row is labelled a rehearsal by the tool itself (one distinct PCI bus id), no efficiency reported
+DABHIP_BENCH_ONE_DEVICE=1 timeout 1500 python tools/scale_sweep.py --one-device --gpus 1,2,4,8 --steps 5 > $O/scale_sweep.json 2> $O/scale_sweep.txt || echo "sweep rc=$?"
+cat $O/scale_sweep.txt
