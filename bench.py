@@ -446,7 +446,7 @@ def single_ensemble(dab, torch, dev, eng, tensors, args):
            "decoder_form": "one wave per code word (k_vitwave.hip) for the %d MSC code words and %d FIC blocks of this decode" % (12 * frames, 4 * (args.tfs - 1)),
            "sync_schedule": "K1 with the look-ahead pass (k_sync.hip: sync_ahead_kernel; default for <= 4 streams): %d of the chain's calls per decode took their estimators from "
                             "its table; with the plain chain this decode's sync stage is 0.58 ms (profiles/r05_batch_curve_plain_chain.json)" % round(stage.get("sync_spec_calls", 0.0) / reps),
-           "batch_curve": "profiles/r05_batch_curve.json (B = 1 .. 64, tools/batch_curve.py; plain chain beside it: r05_batch_curve_plain_chain.json)"}
+           "batch_curve": "profiles/r06_batch_curve.json (B = 1 .. 256, tools/batch_curve.py; the plain chain beside the look-ahead schedule: r05_batch_curve_plain_chain.json)"}
     ntf = min(args.tfs, 40)
     hb = dab.HostBuffer(ntf * dab.TF_BYTES)
     assert dab.lib().dabhip_device_copy(hb.ptr, tensors[0].data_ptr(), ntf * dab.TF_BYTES, 0) == 0
@@ -667,7 +667,7 @@ def run_rank(args, coord):
                                      "constants": dict(zip(("bin_error_over_l2", "product_rounding_over_l1l1"), dab.guard_constants(level))) if level else None,
                                      "decisions_per_step": decisions, "redecided_in_fp64_per_step": flagged,
                                      "note": "hard decisions whose fp32 margin lies inside the error band are re-decided in fp64 from the int8 samples "
-                                             "(k_parity.hip); both levels audited on the shipping kernel: profiles/r06_decision_audit.json; price by level: profiles/r06_guard_levels.jsonl"}
+                                             "(k_parity.hip); both levels audited on the shipping kernel: profiles/r06_decision_audit.json; price by level: profiles/r06_guard_levels.json"}
             # K2 = ofdm_fft_kernel by itself, on the same resident IQ and the frame list of the step just timed
             fft = eng.fft_roofline(max(3, min(args.steps, 10)))
             try:
