@@ -616,7 +616,10 @@ def run_rank(args, coord):
             local_rank = int(os.environ["DABHIP_BENCH_DEVICE"])            # launch_ranks made this rank's GPU the only visible one
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-        bus_id, dev_name = dab.device_identity(local_rank)                 # which physical GPU this rank decodes on (checked across ranks by rank 0)
+        try:                                                               # which physical GPU this rank decodes on (checked across ranks by rank 0)
+            bus_id, dev_name = dab.device_identity(local_rank)
+        except dab.DabhipError as e:                                       # (never seen; an identity that cannot be read must not take the measurement down)
+            bus_id, dev_name = None, "unknown (%s)" % e
         rank_info["device"] = {"index": local_rank, "pci_bus_id": bus_id, "name": dev_name}
         t_gen = time.perf_counter()
         tensors, ndistinct = make_streams(torch, dev, args.streams, args.tfs, min(args.distinct, args.streams), rank, args.snr, args.host_synth)
@@ -767,7 +770,9 @@ def run_rank(args, coord):
         bus_ids = [r["info"].get("device", {}).get("pci_bus_id") for r in rows]
         distinct = len(set(bus_ids))
         rehearsal = os.environ.get("DABHIP_BENCH_ONE_DEVICE") == "1"
-        if distinct != world and not rehearsal:
+        if None in bus_ids:                                                 # identities unreadable: nothing can be shown either way -- say so in the line
+            distinct = None
+        elif distinct != world and not rehearsal:
             sys.stderr.write("bench.py: %d ranks decoded on %d distinct devices (%s): not a %d-GPU measurement -- no line printed "
                              "(DABHIP_BENCH_ONE_DEVICE=1 declares a one-GPU rehearsal)\n" % (world, distinct, ", ".join(map(str, bus_ids)), world))
             coord.close()

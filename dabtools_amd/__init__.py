@@ -177,6 +177,7 @@ _SIGNATURES = {
     "dabhip_engine_parity_guard_level": (C.c_int, [C.c_void_p]),
     "dabhip_parity_guard_default_level": (C.c_int, []),
     "dabhip_parity_guard_constants": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dabhip_parity_guard_bin_scale": (C.c_double, [C.c_int]),
     "dabhip_engine_guard_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "dabhip_engine_guard_overflows": (C.c_int, [C.c_void_p]),
     "dabhip_engine_set_guard_list_cap": (C.c_int, [C.c_void_p, C.c_uint32]),
@@ -288,6 +289,11 @@ def guard_constants(level):
     a, b = C.c_double(0), C.c_double(0)
     _need(lib().dabhip_parity_guard_constants(int(level), C.byref(a), C.byref(b)) == 0, "parity_guard_constants")
     return a.value, b.value
+
+
+def guard_bin_scale(raw_bin):
+    """Fraction of the proven level's bin constant that bounds raw bin k's error (dabhip_parity_guard_bin_scale)."""
+    return lib().dabhip_parity_guard_bin_scale(int(raw_bin))
 
 
 def guard_default_level():

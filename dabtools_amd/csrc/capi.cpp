@@ -320,6 +320,7 @@ int dabhip_engine_set_parity_guard(dabhip_engine* e, int level)
 }
 int dabhip_engine_parity_guard_level(const dabhip_engine* e) { return e ? e->lanes[0]->parity_guard_level() : -1; }
 int dabhip_parity_guard_default_level(void) { return dabhip::kDefaultGuardLevel; }
+double dabhip_parity_guard_bin_scale(int raw_bin) { return (raw_bin >= 0 && raw_bin < 2048) ? static_cast<double>(dabhip::guard_bin_scale(raw_bin)) : -1.0; }
 int dabhip_parity_guard_constants(int level, double* bin_c, double* prod_c)
 {
   if (level < 1 || level > 2) return -1;

@@ -136,6 +136,29 @@ __host__ __device__ __forceinline__ float guard_threshold(float n1c, float n1p, 
 {
   return fmaf(n1c, fmaf(n1p, prod, dp), (n1p + dp) * dc);
 }
+// The proven level lists by the PER-BIN form of the bound (GuardArgs::per_bin): the stage terms depend on the bin's index digits k = a' + 8 b' + 64 c' + 512 d' --
+// output q of a radix-8 block takes no turn when q is even and no table factor when q = 0, and stage A's additions of integers are exact --
+//     kappa_A(a') = 0 | 2.7071 (even) | 6.7013 (odd),   kappa_B(b'), kappa_C(c') = 3 | 5.7071 | 7.7013,   kappa_D = 2
+// so bin k's error is at most guard_bin_scale(k) = (kappa_A + kappa_B + kappa_C + 2) / 24.104 of the worst bin's (0.33 .. 1, 0.79 on average), and its norms
+// enter as |.|_2 (what the derivation bounds) instead of |.|_1: 38 % fewer decisions listed on noisy input than by the flat rule, the same guarantee.
+// tools/fft_error_bound.py computes the same table (bin_bound(k)); tests/test_bench_launch.py holds this function against it.  The measured level keeps the
+// flat rule of rounds 2 - 5 (its constants are measured maxima over all bins, not a per-bin statement).
+__host__ __device__ __forceinline__ float guard_bin_scale(int k)
+{
+  constexpr float kTurn = 1.9942368f, kCmul = 2.7071072f;          // (R2), (R3) of DESIGN.md section 3, rounded up
+  constexpr float kMax = (kTurn + 2.0f + kCmul) + 2.0f * (3.0f + kTurn + kCmul) + 2.0f;
+  const int a = k & 7, b = (k >> 3) & 7, c = (k >> 6) & 7;
+  const float ka = a == 0 ? 0.0f : ((a & 1) ? kTurn + 2.0f + kCmul : kCmul);
+  const float kb = b == 0 ? 3.0f : ((b & 1) ? 3.0f + kTurn + kCmul : 3.0f + kCmul);
+  const float kc = c == 0 ? 3.0f : ((c & 1) ? 3.0f + kTurn + kCmul : 3.0f + kCmul);
+  return (ka + kb + kc + 2.0f) * (1.000004f / kMax);
+}
+__host__ __device__ __forceinline__ float guard_norm2(float x, float y) { return sqrtf(fmaf(x, x, y * y)) * 1.000001f; }     // >= |(x, y)|_2
+__host__ __device__ __forceinline__ float guard_bin_threshold(float cx, float cy, float px, float py, int k, float dc, float dp, float prod)
+{
+  const float f = guard_bin_scale(k);
+  return guard_threshold(guard_norm2(cx, cy), guard_norm2(px, py), f * dc, f * dp, prod);
+}
 // Soft decisions (extension): value = round(soft_scale x) clamped to +-7, x = Re / Im of cur conj(prev).  The scale is made of
 // the two symbols' sample energies -- on a noise-free Mode-I signal mean |x| = (2048 / 1536) s(l) s(l-1) / sqrt(2), s = sqrt(sum_n
 // |x_n|^2), which the factor below maps to 7.0 (= the clamp: see below) -- so it is known before a symbol is transformed (the one-kernel OFDM stage cannot
@@ -166,6 +189,7 @@ struct GuardArgs {
                          // decisions: the same array, read for the scale (list == nullptr then)
   int32_t delta_stride;
   float c, prod;         // the level's constants (guard_c_of / guard_prod_of); soft decisions: c = kSoftNormC
+  int32_t per_bin;       // 1: list by guard_bin_threshold (the proven level), 0: by the flat rule guard_threshold on |.|_1 (the measured level)
   uint32_t cap;          // capacity of list
   uint4* list;           // {frame index, symbol << 16 | raw bin, address of the first byte of the symbol's window in the IQ stream when it and the previous
                          //  symbol's lie contiguously inside what the call read (low, high word; 0: to be looked up through the frame's view)}

@@ -620,7 +620,7 @@ bool Engine::guard_begin(int ntf_in_launch, GuardArgs* out)
   // the capacity THIS launch was given (a later launch of the same decode may find the list re-reserved and larger): guard_check compares with it
   if (guard_caps_.size() <= static_cast<size_t>(guard_launches_)) guard_caps_.resize(static_cast<size_t>(guard_launches_) + 1);
   guard_caps_[static_cast<size_t>(guard_launches_)] = guard_cap_;
-  *out = GuardArgs{d_delta_.get(), kSymbolsPerTf, guard_c_of(level), guard_prod_of(level), guard_cap_, d_guard_list_.get(),
+  *out = GuardArgs{d_delta_.get(), kSymbolsPerTf, guard_c_of(level), guard_prod_of(level), level >= 2 ? 1 : 0, guard_cap_, d_guard_list_.get(),
                    d_guard_counter_.get() + static_cast<size_t>(guard_launches_) * kGuardSlotWords};
   return true;
 }

@@ -285,7 +285,9 @@ __global__ __launch_bounds__(kThreads) void demap_kernel(const float2* __restric
       im[m] = diff_im(cur.x, cur.y, prev[m].x, prev[m].y);   // -Im(cur conj(prev)), as stored at input_sdr.c:139-143
       if (guarded) {
         const float n1c = fabsf(cur.x) + fabsf(cur.y), n1p = fabsf(prev[m].x) + fabsf(prev[m].y);
-        if (fminf(fabsf(re[m]), fabsf(im[m])) < guard_threshold(n1c, n1p, dc, dp, guard.prod)) {
+        const float thr = guard.per_bin ? guard_bin_threshold(cur.x, cur.y, prev[m].x, prev[m].y, (bin[m] + 1024) & 2047, dc, dp, guard.prod)
+                                    : guard_threshold(n1c, n1p, dc, dp, guard.prod);
+        if (fminf(fabsf(re[m]), fabsf(im[m])) < thr) {
           const unsigned at = atomicAdd(guard.counter, 1u);
           if (at < guard.cap) guard.list[at] = make_uint4(static_cast<unsigned>(first + j), (static_cast<unsigned>(l) << 16) | static_cast<unsigned>((bin[m] + 1024) & 2047), 0u, 0u);
         }

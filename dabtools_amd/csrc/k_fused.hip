@@ -203,7 +203,7 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
     maxc = fmaxf(maxc, l1norm(cur));
   }
 #ifndef DABHIP_PROBE_NOTEST
-  const bool any = !(lo > guard_threshold(maxc, maxp, dc, dp, guard.g.prod));
+  const bool any = !(lo > guard_threshold(maxc, maxp, dc, dp, guard.g.prod) * 1.000001f);      // (>= every per-bin threshold below, whichever form: |.|_1 >= |.|_2, scale <= 1)
 #else
   const bool any = false;
 #endif
@@ -222,6 +222,21 @@ __device__ __forceinline__ void decide(const float2 (&x)[4], const float2 (&y)[4
       const unsigned m = __ffs(hits) - 1;
       hits &= hits - 1;
       if (guard.g.delta == nullptr) continue;             // (never in this build: the engine runs the plain kernel when the guard is off)
+      if (guard.g.per_bin) {
+        // The proven level lists by the per-bin form of the bound (device_types.hpp: guard_bin_threshold -- the bin's own stage terms, |.|_2 norms): a subset of what the
+        // flat rule above found.  Rarest path of the kernel: the bin's values are picked by a select chain (m is a run-time value here).
+        float cx = 0.0f, cy = 0.0f, qx = 0.0f, qy = 0.0f;
+#pragma unroll
+        for (unsigned j = 0; j < 8; ++j) {
+          const float2 c = (j & 1) ? y[j >> 1] : x[j >> 1], q = (j & 1) ? py[j >> 1] : px[j >> 1];
+          cx = m == j ? c.x : cx;
+          cy = m == j ? c.y : cy;
+          qx = m == j ? q.x : qx;
+          qy = m == j ? q.y : qy;
+        }
+        const float least = fminf(fabsf(diff_re(cx, cy, qx, qy)), fabsf(diff_im(cx, cy, qx, qy)));
+        if (!(least < guard_bin_threshold(cx, cy, qx, qy, fused_bin(threadIdx.x, static_cast<int>(m)), dc, dp, guard.g.prod) || !(least > 0.0f))) continue;
+      }
       const unsigned at = atomicAdd(guard.g.counter, 1u);
       const unsigned k = static_cast<unsigned>(fused_bin(threadIdx.x, static_cast<int>(m)));
       // (the re-decision reads the two symbols' samples: their address goes along, so that it does not have to walk frame list, descriptor and view first)

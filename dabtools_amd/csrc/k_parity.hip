@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kFft64Threads) void decision_audit_kernel(const uin
                                                                       const float2* __restrict__ prods, int row_lead,
                                                                       const uint32_t* __restrict__ fic_bits, const uint32_t* __restrict__ msc_bits,
                                                                       const double2* __restrict__ tw2048, const uint16_t* __restrict__ qpsk_of_carrier,
-                                                                      AuditOut* __restrict__ out, float guard_c, float guard_prod)
+                                                                      AuditOut* __restrict__ out, float guard_c, float guard_prod, int per_bin)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double2* A = reinterpret_cast<double2*>(smem);           // current symbol, bit-reversed after the transform
@@ -424,7 +424,8 @@ __global__ __launch_bounds__(kFft64Threads) void decision_audit_kernel(const uin
       }
       const float n1c = fabsf(x32.x) + fabsf(x32.y), n1p = fabsf(p32.x) + fabsf(p32.y);
       const float unit = n1c * s_prev + n1p * s_cur;
-      const float t = guard_threshold(n1c, n1p, guard_c * s_cur, guard_c * s_prev, guard_prod);   // the kernels' own test
+      const float t = per_bin ? guard_bin_threshold(x32.x, x32.y, p32.x, p32.y, k, guard_c * s_cur, guard_c * s_prev, guard_prod)
+                              : guard_threshold(n1c, n1p, guard_c * s_cur, guard_c * s_prev, guard_prod);   // the kernels' own test
       // (the fused kernel decides by sign bits and therefore also lists every product with an exact zero in it: k_fused.hip, decide)
       const bool flagged = fminf(fabsf(re32), fabsf(im32)) < t || (kFused && !(fminf(fabsf(re32), fabsf(im32)) > 0.0f));
       n_flag += flagged ? 1 : 0;
@@ -526,10 +527,10 @@ hipError_t launch_decision_audit(const uint8_t* frames_iq, int nframes, const fl
   if (attr != hipSuccess) return attr;
   if (fused_prods)
     hipLaunchKernelGGL(decision_audit_kernel<true>, dim3(nframes), dim3(kFft64Threads), lds, stream, frames_iq, spectra, fused_prods, row_lead, fic_bits, msc_bits,
-                       tw2048, qpsk_of_carrier, static_cast<AuditOut*>(out), guard_c_of(guard_level), guard_prod_of(guard_level));
+                       tw2048, qpsk_of_carrier, static_cast<AuditOut*>(out), guard_c_of(guard_level), guard_prod_of(guard_level), guard_level >= 2 ? 1 : 0);
   else
     hipLaunchKernelGGL(decision_audit_kernel<false>, dim3(nframes), dim3(kFft64Threads), lds, stream, frames_iq, spectra, nullptr, 0, fic_bits, msc_bits, tw2048,
-                       qpsk_of_carrier, static_cast<AuditOut*>(out), guard_c_of(guard_level), guard_prod_of(guard_level));
+                       qpsk_of_carrier, static_cast<AuditOut*>(out), guard_c_of(guard_level), guard_prod_of(guard_level), guard_level >= 2 ? 1 : 0);
   return hipGetLastError();
 }
 

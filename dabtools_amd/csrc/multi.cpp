@@ -12,7 +12,9 @@
 // A device may be listed more than once: every entry is a slice of its own (tests map all eight slices of a node onto GPU 0).
 #include <algorithm>
 #include <chrono>
+#include <deque>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -274,7 +276,10 @@ struct dabhip_multi_stream {
   std::vector<Slice> slices;
   int nstreams = 0;
   bool failed = false;                   // a slice failed a feed: the slices are not in step any more
-  std::vector<int64_t> fetch_frames;     // per slice: frames its outstanding fetch moves (eti_fetch .. eti_fetch_wait)
+  // fetches issued and not yet waited for, oldest first (up to two: the CLI's writer still waits for segment k's frames while the decode thread, through with
+  // segment k + 1, issues the next one): per fetch, which slices took part (a slice without frames issues nothing and must not be waited on)
+  std::deque<std::vector<uint8_t>> fetches;
+  std::mutex fetch_mu;
 
   ~dabhip_multi_stream()
   {
@@ -339,7 +344,6 @@ dabhip_multi_stream* dabhip_multi_stream_create(const int* devices, int n, int n
   if (populated > 1) plan = dabhip::plan_placement(nodes, node_cpus);
   m->slices.resize(static_cast<size_t>(n));
   m->nstreams = nstreams;
-  m->fetch_frames.assign(static_cast<size_t>(n), 0);
   const int base = nstreams / n, rem = nstreams % n;           // the dealing rule of dabhip_multi_plan
   int next = 0;
   for (int i = 0; i < n; ++i) {
@@ -464,10 +468,12 @@ int64_t dabhip_multi_stream_eti_fetch(dabhip_multi_stream* m, uint8_t* dst, int6
   if (total > cap_frames) { set_error("multi_stream_eti_fetch: destination too small"); return -1; }
   int64_t at = 0;
   std::vector<int64_t> offset(m->slices.size(), 0);
+  std::vector<uint8_t> took_part(m->slices.size(), 0);
   for (size_t i = 0; i < m->slices.size(); ++i) {
     offset[i] = at;
-    m->fetch_frames[i] = m->slices[i].count ? m->slices[i].frames : 0;
-    at += m->fetch_frames[i];
+    const int64_t n = m->slices[i].count ? m->slices[i].frames : 0;
+    took_part[i] = n > 0;
+    at += n;
   }
   dabhip_multi_stream::Slice* base = m->slices.data();
   const int64_t* off = offset.data();
@@ -476,18 +482,27 @@ int64_t dabhip_multi_stream_eti_fetch(dabhip_multi_stream* m, uint8_t* dst, int6
     const int64_t got = dabhip_stream_eti_fetch(sl.s, dst + static_cast<size_t>(off[&sl - base]) * DABHIP_ETI_BYTES, sl.frames);
     return got == sl.frames ? got : -1;
   });
+  {
+    std::lock_guard<std::mutex> lk(m->fetch_mu);
+    m->fetches.push_back(std::move(took_part));       // (also after a failure: the slices that did issue a copy are still to be waited for)
+  }
   return ok ? total : -1;
 }
+// waits for the OLDEST fetch not yet waited for (every slice's engine keeps its fetches in issue order, so the slices of that fetch wait for the right one)
 int dabhip_multi_stream_eti_fetch_wait(dabhip_multi_stream* m)
 {
   if (!m) { set_error("multi_stream_eti_fetch_wait: null handle"); return -1; }
-  int rc = 0;
-  for (size_t i = 0; i < m->slices.size(); ++i) {
-    // (the wait itself touches only the slice's fetch events: made from the caller's thread, so that a writer thread can wait while the lanes decode)
-    if (m->fetch_frames[i] == 0) continue;
-    m->fetch_frames[i] = 0;
-    if (dabhip_stream_eti_fetch_wait(m->slices[i].s) != 0) rc = -1;
+  std::vector<uint8_t> took_part;
+  {
+    std::lock_guard<std::mutex> lk(m->fetch_mu);
+    if (m->fetches.empty()) return 0;
+    took_part = std::move(m->fetches.front());
+    m->fetches.pop_front();
   }
+  int rc = 0;
+  // (the wait itself touches only the slice's fetch events: made from the caller's thread, so that a writer thread can wait while the lanes decode)
+  for (size_t i = 0; i < m->slices.size(); ++i)
+    if (took_part[i] && dabhip_stream_eti_fetch_wait(m->slices[i].s) != 0) rc = -1;
   return rc;
 }
 

@@ -180,6 +180,9 @@ int dabhip_engine_parity_guard_level(const dabhip_engine *e);
 int dabhip_parity_guard_default_level(void);
 /* the two constants of a level: bound on a bin's error relative to sqrt(sum |x_n|^2), bound on the product's rounding relative to |cur|_1 |prev|_1 */
 int dabhip_parity_guard_constants(int level, double *bin_c, double *prod_c);
+/* The proven level lists per bin: raw bin k's error bound is this fraction (0.33 .. 1) of the level's bin constant -- the bound's stage terms depend on the
+ * bin's index digits; < 0: no such bin. */
+double dabhip_parity_guard_bin_scale(int raw_bin);
 /* Decisions the guard re-decided in the last decode, and hard decisions taken in all. */
 int dabhip_engine_guard_stats(const dabhip_engine *e, int64_t *flagged, int64_t *decisions);
 /* The guard lists the decisions to re-decide per kernel launch (64 entries per TF, at least 262,144; the proven level: 1024, 1,048,576).  A launch with more of them

@@ -250,6 +250,12 @@ def test_proven_guard_constants_cover_the_rigorous_bound():
     assert 6.4e-5 < c["bin_bound"] < 6.6e-5 and 1.19e-7 < c["prod_bound"] < 1.2e-7
     assert dab.guard_constants(2)[0] >= c["bin_bound"] and dab.guard_constants(2)[1] >= c["prod_bound"]
     assert dab.guard_constants(1)[0] < c["bin_bound"]                       # the measured level does NOT claim the bound
+    # the proven level lists PER BIN: constant x guard_bin_scale(k) covers bin k's own bound (its stage terms by its index digits), for every bin
+    bounds = np.array([fft_error_bound.bin_bound(k, c) for k in range(2048)])
+    scale = np.array([dab.guard_bin_scale(k) for k in range(2048)])
+    assert (dab.guard_constants(2)[0] * scale >= bounds).all() and scale.max() <= 1.00001 and 0.33 < scale.min() < 0.34
+    inband = list(range(1, 769)) + list(range(1280, 2048))
+    assert 0.78 < scale[inband].mean() < 0.80
     assert dab.guard_default_level() in (1, 2)
     rng = np.random.default_rng(6)
     worst = 0.0
@@ -257,7 +263,8 @@ def test_proven_guard_constants_cover_the_rigorous_bound():
         norm = float(np.sqrt(np.sum(np.abs(x) ** 2)))
         if norm == 0:
             continue
-        err = float(np.max(np.abs(fft_error_bound.fft2048_model(x) - np.fft.fft(x)))) / norm
-        assert err <= c["bin_bound"], (name, err)
+        per_bin = np.abs(fft_error_bound.fft2048_model(x) - np.fft.fft(x)) / norm
+        err = float(per_bin.max())
+        assert err <= c["bin_bound"] and (per_bin <= bounds).all(), (name, err)        # every bin below ITS OWN bound
         worst = max(worst, err)
     assert worst > dab.guard_constants(1)[0]                                # a clipped tone: 5.3e-6 |x|_2 > 5e-6

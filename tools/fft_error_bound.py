@@ -26,6 +26,9 @@ at a time; every intermediate result is at most S (1 + 6u)):
 Cone sums: sum over the blocks of cone_s(k) of S = the l1 norm of the cone's input values; by Cauchy-Schwarz and |partial DFT sum of m terms|^2 <= m sum |terms|^2
 it is <= sqrt(2048) |x|_2 (1 + 8u) for every stage (A: |x|_1 <= sqrt(2048) |x|_2; B: 16 x sqrt(8); C: sqrt(32) x 8; D: 2 x sqrt(512)).
     |e_k| <= u sqrt(2048) (kA + kB + kC + kD) (1 + 1e-5) |x|_2 .
+The k's above are the worst outputs' (q odd).  Bin k = a' + 8 b' + 64 c' + 512 d' is output a' of its stage-A blocks, b' of its stage-B blocks, c' of its stage-C blocks,
+so ITS bound takes kA(a') = 0 | 2.7072 (even) | 6.7013 (odd), kB(b'), kC(c') = 3 | 5.7072 | 7.7013: bin_bound(k) below, 0.33 .. 1 of the worst bin's and 0.79 of it on
+average over the carriers' bins -- the proven guard level lists per bin (device_types.hpp: guard_bin_scale), and the model check below holds every bin against its own bound.
 The bound is attained up to its constant by a single tone (all partial sums towards its bin add coherently); for an OFDM symbol of 1536 carriers the partial
 sums add incoherently and the measured errors are ~ 80 x smaller -- which is why the MEASURED level's band is 13 x narrower.
 
@@ -63,7 +66,18 @@ def constants():
     k_d = 2.0 * (1 + 2 * U)
     c_bin = U * math.sqrt(2048.0) * (k_a + 2 * k_general + k_d) * (1 + 1e-5)
     c_prod = 2 * U * (1 + U)
-    return {"u": U, "turn": turn, "cmul": cm, "kappa_A": k_a, "kappa_B": k_general, "kappa_C": k_general, "kappa_D": k_d, "bin_bound": c_bin, "prod_bound": c_prod}
+    # per output index q of a stage (the bin's digits: k = a' + 8 b' + 64 c' + 512 d'): q = 0 takes no table factor, an even q no turned value
+    per_q_a = [0.0 if q == 0 else ((turn + 2.0 + cm) * hi if q & 1 else cm * hi) for q in range(8)]
+    per_q_bc = [3.0 * hi if q == 0 else ((3.0 + turn + cm) * hi if q & 1 else (3.0 + cm) * hi) for q in range(8)]
+    return {"u": U, "turn": turn, "cmul": cm, "kappa_A": k_a, "kappa_B": k_general, "kappa_C": k_general, "kappa_D": k_d, "bin_bound": c_bin, "prod_bound": c_prod,
+            "kappa_A_by_digit": per_q_a, "kappa_BC_by_digit": per_q_bc}
+
+
+def bin_bound(k, c=None):
+    """the bound for raw bin k by itself: its stage terms by its index digits (<= constants()["bin_bound"], the worst bin's)"""
+    c = c or constants()
+    kap = c["kappa_A_by_digit"][k & 7] + c["kappa_BC_by_digit"][(k >> 3) & 7] + c["kappa_BC_by_digit"][(k >> 6) & 7] + c["kappa_D"]
+    return U * math.sqrt(2048.0) * kap * (1 + 1e-5)
 
 
 # ---- fp32 model of the kernels' operation order -----------------------------------------------------------------------------
@@ -154,7 +168,7 @@ def adversarial_inputs(rng):
     n = np.arange(2048)
     yield "zeros", np.zeros(2048, complex)
     yield "constant 127+127i", np.full(2048, 127 + 127j)
-    for k in (1, 73, 585, 767, 1281, 1535, 2047, 511 + 512):
+    for k in (1, 73, 585, 767, 1281, 1535, 2047, 511 + 512, 512, 1536, 520, 576, 8, 64, 2, 16, 1288):      # (the second half: bins whose own bound is small -- even or zero index digits)
         tone = 127 * np.exp(2j * np.pi * k * n / 2048)
         yield "tone %d, rounded to int8" % k, np.round(tone.real) + 1j * np.round(tone.imag)
         yield "tone %d, clipped square wave" % k, 127 * np.sign(np.round(tone.real)) + 127j * np.sign(np.round(tone.imag))
@@ -176,16 +190,19 @@ def adversarial_inputs(rng):
 def main():
     c = constants()
     rng = np.random.default_rng(6)
-    worst, rows = 0.0, []
+    worst, worst_per_bin, rows = 0.0, 0.0, []
+    bounds_by_bin = np.array([bin_bound(k, c) for k in range(2048)])
     for name, x in adversarial_inputs(rng):
         norm = float(np.sqrt(np.sum(np.abs(x) ** 2)))
         if norm == 0:
             continue
         got = fft2048_model(x)
         want = np.fft.fft(x.astype(np.complex128))          # fp64: error 1e-16 |x|_2 sqrt-ish, nothing at this scale
-        err = float(np.max(np.abs(got - want))) / norm
+        per_bin = np.abs(got - want) / norm
+        err = float(np.max(per_bin))
         worst = max(worst, err)
-        rows.append({"input": name, "max_bin_error_over_l2": err, "fraction_of_bound": err / c["bin_bound"]})
+        worst_per_bin = max(worst_per_bin, float(np.max(per_bin / bounds_by_bin)))      # every bin against ITS OWN bound
+        rows.append({"input": name, "max_bin_error_over_l2": err, "fraction_of_bound": err / c["bin_bound"], "worst_fraction_of_the_bins_own_bound": float(np.max(per_bin / bounds_by_bin))})
     # differential product: random pairs, fp32 model vs exact
     a = rng.standard_normal((4, 1 << 20)).astype(f32)
     re = fma32(a[0], a[2], a[1] * a[3])
@@ -193,10 +210,12 @@ def main():
     l2 = np.hypot(a[0].astype(np.float64), a[1]) * np.hypot(a[2].astype(np.float64), a[3])
     worst_prod = float(np.max(np.abs(re - exact) / l2))
     out = {"what": "rigorous forward-error bound of the fp32 OFDM transform (radix 8.8.8.4) and of the differential product; see the docstring",
-           "constants": c, "model_check": {"worst_bin_error_over_l2": worst, "worst_over_bound": worst / c["bin_bound"], "cases": rows,
+           "constants": c, "per_bin_bound": {"mean_over_inband_bins_of_bound_over_worst_bins": float(np.mean([bounds_by_bin[k] for k in list(range(1, 769)) + list(range(1280, 2048))]) / c["bin_bound"]),
+                            "smallest_over_worst": float(np.min(bounds_by_bin) / c["bin_bound"])},
+           "model_check": {"worst_bin_error_over_l2": worst, "worst_over_bound": worst / c["bin_bound"], "worst_over_the_bins_own_bound": worst_per_bin, "cases": rows,
                                            "worst_product_rounding_over_l2l2": worst_prod, "product_over_bound": worst_prod / c["prod_bound"]}}
     print(json.dumps(out, indent=1))
-    return 0 if worst <= c["bin_bound"] and worst_prod <= c["prod_bound"] else 1
+    return 0 if worst <= c["bin_bound"] and worst_per_bin <= 1.0 and worst_prod <= c["prod_bound"] else 1
 
 
 if __name__ == "__main__":

@@ -13,8 +13,10 @@ SHA=$(cat "$S/k_fused.hip" "$S/fft_core.hpp" "$S/device_types.hpp" | sha256sum |
 #   0.5  the byte pack of the previous symbol's decisions by 96 of the 256 threads: two of the four waves enter
 #   R    the parity guard's per-bin repeat (entered by a wave when one of its lanes trips the per-thread threshold) and its list append:
 #        not priced by weight -- their mix prices the instructions the measured count per transform has beyond the weighted static count
-W="${FUSED_WEIGHTS:-BB0_27=0,BB0_29=0,BB0_64=0,BB0_66=0,BB0_41=0.5,BB0_43=0.5,BB0_45=0.5,BB0_70=0.5,BB0_72=0.5,BB0_48=0,BB0_50=0,BB0_52=0,BB0_56=0,BB0_75=0,BB0_77=0,BB0_79=0,BB0_83=0,BB0_40=0,BB0_61=0}"
-RM="${FUSED_REMAINDER:-BB0_48,BB0_50,BB0_52,BB0_75,BB0_77,BB0_79}"
+# (round 6: the list append now also holds the proven level's per-bin test -- BB0_56 / BB0_86, 103 instructions, entered once per listed candidate: weight 0 like the append before it;
+#  the second symbol's blocks moved up by three labels)
+W="${FUSED_WEIGHTS:-BB0_27=0,BB0_29=0,BB0_67=0,BB0_69=0,BB0_41=0.5,BB0_43=0.5,BB0_45=0.5,BB0_73=0.5,BB0_75=0.5,BB0_48=0,BB0_50=0,BB0_52=0,BB0_56=0,BB0_78=0,BB0_80=0,BB0_82=0,BB0_86=0,BB0_40=0,BB0_64=0}"
+RM="${FUSED_REMAINDER:-BB0_48,BB0_50,BB0_52,BB0_78,BB0_80,BB0_82}"
 python3 "$R/tools/isa_mix.py" --asm "$A" --kernel ofdm_demap_kernelILb0 --per-iteration 0.5 --weights "$W" --remainder "$RM" --source-sha "$SHA" > "$R/profiles/r06_fused_isa_mix.txt"
 tail -n 1 "$R/profiles/r06_fused_isa_mix.txt" > "$R/profiles/r06_fused_isa_mix.json"
 rm -f "$A"
