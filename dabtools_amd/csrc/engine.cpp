@@ -809,7 +809,11 @@ bool Engine::scan_streams(const uint8_t* const* iq, const size_t* nbytes, int ns
   // set_sync_speculation(0 / 1): never / always (tests run both); default: up to kAheadMaxStreams streams of at least kAheadMinCalls calls.
   // (forced on, the pass is still bounded: beyond kAheadForcedMaxStreams streams -- where it cannot help and its table, nstreams x nspec x 33 x 8 bytes
   // with nspec >= 64, would run to tens of megabytes and 33 x nspec x nstreams workgroups -- the plain chain runs whatever the mode says)
-  constexpr int kAheadMaxStreams = 4, kAheadMinCalls = 16, kAheadHypotheses = 33, kAheadForcedMaxStreams = 512;
+  constexpr int kAheadMinCalls = 16, kAheadForcedMaxStreams = 512;
+  // measurement knobs (tools/gpu/k1_ahead_sweep.sh): the window of start positions the pass covers (DABHIP_K1_HYP: odd, 3 .. 63; default 33 = +-16 samples) and
+  // the largest batch that takes the pass by default (DABHIP_K1_SPEC_MAX_STREAMS, default 4)
+  static const int kAheadHypotheses = [] { const char* e = std::getenv("DABHIP_K1_HYP"); const int v = e ? std::atoi(e) : 33; return std::max(3, std::min(63, v | 1)); }();
+  static const int kAheadMaxStreams = [] { const char* e = std::getenv("DABHIP_K1_SPEC_MAX_STREAMS"); const int v = e ? std::atoi(e) : 4; return std::max(0, std::min(512, v)); }();
   const bool use_spec = split_wanted && spec_mode_ != 0 &&
                         (spec_mode_ > 0 ? nstreams <= kAheadForcedMaxStreams : (nstreams <= kAheadMaxStreams && max_calls_ >= kAheadMinCalls));
   // calls of a stream per pass: all it has, within a bound on the table (8 bytes per call, start position and stream)

@@ -167,7 +167,9 @@ __device__ __forceinline__ bool bin_in_use(int m) { return m != 4; }
 // fp64 (the test below), as is every decision inside the error band.  The in-loop test is one threshold per thread, made of the largest |bin|_1 among the
 // thread's bins of this symbol (maxc) and of the previous one (maxp; guard_threshold grows with both), against the smallest |re|, |im| of the thread: three
 // instructions per bin (|bin|_1, max, min3) instead of seven.  Only a thread that trips it repeats the exact per-bin test (rare), so the LIST is the one
-// the per-bin rule makes, plus the zeros.
+// the per-bin rule makes, plus the zeros.  Three tiers since round 6: the thread-wide threshold in the loop; the flat per-bin rule on |.|_1 for the thread that trips
+// it; and, at the proven guard level (GuardArgs::per_bin), the bound's per-bin form on |.|_2 (guard_bin_threshold) for each candidate of the flat rule, where the
+// entry is about to be appended -- every tier a subset of the one before, so the two hot ones stay as cheap as they were.
 __device__ __forceinline__ float bins_l1max(const float2 (&x)[4], const float2 (&y)[4])
 {
   float mx = 0.0f;

@@ -2,12 +2,14 @@
 //
 // The reference demaps with sign tests on fp64 FFTW spectra (input_sdr.c:132-162: bit = Re(cur conj(prev)) <= 0 etc.).  K2 /
 // the fused OFDM kernel transform in fp32, so a decision whose |Re| or |Im| lies inside the fp32 error of the product can come
-// out differently.  The demapping kernels therefore flag every decision with
-//     min(|Re|, |Im|)  <  |cur|_1 d(l-1) + |prev|_1 d(l) + kGuardProd |cur|_1 |prev|_1 ,     d(l) = kGuardC sqrt(sum_n |x_n|^2)
-// (d(l) bounds the error of any bin of symbol l's fp32 transform: symbol_delta_kernel; the constants come from the audit
-// below with a 4x margin) and exact_decide_kernel re-decides the flagged carriers from the int8
-// samples in fp64 by direct summation (relative error 1e-13) and patches the two bits.  A few carriers per million at high
-// SNR, ~1e-4 of them at 5 dB: the cost is negligible and the output is the one exact arithmetic gives.
+// out differently.  The demapping kernels therefore list every decision with
+//     min(|Re|, |Im|)  <  |cur| d(l-1) + |prev| d(l) + P |cur| |prev| + d(l) d(l-1),     d(l) = C sqrt(sum_n |x_n|^2)
+// (device_types.hpp: guard_threshold; d(l) bounds the error of any bin of symbol l's fp32 transform, P the rounding of the product) at one of two levels:
+// the MEASURED one (C, P = 5e-6, 5e-7: 4.5 x the worst errors the audit below has measured; |.|_1 norms; one band for all bins) or the PROVEN one, the default
+// (C, P = 6.6e-5, 1.25e-7: >= a rigorous forward-error bound of this transform and product; |.|_2 norms; the band scaled per bin by the
+// bin's own stage terms, guard_bin_scale), and exact_decide_kernel re-decides the listed carriers from the int8 samples in fp64 by direct summation (relative
+// error 1e-13; bins 512 / 1536 and their products exactly) and patches the two bits.  Nothing on clean input, 1e-5 .. 1e-4 of the decisions at 5 dB: the output is
+// the one exact arithmetic gives.
 //
 // decision_audit_kernel is test / calibration infrastructure behind dabhip_stage_decision_audit: fp64 transforms of every
 // symbol on the GPU (fft64.hpp), compared bin by bin and decision by decision with what the fp32 stage produced.

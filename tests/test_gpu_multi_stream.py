@@ -95,7 +95,7 @@ def test_multi_session_prefetch_fetch_pipeline_and_resident_feed():
     many = dab.MultiStream(len(caps), [0, 0, 0])
     out = [dab.HostBuffer(64 * len(caps) * dab.ETI_BYTES) for _ in range(2)]
     got = [[] for _ in caps]
-    pending = None                                       # (output buffer index, per-stream frame counts) of the fetch not yet waited for
+    pending = []                                         # (output buffer index, per-stream frame counts) of the fetches not yet waited for: up to TWO, as in the CLI
     many.prefetch_ptrs(*segs[0][:2])
 
     def collect(item):
@@ -110,13 +110,14 @@ def test_multi_session_prefetch_fetch_pipeline_and_resident_feed():
         if k + 1 < len(segs):
             many.prefetch_ptrs(*segs[k + 1][:2])
         n = many.feed_ptrs(*segs[k][:2])
-        if pending:
-            collect(pending)                             # (the wait for segment k - 1's frames comes after segment k was fed)
+        if len(pending) == 2:
+            collect(pending.pop(0))                      # (segment k - 2's frames: its output buffer is the one segment k's go to; segment k - 1's fetch stays outstanding)
         counts = [many.eti_count(b) for b in range(len(caps))]
         assert sum(counts) == n
         assert many.eti_fetch(out[k & 1].ptr, 64 * len(caps)) == n
-        pending = (k & 1, counts)
-    collect(pending)
+        pending.append((k & 1, counts))
+    while pending:
+        collect(pending.pop(0))                          # oldest first: a slice that had no frames in a fetch is not waited on for it
     for b, w in enumerate(want):
         assert np.array_equal(np.concatenate(got[b]), w), b
     many.close()

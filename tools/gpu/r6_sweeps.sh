@@ -10,3 +10,4 @@ ROUNDS=8 NAME=r06_channel_vs_oracle STRESS_ARGS="--channel" SEED=60612 bash tool
 ROUNDS=8 NAME=r06_reconf_vs_oracle STRESS_ARGS="--reconf" SEED=60613 bash tools/gpu/stress.sh
 ROUNDS=2 NAME=r06_harsh_vs_reference STRESS_ARGS="--reference --harsh" SEED=60601 bash tools/gpu/stress.sh
 ROUNDS=2 NAME=r06_channel_vs_reference STRESS_ARGS="--reference --channel" SEED=60602 bash tools/gpu/stress.sh
+timeout 300 python tools/live_latency.py > gpurun_out/stress/live_latency.json 2> gpurun_out/stress/live_latency.err; echo "latency rc=$?"; cat gpurun_out/stress/live_latency.json
