@@ -236,7 +236,7 @@ const void* dabhip_engine_eti_device_ptr(const dabhip_engine* ce, int64_t* nfram
   size_t off = 0;
   for (size_t l = 0; l < e->lanes.size(); ++l) {
     const size_t bytes = static_cast<size_t>(e->lane_frames[l]) * DABHIP_ETI_BYTES;
-    if (bytes && hipMemcpy(e->combined.get() + off, e->lanes[l]->eti_buffer(), bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
+    if (bytes && blocking_copy(e->combined.get() + off, e->lanes[l]->eti_buffer(), bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
       set_error("eti_device_ptr: concatenation failed");
       return nullptr;
     }
@@ -477,7 +477,7 @@ dabhip_sdr* dabhip_sdr_init(int device)
   StreamState st;
   std::memset(&st, 0, sizeof st);
   fifo_reset(st);
-  if (hipMemcpy(s->state.get(), &st, sizeof st, hipMemcpyHostToDevice) != hipSuccess || hipMemset(s->tail.get(), 0, kTailBytes) != hipSuccess) {
+  if (blocking_copy(s->state.get(), &st, sizeof st, hipMemcpyHostToDevice) != hipSuccess || hipMemset(s->tail.get(), 0, kTailBytes) != hipSuccess) {
     set_error("sdr_init: state upload failed");
     delete s;
     return nullptr;
@@ -500,14 +500,14 @@ int dabhip_sdr_demod(dabhip_sdr* s, const uint8_t* input_buffer, int input_buffe
     const int64_t keep_from = s->fed - kKeepBytes;
     DeviceBuffer<uint8_t> tmp;
     if (!tmp.reserve(kKeepBytes)) return -1;
-    if (hipMemcpy(tmp.get(), s->window.get() + (keep_from - s->base), kKeepBytes, hipMemcpyDeviceToDevice) != hipSuccess ||
-        hipMemcpy(s->window.get(), tmp.get(), kKeepBytes, hipMemcpyDeviceToDevice) != hipSuccess) {
+    if (blocking_copy(tmp.get(), s->window.get() + (keep_from - s->base), kKeepBytes, hipMemcpyDeviceToDevice) != hipSuccess ||
+        blocking_copy(s->window.get(), tmp.get(), kKeepBytes, hipMemcpyDeviceToDevice) != hipSuccess) {
       set_error("sdr_demod: window slide failed");
       return -1;
     }
     s->base = keep_from;
   }
-  if (input_buffer_len && hipMemcpy(s->window.get() + (s->fed - s->base), input_buffer, input_buffer_len, hipMemcpyHostToDevice) != hipSuccess) {
+  if (input_buffer_len && blocking_copy(s->window.get() + (s->fed - s->base), input_buffer, input_buffer_len, hipMemcpyHostToDevice) != hipSuccess) {
     set_error("sdr_demod: IQ upload failed");
     return -1;
   }
@@ -773,6 +773,8 @@ struct dabhip_stream {
   std::vector<int64_t> base, avail;            // per stream: first stream byte still held, bytes received (fed) so far
   std::vector<size_t> org;                     // per stream: offset, in the newest fed window, of stream byte base[b]
   uint64_t fed = 0, queued = 0;                // segments fed / handed over (fed <= queued <= fed + 2)
+  bool queued_ever = false;                    // dabhip_stream_prefetch has been used: its stream has work to forget (reap_stream)
+  uint32_t up_uses = 0;
   // A feed that fails after it has started to move the session on (windows, offsets, the engine's carried state) leaves a session nobody can
   // re-feed correctly: it is marked and refuses everything but its destruction -- an honest error instead of frames decoded at the wrong offsets.
   bool failed = false;
@@ -929,6 +931,7 @@ extern "C" int dabhip_stream_prefetch(dabhip_stream* s, const uint8_t* const* iq
   s->pending[w].iq.assign(iq, iq + s->n);
   s->pending[w].nbytes.assign(nbytes, nbytes + s->n);
   ++s->queued;
+  s->queued_ever = true;
   return 0;
 }
 
@@ -994,6 +997,10 @@ extern "C" int64_t dabhip_stream_feed(dabhip_stream* s, const uint8_t* const* iq
   ++s->fed;
   const int64_t frames = s->eng.feed(virt.data(), avail.data(), s->n, s->first);
   if (frames < 0) return broken(nullptr);        // (the engine's error text stands)
+  // the prefetch stream is only ever waited for through events (engine.hpp: blocking_copy): every 32nd segment, wait for the stream itself -- at
+  // most the upload of the next segment, which the next feed needs anyway
+  if (s->queued_ever && ++s->up_uses % kReapEvery == 0 && reap_enabled())
+    for (auto up : s->up_stream) (void)hipStreamSynchronize(up);
   s->first = false;
   return frames;
 }
@@ -1117,7 +1124,7 @@ extern "C" void dabhip_device_free(void* p) { if (p) (void)hipFree(p); }
 extern "C" int dabhip_device_copy(void* dst, const void* src, size_t nbytes, int to_device)
 {
   if (!dst || !src) { set_error("device_copy: null argument"); return -1; }
-  if (hipMemcpy(dst, src, nbytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost) != hipSuccess) { set_error("device_copy: hipMemcpy failed"); return -1; }
+  if (blocking_copy(dst, src, nbytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost) != hipSuccess) { set_error("device_copy: hipMemcpy failed"); return -1; }
   return 0;
 }
 

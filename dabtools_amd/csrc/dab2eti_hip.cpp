@@ -229,8 +229,10 @@ int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool 
   bool prefetched[kBufs] = {false, false, false};
   int rc = 0, o = 0;
   const double t_ready = now_s();
-  std::vector<double> seg_done;                  // when each segment's feed returned
-  std::vector<long long> seg_frames;
+  // running totals for --stats (not a record per segment: a live receiver runs for weeks)
+  size_t segments = 0;
+  long long all_frames = 0, steady_frames = 0;   // steady state: the frames of the segments AFTER the first one that produced any
+  double t_first_frames = -1.0;                  // when that first segment's feed returned
   for (int k = 0;; k = (k + 1) % kBufs) {
     int state, next_state;
     const int kn = (k + 1) % kBufs;
@@ -258,8 +260,10 @@ int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool 
         for (int i = 0; i < n; ++i)
           if (s->log(i, text, sizeof text) > 0) print_log(text, names[i], n > 1);
       }
-      seg_done.push_back(now_s());
-      seg_frames.push_back(frames);
+      ++segments;
+      all_frames += frames;
+      if (t_first_frames >= 0) steady_frames += frames;
+      else if (frames > 0) t_first_frames = now_s();
     }
     if (rc) std::_Exit(rc);        // readers may be blocked in fread, the writer on its queue
     { std::lock_guard<std::mutex> lk(mu); queue.push_back(OutItem{o, frames, state == 2}); filled[k] = 0; readers_done[k] = 0; readers_at_eof[k] = 0; ++gen[k]; stop = state == 2; }
@@ -276,14 +280,10 @@ int run_streaming(const std::vector<const char*>& names, size_t seg_bytes, bool 
   }
   if (g_stats) {
     // steady state: from the first segment that produced frames to the last, the frames of the segments after that first one
-    size_t first = 0;
-    while (first < seg_frames.size() && seg_frames[first] == 0) ++first;
-    long long steady_frames = 0, all = 0;
-    for (size_t i = 0; i < seg_frames.size(); ++i) { all += seg_frames[i]; if (i > first) steady_frames += seg_frames[i]; }
-    const double steady_s = first < seg_done.size() ? t_written - seg_done[first] : 0.0;
+    const double steady_s = t_first_frames >= 0 ? t_written - t_first_frames : 0.0;
     std::fprintf(stderr, "{\"mode\": \"stream\", \"devices\": %zu, \"streams\": %d, \"segments\": %zu, \"segment_bytes_per_stream\": %zu, \"setup_s\": %.4f, \"run_s\": %.4f, \"eti_frames\": %lld, "
                          "\"steady_frames\": %lld, \"steady_s\": %.4f, \"steady_frames_per_s\": %.1f}\n",
-                 devices.empty() ? size_t(1) : devices.size(), n, seg_frames.size(), seg_bytes, t_ready - t_start, t_written - t_ready, all, steady_frames, steady_s, steady_s > 0 ? steady_frames / steady_s : 0.0);
+                 devices.empty() ? size_t(1) : devices.size(), n, segments, seg_bytes, t_ready - t_start, t_written - t_ready, all_frames, steady_frames, steady_s, steady_s > 0 ? steady_frames / steady_s : 0.0);
   }
   for (auto& b : buf) dabhip_host_free(b);
   for (auto& ob : out) dabhip_host_free(ob);

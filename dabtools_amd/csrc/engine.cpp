@@ -318,7 +318,7 @@ bool Engine::store_tf_bytes(int slot, const uint8_t* fic_bytes, const uint8_t* m
   const size_t fic_words = static_cast<size_t>(kFicWords) * bits, row_words = static_cast<size_t>(kCifWords) * bits, plane_words = 108u * bits;
   std::vector<uint32_t> f(fic_words, 0u), plane(plane_words);
   for (int i = 0; i < kFicBits; ++i) f[i / per] |= (static_cast<uint32_t>(fic_bytes[i]) & vmask) << (bits * (i % per));
-  if (!check(hipMemcpy(d_fic_bits_.get() + static_cast<size_t>(slot) * fic_words, f.data(), f.size() * 4, hipMemcpyHostToDevice), "fic upload")) return false;
+  if (!check(blocking_copy(d_fic_bits_.get() + static_cast<size_t>(slot) * fic_words, f.data(), f.size() * 4, hipMemcpyHostToDevice), "fic upload")) return false;
   for (int q = 0; q < 4; ++q) {
     const uint8_t* cif = msc_bytes + static_cast<size_t>(q) * kCifBits;
     for (int r = 0; r < 16; ++r) {
@@ -326,7 +326,7 @@ bool Engine::store_tf_bytes(int slot, const uint8_t* fic_bytes, const uint8_t* m
       for (int u = 0; u < kCifBits / 16; ++u) plane[u / per] |= (static_cast<uint32_t>(cif[16 * u + r]) & vmask) << (bits * (u % per));
       const size_t row = static_cast<size_t>(kRowLead + 4 * slot + q - tmap[r]);
       // plane r occupies words [108 r, 108 r + 108) (x 4 with soft values) of the logical row (layout of demap_kernel<true>)
-      if (!check(hipMemcpy(d_msc_bits_.get() + row * row_words + r * plane_words, plane.data(), plane_words * 4, hipMemcpyHostToDevice), "msc upload")) return false;
+      if (!check(blocking_copy(d_msc_bits_.get() + row * row_words + r * plane_words, plane.data(), plane_words * 4, hipMemcpyHostToDevice), "msc upload")) return false;
     }
   }
   return true;
@@ -341,8 +341,8 @@ bool Engine::recycle_tf_slots(int used_slots, int keep_slots)
   if (!d_bytes_.reserve(std::max(nrows * kCifWords * 4 * bits, static_cast<size_t>(keep_slots) * kFicWords * 4 * bits))) return false;
   auto mv = [&](void* base, size_t unit, size_t src, size_t n) {
     uint8_t* b = static_cast<uint8_t*>(base);
-    return check(hipMemcpy(d_bytes_.get(), b + src * unit, n * unit, hipMemcpyDeviceToDevice), "slot move") &&
-           check(hipMemcpy(b, d_bytes_.get(), n * unit, hipMemcpyDeviceToDevice), "slot move");
+    return check(blocking_copy(d_bytes_.get(), b + src * unit, n * unit, hipMemcpyDeviceToDevice), "slot move") &&
+           check(blocking_copy(b, d_bytes_.get(), n * unit, hipMemcpyDeviceToDevice), "slot move");
   };
   return mv(d_fic_bits_.get(), kFicWords * 4 * bits, src_slot, keep_slots) && mv(d_fibs_.get(), 384, src_slot, keep_slots) &&
          mv(d_fib_ok_.get(), 12, src_slot, keep_slots) && mv(d_msc_bits_.get(), kCifWords * 4 * bits, row_src, nrows);
@@ -364,8 +364,8 @@ bool Engine::read_demapped_tf(int stream, int tf, int8_t* fic_out, int8_t* msc_o
   const size_t fic_words = static_cast<size_t>(kFicWords) * bits, row_words = static_cast<size_t>(kCifWords) * bits, plane_words = 108u * bits;
   std::vector<uint32_t> f(fic_words), rows(static_cast<size_t>(kRowLead + 4) * row_words);
   const size_t slot = static_cast<size_t>(prev_tf_base_[stream]) + tf, row0 = static_cast<size_t>(prev_row_base_[stream]) + 4 * tf - kRowLead;
-  if (!check(hipMemcpy(f.data(), d_fic_bits_.get() + slot * fic_words, f.size() * 4, hipMemcpyDeviceToHost), "fic download") ||
-      !check(hipMemcpy(rows.data(), d_msc_bits_.get() + row0 * row_words, rows.size() * 4, hipMemcpyDeviceToHost), "msc download"))
+  if (!check(blocking_copy(f.data(), d_fic_bits_.get() + slot * fic_words, f.size() * 4, hipMemcpyDeviceToHost), "fic download") ||
+      !check(blocking_copy(rows.data(), d_msc_bits_.get() + row0 * row_words, rows.size() * 4, hipMemcpyDeviceToHost), "msc download"))
     return false;
   auto value = [&](uint32_t w, int k) -> int8_t {
     const uint32_t v = (w >> (bits * k)) & (soft_bits_ ? 15u : 1u);
@@ -386,8 +386,8 @@ bool Engine::unpack_tf_slot(int slot, uint8_t* fic_bytes, uint8_t* msc_bytes)
 {
   if (!hard_only("unpack_tf_slot")) return false;
   std::vector<uint32_t> f(kFicWords), m(kMscWords);
-  if (!check(hipMemcpy(f.data(), d_fic_bits_.get() + static_cast<size_t>(slot) * kFicWords, f.size() * 4, hipMemcpyDeviceToHost), "fic download") ||
-      !check(hipMemcpy(m.data(), d_msc_bits_.get() + static_cast<size_t>(slot) * kMscWords, m.size() * 4, hipMemcpyDeviceToHost), "msc download"))
+  if (!check(blocking_copy(f.data(), d_fic_bits_.get() + static_cast<size_t>(slot) * kFicWords, f.size() * 4, hipMemcpyDeviceToHost), "fic download") ||
+      !check(blocking_copy(m.data(), d_msc_bits_.get() + static_cast<size_t>(slot) * kMscWords, m.size() * 4, hipMemcpyDeviceToHost), "msc download"))
     return false;
   unpack_bits(f.data(), kFicBits, fic_bytes);
   unpack_bits(m.data(), kMscBits, msc_bytes);
@@ -539,7 +539,9 @@ bool Engine::read_eti(int64_t first, int64_t n, uint8_t* dst)
 {
   if (n <= 0) return true;
   if (!check(hipSetDevice(device_), "hipSetDevice")) return false;   // callers may sit on another device's thread (dabhip_multi)
-  return check(hipMemcpy(dst, d_eti_.get() + first * kEtiBytes, static_cast<size_t>(n) * kEtiBytes, hipMemcpyDeviceToHost), "eti download");
+  // on the download stream and ended by a stream synchronise (engine.hpp: blocking_copy): callers read after every decode or segment, for ever
+  return check(hipMemcpyAsync(dst, d_eti_.get() + first * kEtiBytes, static_cast<size_t>(n) * kEtiBytes, hipMemcpyDeviceToHost, d2h_stream_), "eti download") &&
+         check(hipStreamSynchronize(d2h_stream_), "eti download");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1312,7 +1314,10 @@ bool Engine::eti_fetch_wait()
 {
   const uint64_t waited = eti_fetch_waited_.load();
   if (waited == eti_fetch_issued_.load()) return true;
-  const bool ok = check(hipSetDevice(device_), "hipSetDevice") && check(hipEventSynchronize(ev_eti_fetch_[waited & 1]), "eti fetch");
+  bool ok = check(hipSetDevice(device_), "hipSetDevice") && check(hipEventSynchronize(ev_eti_fetch_[waited & 1]), "eti fetch");
+  // the download stream is only ever waited for through these events: let the runtime drop its records of the finished fetches (engine.hpp:
+  // blocking_copy) whenever that costs nothing -- no newer fetch queued -- and on every 32nd fetch of a pipeline that always has one in flight
+  if (ok && reap_enabled() && (waited + 1 == eti_fetch_issued_.load() || waited % kReapEvery == kReapEvery - 1)) ok = check(hipStreamSynchronize(d2h_stream_), "eti fetch");
   eti_fetch_waited_.store(waited + 1);
   return ok;
 }
@@ -1391,7 +1396,7 @@ int Engine::stage_ofdm_fft(const uint8_t* frames, int nframes, float* spectra, b
   const size_t bytes = static_cast<size_t>(nframes) * kTfBytes;
   const uint8_t* d_in = frames;
   if (!on_device) {
-    if (!d_iq_own_.reserve(bytes) || !check(hipMemcpy(d_iq_own_.get(), frames, bytes, hipMemcpyHostToDevice), "frame upload")) return -1;
+    if (!d_iq_own_.reserve(bytes) || !check(blocking_copy(d_iq_own_.get(), frames, bytes, hipMemcpyHostToDevice), "frame upload")) return -1;
     d_in = d_iq_own_.get();
   }
   std::vector<CallDesc> descs(nframes);
@@ -1418,7 +1423,7 @@ int Engine::stage_ofdm_fft(const uint8_t* frames, int nframes, float* spectra, b
   float ms = 0;
   if (!elapsed(&ms, ev_[0], ev_[1])) return -1;
   if (kernel_ms) *kernel_ms = ms / reps;
-  if (spectra && !check(hipMemcpy(spectra, d_spectra_.get(), nspec * sizeof(float2), hipMemcpyDeviceToHost), "spectra download")) return -1;
+  if (spectra && !check(blocking_copy(spectra, d_spectra_.get(), nspec * sizeof(float2), hipMemcpyDeviceToHost), "spectra download")) return -1;
   return nframes;
 }
 
@@ -1449,7 +1454,7 @@ int Engine::stage_fic_decode(const uint8_t* fic, int nframes, uint8_t* fibs, uin
   if (!reserve_tf_slots(nframes)) return -1;
   std::vector<uint32_t> words(static_cast<size_t>(nframes) * kFicWords);
   for (int j = 0; j < nframes; ++j) pack_bits(fic + static_cast<size_t>(j) * kFicBits, kFicBits, words.data() + static_cast<size_t>(j) * kFicWords);
-  if (!check(hipMemcpy(d_fic_bits_.get(), words.data(), words.size() * 4, hipMemcpyHostToDevice), "fic upload")) return -1;
+  if (!check(blocking_copy(d_fic_bits_.get(), words.data(), words.size() * 4, hipMemcpyHostToDevice), "fic upload")) return -1;
   return fic_decode_slots(0, nframes, fibs, crc_ok) ? nframes : -1;
 }
 
@@ -1476,7 +1481,7 @@ int Engine::stage_decision_audit(const uint8_t* frames, int nframes, bool on_dev
   const uint8_t* d_in = frames;
   if (!on_device) {
     if (!d_iq_own_.reserve(static_cast<size_t>(nframes) * kTfBytes) ||
-        !check(hipMemcpy(d_iq_own_.get(), frames, static_cast<size_t>(nframes) * kTfBytes, hipMemcpyHostToDevice), "frame upload"))
+        !check(blocking_copy(d_iq_own_.get(), frames, static_cast<size_t>(nframes) * kTfBytes, hipMemcpyHostToDevice), "frame upload"))
       return -1;
     d_in = d_iq_own_.get();
   }
@@ -1516,7 +1521,7 @@ int Engine::stage_decision_audit(const uint8_t* frames, int nframes, bool on_dev
     listed += static_cast<uint64_t>(guard_flagged_);
   }
   AuditOut h;
-  if (!check(hipMemcpy(&h, d_out.get(), sizeof h, hipMemcpyDeviceToHost), "audit download")) return -1;
+  if (!check(blocking_copy(&h, d_out.get(), sizeof h, hipMemcpyDeviceToHost), "audit download")) return -1;
   auto f = [](unsigned bits) { float v; std::memcpy(&v, &bits, 4); return static_cast<double>(v); };
   out8[0] = static_cast<double>(h.decisions); out8[1] = static_cast<double>(h.disagree); out8[2] = static_cast<double>(h.outside);
   out8[3] = static_cast<double>(h.flagged); out8[4] = f(h.bin_bits); out8[5] = f(h.dec_bits); out8[6] = f(h.prod_bits); out8[7] = static_cast<double>(listed);
@@ -1535,7 +1540,7 @@ int Engine::stage_decision_audit_fused(const uint8_t* frames, int nframes, bool 
   const uint8_t* d_in = frames;
   if (!on_device) {
     if (!d_iq_own_.reserve(static_cast<size_t>(nframes) * kTfBytes) ||
-        !check(hipMemcpy(d_iq_own_.get(), frames, static_cast<size_t>(nframes) * kTfBytes, hipMemcpyHostToDevice), "frame upload"))
+        !check(blocking_copy(d_iq_own_.get(), frames, static_cast<size_t>(nframes) * kTfBytes, hipMemcpyHostToDevice), "frame upload"))
       return -1;
     d_in = d_iq_own_.get();
   }
@@ -1605,7 +1610,7 @@ int Engine::stage_decision_audit_fused(const uint8_t* frames, int nframes, bool 
     if (!guard_on) bits_equal = bits_equal && bits_a == bits_b;
   }
   AuditOut h;
-  if (!check(hipMemcpy(&h, d_out.get(), sizeof h, hipMemcpyDeviceToHost), "audit download")) return -1;
+  if (!check(blocking_copy(&h, d_out.get(), sizeof h, hipMemcpyDeviceToHost), "audit download")) return -1;
   auto f = [](unsigned bits) { float v; std::memcpy(&v, &bits, 4); return static_cast<double>(v); };
   out8[0] = static_cast<double>(h.decisions); out8[1] = static_cast<double>(h.disagree); out8[2] = static_cast<double>(h.outside);
   out8[3] = static_cast<double>(h.flagged); out8[4] = f(h.bin_bits); out8[5] = f(h.dec_bits); out8[6] = f(h.prod_bits); out8[7] = static_cast<double>(listed);

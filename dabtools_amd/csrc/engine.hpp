@@ -32,6 +32,26 @@ namespace dabhip {
 
 void set_error(const std::string& msg);
 
+// The HIP runtime keeps its records of a stream's finished commands until somebody synchronises THAT STREAM: an event or a blocking copy that waits
+// for the command itself does not let them go (tools/hip_retained_commands.py, ROCm 7.2: 970 bytes of heap per hipMemcpy into pageable memory on the
+// null stream, 2.0 KB per asynchronous copy + event record + event synchronise on a stream of its own, for ever; nothing with a stream synchronise
+// now and then).  A receiver that runs for weeks makes millions of such calls, so every path that is called once per buffer, frame or segment and
+// does not end in a stream synchronise anyway either goes through the helper below or synchronises its stream every kReapEvery uses (the ETI fetches,
+// the sessions' prefetch stream): bounded books, and a wait that is free when the stream is idle.
+constexpr uint32_t kReapEvery = 32;
+inline bool reap_enabled()             // DABHIP_NO_REAP=1: the behaviour before (for tools/soak_cli.py's "before" column only)
+{
+  static const bool on = std::getenv("DABHIP_NO_REAP") == nullptr;
+  return on;
+}
+inline hipError_t blocking_copy(void* dst, const void* src, size_t nbytes, hipMemcpyKind kind)      // hipMemcpy on the null stream
+{
+  static std::atomic<uint32_t> calls{0};
+  const hipError_t e = hipMemcpy(dst, src, nbytes, kind);
+  if (e == hipSuccess && calls.fetch_add(1, std::memory_order_relaxed) % kReapEvery == kReapEvery - 1 && reap_enabled()) (void)hipStreamSynchronize(nullptr);
+  return e;
+}
+
 // grow-only device allocation; contents are NOT preserved on growth
 template <class T>
 class DeviceBuffer {
