@@ -577,7 +577,7 @@ class Dab:
 
     def __init__(self, device=0, soft=False):
         self.frames = []
-        self._cb = ETI_CALLBACK(lambda p: self.frames.append(np.ctypeslib.as_array(p, (ETI_BYTES,)).copy()))
+        self._cb = ETI_CALLBACK(lambda p: self.frames.append(np.frombuffer(C.string_at(p, ETI_BYTES), np.uint8)))
         self._h = lib().dabhip_dab_init(device, self._cb)
         _need(self._h, "dab_init")
         self.fic = np.ctypeslib.as_array(lib().dabhip_dab_tf_fic(self._h), (FIC_BITS,))
@@ -935,7 +935,7 @@ class Multi:
     def drain(self):
         """All frames through dabhip_multi_eti_drain -> [(stream, frame bytes)] in emission order."""
         got = []
-        sink = C.CFUNCTYPE(None, u8p, C.c_int, C.c_void_p)(lambda p, b, _u: got.append((b, bytes(np.ctypeslib.as_array(p, (ETI_BYTES,))))))
+        sink = C.CFUNCTYPE(None, u8p, C.c_int, C.c_void_p)(lambda p, b, _u: got.append((b, C.string_at(p, ETI_BYTES))))      # (not numpy's as_array: it holds on to ~100 bytes per distinct address)
         n = lib().dabhip_multi_eti_drain(self._h, C.cast(sink, C.c_void_p), None)
         _need(n == len(got), "multi_eti_drain")
         return got

@@ -11,9 +11,11 @@ run() { name=$1; shift; timeout ${LIMIT:-900} "$@" > $O/$name.json 2> $O/$name.e
 run r06_soak_session python3 tools/soak.py --total-tf ${TOTAL_TF:-11200}
 run r06_soak_two_slices python3 tools/soak.py --total-tf ${TOTAL_TF2:-2500} --devices 0,0
 run r06_soak_cli python3 tools/soak_cli.py
-DABHIP_NO_REAP=1 run r06_soak_cli_without_reaping python3 tools/soak_cli.py
+DABHIP_NO_REAP=1 run r06_soak_cli_without_reaping python3 tools/soak_cli.py      # (rc=1 expected: this is the growth)
 run r06_soak_cli_two_inputs_two_slices python3 tools/soak_cli.py --inputs 2 --devices 0,0 --total-tf 3000
 python3 tools/hip_retained_commands.py > $O/r06_hip_retained_commands.txt 2>&1; cat $O/r06_hip_retained_commands.txt | cut -c1-300
 # (4) tools/soak_seams.py: the reference's per-buffer call pattern through the S2 + S3 seams, 9,000 buffers; and its "before" column
 run r06_soak_seams python3 tools/soak_seams.py
 DABHIP_NO_REAP=1 run r06_soak_seams_without_reaping python3 tools/soak_seams.py --oracle-tf 0
+# (5) tools/soak_batch.py: the batch entries (engine and multi over two slices) 4,800 times, frames read back three ways
+run r06_soak_batch python3 tools/soak_batch.py --reps 4800

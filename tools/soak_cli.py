@@ -104,7 +104,8 @@ def main():
     rc = p.wait()
     seconds = time.time() - t0
     frames = got[0] // dab.ETI_BYTES
-    half = [s for s in samples if s["calls"] >= ncalls // 2 and "RssAnon" in s]
+    # (samples taken once everything has been written show the process coming down, not running: left out)
+    half = [s for s in samples if ncalls // 2 <= s["calls"] < ncalls and "RssAnon" in s]
     growth = half[-1]["RssAnon"] - half[0]["RssAnon"] if len(half) >= 2 else None
     out = {"what": "%s fed %d x %d calls of 262,144 bytes (a %d-TF capture round and round) through %s" %
                    (" ".join(os.path.basename(x) if x.startswith("/") else x for x in cmd[:4]), a.inputs, ncalls, a.loop_tf, "stdin" if a.inputs == 1 else "named pipes"),
