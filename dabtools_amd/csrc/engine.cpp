@@ -166,6 +166,7 @@ Engine::Engine(int device, int host_threads, std::vector<int> cpus) : device_(de
     }
   }
   if (const char* env = std::getenv("DABHIP_VIT_WAVE_MAX")) wave_max_codewords_ = wave_max_fic_blocks_ = std::max(0, std::atoi(env));
+  if (const char* env = std::getenv("DABHIP_VIT_TWO_LANES")) two_lanes_max_groups_ = std::max(0, std::atoi(env));
   if (const char* env = std::getenv("DABHIP_FIC_WAVE_MAX")) wave_max_fic_blocks_ = std::max(0, std::atoi(env));
   pool_.reset(new ThreadPool(std::max(0, nthreads - 1), host_cpus_));
   host_lane_.reset(new AsyncLane(host_cpus_));
@@ -277,8 +278,16 @@ bool Engine::launch_decode_batch(const DecodeBatch& b, const uint32_t* bits, con
     if (!record(ev_msc_[2], stream_)) return false;
     return true;
   }
+  // mid-size batches (hard decisions): two lanes per code word (engine.hpp: two_lanes_max_groups_; 1 = always)
+  const bool two_lanes = !soft_bits_ && two_lanes_max_groups_ > 0 && (two_lanes_max_groups_ == 1 || static_cast<int>(b.groups.size()) <= two_lanes_max_groups_);
   for (size_t sl = 0; sl + 1 < b.slice_start.size(); ++sl) {
     const int g0 = b.slice_start[sl], n = b.slice_start[sl + 1] - g0;
+    if (two_lanes) {
+      if (!check(launch_viterbi_fused_two(d_groups_.get() + g0, n, ids, d_plans_.get(), d_grouped_.get(), row_words, d_decisions_.get(), prbs, out, record_stride, stream_),
+                 "viterbi (two lanes per code word) launch"))
+        return false;
+      continue;
+    }
     if (!check(launch_viterbi_fused(soft_bits_, d_groups_.get() + g0, n, ids, d_plans_.get(), d_grouped_.get(), row_words, d_decisions_.get(), prbs,
                                     out, record_stride, stream_),
                "viterbi launch"))

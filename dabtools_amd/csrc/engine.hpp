@@ -327,6 +327,10 @@ class Engine {
   // Decodes of at most this many code words (MSC: ETI frames x sub-channels; FIC: 4 per TF) run one WAVE per code word (k_vitwave.hip: latency
   // of a code word 0.1 instead of 1.4 ms) instead of one lane per code word (viterbi_fused_kernel: a sixth of the lane-ops).  DABHIP_VIT_WAVE_MAX.
   int wave_max_codewords_ = 12288, wave_max_fic_blocks_ = 3072;     // measured crossovers (tools/gpu/wavesweep.sh): MSC 5..6 streams x 64 TF, FIC 12..16
+  // Above that, hard-decision decodes of at most this many groups of 64 code words run TWO LANES per code word (vit_two_lanes.hpp): while the lane form
+  // would leave the SIMDs at one or two waves (8 .. 40 streams x 64 TF: decoder stage 1.45 -> 0.96 ms at 16 streams).  Measured crossover between 32 and
+  // 64 streams (1,176 and 2,352 groups; profiles/r06_two_lanes_curve.txt).  DABHIP_VIT_TWO_LANES = 0 / 1 / N: never / always / at most N groups.
+  int two_lanes_max_groups_ = 1536;
   std::mutex* heavy_mu_ = nullptr;
   std::unique_ptr<ThreadPool> pool_;   // host threads for per-stream control-plane work
   std::unique_ptr<AsyncLane> host_lane_;   // the control-plane pass of a decode, beside its GPU work

@@ -848,6 +848,8 @@ namespace dabhip {
 namespace {
 #endif
 
+#include "vit_two_lanes.hpp"
+
 // ---------------------------------------------------------------------------------------
 // batched device-to-device copy (session carry-over of slots and rows): grid (piece, slice)
 __global__ __launch_bounds__(256) void batched_copy_kernel(const CopyDesc* __restrict__ descs)
@@ -1091,6 +1093,16 @@ hipError_t launch_viterbi_fused(int soft_bits, const WaveGroup* groups, int ngro
   else
     hipLaunchKernelGGL(viterbi_fused_kernel<1>, dim3((ngroups + 3) / 4), dim3(256), 0, stream, groups, ngroups, job_ids, plans, grouped, row_words,
                        decisions, prbs_words, out, record_stride);
+  return hipGetLastError();
+}
+
+// hard decisions, two lanes per code word (vit_two_lanes.hpp): two waves per group
+hipError_t launch_viterbi_fused_two(const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans, const uint32_t* grouped, int row_words,
+                                    uint2* decisions, const uint32_t* prbs_words, uint8_t* out, int record_stride, hipStream_t stream)
+{
+  if (ngroups <= 0) return hipSuccess;
+  hipLaunchKernelGGL(viterbi_fused_two_kernel, dim3((2 * ngroups + 3) / 4), dim3(256), 0, stream, groups, ngroups, job_ids, plans, grouped, row_words, decisions,
+                     prbs_words, out, record_stride);
   return hipGetLastError();
 }
 

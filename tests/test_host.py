@@ -505,3 +505,22 @@ def test_documents_name_profile_files_that_exist_and_hold_no_placeholders():
         missing += [(doc, n) for n in sorted(names) if not os.path.exists(os.path.join(root, "profiles", n))]
         assert not re.search(r"\bR\d_[A-Z]+\b|TODO|TBD|XXX", text), doc
     assert not missing, missing
+
+
+def test_two_lane_decoder_index_algebra_model():
+    """tools/models/twolane_model.py: the rotating lane-bit schedule of vit_two_lanes.hpp (register maps, per-lane metric tables, re-pairing, record byte
+    positions) equals a plain 64-state add-compare-select step by step; the header's constexpr helpers are this model's functions."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("twolane_model", os.path.join(ROOT, "tools", "models", "twolane_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    m.check_layouts()
+    old = sys.argv
+    sys.argv = ["twolane_model.py", "192"]
+    try:
+        m.main()
+    finally:
+        sys.argv = old
+    # the header states the same schedule
+    text = open(os.path.join(ROOT, "dabtools_amd", "csrc", "vit_two_lanes.hpp")).read()
+    assert "return (3 + t) % 6" in text and "side * 8 + remove_bit(r, L < tau ? L : L - 1)" in text
