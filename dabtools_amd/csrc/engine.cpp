@@ -167,6 +167,8 @@ Engine::Engine(int device, int host_threads, std::vector<int> cpus) : device_(de
   }
   if (const char* env = std::getenv("DABHIP_VIT_WAVE_MAX")) wave_max_codewords_ = wave_max_fic_blocks_ = std::max(0, std::atoi(env));
   if (const char* env = std::getenv("DABHIP_VIT_TWO_LANES")) two_lanes_max_groups_ = std::max(0, std::atoi(env));
+  if (const char* env = std::getenv("DABHIP_VIT_FOUR_LANES")) four_lanes_max_groups_ = std::max(0, std::atoi(env));
+  if (const char* env = std::getenv("DABHIP_VIT_LANES_PLAIN")) two_lanes_plain_ = std::atoi(env) != 0;
   if (const char* env = std::getenv("DABHIP_FIC_WAVE_MAX")) wave_max_fic_blocks_ = std::max(0, std::atoi(env));
   pool_.reset(new ThreadPool(std::max(0, nthreads - 1), host_cpus_));
   host_lane_.reset(new AsyncLane(host_cpus_));
@@ -280,8 +282,16 @@ bool Engine::launch_decode_batch(const DecodeBatch& b, const uint32_t* bits, con
   }
   // mid-size batches (hard decisions): two lanes per code word (engine.hpp: two_lanes_max_groups_; 1 = always)
   const bool two_lanes = !soft_bits_ && two_lanes_max_groups_ > 0 && (two_lanes_max_groups_ == 1 || static_cast<int>(b.groups.size()) <= two_lanes_max_groups_);
+  const bool four_lanes = !soft_bits_ && four_lanes_max_groups_ > 0 && (four_lanes_max_groups_ == 1 || static_cast<int>(b.groups.size()) <= four_lanes_max_groups_);
   for (size_t sl = 0; sl + 1 < b.slice_start.size(); ++sl) {
     const int g0 = b.slice_start[sl], n = b.slice_start[sl + 1] - g0;
+    if (four_lanes || (two_lanes && two_lanes_plain_)) {
+      if (!check(launch_viterbi_fused_lanes(four_lanes ? 4 : 2, d_groups_.get() + g0, n, ids, d_plans_.get(), d_grouped_.get(), row_words, d_decisions_.get(), prbs, out,
+                                            record_stride, stream_),
+                 "viterbi (lanes per code word) launch"))
+        return false;
+      continue;
+    }
     if (two_lanes) {
       if (!check(launch_viterbi_fused_two(d_groups_.get() + g0, n, ids, d_plans_.get(), d_grouped_.get(), row_words, d_decisions_.get(), prbs, out, record_stride, stream_),
                  "viterbi (two lanes per code word) launch"))

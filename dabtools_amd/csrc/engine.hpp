@@ -331,6 +331,11 @@ class Engine {
   // would leave the SIMDs at one or two waves (8 .. 40 streams x 64 TF: decoder stage 1.45 -> 0.96 ms at 16 streams).  Measured crossover between 32 and
   // 64 streams (1,176 and 2,352 groups; profiles/r06_two_lanes_curve.txt).  DABHIP_VIT_TWO_LANES = 0 / 1 / N: never / always / at most N groups.
   int two_lanes_max_groups_ = 1536;
+  // ... and of at most this many groups FOUR lanes per code word (vit_four_lanes.hpp): decoder stage 0.96 -> 0.82 ms at 8 and 16 streams, the same as
+  // two lanes at 32 (1,176 groups; profiles/r06_lanes_curve.txt).  DABHIP_VIT_FOUR_LANES = 0 / 1 / N likewise;
+  // DABHIP_VIT_LANES_PLAIN=1 (measurement) runs the two-lane decodes through that file's table-free two-lane form instead of vit_two_lanes.hpp's.
+  int four_lanes_max_groups_ = 800;
+  bool two_lanes_plain_ = false;
   std::mutex* heavy_mu_ = nullptr;
   std::unique_ptr<ThreadPool> pool_;   // host threads for per-stream control-plane work
   std::unique_ptr<AsyncLane> host_lane_;   // the control-plane pass of a decode, beside its GPU work

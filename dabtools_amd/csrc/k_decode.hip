@@ -849,6 +849,7 @@ namespace {
 #endif
 
 #include "vit_two_lanes.hpp"
+#include "vit_four_lanes.hpp"
 
 // ---------------------------------------------------------------------------------------
 // batched device-to-device copy (session carry-over of slots and rows): grid (piece, slice)
@@ -1103,6 +1104,20 @@ hipError_t launch_viterbi_fused_two(const WaveGroup* groups, int ngroups, const 
   if (ngroups <= 0) return hipSuccess;
   hipLaunchKernelGGL(viterbi_fused_two_kernel, dim3((2 * ngroups + 3) / 4), dim3(256), 0, stream, groups, ngroups, job_ids, plans, grouped, row_words, decisions,
                      prbs_words, out, record_stride);
+  return hipGetLastError();
+}
+
+// hard decisions, 2^NL lanes per code word without per-lane tables (vit_four_lanes.hpp): lanes = 2 or 4 waves' worth of lanes per group
+hipError_t launch_viterbi_fused_lanes(int lanes, const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans, const uint32_t* grouped,
+                                      int row_words, uint2* decisions, const uint32_t* prbs_words, uint8_t* out, int record_stride, hipStream_t stream)
+{
+  if (ngroups <= 0) return hipSuccess;
+  if (lanes == 4)
+    hipLaunchKernelGGL(viterbi_fused_lanes_kernel<2>, dim3(ngroups), dim3(256), 0, stream, groups, ngroups, job_ids, plans, grouped, row_words, decisions, prbs_words,
+                       out, record_stride);
+  else
+    hipLaunchKernelGGL(viterbi_fused_lanes_kernel<1>, dim3((2 * ngroups + 3) / 4), dim3(256), 0, stream, groups, ngroups, job_ids, plans, grouped, row_words, decisions,
+                       prbs_words, out, record_stride);
   return hipGetLastError();
 }
 

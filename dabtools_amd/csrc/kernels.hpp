@@ -121,6 +121,8 @@ hipError_t launch_fic_group(const uint32_t* fic_rows, int first_block, int nbloc
 hipError_t launch_viterbi_fused(int soft_bits, const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans,
                                 const uint32_t* grouped, int row_words, uint2* decisions, const uint32_t* prbs_words, uint8_t* out,
                                 int record_stride, hipStream_t stream);
+hipError_t launch_viterbi_fused_lanes(int lanes, const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans, const uint32_t* grouped,
+                                      int row_words, uint2* decisions, const uint32_t* prbs_words, uint8_t* out, int record_stride, hipStream_t stream);
 hipError_t launch_viterbi_fused_two(const WaveGroup* groups, int ngroups, const int* job_ids, const CodewordPlan* plans, const uint32_t* grouped, int row_words,
                                     uint2* decisions, const uint32_t* prbs_words, uint8_t* out, int record_stride, hipStream_t stream);
 

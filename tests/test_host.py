@@ -524,3 +524,11 @@ def test_two_lane_decoder_index_algebra_model():
     # the header states the same schedule
     text = open(os.path.join(ROOT, "dabtools_amd", "csrc", "vit_two_lanes.hpp")).read()
     assert "return (3 + t) % 6" in text and "side * 8 + remove_bit(r, L < tau ? L : L - 1)" in text
+    # ... and 2^NL lanes without per-lane tables (vit_four_lanes.hpp): tools/models/multilane_model.py
+    spec = importlib.util.spec_from_file_location("multilane_model", os.path.join(ROOT, "tools", "models", "multilane_model.py"))
+    mm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mm)
+    for starts in ((3,), (3, 5)):
+        assert mm.run(starts, 192, 5)
+    text = open(os.path.join(ROOT, "dabtools_amd", "csrc", "vit_four_lanes.hpp")).read()
+    assert "return ((i == 0 ? 3 : 5) + t) % 6" in text
