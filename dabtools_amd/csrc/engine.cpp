@@ -168,6 +168,7 @@ Engine::Engine(int device, int host_threads, std::vector<int> cpus) : device_(de
   if (const char* env = std::getenv("DABHIP_VIT_WAVE_MAX")) wave_max_codewords_ = wave_max_fic_blocks_ = std::max(0, std::atoi(env));
   if (const char* env = std::getenv("DABHIP_VIT_TWO_LANES")) two_lanes_max_groups_ = std::max(0, std::atoi(env));
   if (const char* env = std::getenv("DABHIP_VIT_FOUR_LANES")) four_lanes_max_groups_ = std::max(0, std::atoi(env));
+  if (const char* env = std::getenv("DABHIP_FIC_FOUR_LANES")) fic_four_lanes_max_tiles_ = std::max(0, std::atoi(env));
   if (const char* env = std::getenv("DABHIP_VIT_LANES_PLAIN")) two_lanes_plain_ = std::atoi(env) != 0;
   if (const char* env = std::getenv("DABHIP_FIC_WAVE_MAX")) wave_max_fic_blocks_ = std::max(0, std::atoi(env));
   pool_.reset(new ThreadPool(std::max(0, nthreads - 1), host_cpus_));
@@ -430,6 +431,9 @@ bool Engine::fic_decode_slots_async(int first, int n, uint8_t* fibs_host, uint8_
   for (int i = 0; i < nblocks; ++i) ids[i] = 4 * first + i;
   std::vector<WaveGroup> groups;
   const bool wave_form = nblocks <= wave_max_fic_blocks_;      // few blocks: one wave per block (k_vitwave.hip), rows per block and chunk of steps
+  // more, but not enough to fill the device with one lane per block (774 dependent steps in front of the control plane): four lanes per block
+  // (vit_four_lanes.hpp; same records, same arguments), up to 128 tiles = 32 streams x 64 TF (measured: nothing to gain above).
+  const bool fic_four_lanes = !wave_form && !soft_bits_ && fic_four_lanes_max_tiles_ > 0 && (fic_four_lanes_max_tiles_ == 1 || ntiles <= fic_four_lanes_max_tiles_);
   const int64_t dr = wave_form ? int64_t(64) * ((plan_table_[pid].nsteps + kWaveChunk - 1) / kWaveChunk) : (plan_table_[pid].nsteps + 7) / 8 * 8;
   for (int g = 0; g < ntiles; ++g) groups.push_back(WaveGroup{pid, 64 * g, std::min(64, nblocks - 64 * g), plan_table_[pid].nsteps, 0, g * dr});
   // The FIC kernels run on the side stream as well, behind what the main stream has queued so far (the FIC bits): 1008 waves of 774
@@ -452,6 +456,9 @@ bool Engine::fic_decode_slots_async(int first, int n, uint8_t* fibs_host, uint8_
       !check(wave_form
                  ? launch_viterbi_wave(soft_bits_, d_groups_.get(), ntiles, d_job_ids_.get(), d_plans_.get(), d_grouped_.get(), block_words,
                                        d_decisions_.get(), d_prbs_.get(), d_fibs_.get(), 96, ks)
+             : fic_four_lanes
+                 ? launch_viterbi_fused_lanes(4, d_groups_.get(), ntiles, d_job_ids_.get(), d_plans_.get(), d_grouped_.get(), block_words, d_decisions_.get(),
+                                              d_prbs_.get(), d_fibs_.get(), 96, ks)
                  : launch_viterbi_fused(soft_bits_, d_groups_.get(), ntiles, d_job_ids_.get(), d_plans_.get(), d_grouped_.get(), block_words,
                                         d_decisions_.get(), d_prbs_.get(), d_fibs_.get(), 96, ks),
              "fic viterbi launch"))

@@ -336,6 +336,9 @@ class Engine {
   // DABHIP_VIT_LANES_PLAIN=1 (measurement) runs the two-lane decodes through that file's table-free two-lane form instead of vit_two_lanes.hpp's.
   int four_lanes_max_groups_ = 800;
   bool two_lanes_plain_ = false;
+  // FIC decodes of at most this many tiles of 64 blocks (above the wave form's range: 12 .. 32 streams x 64 TF) run four lanes per block: FIC stage 0.32 -> 0.24 ms
+  // at 16 streams, 0.58 -> 0.50 at 32, nothing from 64 streams (256 tiles) on.  DABHIP_FIC_FOUR_LANES = 0 / 1 / N
+  int fic_four_lanes_max_tiles_ = 128;
   std::mutex* heavy_mu_ = nullptr;
   std::unique_ptr<ThreadPool> pool_;   // host threads for per-stream control-plane work
   std::unique_ptr<AsyncLane> host_lane_;   // the control-plane pass of a decode, beside its GPU work
